@@ -1,0 +1,160 @@
+/*
+ * shacira_hip.h -- C-ABI of libshacira_hip.so, the MI355X (gfx950) implementation of SHACIRA's hash-grid
+ * interpolation and latent quantisation / entropy path.
+ *
+ * This is the drop-in boundary: exactly the operators the reference binds through pybind11 in
+ * wisp/csrc/bindings.cpp:24-28 (declared in wisp/csrc/ops/hashgrid_interpolate.h:18-50), restated with plain
+ * pointers and sizes (no ATen types), plus the per-entry latent decode / entropy-bit operators that the
+ * reference evaluates as chains of ATen elementwise kernels
+ * (wisp/models/latent_decoders/basic_latent_decoder.py:182-198, wisp/models/grids/latent_grid.py:122-136,
+ * wisp/models/prob_models/bit_estimator.py:27-65).
+ *
+ * Conventions (all entry points):
+ *   - every buffer is CALLER-OWNED device memory (hipMalloc / the PyTorch caching allocator) unless the name
+ *     ends in _host; the library never allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and the call
+ *     returns immediately; calls are reentrant and thread-safe (the backward runs on autograd worker threads);
+ *   - return value: 0 on success, a negative SHACIRA_E* code for invalid arguments (nothing enqueued), or a
+ *     positive hipError_t if the launch failed. shacira_strerror() describes either;
+ *   - tensors are dense row-major.
+ */
+#ifndef SHACIRA_HIP_H
+#define SHACIRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHACIRA_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define SHACIRA_API __attribute__((visibility("default")))
+#else
+#define SHACIRA_API
+#endif
+
+/* table / feature scalar types (AT_DISPATCH_FLOATING_TYPES_AND_HALF in hashgrid_interpolate_cuda.cu:125) */
+#define SHACIRA_F32 0
+#define SHACIRA_F16 1
+
+#define SHACIRA_MAX_LODS 32
+
+#define SHACIRA_EINVAL   (-1) /* bad dim / sizes / bitwidth / null pointer              */
+#define SHACIRA_EDTYPE   (-2) /* unsupported scalar type                                */
+#define SHACIRA_EODD     (-3) /* feature_dim is odd (wisp/ops/grid.py:75-76 raises too) */
+#define SHACIRA_EWORKSPACE (-4) /* workspace too small for the requested algorithm      */
+
+SHACIRA_API int shacira_abi_version(void);
+SHACIRA_API const char *shacira_strerror(int code);
+
+/*
+ * Forward: replaces hashgrid_interpolate_cuda / hashgrid_interpolate2d_cuda
+ * (wisp/csrc/ops/hashgrid_interpolate.cpp:44-66 and :130-152; kernels hashgrid_interpolate_cuda.cu:47-109,
+ * hashgrid_interpolate2d_cuda.cu:44-99). All levels are evaluated by one launch.
+ *
+ *   dim                2 or 3 (coords are [num_coords, dim] fp32 in [-1, 1])
+ *   codebook           [table_rows, feature_dim] of `dtype`; levels concatenated, level l starts at row
+ *                      codebook_first_idx[l]
+ *   codebook_first_idx DEVICE int32 [num_lods] (the module's `codebook_lod_first_idx` buffer)
+ *   resolutions_host   HOST int32 [num_lods] (the Python list the reference converts to std::vector<int32_t>)
+ *   feats              out, [num_coords, num_lods*feature_dim] of `dtype` (level-major, feature-minor)
+ *   table_rows         total rows; used only to keep the reference's out-of-table corner (coord == +1 on a
+ *                      dense level with res >= 258, weight 0) memory-safe
+ */
+SHACIRA_API int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                             const int32_t *resolutions_host, const int32_t *codebook_first_idx,
+                             int64_t table_rows, const float *coords, const void *codebook, int dtype,
+                             void *feats, void *stream);
+
+/*
+ * Backward: replaces hashgrid_interpolate_backward_cuda / hashgrid_interpolate2d_backward_cuda
+ * (hashgrid_interpolate.cpp:68-100 and :154-186; kernels .cu:143-221, 2d.cu:133-208).
+ *
+ *   grad_output    [num_coords, num_lods*feature_dim] of `dtype`
+ *   grad_codebook  out, [table_rows, feature_dim] of `dtype`; the call overwrites it completely
+ *                  (the reference's at::zeros_like + atomicAdd), no pre-zeroing needed
+ *   workspace      scratch of at least shacira_hashgrid_backward_workspace_bytes(...) bytes (may be NULL if 0)
+ *
+ * The reference's `require_grad_coords` output is dead code there (computed into a tensor that is never
+ * returned, hashgrid_interpolate.cpp:96-97; wisp/ops/grid.py:111 returns None for coords) and is not provided.
+ */
+SHACIRA_API size_t shacira_hashgrid_backward_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                                 int codebook_bitwidth, const int32_t *resolutions_host,
+                                                 int64_t table_rows, int dtype);
+
+SHACIRA_API int shacira_hashgrid_backward(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                              const int32_t *resolutions_host, const int32_t *codebook_first_idx,
+                              int64_t table_rows, const float *coords, const void *grad_output, int dtype,
+                              void *grad_codebook, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Latent decode, deterministic (non-SGA) path of LatentDecoder.forward with num_layers_dec == 0
+ * (basic_latent_decoder.py:192-198 with DecoderLayer.forward :86-91):
+ *     q        = rint(latent)                       round-half-to-even, torch.round (StraightThrough :28-36)
+ *     z[c]     = q[c] / div[c]
+ *     y[j]     = (sum_c z[c] * matrix[c, j]) * colscale[j] + shift[j]
+ *     decoded  = clamp(y, -clamp_weights, +clamp_weights) if clamp_weights > 0
+ *   'sq'  decoders pass matrix = scale [latent_dim, feature_dim], colscale = NULL (treated as 1);
+ *   'dft' decoders pass matrix = dft   [latent_dim, feature_dim], colscale = scale [feature_dim].
+ *   shift may be NULL (use_shift False). All fp32.
+ *
+ * Backward (straight-through for the rounding): given grad_decoded [T, feature_dim]
+ *     grad_latent[c]   = (sum_j gy[j] * colscale[j] * matrix[c, j]) / div[c]            (gy zeroed where clamped)
+ *     grad_matrix[c,j] = sum_T z[c] * gy[j] * colscale[j]          ('sq': this is grad(scale))
+ *     grad_colscale[j] = sum_T gy[j] * (sum_c z[c] * matrix[c, j]) ('dft': this is grad(scale))
+ *     grad_shift[j]    = sum_T gy[j]
+ *   Any of grad_latent / grad_matrix / grad_colscale / grad_shift may be NULL (not computed). Reductions over T
+ *   are accumulated in fp64 partials held in `workspace` and written (not accumulated) to the outputs.
+ */
+SHACIRA_API int shacira_latent_decode_forward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,
+                                  const float *div, const float *matrix, const float *colscale,
+                                  const float *shift, float clamp_weights, float *decoded, void *stream);
+
+SHACIRA_API size_t shacira_latent_decode_backward_workspace_bytes(int64_t num_rows, int latent_dim, int feature_dim);
+
+SHACIRA_API int shacira_latent_decode_backward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,
+                                   const float *div, const float *matrix, const float *colscale,
+                                   const float *shift, float clamp_weights, const float *grad_decoded,
+                                   float *grad_latent, float *grad_matrix, float *grad_colscale,
+                                   float *grad_shift, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Entropy bits of the latents under the factorised BitEstimator (latent_grid.py:122-136,
+ * bit_estimator.py:27-65):
+ *     w     = latent + noise           (noise != NULL: training)   or   rint(latent)   (noise == NULL: is_val)
+ *     p     = CDF(w + 0.5) - CDF(w - 0.5)
+ *     bits  = clamp(-log(p + 1e-10) / ln 2, 0, 50)
+ *     *total_bits = sum over all [num_rows, latent_dim] entries          (fp32 scalar on the device)
+ *   CDF: for each of the first (num_layers-1) of {f1,f2,f3}: x = x*softplus(h)+b ; x = x + tanh(x)*tanh(a);
+ *        then f4: sigmoid(x*softplus(h)+b).   params = fp32 [4][3][latent_dim] = (f1.h,f1.b,f1.a, f2..., f4.h,f4.b,unused)
+ *
+ * Backward, given the upstream scalar gradient d(loss)/d(total_bits) (device fp32 scalar):
+ *     grad_latent [num_rows, latent_dim]   (zero where noise == NULL: round() has zero gradient; and where clamped)
+ *     grad_params fp32 [4][3][latent_dim]  (unused slots written as 0)
+ *   Either output may be NULL.
+ */
+SHACIRA_API size_t shacira_entropy_bits_workspace_bytes(int64_t num_rows, int latent_dim);
+
+SHACIRA_API int shacira_entropy_bits_forward(int64_t num_rows, int latent_dim, int num_layers, const float *latent,
+                                 const float *noise, const float *params, float *total_bits, void *workspace,
+                                 size_t workspace_bytes, void *stream);
+
+SHACIRA_API int shacira_entropy_bits_backward(int64_t num_rows, int latent_dim, int num_layers, const float *latent,
+                                  const float *noise, const float *params, const float *grad_total_bits,
+                                  float *grad_latent, float *grad_params, void *workspace, size_t workspace_bytes,
+                                  void *stream);
+
+/*
+ * Tunables (process-wide, read at call time; for benchmarking and A/B only).
+ *   "fwd_variant", "bwd_variant": integer algorithm selectors, -1 = automatic.
+ */
+SHACIRA_API int shacira_set_option(const char *name, int value);
+SHACIRA_API int shacira_get_option(const char *name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHACIRA_HIP_H */

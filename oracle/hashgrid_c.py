@@ -1,0 +1,107 @@
+"""ctypes binding of the scalar C oracle (``oracle/hashgrid_oracle.c``). TEST INFRASTRUCTURE ONLY.
+
+``build()`` compiles it with gcc through ``oracle/Makefile`` into ``oracle/_build/``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libshacira_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "hashgrid_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        i32, i64, f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+        p = ctypes.c_void_p
+        L.shacira_oracle_hash_index3.restype = i32
+        L.shacira_oracle_hash_index3.argtypes = [i32] * 5
+        L.shacira_oracle_hash_index2.restype = i32
+        L.shacira_oracle_hash_index2.argtypes = [i32] * 4
+        L.shacira_oracle_hashgrid_fwd.restype = None
+        L.shacira_oracle_hashgrid_fwd.argtypes = [ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  p, p, i64, p, p, p, p, p]
+        for name in ("shacira_oracle_hashgrid_bwd", "shacira_oracle_hashgrid_bwd_f32"):
+            fn = getattr(L, name)
+            fn.restype = None
+            fn.argtypes = [ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, p, p, i64, p, p, p]
+        L.shacira_oracle_axis.restype = None
+        L.shacira_oracle_axis.argtypes = [f32, i32, p, p, p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def hash_index3(x, y, z, res, cs):
+    return int(lib().shacira_oracle_hash_index3(x, y, z, res, cs))
+
+
+def hash_index2(x, y, res, cs):
+    return int(lib().shacira_oracle_hash_index2(x, y, res, cs))
+
+
+def axis(c, res):
+    pos = np.zeros(1, np.int32)
+    fr = np.zeros(1, np.float32)
+    ifr = np.zeros(1, np.float32)
+    lib().shacira_oracle_axis(float(np.float32(c)), int(res), _ptr(pos), _ptr(fr), _ptr(ifr))
+    return int(pos[0]), np.float32(fr[0]), np.float32(ifr[0])
+
+
+def _prep(coords, table, resolutions, first_idx):
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    res = np.ascontiguousarray(resolutions, dtype=np.int32)
+    fi = np.ascontiguousarray(first_idx, dtype=np.int32)
+    assert coords.ndim == 2 and coords.shape[1] in (2, 3)
+    assert table.ndim == 2 and res.shape == fi.shape
+    return coords, table, res, fi
+
+
+def forward(coords, table, first_idx, resolutions, bitwidth, want_corners=False):
+    """feats [N, L*F] float32 (and optionally level-local corner rows / weights [N, L, 2^d])."""
+    coords, table, res, fi = _prep(coords, table, resolutions, first_idx)
+    N, dim = coords.shape
+    T, F = table.shape
+    L = len(res)
+    feats = np.empty((N, L * F), np.float32)
+    idx = np.empty((N, L, 1 << dim), np.int32) if want_corners else None
+    w = np.empty((N, L, 1 << dim), np.float32) if want_corners else None
+    lib().shacira_oracle_hashgrid_fwd(dim, N, L, F, int(bitwidth), _ptr(res), _ptr(fi), T, _ptr(coords),
+                                      _ptr(table), _ptr(feats), _ptr(idx), _ptr(w))
+    return (feats, idx, w) if want_corners else feats
+
+
+def backward(coords, grad_out, table_shape, first_idx, resolutions, bitwidth, accumulate="f64"):
+    """grad_table [T, F]; float64 (sample-order double accumulation) or float32 (sample-order fp32)."""
+    T, F = table_shape
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    res = np.ascontiguousarray(resolutions, dtype=np.int32)
+    fi = np.ascontiguousarray(first_idx, dtype=np.int32)
+    N, dim = coords.shape
+    L = len(res)
+    grad_out = np.ascontiguousarray(grad_out, dtype=np.float32).reshape(N, L * F)
+    if accumulate == "f64":
+        out = np.zeros((T, F), np.float64)
+        fn = lib().shacira_oracle_hashgrid_bwd
+    else:
+        out = np.zeros((T, F), np.float32)
+        fn = lib().shacira_oracle_hashgrid_bwd_f32
+    fn(dim, N, L, F, int(bitwidth), _ptr(res), _ptr(fi), T, _ptr(coords), _ptr(grad_out), _ptr(out))
+    return out

@@ -1,0 +1,74 @@
+"""ctypes binding of ``libshacira_hip.so`` (the C-ABI declared in ``include/shacira_hip.h``).
+
+The library is the product: there is no eager/CPU fallback. If it is missing, ``lib()`` raises
+``RuntimeError`` telling the user to build it (``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C shacira_amd/csrc``).
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libshacira_hip.so")
+
+F32, F16 = 0, 1
+EINVAL, EDTYPE, EODD, EWORKSPACE = -1, -2, -3, -4
+
+_lock = threading.Lock()
+_lib = None
+
+_i, _i64, _f, _p, _sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list EVERY symbol include/shacira_hip.h declares (tests check this)
+SIGNATURES = {
+    "shacira_abi_version": (_i, []),
+    "shacira_strerror": (ctypes.c_char_p, [_i]),
+    "shacira_set_option": (_i, [ctypes.c_char_p, _i]),
+    "shacira_get_option": (_i, [ctypes.c_char_p]),
+    "shacira_hashgrid_forward": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p]),
+    "shacira_hashgrid_backward_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i, _p, _i64, _i]),
+    "shacira_hashgrid_backward": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p]),
+    "shacira_latent_decode_forward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
+    "shacira_latent_decode_backward_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "shacira_latent_decode_backward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "shacira_entropy_bits_workspace_bytes": (_sz, [_i64, _i]),
+    "shacira_entropy_bits_forward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "shacira_entropy_bits_backward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+}
+
+
+def lib():
+    """Load (once) and return the ctypes handle of libshacira_hip.so."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"shacira_amd: HIP library not built ({LIB_PATH} missing). Build it with "
+                        "`make -C shacira_amd/csrc` (hipcc --offload-arch=gfx950); there is no CPU fallback.")
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = handle
+    return _lib
+
+
+def check(code, what=""):
+    """Raise like the reference does: RuntimeError for operator failures (AT_ERROR -> RuntimeError)."""
+    if code == 0:
+        return
+    msg = lib().shacira_strerror(int(code)).decode()
+    if code == EODD:  # wisp/ops/grid.py:75-76 raises a bare Exception with this text
+        raise Exception(msg)
+    raise RuntimeError(f"{what}: {msg} (code {code})" if what else f"{msg} (code {code})")
+
+
+def set_option(name, value):
+    check(lib().shacira_set_option(name.encode(), int(value)), "shacira_set_option")
+
+
+def get_option(name):
+    return int(lib().shacira_get_option(name.encode()))

@@ -1,0 +1,173 @@
+// api.hip -- the extern "C" entry points declared in include/shacira_hip.h: argument validation, level-table
+// construction and dispatch. No allocation, no synchronisation, no global mutable state besides the tunables.
+#include <atomic>
+#include <cmath>
+#include <cstring>
+
+#include "internal.h"
+
+namespace shacira {
+
+std::atomic<int> g_fwd_variant{-1};
+std::atomic<int> g_bwd_variant{-1};
+
+static int build_level_table(int dim, int num_lods, int feature_dim, int bw, const int32_t *res_host,
+                             int64_t table_rows, LevelTable &lt) {
+    if (dim != 2 && dim != 3) return SHACIRA_EINVAL;
+    if (num_lods < 1 || num_lods > SHACIRA_MAX_LODS) return SHACIRA_EINVAL;
+    if (feature_dim < 1) return SHACIRA_EINVAL;
+    if (feature_dim % 2 == 1) return SHACIRA_EODD;
+    if (bw < 1 || bw > 30) return SHACIRA_EINVAL;  // int32_t codebook_size = pow(2, bw), .cpp:56
+    if (!res_host || table_rows < 0) return SHACIRA_EINVAL;
+    std::memset(&lt, 0, sizeof(lt));
+    const int32_t cs = (int32_t)std::pow(2.0, (double)bw);
+    for (int l = 0; l < num_lods; ++l) {
+        const int32_t r = res_host[l];
+        if (r < 1) return SHACIRA_EINVAL;
+        lt.res[l] = r;
+        lt.hi[l] = (float)((double)r - 1.0 - 1e-5);  // `resolution-1-1e-5` narrowed at the clamp() call
+        lt.dense[l] = level_is_dense(dim, r, cs) ? 1 : 0;
+    }
+    lt.mask = (uint32_t)cs - 1u;
+    lt.num_lods = num_lods;
+    lt.feature_dim = feature_dim;
+    lt.table_rows = table_rows;
+    return 0;
+}
+
+}  // namespace shacira
+
+using namespace shacira;
+
+extern "C" {
+
+int shacira_abi_version(void) { return SHACIRA_ABI_VERSION; }
+
+const char *shacira_strerror(int code) {
+    switch (code) {
+        case 0: return "success";
+        case SHACIRA_EINVAL: return "shacira: invalid argument (dim/sizes/bitwidth/null pointer)";
+        case SHACIRA_EDTYPE: return "shacira: unsupported scalar type or operator shape";
+        case SHACIRA_EODD: return "The codebook feature dimension needs to be a multiple of 2.";
+        case SHACIRA_EWORKSPACE: return "shacira: workspace too small";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "shacira: unknown error";
+}
+
+int shacira_set_option(const char *name, int value) {
+    if (!name) return SHACIRA_EINVAL;
+    if (!std::strcmp(name, "fwd_variant")) { g_fwd_variant = value; return 0; }
+    if (!std::strcmp(name, "bwd_variant")) { g_bwd_variant = value; return 0; }
+    return SHACIRA_EINVAL;
+}
+
+int shacira_get_option(const char *name) {
+    if (!name) return SHACIRA_EINVAL;
+    if (!std::strcmp(name, "fwd_variant")) return g_fwd_variant;
+    if (!std::strcmp(name, "bwd_variant")) return g_bwd_variant;
+    return SHACIRA_EINVAL;
+}
+
+int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                             const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
+                             const float *coords, const void *codebook, int dtype, void *feats, void *stream) {
+    LevelTable lt;
+    int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
+    if (rc) return rc;
+    if (dtype != SHACIRA_F32 && dtype != SHACIRA_F16) return SHACIRA_EDTYPE;
+    if (num_coords < 0) return SHACIRA_EINVAL;
+    if (num_coords == 0) return 0;
+    if (!codebook_first_idx || !coords || !codebook || !feats) return SHACIRA_EINVAL;
+    return (int)hashgrid_forward_dispatch(dim, dtype, lt, codebook_first_idx, coords, codebook, feats, num_coords,
+                                          (hipStream_t)stream);
+}
+
+size_t shacira_hashgrid_backward_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                                 int codebook_bitwidth, const int32_t *resolutions_host,
+                                                 int64_t table_rows, int dtype) {
+    LevelTable lt;
+    if (build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt)) return 0;
+    return hashgrid_backward_workspace(dim, dtype, lt, num_coords);
+}
+
+int shacira_hashgrid_backward(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                              const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
+                              const float *coords, const void *grad_output, int dtype, void *grad_codebook,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+    LevelTable lt;
+    int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
+    if (rc) return rc;
+    if (dtype != SHACIRA_F32 && dtype != SHACIRA_F16) return SHACIRA_EDTYPE;
+    if (num_coords < 0 || !grad_codebook) return SHACIRA_EINVAL;
+    if (num_coords > 0 && (!codebook_first_idx || !coords || !grad_output)) return SHACIRA_EINVAL;
+    const size_t need = hashgrid_backward_workspace(dim, dtype, lt, num_coords);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
+    return (int)hashgrid_backward_dispatch(dim, dtype, lt, codebook_first_idx, coords, grad_output, grad_codebook,
+                                           workspace, workspace_bytes, num_coords, (hipStream_t)stream);
+}
+
+int shacira_latent_decode_forward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,
+                                  const float *div, const float *matrix, const float *colscale, const float *shift,
+                                  float clamp_weights, float *decoded, void *stream) {
+    if (num_rows < 0 || latent_dim < 1 || feature_dim < 1) return SHACIRA_EINVAL;
+    if (!latent_decode_supported(latent_dim, feature_dim)) return SHACIRA_EDTYPE;
+    if (num_rows == 0) return 0;
+    if (!latent || !div || !matrix || !decoded) return SHACIRA_EINVAL;
+    DecodeArgs a{};
+    a.latent = latent; a.div = div; a.matrix = matrix; a.colscale = colscale; a.shift = shift;
+    a.clampw = clamp_weights; a.decoded = decoded; a.rows = num_rows;
+    return (int)latent_decode_dispatch(false, latent_dim, feature_dim, a, (hipStream_t)stream);
+}
+
+size_t shacira_latent_decode_backward_workspace_bytes(int64_t, int, int) { return latent_workspace_bytes(); }
+
+int shacira_latent_decode_backward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,
+                                   const float *div, const float *matrix, const float *colscale, const float *shift,
+                                   float clamp_weights, const float *grad_decoded, float *grad_latent,
+                                   float *grad_matrix, float *grad_colscale, float *grad_shift, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    if (num_rows < 0 || latent_dim < 1 || feature_dim < 1) return SHACIRA_EINVAL;
+    if (!latent_decode_supported(latent_dim, feature_dim)) return SHACIRA_EDTYPE;
+    if (!workspace || workspace_bytes < latent_workspace_bytes()) return SHACIRA_EWORKSPACE;
+    if (num_rows > 0 && (!latent || !div || !matrix || !grad_decoded)) return SHACIRA_EINVAL;
+    DecodeArgs a{};
+    a.latent = latent; a.div = div; a.matrix = matrix; a.colscale = colscale; a.shift = shift;
+    a.clampw = clamp_weights; a.grad_decoded = grad_decoded; a.grad_latent = grad_latent;
+    a.grad_matrix = grad_matrix; a.grad_colscale = grad_colscale; a.grad_shift = grad_shift;
+    a.partials = static_cast<double *>(workspace); a.rows = num_rows;
+    return (int)latent_decode_dispatch(true, latent_dim, feature_dim, a, (hipStream_t)stream);
+}
+
+size_t shacira_entropy_bits_workspace_bytes(int64_t, int) { return latent_workspace_bytes(); }
+
+int shacira_entropy_bits_forward(int64_t num_rows, int latent_dim, int num_layers, const float *latent,
+                                 const float *noise, const float *params, float *total_bits, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    if (num_rows < 0 || latent_dim < 1 || num_layers < 1 || num_layers > 4) return SHACIRA_EINVAL;
+    if (!entropy_supported(latent_dim)) return SHACIRA_EDTYPE;
+    if (!workspace || workspace_bytes < latent_workspace_bytes()) return SHACIRA_EWORKSPACE;
+    if (!params || !total_bits || (num_rows > 0 && !latent)) return SHACIRA_EINVAL;
+    EntropyArgs a{};
+    a.latent = latent; a.noise = noise; a.params = params; a.num_layers = num_layers; a.total_bits = total_bits;
+    a.partials = static_cast<double *>(workspace); a.rows = num_rows;
+    return (int)entropy_dispatch(false, latent_dim, a, (hipStream_t)stream);
+}
+
+int shacira_entropy_bits_backward(int64_t num_rows, int latent_dim, int num_layers, const float *latent,
+                                  const float *noise, const float *params, const float *grad_total_bits,
+                                  float *grad_latent, float *grad_params, void *workspace, size_t workspace_bytes,
+                                  void *stream) {
+    if (num_rows < 0 || latent_dim < 1 || num_layers < 1 || num_layers > 4) return SHACIRA_EINVAL;
+    if (!entropy_supported(latent_dim)) return SHACIRA_EDTYPE;
+    if (!workspace || workspace_bytes < latent_workspace_bytes()) return SHACIRA_EWORKSPACE;
+    if (!params || !grad_total_bits || (num_rows > 0 && !latent)) return SHACIRA_EINVAL;
+    EntropyArgs a{};
+    a.latent = latent; a.noise = noise; a.params = params; a.num_layers = num_layers; a.grad_total = grad_total_bits;
+    a.grad_latent = grad_latent; a.grad_params = grad_params;
+    a.partials = static_cast<double *>(workspace); a.rows = num_rows;
+    return (int)entropy_dispatch(true, latent_dim, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// hashgrid_bwd.hip -- gradient scatter-add into the codebook, backward of the hash-grid lookup (gfx950).
+//
+// Replaces hashgrid_interpolate_backward_cuda / hashgrid_interpolate2d_backward_cuda
+// (wisp/csrc/ops/hashgrid_interpolate.cpp:68-100, :154-186; kernels hashgrid_interpolate_cuda.cu:143-221 and
+// hashgrid_interpolate2d_cuda.cu:133-208):  grad_codebook[first[l] + row_k, j] += grad_output[i, l*F + j] * w_k.
+//
+// Variant 0 ("atomic"): lane = (sample, level); per corner one global_atomic_add_f32 per feature. The
+//   accumulator is always fp32: for fp16 tables the sums are kept in an fp32 workspace and rounded once at the
+//   end (the reference rounds every __half2 atomicAdd, .cu:198-211; ours is the more accurate of the two).
+#include "internal.h"
+
+namespace shacira {
+
+template <int DIM, typename T, int F>
+__global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(LevelTable lt, const int32_t *__restrict__ first_idx,
+                                                                  const float *__restrict__ coords,
+                                                                  const T *__restrict__ grad_out,
+                                                                  float *__restrict__ grad_table, int64_t sample0,
+                                                                  uint32_t num_items) {
+    constexpr int NC = 1 << DIM;
+    const uint32_t L = (uint32_t)lt.num_lods;
+    __shared__ int32_t s_res[SHACIRA_MAX_LODS];
+    __shared__ float s_hi[SHACIRA_MAX_LODS];
+    __shared__ int32_t s_first[SHACIRA_MAX_LODS];
+    __shared__ uint8_t s_dense[SHACIRA_MAX_LODS];
+    if (threadIdx.x < L) {
+        s_res[threadIdx.x] = lt.res[threadIdx.x];
+        s_hi[threadIdx.x] = lt.hi[threadIdx.x];
+        s_dense[threadIdx.x] = lt.dense[threadIdx.x];
+        s_first[threadIdx.x] = first_idx[threadIdx.x];
+    }
+    __syncthreads();
+    const int Fr = (F > 0) ? F : lt.feature_dim;
+
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < num_items; w += stride) {
+        const uint32_t s = w / L;
+        const uint32_t lvl = w - s * L;
+        const int64_t i = sample0 + s;
+        double t[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
+        Corners<DIM> c;
+        compute_corners<DIM>(t, s_res[lvl], s_hi[lvl], s_dense[lvl] != 0, lt.mask, c);
+        const int64_t base = (int64_t)s_first[lvl];
+        const T *g = grad_out + (i * L + lvl) * Fr;
+        if constexpr (F == 2) {
+            float g0 = Scalar<T>::load(g), g1 = Scalar<T>::load(g + 1);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int64_t row = base + (int64_t)c.row[k];
+                if ((uint64_t)row < (uint64_t)lt.table_rows) {
+                    unsafeAtomicAdd(grad_table + row * 2, g0 * c.w[k]);
+                    unsafeAtomicAdd(grad_table + row * 2 + 1, g1 * c.w[k]);
+                }
+            }
+        } else {
+            for (int j = 0; j < Fr; ++j) {
+                const float gj = Scalar<T>::load(g + j);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const int64_t row = base + (int64_t)c.row[k];
+                    if ((uint64_t)row < (uint64_t)lt.table_rows)
+                        unsafeAtomicAdd(grad_table + row * Fr + j, gj * c.w[k]);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float *__restrict__ src, __half *__restrict__ dst,
+                                                         int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = __float2half_rn(src[i]);
+}
+
+template <int DIM, typename T, int F>
+static hipError_t launch_bwd_atomic(const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                                    const void *grad_out, float *acc, int64_t num_coords, hipStream_t stream) {
+    const int64_t L = lt.num_lods;
+    const int64_t max_samples = ((int64_t)1 << 31) / L - 1;
+    for (int64_t s0 = 0; s0 < num_coords; s0 += max_samples) {
+        const int64_t ns = (num_coords - s0 < max_samples) ? (num_coords - s0) : max_samples;
+        const uint32_t items = (uint32_t)(ns * L);
+        const uint32_t blocks = (items + 255u) / 256u;
+        hipLaunchKernelGGL((hashgrid_bwd_atomic_kernel<DIM, T, F>), dim3(blocks), dim3(256), 0, stream, lt, first_idx,
+                           coords, static_cast<const T *>(grad_out), acc, s0, items);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+template <int DIM, typename T>
+static hipError_t bwd_atomic_f(const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                               const void *grad_out, float *acc, int64_t n, hipStream_t s) {
+    if (lt.feature_dim == 2) return launch_bwd_atomic<DIM, T, 2>(lt, first_idx, coords, grad_out, acc, n, s);
+    return launch_bwd_atomic<DIM, T, 0>(lt, first_idx, coords, grad_out, acc, n, s);
+}
+
+size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
+    (void)dim; (void)n;
+    if (dtype == SHACIRA_F16) return (size_t)lt.table_rows * lt.feature_dim * sizeof(float);
+    return 0;
+}
+
+hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
+                                      const float *coords, const void *grad_out, void *grad_table, void *workspace,
+                                      size_t workspace_bytes, int64_t n, hipStream_t s) {
+    (void)workspace_bytes;
+    const int64_t numel = lt.table_rows * lt.feature_dim;
+    float *acc = (dtype == SHACIRA_F32) ? static_cast<float *>(grad_table) : static_cast<float *>(workspace);
+    hipError_t e = hipMemsetAsync(acc, 0, (size_t)numel * sizeof(float), s);  // at::zeros_like, .cpp:81/:167
+    if (e != hipSuccess) return e;
+    if (n > 0) {
+        if (dim == 3) {
+            e = (dtype == SHACIRA_F32) ? bwd_atomic_f<3, float>(lt, first_idx, coords, grad_out, acc, n, s)
+                                       : bwd_atomic_f<3, __half>(lt, first_idx, coords, grad_out, acc, n, s);
+        } else {
+            e = (dtype == SHACIRA_F32) ? bwd_atomic_f<2, float>(lt, first_idx, coords, grad_out, acc, n, s)
+                                       : bwd_atomic_f<2, __half>(lt, first_idx, coords, grad_out, acc, n, s);
+        }
+        if (e != hipSuccess) return e;
+    }
+    if (dtype == SHACIRA_F16) {
+        int64_t blocks = (numel + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        if (blocks > 0)
+            hipLaunchKernelGGL(f32_to_f16_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, acc,
+                               static_cast<__half *>(grad_table), numel);
+        return hipGetLastError();
+    }
+    return hipSuccess;
+}
+
+}  // namespace shacira

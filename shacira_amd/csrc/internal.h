@@ -1,0 +1,46 @@
+// internal.h -- declarations shared between the translation units of libshacira_hip.so (not part of the ABI).
+#pragma once
+
+#include <atomic>
+
+#include "hashgrid_device.h"
+
+namespace shacira {
+
+// hashgrid_fwd.hip
+hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
+                                     const float *coords, const void *table, void *feats, int64_t n, hipStream_t s);
+// hashgrid_bwd.hip
+size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
+hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
+                                      const float *coords, const void *grad_out, void *grad_table, void *workspace,
+                                      size_t workspace_bytes, int64_t n, hipStream_t s);
+
+// latent.hip
+struct DecodeArgs {
+    const float *latent, *div, *matrix, *colscale, *shift;
+    float clampw;
+    float *decoded;
+    const float *grad_decoded;
+    float *grad_latent, *grad_matrix, *grad_colscale, *grad_shift;
+    double *partials;
+    int64_t rows;
+};
+struct EntropyArgs {
+    const float *latent, *noise, *params, *grad_total;
+    int num_layers;
+    float *total_bits, *grad_latent, *grad_params;
+    double *partials;
+    int64_t rows;
+};
+size_t latent_workspace_bytes();
+bool latent_decode_supported(int ld, int f);
+hipError_t latent_decode_dispatch(bool bwd, int ld, int f, const DecodeArgs &a, hipStream_t s);
+bool entropy_supported(int ld);
+hipError_t entropy_dispatch(bool bwd, int ld, const EntropyArgs &a, hipStream_t s);
+
+// api.hip: tunables
+extern std::atomic<int> g_fwd_variant;
+extern std::atomic<int> g_bwd_variant;
+
+}  // namespace shacira

@@ -1,0 +1,376 @@
+// latent.hip -- per-entry latent round/dequantise-decode and entropy-bottleneck (CDF) evaluation (gfx950).
+//
+// The reference evaluates these as chains of ~10-25 ATen elementwise kernels over the whole table on every
+// step: LatentDecoder.forward (wisp/models/latent_decoders/basic_latent_decoder.py:182-198,
+// DecoderLayer.forward :86-91, StraightThrough :28-36), LatentGrid.ent_loss (wisp/models/grids/latent_grid.py:122-136)
+// and BitEstimator/Bitparm.forward (wisp/models/prob_models/bit_estimator.py:27-65). Here each is ONE pass over
+// the table: HBM-bound streaming kernels, one thread per table row, fp32 math; reductions over the table are
+// kept as fp64 block partials (workspace) and finished by one small kernel, so they are bitwise reproducible.
+//
+// The tiny per-channel parameter vectors are read through uniform (scalar) loads from their device pointers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "internal.h"
+
+namespace shacira {
+
+constexpr int kMaxPartialBlocks = 1024;
+constexpr int kThreads = 256;
+constexpr int kMaxRed = 96;  // largest reduction width of any kernel below
+
+size_t latent_workspace_bytes() { return (size_t)kMaxPartialBlocks * kMaxRed * sizeof(double); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// NRED per-thread fp32 partials -> fp64 block partials: partials[block][NRED]
+template <int NRED>
+__device__ __forceinline__ void block_reduce_store(const float (&acc)[NRED], double *__restrict__ partials) {
+    __shared__ double s_part[kThreads / 64][NRED];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NRED; ++q) {
+        double v = wave_sum((double)acc[q]);
+        if (lane == 0) s_part[wave][q] = v;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < NRED; q += kThreads) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) v += s_part[w][q];
+        partials[(size_t)blockIdx.x * NRED + q] = v;
+    }
+}
+
+// out[q] = scale * sum_b partials[b][q]; the nred results are split over up to three fp32 outputs (NULL = skip)
+__global__ void finish_partials_kernel(const double *__restrict__ partials, int nblocks, int nred,
+                                       const float *__restrict__ scale, float *__restrict__ out0, int n0,
+                                       float *__restrict__ out1, int n1, float *__restrict__ out2, int n2) {
+    const double sc = scale ? (double)scale[0] : 1.0;
+    for (int q = threadIdx.x; q < nred; q += blockDim.x) {
+        double v = 0.0;
+        for (int b = 0; b < nblocks; ++b) v += partials[(size_t)b * nred + q];
+        v *= sc;
+        if (q < n0) {
+            if (out0) out0[q] = (float)v;
+        } else if (q < n0 + n1) {
+            if (out1) out1[q - n0] = (float)v;
+        } else if (q < n0 + n1 + n2) {
+            if (out2) out2[q - n0 - n1] = (float)v;
+        }
+    }
+}
+
+static inline int grid_for(int64_t rows) {
+    int64_t b = (rows + kThreads - 1) / kThreads;
+    if (b > kMaxPartialBlocks) b = kMaxPartialBlocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// =========================================================================================================
+// latent decode
+// =========================================================================================================
+template <int LD, int F> struct DecodeConsts {
+    float div[LD], mat[LD * F], cs[F], shift[F], clampw;
+    __device__ __forceinline__ void load(const float *__restrict__ d, const float *__restrict__ m,
+                                         const float *__restrict__ c, const float *__restrict__ s, float cw) {
+        clampw = cw;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) div[i] = d[i];
+#pragma unroll
+        for (int i = 0; i < LD * F; ++i) mat[i] = m[i];
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            cs[j] = c ? c[j] : 1.0f;
+            shift[j] = s ? s[j] : 0.0f;
+        }
+    }
+};
+
+template <int LD, int F>
+__device__ __forceinline__ void decode_row(const DecodeConsts<LD, F> &p, const float *__restrict__ latent, int64_t r,
+                                           float (&z)[LD], float (&zm)[F], float (&y)[F]) {
+#pragma unroll
+    for (int c = 0; c < LD; ++c) z[c] = rintf(latent[r * LD + c]) / p.div[c];  // torch.round: half to even
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+        float s = z[0] * p.mat[j];
+#pragma unroll
+        for (int c = 1; c < LD; ++c) s = fmaf(z[c], p.mat[c * F + j], s);
+        zm[j] = s;
+        y[j] = s * p.cs[j] + p.shift[j];
+    }
+}
+
+template <int LD, int F>
+__global__ __launch_bounds__(kThreads) void latent_decode_fwd_kernel(
+    const float *__restrict__ latent, const float *__restrict__ div, const float *__restrict__ matrix,
+    const float *__restrict__ colscale, const float *__restrict__ shift, float clampw, float *__restrict__ decoded,
+    int64_t rows) {
+    DecodeConsts<LD, F> p;
+    p.load(div, matrix, colscale, shift, clampw);
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < rows; r += stride) {
+        float z[LD], zm[F], y[F];
+        decode_row<LD, F>(p, latent, r, z, zm, y);
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            float v = y[j];
+            if (clampw > 0.0f) v = fminf(fmaxf(v, -clampw), clampw);
+            decoded[r * F + j] = v;
+        }
+    }
+}
+
+// reductions: [LD*F] grad_matrix, [F] grad_colscale, [F] grad_shift
+template <int LD, int F>
+__global__ __launch_bounds__(kThreads) void latent_decode_bwd_kernel(
+    const float *__restrict__ latent, const float *__restrict__ div, const float *__restrict__ matrix,
+    const float *__restrict__ colscale, const float *__restrict__ shift, float clampw,
+    const float *__restrict__ grad_decoded, float *__restrict__ grad_latent, double *__restrict__ partials,
+    int64_t rows) {
+    constexpr int NRED = LD * F + 2 * F;
+    DecodeConsts<LD, F> p;
+    p.load(div, matrix, colscale, shift, clampw);
+    float acc[NRED];
+#pragma unroll
+    for (int q = 0; q < NRED; ++q) acc[q] = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < rows; r += stride) {
+        float z[LD], zm[F], y[F], gy[F];
+        decode_row<LD, F>(p, latent, r, z, zm, y);
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            float g = grad_decoded[r * F + j];
+            // torch.clamp passes the gradient where -c <= y <= c
+            if (clampw > 0.0f && !(y[j] >= -clampw && y[j] <= clampw)) g = 0.0f;
+            gy[j] = g;
+            acc[LD * F + j] += g * zm[j];  // grad_colscale
+            acc[LD * F + F + j] += g;      // grad_shift
+        }
+#pragma unroll
+        for (int c = 0; c < LD; ++c) {
+            float gl = 0.0f;
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                const float gs = gy[j] * p.cs[j];
+                acc[c * F + j] += z[c] * gs;  // grad_matrix
+                gl = fmaf(gs, p.mat[c * F + j], gl);
+            }
+            if (grad_latent) grad_latent[r * LD + c] = gl / p.div[c];  // straight-through rounding
+        }
+    }
+    block_reduce_store<NRED>(acc, partials);
+}
+
+template <int LD, int F> static hipError_t decode_launch(bool bwd, const DecodeArgs &a, hipStream_t s) {
+    const int blocks = grid_for(a.rows);
+    if (!bwd) {
+        hipLaunchKernelGGL((latent_decode_fwd_kernel<LD, F>), dim3(blocks), dim3(kThreads), 0, s, a.latent, a.div,
+                           a.matrix, a.colscale, a.shift, a.clampw, a.decoded, a.rows);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL((latent_decode_bwd_kernel<LD, F>), dim3(blocks), dim3(kThreads), 0, s, a.latent, a.div,
+                       a.matrix, a.colscale, a.shift, a.clampw, a.grad_decoded, a.grad_latent, a.partials, a.rows);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(128), 0, s, a.partials, blocks, LD * F + 2 * F,
+                       (const float *)nullptr, a.grad_matrix, LD * F, a.grad_colscale, F, a.grad_shift, F);
+    return hipGetLastError();
+}
+
+typedef hipError_t (*decode_fn)(bool, const DecodeArgs &, hipStream_t);
+
+static decode_fn decode_lookup(int ld, int f) {
+#define SHACIRA_DEC(LD, F) \
+    if (ld == LD && f == F) return &decode_launch<LD, F>;
+    SHACIRA_DEC(1, 1) SHACIRA_DEC(1, 2) SHACIRA_DEC(1, 4) SHACIRA_DEC(1, 8)
+    SHACIRA_DEC(2, 1) SHACIRA_DEC(2, 2) SHACIRA_DEC(2, 4) SHACIRA_DEC(2, 8)
+    SHACIRA_DEC(3, 1) SHACIRA_DEC(3, 2) SHACIRA_DEC(3, 4) SHACIRA_DEC(3, 8)
+    SHACIRA_DEC(4, 1) SHACIRA_DEC(4, 2) SHACIRA_DEC(4, 4) SHACIRA_DEC(4, 8)
+    SHACIRA_DEC(8, 2) SHACIRA_DEC(8, 4) SHACIRA_DEC(8, 8)
+#undef SHACIRA_DEC
+    return nullptr;
+}
+
+bool latent_decode_supported(int ld, int f) { return decode_lookup(ld, f) != nullptr; }
+
+hipError_t latent_decode_dispatch(bool bwd, int ld, int f, const DecodeArgs &a, hipStream_t s) {
+    return decode_lookup(ld, f)(bwd, a, s);
+}
+
+// =========================================================================================================
+// entropy bits
+// =========================================================================================================
+// params layout fp32 [4][3][LD]: layer k in {f1,f2,f3,f4}, slot {h,b,a}
+template <int LD> struct CdfConsts {
+    float sp[4][LD];   // softplus(h)
+    float sgh[4][LD];  // d softplus / dh = sigmoid(h) (1 above torch's threshold 20)
+    float b[4][LD];
+    float ta[3][LD];   // tanh(a)
+    __device__ __forceinline__ void load(const float *__restrict__ prm) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int c = 0; c < LD; ++c) {
+                const float h = prm[(k * 3 + 0) * LD + c];
+                // F.softplus(beta=1, threshold=20)
+                sp[k][c] = (h > 20.0f) ? h : log1pf(expf(h));
+                sgh[k][c] = (h > 20.0f) ? 1.0f : 1.0f / (1.0f + expf(-h));
+                b[k][c] = prm[(k * 3 + 1) * LD + c];
+                if (k < 3) ta[k][c] = tanhf(prm[(k * 3 + 2) * LD + c]);
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// CDF with the chain's intermediates kept for the backward (NL = num_layers; layers used: first NL-1 of f1..f3, then f4)
+template <int LD> struct CdfTrace {
+    float xin[4];  // input of each applied layer (index = layer slot 0..2, 3 = final)
+    float th[3];   // tanh(u) of each applied non-final layer
+    float s;       // sigmoid output
+};
+
+template <int LD>
+__device__ __forceinline__ float cdf_eval(const CdfConsts<LD> &p, int nl, int c, float x, CdfTrace<LD> &tr) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < nl - 1) {
+            tr.xin[k] = x;
+            const float u = x * p.sp[k][c] + p.b[k][c];
+            const float th = tanhf(u);
+            tr.th[k] = th;
+            x = u + th * p.ta[k][c];
+        }
+    }
+    tr.xin[3] = x;
+    tr.s = sigmoidf_ref(x * p.sp[3][c] + p.b[3][c]);
+    return tr.s;
+}
+
+// back-propagates g = dL/d(cdf output); accumulates parameter grads into acc[(k*3+slot)*LD + c]; returns dL/dx
+template <int LD>
+__device__ __forceinline__ float cdf_backward(const CdfConsts<LD> &p, const float *__restrict__ prm, int nl, int c,
+                                              const CdfTrace<LD> &tr, float g, float (&acc)[12 * LD]) {
+    float du = g * tr.s * (1.0f - tr.s);
+    acc[(3 * 3 + 0) * LD + c] += du * tr.xin[3] * p.sgh[3][c];
+    acc[(3 * 3 + 1) * LD + c] += du;
+    float dx = du * p.sp[3][c];
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {
+        if (k < nl - 1) {
+            const float th = tr.th[k];
+            const float ta = p.ta[k][c];
+            acc[(k * 3 + 2) * LD + c] += dx * th * (1.0f - ta * ta);
+            du = dx * (1.0f + (1.0f - th * th) * ta);
+            acc[(k * 3 + 0) * LD + c] += du * tr.xin[k] * p.sgh[k][c];
+            acc[(k * 3 + 1) * LD + c] += du;
+            dx = du * p.sp[k][c];
+        }
+    }
+    (void)prm;
+    return dx;
+}
+
+constexpr float kLn2 = 0.6931471805599453f;
+
+template <int LD>
+__global__ __launch_bounds__(kThreads) void entropy_fwd_kernel(const float *__restrict__ latent,
+                                                               const float *__restrict__ noise,
+                                                               const float *__restrict__ prm, int nl,
+                                                               double *__restrict__ partials, int64_t rows) {
+    CdfConsts<LD> p;
+    p.load(prm);
+    float acc[1] = {0.0f};
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < rows; r += stride) {
+#pragma unroll
+        for (int c = 0; c < LD; ++c) {
+            const float v = latent[r * LD + c];
+            const float w = noise ? (v + noise[r * LD + c]) : rintf(v);
+            CdfTrace<LD> tp, tn;
+            const float prob = cdf_eval<LD>(p, nl, c, w + 0.5f, tp) - cdf_eval<LD>(p, nl, c, w - 0.5f, tn);
+            float bits = -1.0f * logf(prob + 1e-10f) / kLn2;
+            bits = fminf(fmaxf(bits, 0.0f), 50.0f);
+            acc[0] += bits;
+        }
+    }
+    block_reduce_store<1>(acc, partials);
+}
+
+template <int LD>
+__global__ __launch_bounds__(kThreads) void entropy_bwd_kernel(const float *__restrict__ latent,
+                                                               const float *__restrict__ noise,
+                                                               const float *__restrict__ prm, int nl,
+                                                               const float *__restrict__ grad_total,
+                                                               float *__restrict__ grad_latent,
+                                                               double *__restrict__ partials, int64_t rows) {
+    CdfConsts<LD> p;
+    p.load(prm);
+    float acc[12 * LD];
+#pragma unroll
+    for (int q = 0; q < 12 * LD; ++q) acc[q] = 0.0f;
+    const float gt = grad_total[0];
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < rows; r += stride) {
+#pragma unroll
+        for (int c = 0; c < LD; ++c) {
+            const float v = latent[r * LD + c];
+            const float w = noise ? (v + noise[r * LD + c]) : rintf(v);
+            CdfTrace<LD> tp, tn;
+            const float prob = cdf_eval<LD>(p, nl, c, w + 0.5f, tp) - cdf_eval<LD>(p, nl, c, w - 0.5f, tn);
+            const float q = prob + 1e-10f;
+            const float bits = -1.0f * logf(q) / kLn2;
+            // clamp(., 0, 50) passes the gradient on the closed interval; parameter grads are scaled by gt at the end
+            const float gp = (bits >= 0.0f && bits <= 50.0f) ? (-1.0f / (q * kLn2)) : 0.0f;
+            const float dxp = cdf_backward<LD>(p, prm, nl, c, tp, gp, acc);
+            const float dxn = cdf_backward<LD>(p, prm, nl, c, tn, -gp, acc);
+            if (grad_latent) grad_latent[r * LD + c] = noise ? gt * (dxp + dxn) : 0.0f;  // round(): zero gradient
+        }
+    }
+    block_reduce_store<12 * LD>(acc, partials);
+}
+
+template <int LD> static hipError_t entropy_launch(bool bwd, const EntropyArgs &a, hipStream_t s) {
+    const int blocks = grid_for(a.rows);
+    if (!bwd) {
+        hipLaunchKernelGGL((entropy_fwd_kernel<LD>), dim3(blocks), dim3(kThreads), 0, s, a.latent, a.noise, a.params,
+                           a.num_layers, a.partials, a.rows);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(64), 0, s, a.partials, blocks, 1,
+                           (const float *)nullptr, a.total_bits, 1, (float *)nullptr, 0, (float *)nullptr, 0);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL((entropy_bwd_kernel<LD>), dim3(blocks), dim3(kThreads), 0, s, a.latent, a.noise, a.params,
+                       a.num_layers, a.grad_total, a.grad_latent, a.partials, a.rows);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.grad_params) {
+        hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(128), 0, s, a.partials, blocks, 12 * LD, a.grad_total,
+                           a.grad_params, 12 * LD, (float *)nullptr, 0, (float *)nullptr, 0);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+bool entropy_supported(int ld) { return ld == 1 || ld == 2 || ld == 3 || ld == 4 || ld == 8; }
+
+hipError_t entropy_dispatch(bool bwd, int ld, const EntropyArgs &a, hipStream_t s) {
+    switch (ld) {
+        case 1: return entropy_launch<1>(bwd, a, s);
+        case 2: return entropy_launch<2>(bwd, a, s);
+        case 3: return entropy_launch<3>(bwd, a, s);
+        case 4: return entropy_launch<4>(bwd, a, s);
+        default: return entropy_launch<8>(bwd, a, s);
+    }
+}
+
+}  // namespace shacira

@@ -1,0 +1,183 @@
+"""Tensor-level wrappers over the C-ABI: PyTorch supplies device memory and the stream, nothing else.
+
+These functions have the signatures of the reference's pybind11 operators
+(``wisp._C.ops.hashgrid_interpolate[2d]_cuda`` / ``..._backward_cuda``, wisp/csrc/bindings.cpp:24-28 and
+wisp/csrc/ops/hashgrid_interpolate.h:18-50) so ``wisp/ops/grid.py``-style callers read the same.
+Inputs must live on a HIP device; there is no CPU path (RuntimeError otherwise).
+"""
+import ctypes
+import functools
+
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.F32, torch.float16: _lib.F16}
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@functools.lru_cache(maxsize=64)
+def _res_array(resolutions):
+    return (ctypes.c_int32 * len(resolutions))(*resolutions)
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("shacira_amd: operands must be on the MI355X (HIP) device; there is no CPU fallback")
+
+
+def _dtype_code(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"shacira_amd: unsupported table dtype {t.dtype} (fp32 and fp16 are implemented)")
+
+
+def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth):
+    _need_gpu(coords, codebook, codebook_first_idx)
+    if coords.dtype != torch.float32:
+        raise RuntimeError("expected scalar type Float for coords")  # data_ptr<float>() in the reference
+    res = tuple(int(r) for r in resolution)
+    N, T, F = coords.shape[0], codebook.shape[0], codebook.shape[1]
+    feats = torch.empty((N, F * len(res)), dtype=codebook.dtype, device=codebook.device)
+    with torch.cuda.device(codebook.device):
+        rc = _lib.lib().shacira_hashgrid_forward(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
+                                                 _ptr(codebook_first_idx), T, _ptr(coords), _ptr(codebook),
+                                                 _dtype_code(codebook), _ptr(feats), _stream(codebook))
+    _lib.check(rc, "hashgrid_interpolate")
+    return feats
+
+
+def _hashgrid_backward(dim, coords, grad_output, codebook, codebook_first_idx, resolution, codebook_bitwidth,
+                       feature_dim, require_grad_coords):
+    _need_gpu(coords, grad_output, codebook, codebook_first_idx)
+    res = tuple(int(r) for r in resolution)
+    N, T, F = coords.shape[0], codebook.shape[0], int(feature_dim)
+    dt = _dtype_code(codebook)
+    if grad_output.dtype != codebook.dtype:
+        grad_output = grad_output.to(codebook.dtype)
+    grad_codebook = torch.empty_like(codebook)
+    L = _lib.lib()
+    with torch.cuda.device(codebook.device):
+        nbytes = L.shacira_hashgrid_backward_workspace_bytes(dim, N, len(res), F, int(codebook_bitwidth),
+                                                             _res_array(res), T, dt)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=codebook.device) if nbytes else None
+        rc = L.shacira_hashgrid_backward(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
+                                         _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
+                                         _ptr(grad_codebook), _ptr(ws), nbytes, _stream(codebook))
+    _lib.check(rc, "hashgrid_interpolate_backward")
+    return grad_codebook
+
+
+def hashgrid_interpolate_cuda(coords, codebook, codebook_first_idx, resolution, codebook_bitwidth):
+    """hashgrid_interpolate.h:18-23 -> feats [N, L*F] (3-D coords)."""
+    return _hashgrid_forward(3, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth)
+
+
+def hashgrid_interpolate2d_cuda(coords, codebook, codebook_first_idx, resolution, codebook_bitwidth):
+    """hashgrid_interpolate.h:35-40 -> feats [N, L*F] (2-D coords)."""
+    return _hashgrid_forward(2, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth)
+
+
+def hashgrid_interpolate_backward_cuda(coords, grad_output, codebook, codebook_first_idx, resolution,
+                                       codebook_bitwidth, feature_dim, require_grad_coords):
+    """hashgrid_interpolate.h:25-33 -> grad_codebook [T, F]."""
+    return _hashgrid_backward(3, coords, grad_output, codebook, codebook_first_idx, resolution, codebook_bitwidth,
+                              feature_dim, require_grad_coords)
+
+
+def hashgrid_interpolate2d_backward_cuda(coords, grad_output, codebook, codebook_first_idx, resolution,
+                                         codebook_bitwidth, feature_dim, require_grad_coords):
+    """hashgrid_interpolate.h:42-50 -> grad_codebook [T, F]."""
+    return _hashgrid_backward(2, coords, grad_output, codebook, codebook_first_idx, resolution, codebook_bitwidth,
+                              feature_dim, require_grad_coords)
+
+
+# ------------------------------------------------------------------------------------------------ latent path
+def latent_decode_supported(latent_dim, feature_dim):
+    return latent_dim in (1, 2, 3, 4, 8) and feature_dim in (1, 2, 4, 8) and not (latent_dim == 8 and feature_dim == 1)
+
+
+_ws_cache = {}
+
+
+def _latent_workspace(device):
+    """One reusable scratch buffer per (device, stream): fp64 block partials of the table reductions."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        n = _lib.lib().shacira_entropy_bits_workspace_bytes(0, 1)
+        ws = torch.empty((n,), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def latent_decode_forward(latent, div, matrix, colscale, shift, clamp_weights):
+    _need_gpu(latent, div, matrix, colscale, shift)
+    T, ld = latent.shape
+    F = matrix.shape[1]
+    out = torch.empty((T, F), dtype=torch.float32, device=latent.device)
+    with torch.cuda.device(latent.device):
+        rc = _lib.lib().shacira_latent_decode_forward(T, ld, F, _ptr(latent), _ptr(div), _ptr(matrix), _ptr(colscale),
+                                                      _ptr(shift), float(clamp_weights), _ptr(out), _stream(latent))
+    _lib.check(rc, "latent_decode_forward")
+    return out
+
+
+def latent_decode_backward(latent, div, matrix, colscale, shift, clamp_weights, grad_decoded, need_colscale):
+    _need_gpu(latent, grad_decoded)
+    T, ld = latent.shape
+    F = matrix.shape[1]
+    dev = latent.device
+    g_lat = torch.empty_like(latent)
+    g_mat = torch.empty((ld, F), dtype=torch.float32, device=dev)
+    g_cs = torch.empty((F,), dtype=torch.float32, device=dev) if need_colscale else None
+    g_sh = torch.empty((F,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _latent_workspace(dev)
+        rc = _lib.lib().shacira_latent_decode_backward(T, ld, F, _ptr(latent), _ptr(div), _ptr(matrix), _ptr(colscale),
+                                                       _ptr(shift), float(clamp_weights), _ptr(grad_decoded),
+                                                       _ptr(g_lat), _ptr(g_mat), _ptr(g_cs), _ptr(g_sh), _ptr(ws),
+                                                       ws.numel(), _stream(latent))
+    _lib.check(rc, "latent_decode_backward")
+    return g_lat, g_mat, g_cs, g_sh
+
+
+def entropy_supported(latent_dim):
+    return latent_dim in (1, 2, 3, 4, 8)
+
+
+def entropy_bits_forward(latent, noise, params, num_layers):
+    _need_gpu(latent, noise, params)
+    T, ld = latent.shape
+    dev = latent.device
+    total = torch.empty((), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _latent_workspace(dev)
+        rc = _lib.lib().shacira_entropy_bits_forward(T, ld, int(num_layers), _ptr(latent), _ptr(noise), _ptr(params),
+                                                     _ptr(total), _ptr(ws), ws.numel(), _stream(latent))
+    _lib.check(rc, "entropy_bits_forward")
+    return total
+
+
+def entropy_bits_backward(latent, noise, params, num_layers, grad_total, need_latent=True):
+    _need_gpu(latent, noise, params, grad_total)
+    T, ld = latent.shape
+    dev = latent.device
+    g_lat = torch.empty_like(latent) if need_latent else None
+    g_par = torch.empty((4, 3, ld), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _latent_workspace(dev)
+        rc = _lib.lib().shacira_entropy_bits_backward(T, ld, int(num_layers), _ptr(latent), _ptr(noise), _ptr(params),
+                                                      _ptr(grad_total), _ptr(g_lat), _ptr(g_par), _ptr(ws), ws.numel(),
+                                                      _stream(latent))
+    _lib.check(rc, "entropy_bits_backward")
+    return g_lat, g_par
