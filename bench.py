@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: hash-grid fwd+bwd samples/s (16 levels, F=2) on synthetic point batches.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" = one pass of the hot path over one batch: the forward operator (all 16 levels), the backward operator
+(gradient scatter-add into the 48.8 MB codebook) and, for N > 1, ONE RCCL all-reduce of that gradient over xGMI.
+Workload = BASELINE.json's headline point "H"/config D shape: 3-D `nerf_hash` grid (L=16, F=2, bw=19, res 17..2049,
+T = 6 098 925 rows, fp32), 2^20 uniformly random samples per GPU (weak scaling), inputs resident in HBM.
+Rank 0 prints ONE JSON line (see the driver contract); `roofline` prices the dominant operator against the
+8 TB/s HBM roof with ALGORITHMIC bytes, `cpu_baseline` times the pure-PyTorch restatement of the
+reference kernels (oracle/hashgrid_torch.py) on this box's host cores in the same run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6.3 TB/s
+
+
+def geo(mn, mx, L):
+    b = np.exp((np.log(mx) - np.log(mn)) / (L - 1))
+    return [int(1 + np.floor(mn * (b ** l))) for l in range(L)]
+
+
+WORKLOADS = {
+    # name: (dim, resolutions, bitwidth, feature_dim, samples per GPU)
+    "S1_nerf_hash_3d_L16_F2_bw19_N2^20": (3, geo(16, 2048, 16), 19, 2, 1 << 20),
+    "S2_kodak_2d_L16_F2_bw19_N2^20": (2, geo(16, 2048, 16), 19, 2, 1 << 20),
+    "B_kodak_2d_L16_F2_bw11_N393216": (2, geo(16, 512, 16), 11, 2, 393216),
+    "D_nerf_lego_3d_L16_F2_bw19_N65536": (3, geo(16, 2048, 16), 19, 2, 65536),
+}
+
+
+def algorithmic_bytes_per_sample(dim, L, F, s=4):
+    """fwd = 4d + L*2^d*F*s + L*F*s ; bwd = 4d + L*F*s + L*2^d*F*s."""
+    one = 4 * dim + L * (2 ** dim) * F * s + L * F * s
+    return one, one
+
+
+def cpu_baseline(dim, res, bw, F, first, T, n_samples, iters, seed=0):
+    """Pure-PyTorch restatement of the reference kernels, all host cores, same synthetic distribution."""
+    from oracle import hashgrid_torch as ot
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(seed)
+    coords = torch.rand(n_samples, dim, generator=g) * 2 - 1
+    table = torch.randn(T, F, generator=g) * 0.01
+    go = torch.randn(n_samples, len(res) * F, generator=g)
+    ot.hashgrid_fwd_bwd(coords, table, first, res, bw, go)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ot.hashgrid_fwd_bwd(coords, table, first, res, bw, go)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": n_samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} timed fwd+bwd passes (+1 warm-up) over {n_samples} samples of the same workload, "
+                      f"oracle/hashgrid_torch.py, torch.set_num_threads({cores})", "s_per_pass": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="S1_nerf_hash_3d_L16_F2_bw19_N2^20", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=1 << 20)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    args = ap.parse_args()
+
+    from shacira_amd import dist as sdist
+    from shacira_amd import hip_ops
+    rank, world, device = sdist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        args.gpus = world
+    if device.type != "cuda":
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+
+    dim, res, bw, F, n_local = WORKLOADS[args.workload]
+    L = len(res)
+    sizes = [min(2 ** bw, r ** dim) for r in res]
+    first_np = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)
+    T = int(sum(sizes))
+
+    # synthetic inputs, resident in HBM before the timed region: parameters replicated (same seed), samples per rank
+    gp = torch.Generator().manual_seed(0)
+    table = (torch.randn(T, F, generator=gp) * 0.01).to(device)            # reference init: randn * feature_std
+    gs = torch.Generator().manual_seed(1000 + rank)
+    coords = (torch.rand(n_local, dim, generator=gs) * 2 - 1).to(device)   # U(-1,1)^d, full-entropy mantissas
+    grad_out = torch.randn(n_local, L * F, generator=gs).to(device)
+    first = torch.from_numpy(first_np).to(device)
+    fwd = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        feats = fwd(coords, table, first, res, bw)
+        if ev:
+            ev[1].record()
+        grad = hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F)
+        if ev:
+            ev[2].record()
+        if world > 1:
+            dist.all_reduce(grad)                                          # one RCCL all-reduce (sum) per step
+        if ev:
+            ev[3].record()
+        return feats, grad
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+        ms_bwd = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+        ms_ar = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
+        b_fwd, b_bwd = algorithmic_bytes_per_sample(dim, L, F)
+        ms_step = elapsed / args.steps * 1e3
+        value = world * n_local * args.steps / elapsed
+        dom = ("backward", ms_bwd, b_bwd) if ms_bwd >= ms_fwd else ("forward", ms_fwd, b_fwd)
+        achieved = dom[2] * n_local / (dom[1] * 1e-3) / 1e9
+        path_gbs = (b_fwd + b_bwd) * n_local / ((ms_fwd + ms_bwd) * 1e-3) / 1e9
+        out = {
+            "metric": "hash-grid samples/sec fwd+bwd (16 lvl, F=2)",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "dim": dim, "levels": L, "feature_dim": F, "bitwidth": bw,
+                       "table_rows": T, "samples_per_gpu": n_local,
+                       "parallelism": f"dp{world}" + ("+allreduce(grad_codebook)" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": f"hashgrid_{dom[0]} (C-ABI call, HIP events on its stream)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": dom[2] * n_local,
+                         "ms_per_launch": dom[1],
+                         "fwd_bwd_path": {"achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS,
+                                          "bytes_per_sample": b_fwd + b_bwd}},
+            "ms": {"forward": ms_fwd, "backward": ms_bwd, "allreduce": ms_ar},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dim, res, bw, F, first_np, T, min(args.cpu_samples, n_local),
+                                               args.cpu_iters)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,23 +56,27 @@ def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, cod
     return feats
 
 
-def _hashgrid_backward(dim, coords, grad_output, codebook, codebook_first_idx, resolution, codebook_bitwidth,
-                       feature_dim, require_grad_coords):
-    _need_gpu(coords, grad_output, codebook, codebook_first_idx)
+def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codebook_first_idx, resolution,
+                      codebook_bitwidth, feature_dim):
+    """grad_codebook [table_rows, feature_dim] of ``table_dtype`` (the codebook's values are not needed)."""
+    _need_gpu(coords, grad_output, codebook_first_idx)
     res = tuple(int(r) for r in resolution)
-    N, T, F = coords.shape[0], codebook.shape[0], int(feature_dim)
-    dt = _dtype_code(codebook)
-    if grad_output.dtype != codebook.dtype:
-        grad_output = grad_output.to(codebook.dtype)
-    grad_codebook = torch.empty_like(codebook)
+    N, T, F = coords.shape[0], int(table_rows), int(feature_dim)
+    if table_dtype not in _DTYPES:
+        raise RuntimeError(f"shacira_amd: unsupported table dtype {table_dtype} (fp32 and fp16 are implemented)")
+    dt = _DTYPES[table_dtype]
+    if grad_output.dtype != table_dtype:
+        grad_output = grad_output.to(table_dtype)
+    device = grad_output.device
+    grad_codebook = torch.empty((T, F), dtype=table_dtype, device=device)
     L = _lib.lib()
-    with torch.cuda.device(codebook.device):
+    with torch.cuda.device(device):
         nbytes = L.shacira_hashgrid_backward_workspace_bytes(dim, N, len(res), F, int(codebook_bitwidth),
                                                              _res_array(res), T, dt)
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=codebook.device) if nbytes else None
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
         rc = L.shacira_hashgrid_backward(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
                                          _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
-                                         _ptr(grad_codebook), _ptr(ws), nbytes, _stream(codebook))
+                                         _ptr(grad_codebook), _ptr(ws), nbytes, _stream(grad_output))
     _lib.check(rc, "hashgrid_interpolate_backward")
     return grad_codebook
 
@@ -90,15 +94,15 @@ def hashgrid_interpolate2d_cuda(coords, codebook, codebook_first_idx, resolution
 def hashgrid_interpolate_backward_cuda(coords, grad_output, codebook, codebook_first_idx, resolution,
                                        codebook_bitwidth, feature_dim, require_grad_coords):
     """hashgrid_interpolate.h:25-33 -> grad_codebook [T, F]."""
-    return _hashgrid_backward(3, coords, grad_output, codebook, codebook_first_idx, resolution, codebook_bitwidth,
-                              feature_dim, require_grad_coords)
+    return hashgrid_backward(3, coords, grad_output, codebook.shape[0], codebook.dtype, codebook_first_idx, resolution,
+                             codebook_bitwidth, feature_dim)
 
 
 def hashgrid_interpolate2d_backward_cuda(coords, grad_output, codebook, codebook_first_idx, resolution,
                                          codebook_bitwidth, feature_dim, require_grad_coords):
     """hashgrid_interpolate.h:42-50 -> grad_codebook [T, F]."""
-    return _hashgrid_backward(2, coords, grad_output, codebook, codebook_first_idx, resolution, codebook_bitwidth,
-                              feature_dim, require_grad_coords)
+    return hashgrid_backward(2, coords, grad_output, codebook.shape[0], codebook.dtype, codebook_first_idx, resolution,
+                             codebook_bitwidth, feature_dim)
 
 
 # ------------------------------------------------------------------------------------------------ latent path

@@ -1,0 +1,177 @@
+"""``LatentGrid``: SHACIRA's core module -- a hash grid whose table stores integer-ish *latents* that are rounded
+and affinely decoded into the feature table on every query, with an entropy model on the latents.
+
+Mirror of reference wisp/models/grids/latent_grid.py:23-415: same constructor / ``from_*`` signatures and config
+dict keys, same parameter names (``codebook``, ``latent_dec.*``, ``prob_model.f*.{h,b,a}``), same RNG draw order
+at init, ``interpolate`` / ``ent_loss`` / ``size`` / ``freeze`` semantics (including the F==1 "repeat" trick).
+
+Per step on the GPU this is three fused HIP passes instead of ~35 ATen kernels: decode (latent_dec), lookup
+(hashgrid), entropy bits (prob_model.total_bits).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Any, Dict, List
+
+import torch
+
+from ..latent_decoders import DecoderIdentity, HierarchicalLatentDecoder, LatentDecoder
+from ..prob_models import BitEstimator
+from .hash_grid import _MultiLevelTable, geometric_resolutions
+
+
+class LatentGrid(_MultiLevelTable):
+    def __init__(self, feature_dim: int, latent_dim: int, resolutions: List[int], multiscale_type: str = "sum",
+                 resolution_dim: int = 3, feature_std: float = 0.0, feature_bias: float = 0.0,
+                 codebook_bitwidth: int = 8, blas_level: int = 7, init_grid: str = "normal",
+                 conf_latent_decoder: Dict[str, Any] = {}, conf_entropy_reg: Dict[str, Any] = {}):
+        self._setup_occupancy(blas_level)
+        self.feature_dim = feature_dim
+        self.latent_dim = feature_dim if latent_dim == 0 else latent_dim
+        self.multiscale_type = multiscale_type
+        self.feature_std = feature_std
+        self.feature_bias = feature_bias
+        self._setup_levels(resolutions, codebook_bitwidth)
+
+        def fill(rows, width):
+            if init_grid == "uniform":
+                return torch.zeros(rows, width) + (torch.rand(rows, width) - 0.5) * 2 * feature_std
+            if init_grid == "normal":
+                return torch.zeros(rows, width) + torch.randn(rows, width) * feature_std
+            return torch.zeros(rows, width)
+
+        self._allocate_table(self.latent_dim, resolution_dim, fill)
+
+        self.latent_dec = self.setup_decoders(conf_latent_decoder)
+        self.prob_model = None
+        self.noise = None
+        if conf_latent_decoder["ldecode_enabled"] and (conf_entropy_reg["entropy_reg"] > 0.0
+                                                       or conf_entropy_reg["entropy_reg_end"] > 0.0):
+            self.prob_model = BitEstimator(self.latent_dim, num_layers=conf_entropy_reg["num_prob_layers"])
+            self.noise_freq = conf_entropy_reg["noise_freq"]
+
+    # ---------------------------------------------------------------------------------------------- entropy
+    def _draw_noise(self):
+        # U(-1/2, 1/2) drawn with the CPU generator and moved to the table's device, exactly as the reference
+        # does (latent_grid.py:128-131), so a given torch.manual_seed reproduces the reference's noise stream.
+        return torch.rand(self.codebook.shape).to(self.codebook) - 0.5
+
+    def ent_loss(self, idx, is_val=False):
+        """(average bits per table row, total bits) of the latents under the entropy model; (0.0, 0.0) without one."""
+        if self.prob_model is None:
+            return 0.0, 0.0
+        noise = self.noise
+        if self.noise_freq == 1:
+            noise = self._draw_noise()
+        elif idx % self.noise_freq == 0:
+            self.noise = self._draw_noise()
+            noise = self.noise
+        total_bits = self.prob_model.total_bits(self.codebook, None if is_val else noise)
+        return total_bits / self.codebook.shape[0], total_bits
+
+    def size(self, use_torchac=False, use_prob_model=False):
+        """(decoder bits, latent bits): empirical (or model) entropy of the rounded latents per channel."""
+        ldec_size = self.latent_dec.size(use_torchac)
+        if use_torchac:
+            raise NotImplementedError("torchac arithmetic coding is not available (un-pinned third-party dependency "
+                                      "of the reference, latent_grid.py:154-172); use use_torchac=False")
+        codebook_bits = 0
+        for dim in range(self.codebook.size(1)):
+            weight = torch.round(self.codebook[:, dim]).long()
+            unique_vals, counts = torch.unique(weight, return_counts=True)
+            if not use_prob_model:
+                probs = counts / torch.sum(counts)
+            else:
+                assert self.prob_model is not None
+                probs = self.prob_model(unique_vals + 0.5, single_channel=dim) \
+                    - self.prob_model(unique_vals - 0.5, single_channel=dim)
+            information_bits = torch.clamp(-1.0 * torch.log(probs + 1e-10) / math.log(2.0), 0, 1000)
+            codebook_bits += torch.sum(information_bits * counts).item()
+        return ldec_size, codebook_bits
+
+    def setup_decoders(self, decoder_cfg):
+        if not decoder_cfg["ldecode_enabled"]:
+            return DecoderIdentity()
+        decoder_cfg["feature_dim"] = self.feature_dim
+        decoder_cfg["latent_dim"] = self.latent_dim
+        kind = decoder_cfg["ldecode_type"]
+        if kind == "hierarchical":
+            # (sic) last boundary = size of the last level, as in the reference (latent_grid.py:182)
+            offsets = torch.cat((self.codebook_lod_first_idx, self.codebook_lod_sizes[-1:]))
+            return HierarchicalLatentDecoder(self.num_lods, offsets, decoder_cfg)
+        if kind == "multi":
+            raise NotImplementedError("ldecode_type='multi' (MultiLatentDecoder) is a 'next' row (SURVEY.md 8 f4)")
+        if kind == "single":
+            return LatentDecoder(**decoder_cfg)
+
+    # ---------------------------------------------------------------------------------------- constructors
+    @classmethod
+    def from_octree(cls, feature_dim: int, latent_dim: int = 0, base_lod: int = 2, num_lods: int = 1,
+                    multiscale_type: str = "sum", resolution_dim: int = 3, feature_std: float = 0.0,
+                    feature_bias: float = 0.0, codebook_bitwidth: int = 8, blas_level: int = 7,
+                    init_grid: str = "normal", conf_latent_decoder: dict = {},
+                    conf_entropy_reg: dict = {}) -> LatentGrid:
+        resolutions = [2 ** (base_lod + x) for x in range(num_lods)]
+        return cls(feature_dim=feature_dim, resolutions=resolutions, multiscale_type=multiscale_type,
+                   feature_std=feature_std, feature_bias=feature_bias, codebook_bitwidth=codebook_bitwidth,
+                   blas_level=blas_level, latent_dim=latent_dim, conf_latent_decoder=conf_latent_decoder,
+                   conf_entropy_reg=conf_entropy_reg, resolution_dim=resolution_dim, init_grid=init_grid)
+
+    @classmethod
+    def from_geometric(cls, feature_dim: int, num_lods: int, latent_dim: int = 0, multiscale_type: str = "sum",
+                       resolution_dim: int = 3, feature_std: float = 0.0, feature_bias: float = 0.0,
+                       codebook_bitwidth: int = 8, min_grid_res: int = 16, max_grid_res: int = None,
+                       blas_level: int = 7, init_grid: str = "normal", conf_latent_decoder: dict = {},
+                       conf_entropy_reg: dict = {}) -> LatentGrid:
+        return cls(feature_dim=feature_dim, resolutions=geometric_resolutions(min_grid_res, max_grid_res, num_lods),
+                   multiscale_type=multiscale_type, feature_std=feature_std, feature_bias=feature_bias,
+                   codebook_bitwidth=codebook_bitwidth, blas_level=blas_level, latent_dim=latent_dim,
+                   conf_latent_decoder=conf_latent_decoder, conf_entropy_reg=conf_entropy_reg,
+                   resolution_dim=resolution_dim, init_grid=init_grid)
+
+    @classmethod
+    def from_resolutions(cls, feature_dim: int, resolutions: List[int], latent_dim: int = 0,
+                         multiscale_type: str = "sum", resolution_dim: int = 3, feature_std: float = 0.0,
+                         feature_bias: float = 0.0, codebook_bitwidth: int = 8, blas_level: int = 7,
+                         init_grid: str = "normal", conf_latent_decoder: dict = {},
+                         conf_entropy_reg: dict = {}) -> LatentGrid:
+        return cls(feature_dim=feature_dim, resolutions=resolutions, multiscale_type=multiscale_type,
+                   feature_std=feature_std, feature_bias=feature_bias, codebook_bitwidth=codebook_bitwidth,
+                   blas_level=blas_level, latent_dim=latent_dim, conf_latent_decoder=conf_latent_decoder,
+                   conf_entropy_reg=conf_entropy_reg, resolution_dim=resolution_dim, init_grid=init_grid)
+
+    def freeze(self):
+        self.codebook.requires_grad_(False)
+        for p in self.latent_dec.parameters():
+            p.requires_grad_(False)
+        if self.prob_model is not None:
+            for p in self.prob_model.parameters():
+                p.requires_grad_(False)
+
+    # ------------------------------------------------------------------------------------------ interpolate
+    def interpolate(self, coords, lod_idx):
+        """Decode the whole latent table, then query it: [batch, (num_samples,) 2|3] -> [batch, (num_samples,) feats]."""
+        table = self.latent_dec(self.codebook)
+        rep = table.size(1) == 1  # the operator needs an even feature dim: duplicate the column, drop it after
+        if rep:
+            table = table.repeat(1, 2)
+        feats, output_shape = self._lookup(coords, lod_idx, table)
+        if rep:
+            feats = feats[:, ::2]
+        return self._aggregate(feats, lod_idx, output_shape)
+
+    def name(self) -> str:
+        return "Latent Grid"
+
+    def public_properties(self) -> Dict[str, Any]:
+        properties = {
+            "Feature Dims": self.feature_dim,
+            "Latent Dims": self.latent_dim,
+            "Total LODs": self.max_lod,
+            "Active feature LODs": self._lod_range(),
+            "Interpolation": "linear",
+            "Multiscale aggregation": self.multiscale_type,
+            "HashTable Size": f"2^{self.codebook_bitwidth}",
+        }
+        return {**super().public_properties(), **properties}

@@ -1,0 +1,81 @@
+"""world_size-2 gloo test of the data-parallel path: sharded batch + one flat all-reduce == single-process gradient.
+The hash-grid op on CPU is the torch oracle (test-only stand-in: the product op has no CPU path)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import CONFIGS, table_layout
+from oracle import hashgrid_torch as ot
+from shacira_amd import dist as sdist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem():
+    dim, res, bw = CONFIGS["A"]
+    _, first, T = table_layout(res, bw, dim)
+    g = torch.Generator().manual_seed(0)
+    coords = torch.rand(1001, dim, generator=g) * 2 - 1          # odd size: ragged shards
+    target = torch.randn(1001, len(res) * 2, generator=g)
+    table = torch.randn(T, 2, generator=g) * 0.1
+    extra = torch.randn(7, generator=g)
+    return res, bw, first, coords, target, table, extra
+
+
+def _loss_sum(table, extra, coords, target, res, bw, first):
+    feats = ot.hashgrid_forward(coords, table, first, res, bw)
+    return ((feats * extra.sum() - target) ** 2).sum()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, dev = sdist.init_from_env("gloo")
+    assert (r, w, dev.type) == (rank, world, "cpu")
+    res, bw, first, coords, target, table, extra = _problem()
+    table = torch.nn.Parameter(table)
+    extra = torch.nn.Parameter(extra)
+    bucket = sdist.FlatGradients([table, extra])
+    c, t = sdist.shard_batch(coords, rank, world), sdist.shard_batch(target, rank, world)
+    for step in range(2):                                   # second step checks zero_() + re-accumulation into views
+        bucket.zero_()
+        loss = _loss_sum(table, extra, c, t, res, bw, first) / (coords.shape[0] * target.shape[1])
+        loss.backward()
+        assert table.grad.data_ptr() == bucket.view_of(table).data_ptr()   # autograd wrote into the flat buffer
+        bucket.allreduce()
+    if rank == 0:
+        torch.save({"table": table.grad.clone(), "extra": extra.grad.clone(), "nbytes": bucket.nbytes}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
+    out = str(tmp_path / "grads.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    res, bw, first, coords, target, table, extra = _problem()
+    table.requires_grad_(True)
+    extra.requires_grad_(True)
+    (_loss_sum(table, extra, coords, target, res, bw, first) / (coords.shape[0] * target.shape[1])).backward()
+    np.testing.assert_allclose(got["table"].numpy(), table.grad.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(got["extra"].numpy(), extra.grad.numpy(), rtol=1e-4, atol=1e-6)
+    assert got["nbytes"] >= (table.numel() + extra.numel()) * 4
+
+
+def test_shard_bounds_cover_batch_exactly():
+    for n in (0, 1, 7, 1001, 1 << 20):
+        for world in (1, 2, 3, 8):
+            spans = [sdist.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+    assert sdist.global_mean_loss(torch.tensor(8.0), 4, 2).item() == 1.0

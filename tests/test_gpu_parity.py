@@ -1,0 +1,354 @@
+"""Parity of the HIP path against the CPU oracle and the committed golden vectors, THROUGH the C-ABI
+(shacira_amd.hip_ops -> ctypes -> libshacira_hip.so). Bars (BASELINE.json north_star): hash indices bit-exact --
+observable as bit-identical forward features, since any wrong index or weight changes them -- interpolated
+features and gradients within 1e-5 relative fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import CONFIGS, geo, npz_json, table_layout
+from oracle import hashgrid_c as oc
+from oracle import latent as ol
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5  # the tolerance north_star states for features and gradients
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from shacira_amd import _lib
+    _lib.lib()  # fails loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from shacira_amd import hip_ops
+    return hip_ops
+
+
+def _problem(dim, res, bw, N, F=2, seed=0, edge=True):
+    sizes, first, T = table_layout(res, bw, dim)
+    rng = np.random.default_rng(seed)
+    coords = rng.uniform(-1, 1, (N, dim)).astype(np.float32)
+    if edge and N >= 16:
+        coords[0] = 1.0
+        coords[1] = -1.0
+        coords[2] = np.nan
+        coords[3] = 2.5
+        coords[4] = -9.0
+        coords[5] = np.float32(1.0) - np.float32(2.0 ** -24)
+        coords[6] = np.float32(-1.0) + np.float32(2.0 ** -24)
+        coords[7, 0] = 1.0
+    table = (rng.standard_normal((T, F)) * 0.01).astype(np.float32)
+    go = rng.standard_normal((N, len(res) * F)).astype(np.float32)
+    return sizes, first, T, coords, table, go
+
+
+def _run(dev, dim, res, bw, coords, table, go, first, dtype=torch.float32):
+    ops = _ops()
+    tc = torch.from_numpy(coords).to(dev)
+    tt = torch.from_numpy(table).to(dev).to(dtype)
+    tg = torch.from_numpy(go).to(dev).to(dtype)
+    tf = torch.from_numpy(first).to(dev)
+    fwd = ops.hashgrid_interpolate_cuda if dim == 3 else ops.hashgrid_interpolate2d_cuda
+    bwd = ops.hashgrid_interpolate_backward_cuda if dim == 3 else ops.hashgrid_interpolate2d_backward_cuda
+    feats = fwd(tc, tt, tf, res, bw)
+    grad = bwd(tc, tg, tt, tf, res, bw, table.shape[1], False)
+    torch.cuda.synchronize()
+    return feats, grad
+
+
+@pytest.mark.parametrize("name", ["A", "B", "Bp", "D"])
+@pytest.mark.parametrize("variant", [(-1, -1), (0, 0)])
+def test_forward_bit_exact_backward_within_tolerance(dev, name, variant):
+    from shacira_amd import _lib
+    dim, res, bw = CONFIGS[name]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, 40_001)   # ragged: not a multiple of any tile
+    _lib.set_option("fwd_variant", variant[0])
+    _lib.set_option("bwd_variant", variant[1])
+    try:
+        feats, grad = _run(dev, dim, res, bw, coords, table, go, first)
+    finally:
+        _lib.set_option("fwd_variant", -1)
+        _lib.set_option("bwd_variant", -1)
+    ref_f = oc.forward(coords, table, first, res, bw)
+    got_f = feats.cpu().numpy()
+    assert got_f.shape == ref_f.shape and got_f.dtype == np.float32
+    assert np.array_equal(got_f, ref_f), f"forward not bit-identical: {np.abs(got_f - ref_f).max()}"
+    ref_g = oc.backward(coords, go, (T, 2), first, res, bw)
+    got_g = grad.cpu().numpy().astype(np.float64)
+    scale = np.abs(ref_g).max()
+    np.testing.assert_allclose(got_g, ref_g, rtol=RTOL, atol=RTOL * scale)
+    # per-level conservation: sum of the gradient rows of level l == sum of grad_output columns of level l
+    for l in range(len(res)):
+        lo, hi = first[l], first[l] + sizes[l]
+        np.testing.assert_allclose(got_g[lo:hi].sum(0), go[:, 2 * l:2 * l + 2].astype(np.float64).sum(0),
+                                   rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 257, 1000])
+def test_empty_single_and_ragged_sizes(dev, n):
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, edge=False)
+    feats, grad = _run(dev, dim, res, bw, coords, table, go, first)
+    assert feats.shape == (n, 32) and grad.shape == (T, 2)
+    assert np.array_equal(feats.cpu().numpy(), oc.forward(coords, table, first, res, bw))
+    ref_g = oc.backward(coords, go, (T, 2), first, res, bw)
+    np.testing.assert_allclose(grad.cpu().numpy(), ref_g, rtol=RTOL, atol=RTOL * max(np.abs(ref_g).max(), 1e-30))
+    if n == 0:
+        assert float(grad.abs().sum()) == 0.0      # zeros_like semantics: the output is fully overwritten
+
+
+def test_backward_overwrites_stale_output(dev):
+    """grad_codebook is written completely by the call (no pre-zeroing by the caller, .cpp:81 zeros_like)."""
+    ops = _ops()
+    dim, res, bw = CONFIGS["A"]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, 500)
+    torch.cuda.empty_cache()
+    junk = torch.full((T, 2), 1e30, device=dev)
+    del junk                                              # the caching allocator hands the same block back
+    _, grad = _run(dev, dim, res, bw, coords, table, go, first)
+    ref_g = oc.backward(coords, go, (T, 2), first, res, bw)
+    np.testing.assert_allclose(grad.cpu().numpy(), ref_g, rtol=RTOL, atol=RTOL * np.abs(ref_g).max())
+
+
+@pytest.mark.parametrize("F", [4, 6, 8])
+@pytest.mark.parametrize("dim", [2, 3])
+def test_other_feature_dims(dev, dim, F):
+    res, bw = geo(16, 512, 24) if dim == 3 else geo(16, 512, 8), 19 if dim == 3 else 11
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, 5000, F=F)
+    feats, grad = _run(dev, dim, res, bw, coords, table, go, first)
+    assert np.array_equal(feats.cpu().numpy(), oc.forward(coords, table, first, res, bw))
+    ref_g = oc.backward(coords, go, (T, F), first, res, bw)
+    np.testing.assert_allclose(grad.cpu().numpy(), ref_g, rtol=RTOL, atol=RTOL * np.abs(ref_g).max())
+
+
+def test_out_of_table_corner_is_memory_safe(dev):
+    # dense 2-D level, res >= 258, coord == +1: the reference reads one row past the table with weight 0 (UB)
+    res, bw = [300], 19
+    sizes, first, T = table_layout(res, bw, 2)
+    coords = np.array([[1.0, 1.0], [1.0, -1.0], [0.3, 1.0]], np.float32)
+    table = np.ones((T, 2), np.float32)
+    go = np.ones((3, 2), np.float32)
+    feats, grad = _run(dev, 2, res, bw, coords, table, go, first)
+    assert np.array_equal(feats.cpu().numpy(), oc.forward(coords, table, first, res, bw))
+    assert float(grad.sum()) == pytest.approx(6.0, rel=1e-6)
+
+
+def test_half_precision_tables(dev):
+    """fp16 instantiation (what the reference's NeRF AMP path runs, grid.py:73 + .cu:198-211)."""
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, 20_000)
+    table16 = table.astype(np.float16).astype(np.float32)
+    go16 = go.astype(np.float16).astype(np.float32)
+    feats, grad = _run(dev, dim, res, bw, coords, table, go, first, dtype=torch.float16)
+    assert feats.dtype == torch.float16 and grad.dtype == torch.float16
+    ref_f = oc.forward(coords, table16, first, res, bw)
+    # same fp32 math, one final rounding to fp16
+    assert np.array_equal(feats.cpu().numpy(), ref_f.astype(np.float16))
+    ref_g = oc.backward(coords, go16, (T, 2), first, res, bw)
+    np.testing.assert_allclose(grad.float().cpu().numpy(), ref_g, rtol=2e-3, atol=2e-3 * np.abs(ref_g).max())
+
+
+def test_full_size_properties(dev):
+    """BASELINE headline size (N = 2^20, config D): size-independent properties instead of the (slow) oracle."""
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T = table_layout(res, bw, dim)
+    N = 1 << 20
+    g = torch.Generator(device="cpu").manual_seed(0)
+    coords = (torch.rand(N, 3, generator=g) * 2 - 1).to(dev)
+    tf = torch.from_numpy(first).to(dev)
+    t1 = (torch.randn(T, 2, generator=g) * 0.01).to(dev)
+    t2 = (torch.randn(T, 2, generator=g) * 0.01).to(dev)
+    # constant table -> constant features (partition of unity)
+    const = ops.hashgrid_interpolate_cuda(coords, torch.full((T, 2), 0.5, device=dev), tf, res, bw)
+    assert float((const - 0.5).abs().max()) < 1e-6
+    # linearity in the table
+    f1 = ops.hashgrid_interpolate_cuda(coords, t1, tf, res, bw)
+    f2 = ops.hashgrid_interpolate_cuda(coords, t2, tf, res, bw)
+    f12 = ops.hashgrid_interpolate_cuda(coords, t1 + 2 * t2, tf, res, bw)
+    assert float((f12 - (f1 + 2 * f2)).abs().max()) < 1e-6
+    # a 4096-sample slice against the oracle, bit for bit
+    sl = slice(500_000, 504_096)
+    assert np.array_equal(f1[sl].cpu().numpy(), oc.forward(coords[sl].cpu().numpy(), t1.cpu().numpy(), first, res, bw))
+    # adjointness: <feats(table), go> == <table, grad(go)>   (checksum of checksums for the backward)
+    go = torch.randn(N, 32, generator=g).to(dev)
+    grad = ops.hashgrid_interpolate_backward_cuda(coords, go, t1, tf, res, bw, 2, False)
+    lhs = float((f1.double() * go.double()).sum())
+    rhs = float((t1.double() * grad.double()).sum())
+    assert lhs == pytest.approx(rhs, rel=1e-4)
+    for l in (0, 7, 15):
+        lo, hi = int(first[l]), int(first[l]) + sizes[l]
+        np.testing.assert_allclose(grad[lo:hi].double().sum(0).cpu().numpy(),
+                                   go[:, 2 * l:2 * l + 2].double().sum(0).cpu().numpy(), rtol=1e-3, atol=5e-2)
+    # determinism of the forward
+    assert torch.equal(f1, ops.hashgrid_interpolate_cuda(coords, t1, tf, res, bw))
+
+
+# ------------------------------------------------------------------------------------------------ latent kernels
+def test_latent_decode_against_reference_vectors(dev, golden):
+    ops = _ops()
+    g = golden("latent_decoder.npz")
+    for ci, case in enumerate(npz_json(g["cases_json"])):
+        p = f"c{ci}_"
+        dft = "dft" in case["ldecode_matrix"]
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        matrix = to(g[p + "dft"] if dft else g[p + "scale"])
+        colscale = to(g[p + "scale"]) if dft else None
+        shift = to(g[p + "shift"]) if case["use_shift"] else None
+        lat, div = to(g[p + "latent"]), to(g[p + "div"])
+        out = ops.latent_decode_forward(lat, div, matrix, colscale, shift, case["clamp_weights"])
+        np.testing.assert_allclose(out.cpu().numpy(), g[p + "out"], rtol=RTOL, atol=1e-7)
+        gl, gm, gc, gs = ops.latent_decode_backward(lat, div, matrix, colscale, shift, case["clamp_weights"],
+                                                    to(g[p + "grad_out"]), need_colscale=dft)
+        np.testing.assert_allclose(gl.cpu().numpy(), g[p + "grad_latent"], rtol=RTOL, atol=1e-7)
+        gscale = gc.reshape(1, -1) if dft else gm
+        np.testing.assert_allclose(gscale.cpu().numpy(), g[p + "grad_scale"], rtol=RTOL, atol=1e-5)
+        if case["use_shift"]:
+            np.testing.assert_allclose(gs.reshape(1, -1).cpu().numpy(), g[p + "grad_shift"], rtol=RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("ld,F", [(1, 2), (2, 2), (1, 4), (4, 4), (3, 2), (8, 8)])
+def test_latent_decode_large_against_oracle(dev, ld, F):
+    ops = _ops()
+    rng = np.random.default_rng(ld * 10 + F)
+    T = 300_007
+    lat = rng.uniform(-6, 6, (T, ld)).astype(np.float32)
+    lat[:9, 0] = [0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 3.5, 1e-9, -1e-9]
+    div = rng.uniform(0.5, 3, ld).astype(np.float32)
+    mat = (rng.standard_normal((ld, F)) * 0.2).astype(np.float32)
+    cs = rng.uniform(0.5, 2, F).astype(np.float32)
+    sh = (rng.standard_normal(F) * 0.05).astype(np.float32)
+    gy = rng.standard_normal((T, F)).astype(np.float32)
+    to = lambda a: torch.from_numpy(a).to(dev)
+    for clampw in (0.0, 0.3):
+        out = ops.latent_decode_forward(to(lat), to(div), to(mat), to(cs), to(sh), clampw)
+        ref, _ = ol.decode_forward(lat, div, mat, cs, sh, clampw)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=1e-6)
+        gl, gm, gc, gs = ops.latent_decode_backward(to(lat), to(div), to(mat), to(cs), to(sh), clampw, to(gy), True)
+        r = ol.decode_backward(lat, div, mat, cs, sh, clampw, gy)
+        np.testing.assert_allclose(gl.cpu().numpy(), r["latent"], rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(gm.cpu().numpy(), r["matrix"], rtol=1e-4, atol=1e-2)
+        np.testing.assert_allclose(gc.cpu().numpy(), r["colscale"], rtol=1e-4, atol=1e-2)
+        np.testing.assert_allclose(gs.cpu().numpy(), r["shift"], rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("name", ["g2cat", "g2sum", "g2rep", "g3cat", "g3sum"])
+def test_entropy_bits_against_reference_vectors(dev, golden, name):
+    ops = _ops()
+    g = golden("latent_grid.npz")
+    meta = npz_json(g["meta_json"])[name]
+    p = name + "_"
+    ld = meta["latent_dim"]
+    params = ol.pack_params({k[len(p) + 2:]: v for k, v in g.items() if k.startswith(p + "p_prob_model.")},
+                            "prob_model.", ld)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lat, noise, prm = to(g[p + "codebook"]), to(g[p + "noise"]), to(params)
+    tot = ops.entropy_bits_forward(lat, noise, prm, 2)
+    assert float(tot) == pytest.approx(float(g[p + "ent_total"]), rel=RTOL)
+    totv = ops.entropy_bits_forward(lat, None, prm, 2)
+    assert float(totv) == pytest.approx(float(g[p + "ent_total_val"]), rel=RTOL)
+    one = torch.ones((), device=dev)
+    gl, gp = ops.entropy_bits_backward(lat, noise, prm, 2, one)
+    np.testing.assert_allclose(gl.cpu().numpy(), g[p + "ent_grad_codebook"], rtol=1e-4, atol=1e-6)
+    gp = gp.cpu().numpy()
+    for k, f in enumerate(("f1", "f2", "f3", "f4")):
+        for s_i, slot in enumerate(("h", "b", "a")):
+            key = f"{p}ent_g_{f}.{slot}"
+            if key in g:
+                np.testing.assert_allclose(gp[k, s_i], g[key].reshape(-1), rtol=1e-3, atol=1e-3, err_msg=key)
+    glv, _ = ops.entropy_bits_backward(lat, None, prm, 2, one)
+    assert float(glv.abs().sum()) == 0.0              # round() has zero gradient (is_val)
+
+
+@pytest.mark.parametrize("nl", [1, 2, 3, 4])
+@pytest.mark.parametrize("ld", [1, 2, 3, 4, 8])
+def test_entropy_bits_large_against_oracle(dev, nl, ld):
+    ops = _ops()
+    rng = np.random.default_rng(nl * 7 + ld)
+    T = 200_003
+    lat = rng.uniform(-8, 8, (T, ld)).astype(np.float32)
+    noise = rng.uniform(-0.5, 0.5, (T, ld)).astype(np.float32)
+    params = (rng.standard_normal((4, 3, ld)) * 0.4).astype(np.float32)
+    to = lambda a: torch.from_numpy(a).to(dev)
+    tot = float(ops.entropy_bits_forward(to(lat), to(noise), to(params), nl))
+    assert tot == pytest.approx(ol.entropy_bits(lat, noise, params, nl), rel=RTOL)
+    gt = torch.full((), 0.25, device=dev)
+    gl, gp = ops.entropy_bits_backward(to(lat), to(noise), to(params), nl, gt)
+    rl, rp = ol.entropy_bits_backward(lat, noise, params, nl, 0.25)
+    np.testing.assert_allclose(gl.cpu().numpy(), rl, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(gp.cpu().numpy(), rp, rtol=1e-4, atol=1e-3 * np.abs(rp).max())
+
+
+# ------------------------------------------------------------------------------------------------ module level
+def _conf(ld):
+    cdec = dict(ldecode_enabled=True, ldecode_type="single", use_sga=False, diff_sampling=False, ldecode_matrix="sq",
+                latent_dim=ld, norm="none", norm_every=10, use_shift=True, num_layers_dec=0, hidden_dim_dec=0,
+                activation="none", final_activation="none", clamp_weights=0.0, ldec_std=0.1, num_decoders=1,
+                temperature=0.1, decay_period=0.9, alpha_std=1.0)
+    cent = dict(num_prob_layers=2, entropy_reg=1e-4, entropy_reg_end=1e-4, entropy_reg_sched="cosine", noise_freq=1)
+    return cdec, cent
+
+
+@pytest.mark.parametrize("name", ["g2cat", "g2sum", "g2rep", "g3cat", "g3sum"])
+def test_latent_grid_module_on_gpu_matches_reference_run(dev, golden, name):
+    """The whole module path (fused decode -> HIP lookup -> aggregate; fused entropy) against vectors produced by
+    the reference's LatentGrid with the same parameters."""
+    from shacira_amd.wisp.models.grids import LatentGrid
+    g = golden("latent_grid.npz")
+    meta = npz_json(g["meta_json"])[name]
+    p = name + "_"
+    cdec, cent = _conf(meta["latent_dim"])
+    grid = LatentGrid.from_geometric(feature_dim=meta["feature_dim"], num_lods=6, latent_dim=meta["latent_dim"],
+                                     multiscale_type=meta["multiscale_type"], resolution_dim=meta["dim"],
+                                     feature_std=2.0, codebook_bitwidth=9, min_grid_res=4, max_grid_res=64,
+                                     init_grid="uniform", blas_level=3, conf_latent_decoder=cdec, conf_entropy_reg=cent)
+    sd = {k[len(p) + 2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(p + "p_")}
+    sd["codebook"] = torch.from_numpy(g[p + "codebook"])
+    grid.load_state_dict(sd, strict=False)
+    grid = grid.to(dev)
+    coords = torch.from_numpy(g[p + "coords"]).to(dev)
+    f = grid.interpolate(coords, 0)
+    np.testing.assert_allclose(f.detach().cpu().numpy(), g[p + "interp"], rtol=RTOL, atol=1e-6)
+    f.backward(torch.from_numpy(g[p + "interp_grad_out"]).to(dev))
+    np.testing.assert_allclose(grid.codebook.grad.cpu().numpy(), g[p + "interp_grad_codebook"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(grid.latent_dec.layers[0].scale.grad.cpu().numpy(), g[p + "interp_grad_scale"],
+                               rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(grid.latent_dec.layers[0].shift.grad.cpu().numpy(), g[p + "interp_grad_shift"],
+                               rtol=1e-4, atol=1e-4)
+    assert list(grid.interpolate(coords.reshape(8, 8, meta["dim"]), 0).shape) == g[p + "interp_bs_shape"].tolist()
+    grid.zero_grad()
+    grid.noise_freq = 1000
+    grid.noise = torch.from_numpy(g[p + "noise"]).to(dev)
+    avg, tot = grid.ent_loss(1, is_val=False)
+    tot.backward()
+    assert tot.item() == pytest.approx(float(g[p + "ent_total"]), rel=RTOL)
+    assert avg.item() == pytest.approx(float(g[p + "ent_avg"]), rel=RTOL)
+    np.testing.assert_allclose(grid.codebook.grad.cpu().numpy(), g[p + "ent_grad_codebook"], rtol=1e-4, atol=1e-6)
+    for n, prm in grid.prob_model.named_parameters():
+        if prm.grad is not None:
+            np.testing.assert_allclose(prm.grad.cpu().numpy(), g[p + "ent_g_" + n], rtol=1e-3, atol=1e-3)
+    _, totv = grid.ent_loss(1, is_val=True)
+    assert totv.item() == pytest.approx(float(g[p + "ent_total_val"]), rel=RTOL)
+    np.testing.assert_allclose(list(grid.size()), g[p + "size"][:2], rtol=1e-5)
+
+
+def test_autocast_runs_the_half_instantiation(dev):
+    from shacira_amd.wisp.models.grids import HashGrid
+    torch.manual_seed(0)
+    grid = HashGrid.from_geometric(feature_dim=2, num_lods=8, multiscale_type="cat", resolution_dim=3,
+                                   feature_std=0.01, codebook_bitwidth=12, min_grid_res=4, max_grid_res=64,
+                                   blas_level=3).to(dev)
+    coords = torch.rand(4096, 3, device=dev) * 2 - 1
+    with torch.autocast("cuda", dtype=torch.float16):
+        f = grid.interpolate(coords, 0)
+    assert f.dtype == torch.float16
+    f.float().sum().backward()
+    assert grid.codebook.grad is not None and grid.codebook.grad.dtype == torch.float32
+    f32 = grid.interpolate(coords, 0)
+    assert float((f.float() - f32).abs().max()) < 5e-4
