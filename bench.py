@@ -48,23 +48,35 @@ def algorithmic_bytes_per_sample(dim, L, F, s=4):
     return one, one
 
 
-def cpu_baseline(dim, res, bw, F, first, T, n_samples, iters, seed=0):
-    """Pure-PyTorch restatement of the reference kernels, all host cores, same synthetic distribution."""
+def cpu_baseline(dim, res, bw, F, first, T, n_samples, budget_s, seed=0):
+    """Pure-PyTorch restatement of the reference kernels on the host cores, same synthetic distribution, bounded to
+    about `budget_s` seconds of CPU work (the first pass sizes the number of timed passes)."""
+    from oracle import hashgrid_c as oc
     from oracle import hashgrid_torch as ot
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)   # more threads only add contention to index_add_ on this workload
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(seed)
     coords = torch.rand(n_samples, dim, generator=g) * 2 - 1
     table = torch.randn(T, F, generator=g) * 0.01
     go = torch.randn(n_samples, len(res) * F, generator=g)
-    ot.hashgrid_fwd_bwd(coords, table, first, res, bw, go)  # warm-up
+    t0 = time.perf_counter()
+    ot.hashgrid_fwd_bwd(coords, table, first, res, bw, go)  # warm-up, also sizes the run
+    warm = time.perf_counter() - t0
+    iters = max(1, min(10, int(budget_s / max(warm, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(iters):
         ot.hashgrid_fwd_bwd(coords, table, first, res, bw, go)
     dt = (time.perf_counter() - t0) / iters
+    # sanity figure: the scalar C oracle, one thread, on a slice
+    n_c = min(n_samples, 1 << 16)
+    t0 = time.perf_counter()
+    oc.forward(coords[:n_c].numpy(), table.numpy(), first, res, bw)
+    oc.backward(coords[:n_c].numpy(), go[:n_c].numpy(), (T, F), first, res, bw)
+    dt_c = time.perf_counter() - t0
     return {"value": n_samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} timed fwd+bwd passes (+1 warm-up) over {n_samples} samples of the same workload, "
-                      f"oracle/hashgrid_torch.py, torch.set_num_threads({cores})", "s_per_pass": dt}
+            "sample": f"{iters} timed fwd+bwd passes (+1 warm-up) over {n_samples} samples of the same workload "
+                      f"(same table, same coordinate distribution), oracle/hashgrid_torch.py, {cores} torch threads",
+            "s_per_pass": dt, "c_oracle_1thread_samples_per_s": n_c / dt_c}
 
 
 def main():
@@ -74,8 +86,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="S1_nerf_hash_3d_L16_F2_bw19_N2^20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=1 << 20)
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-samples", type=int, default=1 << 17)
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()
 
     from shacira_amd import dist as sdist
@@ -166,7 +178,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, res, bw, F, first_np, T, min(args.cpu_samples, n_local),
-                                               args.cpu_iters)
+                                               args.cpu_budget_s)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -99,10 +99,28 @@ static hipError_t bwd_atomic_f(const LevelTable &lt, const int32_t *first_idx, c
     return launch_bwd_atomic<DIM, T, 0>(lt, first_idx, coords, grad_out, acc, n, s);
 }
 
+// hashgrid_bwd_bin.hip
+bool bin_supported(int dim, const LevelTable &lt);
+size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n);
+float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace);
+hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s);
+
+// variant 1 ("bin") whenever the shape allows it and the batch is big enough to amortise its fixed passes
+static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
+    const int v = g_bwd_variant.load();
+    if (v == 0 || !bin_supported(dim, lt)) return false;
+    if (v == 1) return true;
+    return n >= 8192;
+}
+
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
-    (void)dim; (void)n;
-    if (dtype == SHACIRA_F16) return (size_t)lt.table_rows * lt.feature_dim * sizeof(float);
-    return 0;
+    size_t need = (dtype == SHACIRA_F16) ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0;
+    if (bin_supported(dim, lt) && n > 0) {
+        const size_t b = bin_workspace_bytes(dim, dtype, lt, n);
+        if (b > need) need = b;
+    }
+    return need;
 }
 
 hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
@@ -110,10 +128,18 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
                                       size_t workspace_bytes, int64_t n, hipStream_t s) {
     (void)workspace_bytes;
     const int64_t numel = lt.table_rows * lt.feature_dim;
-    float *acc = (dtype == SHACIRA_F32) ? static_cast<float *>(grad_table) : static_cast<float *>(workspace);
+    const bool bin = n > 0 && use_bin(dim, lt, n);
+    // fp16 tables accumulate in an fp32 image: the tail of the bin workspace, or the whole workspace (atomic variant)
+    float *acc = static_cast<float *>(grad_table);
+    if (dtype == SHACIRA_F16) {
+        acc = bin ? bin_acc32(dim, dtype, lt, n, workspace) : static_cast<float *>(workspace);
+    }
     hipError_t e = hipMemsetAsync(acc, 0, (size_t)numel * sizeof(float), s);  // at::zeros_like, .cpp:81/:167
     if (e != hipSuccess) return e;
-    if (n > 0) {
+    if (bin) {
+        e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s);
+        if (e != hipSuccess) return e;
+    } else if (n > 0) {
         if (dim == 3) {
             e = (dtype == SHACIRA_F32) ? bwd_atomic_f<3, float>(lt, first_idx, coords, grad_out, acc, n, s)
                                        : bwd_atomic_f<3, __half>(lt, first_idx, coords, grad_out, acc, n, s);

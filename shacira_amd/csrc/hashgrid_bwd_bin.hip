@@ -1,0 +1,601 @@
+// hashgrid_bwd_bin.hip -- backward of the hash-grid lookup WITHOUT scattered global atomics (gfx950).
+//
+// Why: on MI355X a scattered global float atomic costs one memory-side request (~21 G requests/s chip-wide,
+// profiles/r01_microbench_rates.txt) and LDS ds_add_f32 runs at 0.33 op/clk/CU, while LDS ds_add_f64 sustains
+// ~1.3 T adds/s (profiles/r01_microbench2_lds_gather.txt). The reference's design (one atomicAdd per corner per
+// feature, hashgrid_interpolate_cuda.cu:212-221) therefore runs ~30x under the HBM roof here. This file replaces
+// it by "partition, then accumulate on chip":
+//
+//   pass T  transpose   grad_output [N, L*F] -> gT [L][N][F]            (coalesced both ways through LDS)
+//   pass A  count       per (level, tile of samples): how many items fall into each bucket  -> cnt[bucket][tile]
+//   pass S  scan        exclusive scans: per bucket over tiles, then over buckets; builds the consumer work list
+//   pass B  bin         recompute the corners, stage the tile's items in LDS sorted by bucket, write each bucket's
+//                       run to its exact slot in HBM with coalesced 16-byte stores
+//   pass C  consume     one workgroup per (bucket, chunk): accumulate the items into an LDS-resident fp64 image of
+//                       the bucket's rows (ds_add_f64), then write the rows out (plain coalesced stores when the
+//                       bucket has a single chunk, coalesced float atomics otherwise)
+//
+// A *bucket* is a range of <= BR consecutive rows of one level (BR*F*8 B = 128 KiB of LDS). An *item* is one
+// x-pair of corners (x, x+1) at fixed (y[,z]) offsets: both rows always share a bucket (hashed levels: the rows
+// differ only in the low bits x ^ (x+1); dense levels: buckets hold whole x-lines), so an item is 8 + 4F bytes:
+//   { key = rowA | rowB << 13 | validA << 26 | validB << 27,  fx,  a_j = grad_j * w_rest }   (rows bucket-local)
+// and the consumer adds a_j*(1-fx) to rowA and a_j*fx to rowB. The sum is kept in fp64 and rounded once.
+//
+// Results differ from the reference only by summation order / two fp32 roundings per term (the reference's own
+// atomicAdd order is unspecified); tests hold them to 1e-5 relative against the fp64-accumulating oracle.
+#include <mutex>
+
+#include "internal.h"
+
+namespace shacira {
+
+constexpr int kTile = 1024;           // samples per (level, tile) block in passes A and B
+constexpr int kBinThreads = 512;      // threads of passes A and B
+constexpr int kConsumeThreads = 1024;
+constexpr int kMaxBuckets = 2048;     // over all levels
+constexpr int kMaxLevelBuckets = 128; // per level (LDS histogram size)
+constexpr int kTransposeSamples = 64; // samples per block of pass T
+
+struct BinLevel {
+    uint32_t nb;        // buckets in this level
+    uint32_t bucket0;   // global index of its first bucket
+    uint32_t rows_pb;   // rows per bucket (hashed: BR; dense: G*res)
+    uint32_t G;         // dense: x-lines per bucket
+    uint64_t magicG;    // ceil(2^40 / G): line / G == (line * magicG) >> 40 for line < 2^20
+    uint32_t used;      // rows of the level the kernels can touch: dense res^d, hashed 2^bw
+    uint32_t shift;     // hashed: log2(BR)
+};
+
+struct BinPlan {
+    BinLevel lv[SHACIRA_MAX_LODS];
+    uint32_t total_buckets;
+    uint32_t BR;
+    uint32_t num_tiles;
+    uint32_t pairs;     // items per (sample, level) = 2^(dim-1)
+    uint32_t chunk;     // items per consumer work unit
+};
+
+template <int F> struct Item {
+    uint32_t key;
+    float fx;
+    float a[F];
+};
+
+// One x-pair of corners of a (sample, level), in bucket coordinates.
+struct PairSlot {
+    uint32_t bucket;  // level-local bucket index
+    uint32_t key;     // rowA | rowB << 13 | validA << 26 | validB << 27   (0 valid bits -> nothing to add)
+    float wrest;      // product of the non-x weights
+};
+
+// Enumerates the 2^(DIM-1) x-pairs of one (sample, level). fx/gx are the x-axis weights (corner x+1 / corner x).
+template <int DIM>
+__device__ __forceinline__ void enumerate_pairs(const double (&t)[DIM], int32_t res, float hi, bool dense,
+                                                uint32_t mask, const BinLevel &bl, uint32_t BR, float &fx,
+                                                PairSlot (&out)[1 << (DIM - 1)]) {
+    int32_t p[DIM];
+    float f[DIM], g[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) axis_transform(t[a], res, hi, p[a], f[a], g[a]);
+    fx = f[0];
+    const uint32_t ux = (uint32_t)p[0];
+    const uint32_t r = (uint32_t)res;
+    constexpr int NP = 1 << (DIM - 1);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        // q bit (DIM-2) -> y offset, bit 0 -> z offset (3-D); q -> y offset (2-D): same order as the corner bits
+        const int dy = (DIM == 3) ? ((q >> 1) & 1) : (q & 1);
+        const int dz = (DIM == 3) ? (q & 1) : 0;
+        float w = dy ? f[1] : g[1];
+        if constexpr (DIM == 3) w = w * (dz ? f[2] : g[2]);
+        out[q].wrest = w;
+        const uint32_t uy = (uint32_t)p[1] + dy;
+        uint32_t uz = 0;
+        if constexpr (DIM == 3) uz = (uint32_t)p[2] + dz;
+        if (dense) {
+            // corners with a coordinate == res lie outside the level (weight 0 in the reference): dropped
+            bool ok = uy < r;
+            uint32_t line = uy;
+            if constexpr (DIM == 3) {
+                ok = ok && uz < r;
+                line += uz * r;
+            }
+            const uint32_t b = (uint32_t)(((uint64_t)line * bl.magicG) >> 40);
+            const uint32_t ra = (line - b * bl.G) * r + ux;
+            const uint32_t va = ok ? 1u : 0u;
+            const uint32_t vb = (ok && (ux + 1u) < r) ? 1u : 0u;
+            out[q].bucket = ok ? b : 0u;
+            out[q].key = (ra & 0x1FFFu) | (((ra + 1u) & 0x1FFFu) << 13) | (va << 26) | (vb << 27);
+        } else {
+            uint32_t h = uy * kPrimeY;
+            if constexpr (DIM == 3) h ^= uz * kPrimeZ;
+            const uint32_t rowA = (ux ^ h) & mask;
+            const uint32_t rowB = ((ux + 1u) ^ h) & mask;
+            out[q].bucket = rowA >> bl.shift;
+            out[q].key = (rowA & (BR - 1u)) | ((rowB & (BR - 1u)) << 13) | (3u << 26);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- pass T
+// grad_output [N, LF] (T) -> gT [L][N][F] fp32. Block: kTransposeSamples samples.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict__ go, float *__restrict__ gT,
+                                                             int64_t N, int LF, int F) {
+    extern __shared__ float s_tile[];  // [kTransposeSamples][LF + 1]
+    const int64_t s0 = (int64_t)blockIdx.x * kTransposeSamples;
+    const int ns = (int)((N - s0 < kTransposeSamples) ? (N - s0) : kTransposeSamples);
+    const int total = ns * LF;
+    const T *src = go + s0 * LF;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int s = e / LF, c = e - s * LF;
+        s_tile[s * (LF + 1) + c] = Scalar<T>::load(src + e);
+    }
+    __syncthreads();
+    const int L = LF / F;
+    const int per_level = ns * F;
+    for (int l = 0; l < L; ++l) {
+        float *dst = gT + ((int64_t)l * N + s0) * F;
+        for (int e = threadIdx.x; e < per_level; e += 256) {
+            const int s = e / F, j = e - s * F;
+            dst[e] = s_tile[s * (LF + 1) + l * F + j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- pass A
+template <int DIM>
+__global__ __launch_bounds__(kBinThreads) void bin_count_kernel(LevelTable lt, BinPlan plan,
+                                                                const float *__restrict__ coords,
+                                                                uint32_t *__restrict__ cnt, int64_t sample0,
+                                                                int64_t N) {
+    __shared__ uint32_t s_hist[kMaxLevelBuckets];
+    const uint32_t tile = blockIdx.x, lvl = blockIdx.y;
+    const BinLevel bl = plan.lv[lvl];
+    if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t res = lt.res[lvl];
+    const float hi = lt.hi[lvl];
+    const bool dense = lt.dense[lvl] != 0;
+    for (int k = threadIdx.x; k < kTile; k += kBinThreads) {
+        const int64_t i = sample0 + (int64_t)tile * kTile + k;
+        if (i >= N) break;
+        double t[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
+        float fx;
+        PairSlot ps[1 << (DIM - 1)];
+        enumerate_pairs<DIM>(t, res, hi, dense, lt.mask, bl, plan.BR, fx, ps);
+#pragma unroll
+        for (int q = 0; q < (1 << (DIM - 1)); ++q)
+            if (ps[q].key >> 26) atomicAdd(&s_hist[ps[q].bucket], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < bl.nb)
+        cnt[(size_t)(bl.bucket0 + threadIdx.x) * plan.num_tiles + tile] = s_hist[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------- pass S
+// one wave per bucket: exclusive scan of cnt[bucket][0..num_tiles) in place; total -> totals[bucket]
+__global__ __launch_bounds__(64) void bin_scan_tiles_kernel(uint32_t *__restrict__ cnt, uint32_t *__restrict__ totals,
+                                                            uint32_t num_tiles) {
+    uint32_t *row = cnt + (size_t)blockIdx.x * num_tiles;
+    const uint32_t lane = threadIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < num_tiles; base += 64) {
+        const uint32_t idx = base + lane;
+        uint32_t v = (idx < num_tiles) ? row[idx] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t n = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += n;
+        }
+        if (idx < num_tiles) row[idx] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) totals[blockIdx.x] = carry;
+}
+
+// single block: bucket bases (exclusive scan of totals) and the consumer work list
+//   base[b]        first item of bucket b in the item array
+//   unit_first[b]  first work unit of bucket b; unit_first[total_buckets] = number of units
+__global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *__restrict__ totals,
+                                                                uint64_t *__restrict__ base,
+                                                                uint32_t *__restrict__ unit_first, uint32_t nb,
+                                                                uint32_t chunk_items) {
+    __shared__ uint64_t s_items[kMaxBuckets];
+    __shared__ uint32_t s_units[kMaxBuckets];
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+        const uint32_t c = totals[b];
+        s_items[b] = c;
+        s_units[b] = (c + chunk_items - 1) / chunk_items;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // <= 2048 entries: a serial scan costs ~2 us and keeps this trivially correct
+        uint64_t acc = 0;
+        uint32_t u = 0;
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint64_t c = s_items[b];
+            const uint32_t n = s_units[b];
+            base[b] = acc;
+            unit_first[b] = u;
+            acc += c;
+            u += n;
+        }
+        base[nb] = acc;
+        unit_first[nb] = u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- pass B
+template <int DIM, int F>
+__global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt, BinPlan plan,
+                                                                  const float *__restrict__ coords,
+                                                                  const float *__restrict__ gT,
+                                                                  const uint32_t *__restrict__ tile_off,
+                                                                  const uint64_t *__restrict__ base,
+                                                                  Item<F> *__restrict__ items, int64_t sample0,
+                                                                  int64_t N, int64_t Ntotal) {
+    constexpr int NP = 1 << (DIM - 1);
+    constexpr int SPT = kTile / kBinThreads;   // samples per thread
+    constexpr int kStage = kTile * NP;         // staged items per block
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    Item<F> *s_items = reinterpret_cast<Item<F> *>(s_raw);
+    uint8_t *s_bucket = reinterpret_cast<uint8_t *>(s_items + kStage);
+    __shared__ uint32_t s_hist[kMaxLevelBuckets];
+    __shared__ uint32_t s_start[kMaxLevelBuckets + 1];
+    __shared__ uint64_t s_gbase[kMaxLevelBuckets];
+
+    const uint32_t tile = blockIdx.x, lvl = blockIdx.y;
+    const BinLevel bl = plan.lv[lvl];
+    if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t res = lt.res[lvl];
+    const float hi = lt.hi[lvl];
+    const bool dense = lt.dense[lvl] != 0;
+
+    PairSlot ps[SPT][NP];
+    uint32_t rank[SPT][NP];
+    float fx[SPT];
+    float g[SPT][F];
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+        const int k = threadIdx.x + u * kBinThreads;
+        const int64_t i = sample0 + (int64_t)tile * kTile + k;
+        const bool live = i < N;
+        double t[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live ? coords[i * DIM + a] : 0.0f);
+        enumerate_pairs<DIM>(t, res, hi, dense, lt.mask, bl, plan.BR, fx[u], ps[u]);
+        if (live) {
+            const float *gp = gT + ((int64_t)lvl * Ntotal + i) * F;
+            if constexpr (F == 2) {
+                const float2 v = *reinterpret_cast<const float2 *>(gp);
+                g[u][0] = v.x; g[u][1] = v.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < F; ++j) g[u][j] = gp[j];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (!live) ps[u][q].key = 0;
+            rank[u][q] = (ps[u][q].key >> 26) ? atomicAdd(&s_hist[ps[u][q].bucket], 1u) : 0u;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t b = 0; b < bl.nb; ++b) {
+            s_start[b] = acc;
+            acc += s_hist[b];
+        }
+        s_start[bl.nb] = acc;
+    }
+    if (threadIdx.x < bl.nb) {
+        const size_t gb = bl.bucket0 + threadIdx.x;
+        s_gbase[threadIdx.x] = base[gb] + tile_off[gb * plan.num_tiles + tile];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (ps[u][q].key >> 26) {
+                const uint32_t pos = s_start[ps[u][q].bucket] + rank[u][q];
+                Item<F> it;
+                it.key = ps[u][q].key;
+                it.fx = fx[u];
+#pragma unroll
+                for (int j = 0; j < F; ++j) it.a[j] = g[u][j] * ps[u][q].wrest;
+                s_items[pos] = it;
+                s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t staged = s_start[bl.nb];
+    for (uint32_t pos = threadIdx.x; pos < staged; pos += kBinThreads) {
+        const uint32_t b = s_bucket[pos];
+        items[s_gbase[b] + (pos - s_start[b])] = s_items[pos];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- pass C
+template <int F>
+__global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable lt, BinPlan plan,
+                                                                      const int32_t *__restrict__ first_idx,
+                                                                      const uint64_t *__restrict__ base,
+                                                                      const uint32_t *__restrict__ unit_first,
+                                                                      const Item<F> *__restrict__ items,
+                                                                      float *__restrict__ grad_table,
+                                                                      int force_atomic) {
+    extern __shared__ double s_acc[];  // [rows_pb][F]
+    __shared__ uint32_t s_bucket;
+    const uint32_t nbk = plan.total_buckets;
+    const uint32_t unit = blockIdx.x;
+    if (unit >= unit_first[nbk]) return;
+    if (threadIdx.x == 0) {  // bucket of this unit: last b with unit_first[b] <= unit
+        uint32_t lo = 0, hi = nbk;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (unit_first[mid] <= unit) lo = mid; else hi = mid;
+        }
+        s_bucket = lo;
+    }
+    __syncthreads();
+    const uint32_t gb = s_bucket;
+    // level of the bucket
+    uint32_t lvl = 0;
+    for (uint32_t l = 1; l < (uint32_t)lt.num_lods; ++l)
+        if (plan.lv[l].bucket0 <= gb) lvl = l;
+    const BinLevel bl = plan.lv[lvl];
+    const uint32_t b = gb - bl.bucket0;
+    const uint32_t row0 = b * bl.rows_pb;
+    const uint32_t nrows = (bl.used - row0 < bl.rows_pb) ? (bl.used - row0) : bl.rows_pb;
+
+    for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) s_acc[e] = 0.0;
+    __syncthreads();
+
+    const uint32_t chunk = unit - unit_first[gb];
+    const uint64_t begin = base[gb] + (uint64_t)chunk * plan.chunk;
+    const uint64_t bucket_end = base[gb + 1];
+    const uint64_t end = (begin + plan.chunk < bucket_end) ? (begin + plan.chunk) : bucket_end;
+    for (uint64_t p = begin + threadIdx.x; p < end; p += kConsumeThreads) {
+        const Item<F> it = items[p];
+        const uint32_t ra = it.key & 0x1FFFu, rb = (it.key >> 13) & 0x1FFFu;
+        const float gx = 1.0f - it.fx;
+        if (it.key & (1u << 26)) {
+#pragma unroll
+            for (int j = 0; j < F; ++j) atomicAdd(&s_acc[ra * F + j], (double)(it.a[j] * gx));
+        }
+        if (it.key & (1u << 27)) {
+#pragma unroll
+            for (int j = 0; j < F; ++j) atomicAdd(&s_acc[rb * F + j], (double)(it.a[j] * it.fx));
+        }
+    }
+    __syncthreads();
+
+    const bool single = (unit_first[gb + 1] - unit_first[gb]) == 1 && !force_atomic;
+    const int64_t grow0 = (int64_t)first_idx[lvl] + row0;
+    for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) {
+        const int64_t grow = grow0 + e / F;
+        if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
+        const float v = (float)s_acc[e];
+        float *dst = grad_table + grow * F + (e % F);
+        if (single) *dst = v;
+        else if (v != 0.0f) unsafeAtomicAdd(dst, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan);
+
+bool bin_supported(int dim, const LevelTable &lt) {
+    const int F = lt.feature_dim;
+    if (F != 2 && F != 4) return false;
+    const uint32_t BR = 16384u / (uint32_t)F;  // 128 KiB of fp64 accumulators
+    for (int l = 0; l < lt.num_lods; ++l) {
+        const uint32_t res = (uint32_t)lt.res[l];
+        if (lt.dense[l]) {
+            if (res > BR) return false;  // a bucket must hold at least one x-line
+        } else {
+            // x ^ (x+1) must stay below BR so that both rows of a pair share a bucket
+            uint32_t bits = 0;
+            while ((1u << bits) <= res) ++bits;
+            if ((1u << bits) > BR && (lt.mask + 1u) > BR) return false;
+        }
+    }
+    BinPlan plan;
+    make_plan(dim, lt, kTile, plan);
+    if (plan.total_buckets > (uint32_t)kMaxBuckets) return false;
+    for (int l = 0; l < lt.num_lods; ++l)
+        if (plan.lv[l].nb > (uint32_t)kMaxLevelBuckets) return false;
+    return true;
+}
+
+static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan) {
+    const int F = lt.feature_dim;
+    const uint32_t BR = 16384u / (uint32_t)F;
+    uint32_t shift = 0;
+    while ((1u << shift) < BR) ++shift;
+    uint32_t nbk = 0;
+    for (int l = 0; l < lt.num_lods; ++l) {
+        BinLevel &bl = plan.lv[l];
+        const uint64_t res = (uint64_t)lt.res[l];
+        bl.bucket0 = nbk;
+        bl.shift = shift;
+        if (lt.dense[l]) {
+            const uint64_t lines = (dim == 3) ? res * res : res;
+            bl.used = (uint32_t)(lines * res);
+            bl.G = (uint32_t)(BR / res);
+            if (bl.G > lines) bl.G = (uint32_t)lines;
+            bl.rows_pb = (uint32_t)(bl.G * res);
+            bl.nb = (uint32_t)((lines + bl.G - 1) / bl.G);
+            bl.magicG = (((uint64_t)1 << 40) + bl.G - 1) / bl.G;
+        } else {
+            bl.used = lt.mask + 1u;
+            bl.rows_pb = (bl.used < BR) ? bl.used : BR;
+            bl.nb = (bl.used + BR - 1) / BR;
+            bl.G = 1;
+            bl.magicG = 0;
+        }
+        nbk += bl.nb;
+    }
+    plan.total_buckets = nbk;
+    plan.BR = BR;
+    plan.num_tiles = (uint32_t)((n_batch + kTile - 1) / kTile);
+    plan.pairs = 1u << (dim - 1);
+    // work-unit size: ~1/768 of the items so that an evenly loaded hashed bucket (1/64 of a level) is ONE unit
+    // (plain-store flush) while over-full coarse buckets split into equal chunks that keep all 256 CUs busy
+    uint64_t items = (uint64_t)n_batch * lt.num_lods * plan.pairs;
+    uint64_t chunk = items / 768 + 1024;
+    if (chunk < 8192) chunk = 8192;
+    if (chunk > (1u << 22)) chunk = 1u << 22;
+    plan.chunk = (uint32_t)chunk;
+}
+
+// sub-batch so that the item array stays below ~1.5 GiB
+static int64_t bin_batch_samples(int dim, const LevelTable &lt, int64_t n) {
+    const size_t item = 8 + 4 * (size_t)lt.feature_dim;
+    const size_t per_sample = (size_t)lt.num_lods * (1u << (dim - 1)) * item;
+    int64_t cap = (int64_t)(((size_t)1536 << 20) / per_sample);
+    cap = cap / kTile * kTile;
+    if (cap < kTile) cap = kTile;
+    return n < cap ? n : cap;
+}
+
+struct BinWorkspace {
+    float *gT;
+    unsigned char *items;
+    uint32_t *cnt;
+    uint32_t *totals;
+    uint64_t *base;
+    uint32_t *unit_first;
+    float *acc32;  // fp32 accumulation image for fp16 tables
+    size_t bytes;
+};
+
+static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, void *ws) {
+    BinPlan plan;
+    const int64_t nb = bin_batch_samples(dim, lt, n);
+    make_plan(dim, lt, nb, plan);
+    const size_t item = 8 + 4 * (size_t)lt.feature_dim;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_gT = take((size_t)n * lt.num_lods * lt.feature_dim * sizeof(float));
+    const size_t o_items = take((size_t)nb * lt.num_lods * plan.pairs * item);
+    const size_t o_cnt = take((size_t)plan.total_buckets * plan.num_tiles * sizeof(uint32_t));
+    const size_t o_tot = take((size_t)(plan.total_buckets + 1) * sizeof(uint32_t));
+    const size_t o_base = take((size_t)(plan.total_buckets + 1) * sizeof(uint64_t));
+    const size_t o_unit = take((size_t)(plan.total_buckets + 1) * sizeof(uint32_t));
+    const size_t o_acc = take(dtype == SHACIRA_F16 ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0);
+    BinWorkspace w{};
+    unsigned char *p = static_cast<unsigned char *>(ws);
+    if (p) {
+        w.gT = reinterpret_cast<float *>(p + o_gT);
+        w.items = p + o_items;
+        w.cnt = reinterpret_cast<uint32_t *>(p + o_cnt);
+        w.totals = reinterpret_cast<uint32_t *>(p + o_tot);
+        w.base = reinterpret_cast<uint64_t *>(p + o_base);
+        w.unit_first = reinterpret_cast<uint32_t *>(p + o_unit);
+        w.acc32 = reinterpret_cast<float *>(p + o_acc);
+    }
+    w.bytes = off;
+    return w;
+}
+
+size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n) {
+    return carve(dim, dtype, lt, n, nullptr).bytes;
+}
+
+float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace) {
+    return carve(dim, dtype, lt, n, workspace).acc32;
+}
+
+#define SHACIRA_CHECK_LAUNCH()                 \
+    do {                                       \
+        hipError_t e_ = hipGetLastError();     \
+        if (e_ != hipSuccess) return e_;       \
+    } while (0)
+
+template <int DIM, int F>
+static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                          const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s) {
+    const int L = lt.num_lods;
+    const int LF = L * F;
+    // pass T over the whole batch
+    {
+        const uint32_t blocks = (uint32_t)((n + kTransposeSamples - 1) / kTransposeSamples);
+        const size_t shmem = (size_t)kTransposeSamples * (LF + 1) * sizeof(float);
+        if (dtype == SHACIRA_F32)
+            hipLaunchKernelGGL(transpose_grad_kernel<float>, dim3(blocks), dim3(256), shmem, s,
+                               static_cast<const float *>(grad_out), w.gT, n, LF, F);
+        else
+            hipLaunchKernelGGL(transpose_grad_kernel<__half>, dim3(blocks), dim3(256), shmem, s,
+                               static_cast<const __half *>(grad_out), w.gT, n, LF, F);
+        SHACIRA_CHECK_LAUNCH();
+    }
+    const int64_t nb = bin_batch_samples(DIM, lt, n);
+    const bool multi = nb < n;
+    for (int64_t s0 = 0; s0 < n; s0 += nb) {
+        const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
+        BinPlan plan;
+        make_plan(DIM, lt, hi - s0, plan);
+        const dim3 grid(plan.num_tiles, (uint32_t)L);
+        hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, s, lt, plan, coords, w.cnt, s0, hi);
+        SHACIRA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, s, w.cnt, w.totals,
+                           plan.num_tiles);
+        SHACIRA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
+                           plan.total_buckets, plan.chunk);
+        SHACIRA_CHECK_LAUNCH();
+        constexpr int NP = 1 << (DIM - 1);
+        const size_t stage = (size_t)kTile * NP * (sizeof(Item<F>) + 1);
+        hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,
+                           w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n);
+        SHACIRA_CHECK_LAUNCH();
+        const uint64_t max_items = (uint64_t)(hi - s0) * L * NP;
+        const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + plan.total_buckets + 1;
+        const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
+        hipLaunchKernelGGL((bin_consume_kernel<F>), dim3(max_units), dim3(kConsumeThreads), acc_bytes, s, lt, plan,
+                           first_idx, w.base, w.unit_first, reinterpret_cast<const Item<F> *>(w.items), acc,
+                           multi ? 1 : 0);
+        SHACIRA_CHECK_LAUNCH();
+    }
+    return hipSuccess;
+}
+
+hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s) {
+    const BinWorkspace w = carve(dim, dtype, lt, n, workspace);
+    static std::once_flag once;  // kernels that use more than 64 KiB of dynamic LDS must opt in once per process
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        // dynamic LDS actually requested (static LDS of the kernels comes on top and must fit in 160 KiB too)
+        auto set = [](const void *fn, size_t bytes) {
+            if (bytes <= 64 * 1024) return;
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess) attr_err = e;
+        };
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<2>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<4>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4>), (size_t)kTile * 2 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
+    });
+    if (attr_err != hipSuccess) return attr_err;
+    if (dim == 3) {
+        return lt.feature_dim == 2 ? run_bin<3, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s)
+                                   : run_bin<3, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s);
+    }
+    return lt.feature_dim == 2 ? run_bin<2, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s)
+                               : run_bin<2, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s);
+}
+
+}  // namespace shacira
