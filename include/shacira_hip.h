@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SHACIRA_ABI_VERSION 1
+#define SHACIRA_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define SHACIRA_API __attribute__((visibility("default")))
@@ -63,11 +63,17 @@ SHACIRA_API const char *shacira_strerror(int code);
  *   feats              out, [num_coords, num_lods*feature_dim] of `dtype` (level-major, feature-minor)
  *   table_rows         total rows; used only to keep the reference's out-of-table corner (coord == +1 on a
  *                      dense level with res >= 258, weight 0) memory-safe
+ *   workspace          scratch of at least shacira_hashgrid_forward_workspace_bytes(...) bytes (level-major staging
+ *                      of the features; may be NULL when that returns 0)
  */
+SHACIRA_API size_t shacira_hashgrid_forward_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                                int codebook_bitwidth, const int32_t *resolutions_host,
+                                                int64_t table_rows, int dtype);
+
 SHACIRA_API int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
                              const int32_t *resolutions_host, const int32_t *codebook_first_idx,
                              int64_t table_rows, const float *coords, const void *codebook, int dtype,
-                             void *feats, void *stream);
+                             void *feats, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Backward: replaces hashgrid_interpolate_backward_cuda / hashgrid_interpolate2d_backward_cuda

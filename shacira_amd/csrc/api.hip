@@ -70,9 +70,18 @@ int shacira_get_option(const char *name) {
     return SHACIRA_EINVAL;
 }
 
+size_t shacira_hashgrid_forward_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                                int codebook_bitwidth, const int32_t *resolutions_host,
+                                                int64_t table_rows, int dtype) {
+    LevelTable lt;
+    if (build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt)) return 0;
+    return hashgrid_forward_workspace(dim, dtype, lt, num_coords);
+}
+
 int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
                              const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
-                             const float *coords, const void *codebook, int dtype, void *feats, void *stream) {
+                             const float *coords, const void *codebook, int dtype, void *feats, void *workspace,
+                             size_t workspace_bytes, void *stream) {
     LevelTable lt;
     int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
     if (rc) return rc;
@@ -80,8 +89,10 @@ int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feat
     if (num_coords < 0) return SHACIRA_EINVAL;
     if (num_coords == 0) return 0;
     if (!codebook_first_idx || !coords || !codebook || !feats) return SHACIRA_EINVAL;
-    return (int)hashgrid_forward_dispatch(dim, dtype, lt, codebook_first_idx, coords, codebook, feats, num_coords,
-                                          (hipStream_t)stream);
+    const size_t need = hashgrid_forward_workspace(dim, dtype, lt, num_coords);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
+    return (int)hashgrid_forward_dispatch(dim, dtype, lt, codebook_first_idx, coords, codebook, feats, workspace,
+                                          num_coords, (hipStream_t)stream);
 }
 
 size_t shacira_hashgrid_backward_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,

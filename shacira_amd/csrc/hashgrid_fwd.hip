@@ -14,6 +14,8 @@
 
 namespace shacira {
 
+static bool use_staged(int dim, const LevelTable &lt, int64_t n);
+
 template <typename T, int F> struct RowVec;  // one table row as a single vector access
 template <> struct RowVec<float, 2> { using type = float2; };
 template <> struct RowVec<float, 4> { using type = float4; };
@@ -113,9 +115,422 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(LevelTable lt, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Variant 1 ("sample per thread"): a thread walks the levels of ONE sample, keeps the L*F results in registers and
+// writes its feats row with full-width vector stores. All waves of the chip advance through the levels at about
+// the same pace, so at any moment the gathers of the whole chip target one or two level tables (<= 4 MiB each:
+// L2-resident) instead of all of them (48.8 MiB: Infinity-Cache bound, profiles/r01_microbench2_lds_gather.txt).
+// Level parameters are wave-uniform (scalar registers). MAXL bounds the register array.
+template <int DIM, typename T, int F>
+__global__ __launch_bounds__(256) void hashgrid_fwd_sample_kernel(LevelTable lt, const int32_t *__restrict__ first_idx,
+                                                                  const float *__restrict__ coords,
+                                                                  const T *__restrict__ table, T *__restrict__ feats,
+                                                                  int64_t N) {
+    constexpr int NC = 1 << DIM;
+    extern __shared__ __align__(16) float s_out[];  // [4 waves][64 samples][LFP], wave-private: no block barrier
+    const int L = lt.num_lods;
+    const int LF = L * F;
+    const int LFP = (LF + 3) / 4 * 4 + 4;  // row pitch in floats: 16-byte aligned rows, +4 to spread banks
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *my = s_out + (size_t)wave * 64 * LFP;
+    const int64_t wave_s0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    const int64_t i = wave_s0 + lane;
+    const bool live = i < N;
+    double t[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live ? coords[i * DIM + a] : 0.0f);
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+        Corners<DIM> c;
+        compute_corners<DIM>(t, lt.res[l], lt.hi[l], lt.dense[l] != 0, lt.mask, c);
+        const int64_t base = (int64_t)first_idx[l];
+        float acc[F];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int64_t row = base + (int64_t)c.row[k];
+            float v[F];
+            if (live && (uint64_t)row < (uint64_t)lt.table_rows) {
+                load_row<T, F>(table + row * F, v);
+            } else {
+#pragma unroll
+                for (int j = 0; j < F; ++j) v[j] = 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < F; ++j) acc[j] = (k == 0) ? v[j] * c.w[0] : fmaf(v[j], c.w[k], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < F; ++j) my[lane * LFP + l * F + j] = acc[j];
+    }
+    // the wave's 64 rows are contiguous in feats: write them with lane-consecutive addresses
+    const int64_t rows = (N - wave_s0 < 64) ? (N - wave_s0) : 64;
+    if (rows <= 0) return;
+    T *dst = feats + wave_s0 * LF;
+    const int total = (int)rows * LF;
+    if constexpr (sizeof(T) == 4) {
+        if ((LF & 3) == 0) {
+            const int q4 = LF >> 2;
+            for (int e = lane; e < total / 4; e += 64) {
+                const int r = e / q4, c4 = e - r * q4;
+                reinterpret_cast<float4 *>(dst)[e] = *reinterpret_cast<const float4 *>(my + r * LFP + c4 * 4);
+            }
+            return;
+        }
+    }
+    for (int e = lane; e < total; e += 64) {
+        const int r = e / LF, cc = e - r * LF;
+        Scalar<T>::store(dst + e, my[r * LFP + cc]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 3 ("x-pair per lane pair"): two adjacent lanes serve one sample; lane dx in {0,1} gathers the corners
+// (x+dx, y+dy, z+dz). Corners x and x+1 of a cell are neighbouring rows (dense levels) or rows that differ only in
+// low bits (hashed levels: row = (x ^ h) & mask), i.e. almost always the same 128-byte line -- and lanes of ONE wave
+// instruction that hit one line are merged into one L2 request (profiles/r01_microbench2_lds_gather.txt), so this
+// halves the L2 request count, the resource the forward is bound by. The even lane pulls its partner's values with
+// DPP (no LDS) and runs the reference's fmaf chain in the reference's corner order (k = dx*4 + dy*2 + dz), so the
+// result stays bit-identical. Levels are walked in a rolled loop (wave-uniform parameters), results staged in
+// wave-private LDS and written as contiguous float4 rows, like variant 1.
+template <int DIM, typename T, int F>
+__global__ __launch_bounds__(256) void hashgrid_fwd_pair_kernel(LevelTable lt, const int32_t *__restrict__ first_idx,
+                                                                const float *__restrict__ coords,
+                                                                const T *__restrict__ table, T *__restrict__ feats,
+                                                                int64_t N) {
+    constexpr int NH = 1 << (DIM - 1);              // corners per lane
+    extern __shared__ __align__(16) float s_out[];  // [4 waves][32 samples][LFP]
+    const int L = lt.num_lods;
+    const int LF = L * F;
+    const int LFP = (LF + 3) / 4 * 4 + 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dx = lane & 1, sl = lane >> 1;        // x offset of this lane, sample slot within the wave
+    float *my = s_out + (size_t)wave * 32 * LFP;
+    const int64_t wave_s0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t i = wave_s0 + sl;
+    const bool live = i < N;
+    double t[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live ? coords[i * DIM + a] : 0.0f);
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+        const int32_t res = lt.res[l];
+        const float hi = lt.hi[l];
+        const bool dense = lt.dense[l] != 0;
+        int32_t p[DIM];
+        float f[DIM], g[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) axis_transform(t[a], res, hi, p[a], f[a], g[a]);
+        const uint32_t ux = (uint32_t)p[0] + (uint32_t)dx;
+        const uint32_t r = (uint32_t)res;
+        const int64_t base = (int64_t)first_idx[l];
+        float v[NH][F];
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const int dy = (DIM == 3) ? (q >> 1) : q;
+            const int dz = (DIM == 3) ? (q & 1) : 0;
+            const uint32_t uy = (uint32_t)p[1] + dy;
+            uint32_t row;
+            if (dense) {
+                row = ux + uy * r;
+                if constexpr (DIM == 3) row += ((uint32_t)p[2] + dz) * r * r;
+            } else {
+                row = ux ^ (uy * kPrimeY);
+                if constexpr (DIM == 3) row ^= ((uint32_t)p[2] + dz) * kPrimeZ;
+                row &= lt.mask;
+            }
+            const int64_t grow = base + (int64_t)row;
+            if (live && (uint64_t)grow < (uint64_t)lt.table_rows) {
+                load_row<T, F>(table + grow * F, v[q]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < F; ++j) v[q][j] = 0.0f;
+            }
+        }
+        // partner's values: lane ^ 1 (DPP quad_perm [1,0,3,2])
+        float pv[NH][F];
+#pragma unroll
+        for (int q = 0; q < NH; ++q)
+#pragma unroll
+            for (int j = 0; j < F; ++j)
+                pv[q][j] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[q][j]), 0xB1, 0xF, 0xF, true));
+        if (dx == 0) {
+            // weights in the reference's order: (wx*wy)*wz, corner k = dx*4 + dy*2 + dz (3-D) / dx*2 + dy (2-D)
+            float acc[F];
+#pragma unroll
+            for (int k = 0; k < 2 * NH; ++k) {
+                const int kx = k / NH, q = k % NH;
+                const int dy = (DIM == 3) ? (q >> 1) : q;
+                const int dz = (DIM == 3) ? (q & 1) : 0;
+                float w = (kx ? f[0] : g[0]) * (dy ? f[1] : g[1]);
+                if constexpr (DIM == 3) w = w * (dz ? f[2] : g[2]);
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    const float tv = kx ? pv[q][j] : v[q][j];
+                    acc[j] = (k == 0) ? tv * w : fmaf(tv, w, acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < F; ++j) my[sl * LFP + l * F + j] = acc[j];
+        }
+    }
+    const int64_t rows = (N - wave_s0 < 32) ? (N - wave_s0) : 32;
+    if (rows <= 0) return;
+    T *dst = feats + wave_s0 * LF;
+    const int total = (int)rows * LF;
+    if constexpr (sizeof(T) == 4) {
+        if ((LF & 3) == 0) {
+            const int q4 = LF >> 2;
+            for (int e = lane; e < total / 4; e += 64) {
+                const int rr = e / q4, c4 = e - rr * q4;
+                reinterpret_cast<float4 *>(dst)[e] = *reinterpret_cast<const float4 *>(my + rr * LFP + c4 * 4);
+            }
+            return;
+        }
+    }
+    for (int e = lane; e < total; e += 64) {
+        const int rr = e / LF, cc = e - rr * LF;
+        Scalar<T>::store(dst + e, my[rr * LFP + cc]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 2 ("level per XCD"): block = (level, tile of 256 samples). Blocks are numbered so that the blocks an
+// XCD receives under round-robin dispatch (blockIdx % 8, a speed assumption only) all work on the same level:
+// XCD k walks levels k, k+8, k+16, ... one after the other, so its 4 MiB L2 holds exactly one level table and
+// every table is pulled from the Infinity Cache by one XCD only.
+template <int DIM, typename T, int F>
+__global__ __launch_bounds__(256) void hashgrid_fwd_level_kernel(LevelTable lt, const int32_t *__restrict__ first_idx,
+                                                                 const float *__restrict__ coords,
+                                                                 const T *__restrict__ table, T *__restrict__ feats,
+                                                                 int64_t N, uint32_t tiles) {
+    constexpr int NC = 1 << DIM;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t q = blockIdx.x >> 3;
+    const uint32_t lvl = xcd + 8u * (q / tiles);
+    const uint32_t tile = q % tiles;
+    if (lvl >= (uint32_t)lt.num_lods) return;
+    const int64_t i = (int64_t)tile * 256 + threadIdx.x;
+    if (i >= N) return;
+    double t[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
+    Corners<DIM> c;
+    compute_corners<DIM>(t, lt.res[lvl], lt.hi[lvl], lt.dense[lvl] != 0, lt.mask, c);
+    const int64_t base = (int64_t)first_idx[lvl];
+    float acc[F];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int64_t row = base + (int64_t)c.row[k];
+        float v[F];
+        if ((uint64_t)row < (uint64_t)lt.table_rows) {
+            load_row<T, F>(table + row * F, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < F; ++j) v[j] = 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < F; ++j) acc[j] = (k == 0) ? v[j] * c.w[0] : fmaf(v[j], c.w[k], acc[j]);
+    }
+    store_row<T, F>(feats + (i * lt.num_lods + lvl) * F, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 4 = variant 2's schedule (one level per XCD at a time, so the XCD's 4 MiB L2 holds exactly that level's
+// table) + variant 3's lane pairing (corners x / x+1 in one instruction -> one L2 request). The per-level feature
+// piece of a sample (F scalars) is written with a non-temporal store and coords are read non-temporally so that
+// the streams do not evict the table from L2 (a plain 8-byte store allocates a whole 128-byte line).
+template <int DIM, typename T, int F, int U, bool TRANSPOSED = false>
+__global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable lt,
+                                                                      const int32_t *__restrict__ first_idx,
+                                                                      const float *__restrict__ coords,
+                                                                      const T *__restrict__ table,
+                                                                      T *__restrict__ feats, int64_t N,
+                                                                      uint32_t tiles) {
+    constexpr int NH = 1 << (DIM - 1);
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t qb = blockIdx.x >> 3;
+    const uint32_t lvl = xcd + 8u * (qb / tiles);
+    const uint32_t tile = qb % tiles;
+    if (lvl >= (uint32_t)lt.num_lods) return;
+    const int dx = threadIdx.x & 1;
+    const int32_t res = lt.res[lvl];
+    const float hi = lt.hi[lvl];
+    const bool dense = lt.dense[lvl] != 0;
+    const uint32_t r = (uint32_t)res;
+    const int64_t base = (int64_t)first_idx[lvl];
+    float v[U][NH][F];
+    float f[U][DIM], g[U][DIM];
+    bool live[U];
+    int64_t idx[U];
+    // issue all U*NH gathers before consuming any (memory-level parallelism)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = ((int64_t)tile * U + u) * 128 + (threadIdx.x >> 1);
+        idx[u] = i;
+        live[u] = i < N;
+        double t[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live[u] ? coords[i * DIM + a] : 0.0f);
+        int32_t p[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) axis_transform(t[a], res, hi, p[a], f[u][a], g[u][a]);
+        const uint32_t ux = (uint32_t)p[0] + (uint32_t)dx;
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const int dy = (DIM == 3) ? (q >> 1) : q;
+            const int dz = (DIM == 3) ? (q & 1) : 0;
+            const uint32_t uy = (uint32_t)p[1] + dy;
+            uint32_t row;
+            if (dense) {
+                row = ux + uy * r;
+                if constexpr (DIM == 3) row += ((uint32_t)p[2] + dz) * r * r;
+            } else {
+                row = ux ^ (uy * kPrimeY);
+                if constexpr (DIM == 3) row ^= ((uint32_t)p[2] + dz) * kPrimeZ;
+                row &= lt.mask;
+            }
+            const int64_t grow = base + (int64_t)row;
+            if (live[u] && (uint64_t)grow < (uint64_t)lt.table_rows) {
+                load_row<T, F>(table + grow * F, v[u][q]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < F; ++j) v[u][q][j] = 0.0f;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float pv[NH][F];
+#pragma unroll
+        for (int q = 0; q < NH; ++q)
+#pragma unroll
+            for (int j = 0; j < F; ++j)
+                pv[q][j] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[u][q][j]), 0xB1, 0xF, 0xF, true));
+        if (dx == 0 && live[u]) {
+            float acc[F];
+#pragma unroll
+            for (int k = 0; k < 2 * NH; ++k) {
+                const int kx = k / NH, q = k % NH;
+                const int dy = (DIM == 3) ? (q >> 1) : q;
+                const int dz = (DIM == 3) ? (q & 1) : 0;
+                float w = (kx ? f[u][0] : g[u][0]) * (dy ? f[u][1] : g[u][1]);
+                if constexpr (DIM == 3) w = w * (dz ? f[u][2] : g[u][2]);
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    const float tv = kx ? pv[q][j] : v[u][q][j];
+                    acc[j] = (k == 0) ? tv * w : fmaf(tv, w, acc[j]);
+                }
+            }
+            if constexpr (TRANSPOSED) store_row<T, F>(feats + ((int64_t)lvl * N + idx[u]) * F, acc);
+            else store_row<T, F>(feats + (idx[u] * lt.num_lods + lvl) * F, acc);
+        }
+    }
+}
+
+// [L][N][F] -> [N][L*F] through LDS: both sides coalesced. Block: 64 samples.
+template <typename T>
+__global__ __launch_bounds__(256) void untranspose_feats_kernel(const T *__restrict__ src, T *__restrict__ dst,
+                                                                int64_t N, int L, int F) {
+    extern __shared__ __align__(16) unsigned char s_raw_t[];
+    T *s_tile = reinterpret_cast<T *>(s_raw_t);  // [64][LF + 2]
+    const int LF = L * F;
+    const int pitch = LF + 2;
+    const int64_t s0 = (int64_t)blockIdx.x * 64;
+    const int ns = (int)((N - s0 < 64) ? (N - s0) : 64);
+    const int per_level = ns * F;
+    for (int l = 0; l < L; ++l) {
+        const T *p = src + ((int64_t)l * N + s0) * F;
+        for (int e = threadIdx.x; e < per_level; e += 256) {
+            const int sm = e / F, j = e - sm * F;
+            s_tile[sm * pitch + l * F + j] = p[e];
+        }
+    }
+    __syncthreads();
+    T *out = dst + s0 * LF;
+    const int total = ns * LF;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int sm = e / LF, c = e - sm * LF;
+        out[e] = s_tile[sm * pitch + c];
+    }
+}
+
 template <int DIM, typename T, int F>
 static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, const float *coords, const void *table,
-                             void *feats, int64_t num_coords, hipStream_t stream) {
+                             void *feats, void *workspace, int64_t num_coords, hipStream_t stream) {
+    const int variant = g_fwd_variant.load();
+    if constexpr (F > 0) {
+        if (use_staged(DIM, lt, num_coords) && workspace) {
+            // variant 6: level-per-XCD schedule with lane pairing, features staged level-major (coalesced stores),
+            // then one transposing copy into the caller's [N, L*F] layout
+            const uint32_t groups = (uint32_t)((lt.num_lods + 7) / 8);
+            const uint32_t tiles = (uint32_t)((num_coords + 127) / 128);
+            hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true>), dim3(8u * tiles * groups),
+                               dim3(256), 0, stream, lt, first_idx, coords, static_cast<const T *>(table),
+                               static_cast<T *>(workspace), num_coords, tiles);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            const int LF = lt.num_lods * F;
+            const size_t shmem = (size_t)64 * (LF + 2) * sizeof(T);
+            hipLaunchKernelGGL(untranspose_feats_kernel<T>, dim3((uint32_t)((num_coords + 63) / 64)), dim3(256), shmem,
+                               stream, static_cast<const T *>(workspace), static_cast<T *>(feats), num_coords,
+                               lt.num_lods, F);
+            return hipGetLastError();
+        }
+        if (variant == 1) {
+            const uint32_t blocks = (uint32_t)((num_coords + 255) / 256);
+            const int LFP = (lt.num_lods * F + 3) / 4 * 4 + 4;
+            const size_t shmem = (size_t)256 * LFP * sizeof(float);
+            if (shmem <= 64 * 1024) {
+                hipLaunchKernelGGL((hashgrid_fwd_sample_kernel<DIM, T, F>), dim3(blocks), dim3(256), shmem, stream, lt,
+                                   first_idx, coords, static_cast<const T *>(table), static_cast<T *>(feats),
+                                   num_coords);
+                return hipGetLastError();
+            }
+        }
+        if (variant == 3 || variant < 0) {
+            const uint32_t blocks = (uint32_t)((num_coords + 127) / 128);
+            const int LFP = (lt.num_lods * F + 3) / 4 * 4 + 4;
+            const size_t shmem = (size_t)128 * LFP * sizeof(float);
+            if (shmem <= 64 * 1024) {
+                hipLaunchKernelGGL((hashgrid_fwd_pair_kernel<DIM, T, F>), dim3(blocks), dim3(256), shmem, stream, lt,
+                                   first_idx, coords, static_cast<const T *>(table), static_cast<T *>(feats),
+                                   num_coords);
+                return hipGetLastError();
+            }
+        }
+        if (variant == 96) {  // EXPERIMENT ONLY: level-major output layout (wrong for callers), to price the stores
+            const uint32_t groups = (uint32_t)((lt.num_lods + 7) / 8);
+            const uint32_t tiles = (uint32_t)((num_coords + 127) / 128);
+            hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true>), dim3(8u * tiles * groups),
+                               dim3(256), 0, stream, lt, first_idx, coords, static_cast<const T *>(table),
+                               static_cast<T *>(feats), num_coords, tiles);
+            return hipGetLastError();
+        }
+        if (variant == 4 || variant == 5) {
+            const uint32_t groups = (uint32_t)((lt.num_lods + 7) / 8);
+            if (variant == 4) {
+                const uint32_t tiles = (uint32_t)((num_coords + 127) / 128);
+                hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1>), dim3(8u * tiles * groups), dim3(256),
+                                   0, stream, lt, first_idx, coords, static_cast<const T *>(table),
+                                   static_cast<T *>(feats), num_coords, tiles);
+            } else {
+                const uint32_t tiles = (uint32_t)((num_coords + 511) / 512);
+                hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 4>), dim3(8u * tiles * groups), dim3(256),
+                                   0, stream, lt, first_idx, coords, static_cast<const T *>(table),
+                                   static_cast<T *>(feats), num_coords, tiles);
+            }
+            return hipGetLastError();
+        }
+        if (variant == 2) {
+            const uint32_t tiles = (uint32_t)((num_coords + 255) / 256);
+            const uint32_t groups = (uint32_t)((lt.num_lods + 7) / 8);
+            hipLaunchKernelGGL((hashgrid_fwd_level_kernel<DIM, T, F>), dim3(8u * tiles * groups), dim3(256), 0, stream,
+                               lt, first_idx, coords, static_cast<const T *>(table), static_cast<T *>(feats),
+                               num_coords, tiles);
+            return hipGetLastError();
+        }
+    }
     // items are indexed with 32 bits inside a launch; chunk the samples so that samples*L < 2^31
     const int64_t L = lt.num_lods;
     const int64_t max_samples = ((int64_t)1 << 31) / L - 1;
@@ -133,23 +548,37 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
 
 template <int DIM, typename T>
 static hipError_t dispatch_f(const LevelTable &lt, const int32_t *first_idx, const float *coords, const void *table,
-                             void *feats, int64_t n, hipStream_t s) {
+                             void *feats, void *ws, int64_t n, hipStream_t s) {
     switch (lt.feature_dim) {
-        case 2: return launch_fwd<DIM, T, 2>(lt, first_idx, coords, table, feats, n, s);
-        case 4: return launch_fwd<DIM, T, 4>(lt, first_idx, coords, table, feats, n, s);
-        default: return launch_fwd<DIM, T, 0>(lt, first_idx, coords, table, feats, n, s);
+        case 2: return launch_fwd<DIM, T, 2>(lt, first_idx, coords, table, feats, ws, n, s);
+        case 4: return launch_fwd<DIM, T, 4>(lt, first_idx, coords, table, feats, ws, n, s);
+        default: return launch_fwd<DIM, T, 0>(lt, first_idx, coords, table, feats, ws, n, s);
     }
 }
 
+// level-major staging buffer [L][N][F] of the table's scalar type (variant 6)
+static bool use_staged(int dim, const LevelTable &lt, int64_t n) {
+    const int v = g_fwd_variant.load();
+    if (lt.feature_dim != 2 && lt.feature_dim != 4) return false;
+    if (v == 6) return true;
+    return v < 0 && dim == 3 && n >= 16384;   // measured: 3-D large batches; 2-D and small batches: variant 3
+}
+
+size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
+    if (lt.feature_dim != 2 && lt.feature_dim != 4) return 0;
+    (void)dim;
+    return (size_t)n * lt.num_lods * lt.feature_dim * (dtype == SHACIRA_F32 ? 4 : 2);
+}
+
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
-                                     const float *coords, const void *table, void *feats, int64_t n,
+                                     const float *coords, const void *table, void *feats, void *ws, int64_t n,
                                      hipStream_t s) {
     if (dim == 3) {
-        return dtype == SHACIRA_F32 ? dispatch_f<3, float>(lt, first_idx, coords, table, feats, n, s)
-                                    : dispatch_f<3, __half>(lt, first_idx, coords, table, feats, n, s);
+        return dtype == SHACIRA_F32 ? dispatch_f<3, float>(lt, first_idx, coords, table, feats, ws, n, s)
+                                    : dispatch_f<3, __half>(lt, first_idx, coords, table, feats, ws, n, s);
     }
-    return dtype == SHACIRA_F32 ? dispatch_f<2, float>(lt, first_idx, coords, table, feats, n, s)
-                                : dispatch_f<2, __half>(lt, first_idx, coords, table, feats, n, s);
+    return dtype == SHACIRA_F32 ? dispatch_f<2, float>(lt, first_idx, coords, table, feats, ws, n, s)
+                                : dispatch_f<2, __half>(lt, first_idx, coords, table, feats, ws, n, s);
 }
 
 }  // namespace shacira

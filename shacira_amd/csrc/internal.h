@@ -8,8 +8,10 @@
 namespace shacira {
 
 // hashgrid_fwd.hip
+size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
-                                     const float *coords, const void *table, void *feats, int64_t n, hipStream_t s);
+                                     const float *coords, const void *table, void *feats, void *workspace, int64_t n,
+                                     hipStream_t s);
 // hashgrid_bwd.hip
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
 hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,

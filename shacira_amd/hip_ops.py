@@ -48,10 +48,15 @@ def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, cod
     res = tuple(int(r) for r in resolution)
     N, T, F = coords.shape[0], codebook.shape[0], codebook.shape[1]
     feats = torch.empty((N, F * len(res)), dtype=codebook.dtype, device=codebook.device)
+    dt = _dtype_code(codebook)
+    L = _lib.lib()
     with torch.cuda.device(codebook.device):
-        rc = _lib.lib().shacira_hashgrid_forward(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
-                                                 _ptr(codebook_first_idx), T, _ptr(coords), _ptr(codebook),
-                                                 _dtype_code(codebook), _ptr(feats), _stream(codebook))
+        nbytes = L.shacira_hashgrid_forward_workspace_bytes(dim, N, len(res), F, int(codebook_bitwidth),
+                                                            _res_array(res), T, dt)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=codebook.device) if nbytes else None
+        rc = L.shacira_hashgrid_forward(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
+                                        _ptr(codebook_first_idx), T, _ptr(coords), _ptr(codebook), dt, _ptr(feats),
+                                        _ptr(ws), nbytes, _stream(codebook))
     _lib.check(rc, "hashgrid_interpolate")
     return feats
 

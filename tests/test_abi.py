@@ -19,7 +19,7 @@ def declared_symbols():
 
 def test_header_and_binding_list_the_same_symbols():
     syms = declared_symbols()
-    assert len(syms) >= 13
+    assert len(syms) >= 14
     assert sorted(_lib.SIGNATURES.keys()) == syms
 
 
@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(handle, name), name
-    assert _lib.lib().shacira_abi_version() == 1
+    assert _lib.lib().shacira_abi_version() == 2
 
 
 def test_argument_validation_codes():
@@ -36,20 +36,23 @@ def test_argument_validation_codes():
     res = (ctypes.c_int32 * 2)(16, 32)
     one = ctypes.c_void_p(16)  # never dereferenced: validation fails first or N == 0
     fwd = L.shacira_hashgrid_forward
-    assert fwd(4, 0, 2, 2, 8, res, one, 10, one, one, 0, one, None) == _lib.EINVAL          # dim
-    assert fwd(2, 0, 0, 2, 8, res, one, 10, one, one, 0, one, None) == _lib.EINVAL          # num_lods
-    assert fwd(2, 0, 33, 2, 8, res, one, 10, one, one, 0, one, None) == _lib.EINVAL         # > SHACIRA_MAX_LODS
-    assert fwd(2, 0, 2, 3, 8, res, one, 10, one, one, 0, one, None) == _lib.EODD            # odd feature dim
-    assert fwd(2, 0, 2, 2, 31, res, one, 10, one, one, 0, one, None) == _lib.EINVAL         # bitwidth
-    assert fwd(2, 0, 2, 2, 8, res, one, 10, one, one, 7, one, None) == _lib.EDTYPE          # dtype
-    assert fwd(2, -1, 2, 2, 8, res, one, 10, one, one, 0, one, None) == _lib.EINVAL         # negative N
-    assert fwd(2, 0, 2, 2, 8, res, one, 10, one, one, 0, one, None) == 0                    # N == 0: nothing to do
-    assert fwd(2, 5, 2, 2, 8, res, None, 10, one, one, 0, one, None) == _lib.EINVAL         # null pointer
+    assert fwd(4, 0, 2, 2, 8, res, one, 10, one, one, 0, one, None, 0, None) == _lib.EINVAL     # dim
+    assert fwd(2, 0, 0, 2, 8, res, one, 10, one, one, 0, one, None, 0, None) == _lib.EINVAL     # num_lods
+    assert fwd(2, 0, 33, 2, 8, res, one, 10, one, one, 0, one, None, 0, None) == _lib.EINVAL    # > SHACIRA_MAX_LODS
+    assert fwd(2, 0, 2, 3, 8, res, one, 10, one, one, 0, one, None, 0, None) == _lib.EODD       # odd feature dim
+    assert fwd(2, 0, 2, 2, 31, res, one, 10, one, one, 0, one, None, 0, None) == _lib.EINVAL    # bitwidth
+    assert fwd(2, 0, 2, 2, 8, res, one, 10, one, one, 7, one, None, 0, None) == _lib.EDTYPE     # dtype
+    assert fwd(2, -1, 2, 2, 8, res, one, 10, one, one, 0, one, None, 0, None) == _lib.EINVAL    # negative N
+    assert fwd(2, 0, 2, 2, 8, res, one, 10, one, one, 0, one, None, 0, None) == 0               # N == 0: nothing to do
+    assert fwd(2, 5, 2, 2, 8, res, None, 10, one, one, 0, one, None, 0, None) == _lib.EINVAL    # null pointer
+    assert fwd(2, 5, 2, 2, 8, res, one, 10, one, one, 0, one, None, 0, None) == _lib.EWORKSPACE # workspace missing
+    assert L.shacira_hashgrid_forward_workspace_bytes(2, 5, 2, 2, 8, res, 10, 0) == 5 * 2 * 2 * 4
     assert L.shacira_latent_decode_forward(0, 5, 2, one, one, one, None, None, 0.0, one, None) == _lib.EDTYPE
     assert L.shacira_latent_decode_forward(0, 2, 2, one, one, one, None, None, 0.0, one, None) == 0
     assert L.shacira_entropy_bits_forward(0, 2, 5, one, None, one, one, one, 1 << 20, None) == _lib.EINVAL
     assert L.shacira_entropy_bits_forward(0, 2, 2, one, None, one, one, one, 16, None) == _lib.EWORKSPACE
-    assert L.shacira_hashgrid_backward_workspace_bytes(3, 1000, 2, 2, 8, res, 100, 1) == 100 * 2 * 4
+    assert L.shacira_hashgrid_backward_workspace_bytes(3, 1000, 2, 2, 8, res, 100, 1) >= 100 * 2 * 4   # fp16: fp32 image
+    assert L.shacira_hashgrid_backward_workspace_bytes(3, 0, 2, 2, 8, res, 100, 0) == 0
     assert b"multiple of 2" in L.shacira_strerror(_lib.EODD)
     assert L.shacira_set_option(b"nope", 1) == _lib.EINVAL
     with pytest.raises(Exception, match="multiple of 2"):

@@ -51,11 +51,21 @@ def run(dim, res, bw, N, F=2, seed=0, check=True, iters=20):
     tfw /= iters; tbw /= iters
     nc = 2 ** dim
     bytes_f = 4 * dim + len(res) * nc * F * 4 + len(res) * F * 4
-    msg += f"  fwd {tfw:.3f} ms ({N*bytes_f/tfw/1e9:.0f} GB/s)  bwd {tbw:.3f} ms ({N*bytes_f/tbw/1e9:.0f} GB/s)  fwd+bwd {N/(tfw+tbw)/1e6:.1f} Msamples/s"
+    msg += f"  fwd {tfw:.3f} ms ({N*bytes_f/tfw/1e6:.0f} GB/s)  bwd {tbw:.3f} ms ({N*bytes_f/tbw/1e6:.0f} GB/s)  fwd+bwd {N/(tfw+tbw)/1e3:.1f} Msamples/s"
     print(msg, flush=True)
 
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), "abi", _lib.lib().shacira_abi_version())
+    for fv in (3, 6, -1):
+        _lib.set_option("fwd_variant", fv)
+        print("fwd_variant", fv)
+        run(3, geo(16, 2048, 16), 19, 20000)
+        run(3, geo(16, 2048, 16), 19, 1 << 20, check=False)
+        run(2, geo(16, 2048, 16), 19, 1 << 20, check=False)
+        run(2, geo(16, 512, 16), 11, 393216, check=False)
+        run(3, geo(16, 2048, 16), 19, 65536, check=False)
+    _lib.set_option("fwd_variant", -1)
+    print("auto")
     run(2, geo(16, 512, 8), 11, 50000)
     run(2, geo(16, 512, 16), 11, 50000)
     run(2, geo(16, 2048, 16), 19, 50000)
