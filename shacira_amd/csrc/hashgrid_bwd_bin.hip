@@ -44,6 +44,8 @@ struct BinLevel {
     uint64_t magicG;    // ceil(2^40 / G): line / G == (line * magicG) >> 40 for line < 2^20
     uint32_t used;      // rows of the level the kernels can touch: dense res^d, hashed 2^bw
     uint32_t shift;     // hashed: log2(BR)
+    int32_t dgroup;     // >= 0: "direct" level (fits one LDS image): index of its group; -1: binned level
+    uint32_t drow0;     // direct: first row of the level inside its group's LDS image
 };
 
 struct BinPlan {
@@ -53,6 +55,11 @@ struct BinPlan {
     uint32_t num_tiles;
     uint32_t pairs;     // items per (sample, level) = 2^(dim-1)
     uint32_t chunk;     // items per consumer work unit
+    uint32_t nbl;       // number of binned levels
+    uint8_t blevel[SHACIRA_MAX_LODS];   // their level indices (grid.y of passes A/B)
+    uint32_t ngroups;   // groups of direct levels
+    uint32_t gmask[SHACIRA_MAX_LODS];   // levels of each group (bit l)
+    uint32_t grows[SHACIRA_MAX_LODS];   // rows of each group's LDS image
 };
 
 template <int F> struct Item {
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(LevelTable lt, B
                                                                 uint32_t *__restrict__ cnt, int64_t sample0,
                                                                 int64_t N) {
     __shared__ uint32_t s_hist[kMaxLevelBuckets];
-    const uint32_t tile = blockIdx.x, lvl = blockIdx.y;
+    const uint32_t tile = blockIdx.x, lvl = plan.blevel[blockIdx.y];
     const BinLevel bl = plan.lv[lvl];
     if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     __shared__ uint32_t s_start[kMaxLevelBuckets + 1];
     __shared__ uint64_t s_gbase[kMaxLevelBuckets];
 
-    const uint32_t tile = blockIdx.x, lvl = blockIdx.y;
+    const uint32_t tile = blockIdx.x, lvl = plan.blevel[blockIdx.y];
     const BinLevel bl = plan.lv[lvl];
     if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -347,9 +354,9 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     __syncthreads();
     const uint32_t gb = s_bucket;
     // level of the bucket
-    uint32_t lvl = 0;
-    for (uint32_t l = 1; l < (uint32_t)lt.num_lods; ++l)
-        if (plan.lv[l].bucket0 <= gb) lvl = l;
+    uint32_t lvl = plan.blevel[0];
+    for (uint32_t q = 1; q < plan.nbl; ++q)
+        if (plan.lv[plan.blevel[q]].bucket0 <= gb) lvl = plan.blevel[q];
     const BinLevel bl = plan.lv[lvl];
     const uint32_t b = gb - bl.bucket0;
     const uint32_t row0 = b * bl.rows_pb;
@@ -362,17 +369,27 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     const uint64_t begin = base[gb] + (uint64_t)chunk * plan.chunk;
     const uint64_t bucket_end = base[gb + 1];
     const uint64_t end = (begin + plan.chunk < bucket_end) ? (begin + plan.chunk) : bucket_end;
-    for (uint64_t p = begin + threadIdx.x; p < end; p += kConsumeThreads) {
-        const Item<F> it = items[p];
-        const uint32_t ra = it.key & 0x1FFFu, rb = (it.key >> 13) & 0x1FFFu;
-        const float gx = 1.0f - it.fx;
-        if (it.key & (1u << 26)) {
+    constexpr int UN = 4;  // items in flight per thread
+    for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
+        Item<F> it[UN];
 #pragma unroll
-            for (int j = 0; j < F; ++j) atomicAdd(&s_acc[ra * F + j], (double)(it.a[j] * gx));
+        for (int u = 0; u < UN; ++u) {
+            const uint64_t p = p0 + (uint64_t)u * kConsumeThreads;
+            if (p < end) it[u] = items[p];
+            else it[u].key = 0;
         }
-        if (it.key & (1u << 27)) {
 #pragma unroll
-            for (int j = 0; j < F; ++j) atomicAdd(&s_acc[rb * F + j], (double)(it.a[j] * it.fx));
+        for (int u = 0; u < UN; ++u) {
+            const uint32_t ra = it[u].key & 0x1FFFu, rb = (it[u].key >> 13) & 0x1FFFu;
+            const float gx = 1.0f - it[u].fx;
+            if (it[u].key & (1u << 26)) {
+#pragma unroll
+                for (int j = 0; j < F; ++j) atomicAdd(&s_acc[ra * F + j], (double)(it[u].a[j] * gx));
+            }
+            if (it[u].key & (1u << 27)) {
+#pragma unroll
+                for (int j = 0; j < F; ++j) atomicAdd(&s_acc[rb * F + j], (double)(it[u].a[j] * it[u].fx));
+            }
         }
     }
     __syncthreads();
@@ -386,6 +403,62 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         float *dst = grad_table + grow * F + (e % F);
         if (single) *dst = v;
         else if (v != 0.0f) unsafeAtomicAdd(dst, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- direct levels
+// Levels whose whole (used) row range fits one LDS image need no partitioning at all: a workgroup keeps a private
+// fp64 image of a GROUP of such levels, walks its share of the samples adding every corner with ds_add_f64, and
+// adds the image to the (zeroed) gradient table with coalesced float atomics at the end.
+template <int DIM, int F>
+__global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(LevelTable lt, BinPlan plan,
+                                                                            const int32_t *__restrict__ first_idx,
+                                                                            const float *__restrict__ coords,
+                                                                            const float *__restrict__ gT,
+                                                                            float *__restrict__ grad_table,
+                                                                            int64_t N) {
+    constexpr int NC = 1 << DIM;
+    extern __shared__ double s_acc[];
+    const uint32_t grp = blockIdx.y;
+    const uint32_t rows = plan.grows[grp];
+    const uint32_t mask = plan.gmask[grp];
+    for (uint32_t e = threadIdx.x; e < rows * F; e += kConsumeThreads) s_acc[e] = 0.0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kConsumeThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kConsumeThreads + threadIdx.x; i < N; i += stride) {
+        double t[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
+        for (int l = 0; l < lt.num_lods; ++l) {
+            if (!((mask >> l) & 1u)) continue;
+            const BinLevel bl = plan.lv[l];
+            Corners<DIM> c;
+            compute_corners<DIM>(t, lt.res[l], lt.hi[l], lt.dense[l] != 0, lt.mask, c);
+            const float *gp = gT + ((int64_t)l * N + i) * F;
+            float g[F];
+#pragma unroll
+            for (int j = 0; j < F; ++j) g[j] = gp[j];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if (c.row[k] < bl.used) {
+                    double *dst = s_acc + (size_t)(bl.drow0 + c.row[k]) * F;
+#pragma unroll
+                    for (int j = 0; j < F; ++j) atomicAdd(dst + j, (double)(g[j] * c.w[k]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int l = 0; l < lt.num_lods; ++l) {
+        if (!((mask >> l) & 1u)) continue;
+        const BinLevel bl = plan.lv[l];
+        const int64_t grow0 = (int64_t)first_idx[l];
+        for (uint32_t e = threadIdx.x; e < bl.used * F; e += kConsumeThreads) {
+            const int64_t grow = grow0 + e / F;
+            if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
+            const float v = (float)s_acc[(size_t)bl.drow0 * F + e];
+            if (v != 0.0f) unsafeAtomicAdd(grad_table + grow * F + (e % F), v);
+        }
     }
 }
 
@@ -423,11 +496,15 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
     uint32_t shift = 0;
     while ((1u << shift) < BR) ++shift;
     uint32_t nbk = 0;
+    plan.nbl = 0;
+    plan.ngroups = 0;
     for (int l = 0; l < lt.num_lods; ++l) {
         BinLevel &bl = plan.lv[l];
         const uint64_t res = (uint64_t)lt.res[l];
         bl.bucket0 = nbk;
         bl.shift = shift;
+        bl.dgroup = -1;
+        bl.drow0 = 0;
         if (lt.dense[l]) {
             const uint64_t lines = (dim == 3) ? res * res : res;
             bl.used = (uint32_t)(lines * res);
@@ -443,7 +520,25 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
             bl.G = 1;
             bl.magicG = 0;
         }
-        nbk += bl.nb;
+        if (bl.nb == 1 && bl.used <= BR) {
+            // direct level: first group with room (greedy); groups hold <= BR rows
+            uint32_t gi = 0;
+            while (gi < plan.ngroups && plan.grows[gi] + bl.used > BR) ++gi;
+            if (gi == plan.ngroups) {
+                plan.gmask[gi] = 0;
+                plan.grows[gi] = 0;
+                ++plan.ngroups;
+            }
+            bl.dgroup = (int32_t)gi;
+            bl.drow0 = plan.grows[gi];
+            plan.grows[gi] += bl.used;
+            plan.gmask[gi] |= 1u << l;
+            bl.bucket0 = 0xFFFFFFFFu;
+            bl.nb = 0;
+        } else {
+            plan.blevel[plan.nbl++] = (uint8_t)l;
+            nbk += bl.nb;
+        }
     }
     plan.total_buckets = nbk;
     plan.BR = BR;
@@ -451,7 +546,7 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
     plan.pairs = 1u << (dim - 1);
     // work-unit size: ~1/768 of the items so that an evenly loaded hashed bucket (1/64 of a level) is ONE unit
     // (plain-store flush) while over-full coarse buckets split into equal chunks that keep all 256 CUs busy
-    uint64_t items = (uint64_t)n_batch * lt.num_lods * plan.pairs;
+    uint64_t items = (uint64_t)n_batch * plan.nbl * plan.pairs;
     uint64_t chunk = items / 768 + 1024;
     if (chunk < 8192) chunk = 8192;
     if (chunk > (1u << 22)) chunk = 1u << 22;
@@ -461,7 +556,9 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
 // sub-batch so that the item array stays below ~1.5 GiB
 static int64_t bin_batch_samples(int dim, const LevelTable &lt, int64_t n) {
     const size_t item = 8 + 4 * (size_t)lt.feature_dim;
-    const size_t per_sample = (size_t)lt.num_lods * (1u << (dim - 1)) * item;
+    BinPlan plan;
+    make_plan(dim, lt, kTile, plan);
+    const size_t per_sample = (size_t)(plan.nbl ? plan.nbl : 1) * (1u << (dim - 1)) * item;
     int64_t cap = (int64_t)(((size_t)1536 << 20) / per_sample);
     cap = cap / kTile * kTile;
     if (cap < kTile) cap = kTile;
@@ -487,7 +584,7 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_gT = take((size_t)n * lt.num_lods * lt.feature_dim * sizeof(float));
-    const size_t o_items = take((size_t)nb * lt.num_lods * plan.pairs * item);
+    const size_t o_items = take((size_t)nb * plan.nbl * plan.pairs * item);
     const size_t o_cnt = take((size_t)plan.total_buckets * plan.num_tiles * sizeof(uint32_t));
     const size_t o_tot = take((size_t)(plan.total_buckets + 1) * sizeof(uint32_t));
     const size_t o_base = take((size_t)(plan.total_buckets + 1) * sizeof(uint64_t));
@@ -539,13 +636,29 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                                static_cast<const __half *>(grad_out), w.gT, n, LF, F);
         SHACIRA_CHECK_LAUNCH();
     }
+    // direct levels: one pass over the whole batch, no items
+    {
+        BinPlan plan;
+        make_plan(DIM, lt, n, plan);
+        if (plan.ngroups > 0) {
+            uint32_t bpg = 512u / plan.ngroups;                       // ~512 workgroups in total
+            const uint32_t need = (uint32_t)((n + 2047) / 2048);      // at least ~2 samples per thread each
+            if (bpg > need) bpg = need;
+            if (bpg < 1) bpg = 1;
+            const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
+            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F>), dim3(bpg, plan.ngroups), dim3(kConsumeThreads),
+                               acc_bytes, s, lt, plan, first_idx, coords, w.gT, acc, n);
+            SHACIRA_CHECK_LAUNCH();
+        }
+        if (plan.nbl == 0) return hipSuccess;
+    }
     const int64_t nb = bin_batch_samples(DIM, lt, n);
     const bool multi = nb < n;
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
         BinPlan plan;
         make_plan(DIM, lt, hi - s0, plan);
-        const dim3 grid(plan.num_tiles, (uint32_t)L);
+        const dim3 grid(plan.num_tiles, plan.nbl);
         hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, s, lt, plan, coords, w.cnt, s0, hi);
         SHACIRA_CHECK_LAUNCH();
         hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, s, w.cnt, w.totals,
@@ -559,7 +672,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,
                            w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n);
         SHACIRA_CHECK_LAUNCH();
-        const uint64_t max_items = (uint64_t)(hi - s0) * L * NP;
+        const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NP;
         const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + plan.total_buckets + 1;
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         hipLaunchKernelGGL((bin_consume_kernel<F>), dim3(max_units), dim3(kConsumeThreads), acc_bytes, s, lt, plan,
@@ -582,6 +695,10 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (e != hipSuccess) attr_err = e;
         };
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<2, 2>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<2, 4>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<3, 2>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<3, 4>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
