@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="S1_nerf_hash_3d_L16_F2_bw19_N2^20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--psnr-steps", type=int, default=1000, help="image-fit steps for the PSNR figure (0 = skip)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 17)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()
@@ -150,6 +151,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # PSNR at a fixed step (second half of BASELINE.json's metric): config-B LatentGrid (16-level 2-D, F=2, latent
+    # quantisation + entropy model on) fitted to a 512x768 procedural image, pixels sharded over the ranks with one
+    # gradient all-reduce per step; OUTSIDE the timed throughput region.
+    psnr = None
+    if args.psnr_steps > 0:
+        from shacira_amd import harness
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        fit = harness.fit_image(device, steps=args.psnr_steps, rank=rank, world=world)
+        torch.cuda.synchronize()
+        psnr = {"value": fit["psnr"], "unit": "dB (clamped_psnr)", "step": args.psnr_steps,
+                "config": "B: 2-D LatentGrid L16 F2 ld1 bw11 res16..512, quant+entropy on, 512x768 procedural image, "
+                          "Adam (kodak.yaml learning rates)", "bpp": fit["bpp"], "rgb_loss": fit["rgb_loss"],
+                "seconds": time.perf_counter() - tp, "n_gpus": world}
+
     if rank == 0:
         ms_fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
         ms_bwd = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
@@ -175,6 +191,7 @@ def main():
                          "fwd_bwd_path": {"achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS,
                                           "bytes_per_sample": b_fwd + b_bwd}},
             "ms": {"forward": ms_fwd, "backward": ms_bwd, "allreduce": ms_ar},
+            "psnr": psnr,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, res, bw, F, first_np, T, min(args.cpu_samples, n_local),

@@ -79,3 +79,53 @@ def test_shard_bounds_cover_batch_exactly():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
     assert sdist.global_mean_loss(torch.tensor(8.0), 4, 2).item() == 1.0
+
+
+# ------------------------------------------------------------------------------------------------ DP image fit
+def _patch_oracle_ops():
+    """Test-only: the hash-grid operator on CPU is the C oracle (the product has no CPU path)."""
+    from oracle import hashgrid_c as oc
+    from shacira_amd import hip_ops
+
+    def fwd(coords, codebook, first_idx, resolution, bw):
+        return torch.from_numpy(oc.forward(coords.detach().numpy(), codebook.detach().numpy(), first_idx.numpy(),
+                                           list(resolution), bw))
+
+    def bwd(dim, coords, grad_output, table_rows, table_dtype, first_idx, resolution, bw, feature_dim):
+        g = oc.backward(coords.detach().numpy(), grad_output.detach().numpy(), (table_rows, feature_dim),
+                        first_idx.numpy(), list(resolution), bw)
+        return torch.from_numpy(g.astype(np.float32))
+
+    hip_ops.hashgrid_interpolate2d_cuda = fwd
+    hip_ops.hashgrid_interpolate_cuda = fwd
+    hip_ops.hashgrid_backward = bwd
+
+
+def _fit_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from shacira_amd import harness
+    _patch_oracle_ops()
+    sdist.init_from_env("gloo")
+    r = harness.fit_image(torch.device("cpu"), steps=25, height=32, width=48, seed=4, rank=rank, world=world)
+    if rank == 0:
+        torch.save(r, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_image_fit_two_ranks_matches_one_rank(tmp_path, monkeypatch):
+    """Sharded pixels + one gradient all-reduce per step reproduce the single-process fit (PSNR at a fixed step)."""
+    out = str(tmp_path / "fit.pt")
+    mp.spawn(_fit_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    two = torch.load(out)
+    from shacira_amd import harness, hip_ops
+    saved = (hip_ops.hashgrid_interpolate2d_cuda, hip_ops.hashgrid_interpolate_cuda, hip_ops.hashgrid_backward)
+    try:
+        _patch_oracle_ops()
+        one = harness.fit_image(torch.device("cpu"), steps=25, height=32, width=48, seed=4)
+    finally:
+        hip_ops.hashgrid_interpolate2d_cuda, hip_ops.hashgrid_interpolate_cuda, hip_ops.hashgrid_backward = saved
+    assert abs(two["psnr"] - one["psnr"]) < 0.05, (two["psnr"], one["psnr"])
+    assert two["rgb_loss"] == pytest.approx(one["rgb_loss"], rel=1e-3)
+    assert two["bpp"] == pytest.approx(one["bpp"], rel=1e-2)

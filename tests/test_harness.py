@@ -1,0 +1,73 @@
+"""The minimal image-fit caller (shacira_amd/harness.py): host logic on CPU with the operator swapped for the oracle
+(test-only), and -- on the GPU -- PSNR at a fixed step of the HIP path against that CPU restatement."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hashgrid_c as oc
+from shacira_amd import harness, hip_ops
+
+
+@pytest.fixture
+def oracle_op(monkeypatch):
+    def fwd(dim):
+        def f(coords, codebook, first_idx, resolution, bw):
+            return torch.from_numpy(oc.forward(coords.detach().numpy(), codebook.detach().numpy(), first_idx.numpy(),
+                                               list(resolution), bw))
+        return f
+
+    def bwd(dim, coords, grad_output, table_rows, table_dtype, first_idx, resolution, bw, feature_dim):
+        g = oc.backward(coords.detach().numpy(), grad_output.detach().numpy(), (table_rows, feature_dim),
+                        first_idx.numpy(), list(resolution), bw)
+        return torch.from_numpy(g.astype(np.float32))
+
+    monkeypatch.setattr(hip_ops, "hashgrid_interpolate_cuda", fwd(3))
+    monkeypatch.setattr(hip_ops, "hashgrid_interpolate2d_cuda", fwd(2))
+    monkeypatch.setattr(hip_ops, "hashgrid_backward", bwd)
+
+
+def test_image_and_coords_are_deterministic():
+    a, b = harness.make_test_image(32, 48, seed=3), harness.make_test_image(32, 48, seed=3)
+    assert a.shape == (32, 48, 3) and a.dtype == np.float32 and np.array_equal(a, b)
+    assert 0.0 <= a.min() and a.max() <= 1.0 and a.std() > 0.05
+    c = harness.image_coords(4, 6)
+    assert c.shape == (24, 2) and float(c.min()) == -1.0 and float(c.max()) < 1.0
+    assert torch.allclose(c[7], torch.tensor([(1 / 4 - 0.5) * 2, (1 / 6 - 0.5) * 2]))   # axis 0 = image row
+
+
+def test_param_groups_follow_reference_names():
+    grid, cdec, cent = harness.kodak_like_grid(num_lods=4)
+    nef = harness.NeuralImage(grid, hidden_dim=8)
+    groups = {g["name"]: g for g in harness.param_groups(nef)}
+    names = {id(p): n for n, p in nef.named_parameters()}
+    assert sorted(names[id(p)] for p in groups["grid"]["params"]) == ["grid.codebook"]
+    assert sorted(names[id(p)] for p in groups["latent_dec"]["params"]) == \
+        ["grid.latent_dec.div", "grid.latent_dec.layers.0.scale", "grid.latent_dec.layers.0.shift"]
+    assert all(names[id(p)].startswith("grid.prob_model.") for p in groups["prob_models"]["params"])
+    assert all(names[id(p)].startswith("decoder_color.") for p in groups["decoder"]["params"])
+    assert (groups["grid"]["lr"], groups["latent_dec"]["lr"], groups["prob_models"]["lr"]) == (0.02, 0.01, 1e-4)
+    assert groups["latent_dec"]["weight_decay"] == 0.01 and groups["decoder"]["weight_decay"] == 0.0
+
+
+def test_fit_improves_psnr_on_cpu_restatement(oracle_op):
+    r = harness.fit_image(torch.device("cpu"), steps=60, height=48, width=64, seed=1, log_every=20)
+    first, last = r["history"][0], r["history"][-1]
+    assert last[2] > first[2] + 1.0, r["history"]          # PSNR rises
+    assert np.isfinite(r["bpp"]) and r["bpp"] > 0 and r["avg_bits"] > 0
+
+
+@pytest.mark.gpu
+def test_psnr_at_fixed_step_gpu_vs_cpu_restatement(oracle_op, monkeypatch):
+    """Same init, same batches, same (CPU-drawn) entropy noise: the HIP path and the CPU restatement of the
+    reference kernels must reach the same PSNR at step 300 (fp32 summation order differs, so not bit-equal)."""
+    cpu = harness.fit_image(torch.device("cpu"), steps=300, height=96, width=128, seed=2, log_every=1)
+    monkeypatch.undo()                                      # the real HIP operators
+    gpu = harness.fit_image(torch.device("cuda:0"), steps=300, height=96, width=128, seed=2, log_every=1)
+    # rounding (STE) makes the trajectory chaotic in its last bits (the torch MLP GEMMs differ between the devices
+    # too), so compare the level reached -- mean over the last 20 steps -- not one noisy sample
+    tail = lambda r: float(np.mean([h[2] for h in r["history"][-20:]]))
+    assert abs(tail(gpu) - tail(cpu)) <= 0.25, (tail(gpu), tail(cpu))
+    first10 = lambda r: np.array([h[2] for h in r["history"][:10]])
+    np.testing.assert_allclose(first10(gpu), first10(cpu), atol=0.02)   # early steps: still the same trajectory
+    assert gpu["psnr"] > 20.0
+    assert abs(gpu["bpp"] - cpu["bpp"]) / cpu["bpp"] < 0.05
