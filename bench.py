@@ -174,6 +174,13 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         value = world * n_local * args.steps / elapsed
         dom = ("backward", ms_bwd, b_bwd) if ms_bwd >= ms_fwd else ("forward", ms_fwd, b_fwd)
+        # HBM bytes per launch from the PMC counters (collected offline with rocprofv3 --pmc in separate passes on
+        # the same operators and workload; see the note inside the file). Only valid for the workload it was taken on.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if args.workload.startswith("S1_") and os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh)["operators"].get(dom[0], {}).get("hbm_bytes_per_launch")
         achieved = dom[2] * n_local / (dom[1] * 1e-3) / 1e9
         path_gbs = (b_fwd + b_bwd) * n_local / ((ms_fwd + ms_bwd) * 1e-3) / 1e9
         out = {
@@ -184,9 +191,13 @@ def main():
             "config": {"workload": args.workload, "dim": dim, "levels": L, "feature_dim": F, "bitwidth": bw,
                        "table_rows": T, "samples_per_gpu": n_local,
                        "parallelism": f"dp{world}" + ("+allreduce(grad_codebook)" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": f"hashgrid_{dom[0]} (C-ABI call, HIP events on its stream)",
+            "roofline": {"bound": "hbm",
+                         "kernel": (f"hashgrid_{dom[0]} operator = one C-ABI call, HIP events on its stream; kernels: "
+                                    + ("transpose_grad + bin_count + 2 scans + bin_scatter + bin_consume + "
+                                       "direct_accumulate" if dom[0] == "backward" else
+                                       "hashgrid_fwd_level_pair + untranspose_feats")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": dom[2] * n_local,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": dom[2] * n_local,
                          "ms_per_launch": dom[1],
                          "fwd_bwd_path": {"achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS,
                                           "bytes_per_sample": b_fwd + b_bwd}},
