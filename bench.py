@@ -126,14 +126,14 @@ def main():
         grad = hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F)
         if ev:
             ev[2].record()
-        if world > 1:
+        if dist.is_initialized():
             dist.all_reduce(grad)                                          # one RCCL all-reduce (sum) per step
         if ev:
             ev[3].record()
         return feats, grad
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,7 +147,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -210,7 +210,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -34,7 +34,6 @@ constexpr int kBinThreads = 512;      // threads of passes A and B
 constexpr int kConsumeThreads = 1024;
 constexpr int kMaxBuckets = 2048;     // over all levels
 constexpr int kMaxLevelBuckets = 128; // per level (LDS histogram size)
-constexpr int kTransposeSamples = 64; // samples per block of pass T
 
 struct BinLevel {
     uint32_t nb;        // buckets in this level
@@ -125,29 +124,31 @@ __device__ __forceinline__ void enumerate_pairs(const double (&t)[DIM], int32_t 
 }
 
 // ------------------------------------------------------------------------------------------------- pass T
-// grad_output [N, LF] (T) -> gT [L][N][F] fp32. Block: kTransposeSamples samples.
-template <typename T>
+// grad_output [N, L*F] (T) -> gT [L][N][F] fp32, through LDS, F scalars per lane per access. Block: 256 samples.
+template <typename T, int F>
 __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict__ go, float *__restrict__ gT,
-                                                             int64_t N, int LF, int F) {
-    extern __shared__ float s_tile[];  // [kTransposeSamples][LF + 1]
-    const int64_t s0 = (int64_t)blockIdx.x * kTransposeSamples;
-    const int ns = (int)((N - s0 < kTransposeSamples) ? (N - s0) : kTransposeSamples);
-    const int total = ns * LF;
-    const T *src = go + s0 * LF;
+                                                             int64_t N, int L) {
+    struct alignas(sizeof(T) * F) PieceIn { T v[F]; };
+    struct alignas(sizeof(float) * F) PieceOut { float v[F]; };
+    extern __shared__ __align__(16) unsigned char s_raw_g[];
+    PieceOut *s_tile = reinterpret_cast<PieceOut *>(s_raw_g);  // [256][L + 1]
+    const int pitch = L + 1;
+    const int64_t s0 = (int64_t)blockIdx.x * 256;
+    const int ns = (int)((N - s0 < 256) ? (N - s0) : 256);
+    const PieceIn *in = reinterpret_cast<const PieceIn *>(go) + s0 * L;
+    const int total = ns * L;
     for (int e = threadIdx.x; e < total; e += 256) {
-        const int s = e / LF, c = e - s * LF;
-        s_tile[s * (LF + 1) + c] = Scalar<T>::load(src + e);
+        const int sm = e / L, l = e - sm * L;
+        const PieceIn p = in[e];
+        PieceOut q;
+#pragma unroll
+        for (int j = 0; j < F; ++j) q.v[j] = Scalar<T>::load(&p.v[j]);
+        s_tile[sm * pitch + l] = q;
     }
     __syncthreads();
-    const int L = LF / F;
-    const int per_level = ns * F;
-    for (int l = 0; l < L; ++l) {
-        float *dst = gT + ((int64_t)l * N + s0) * F;
-        for (int e = threadIdx.x; e < per_level; e += 256) {
-            const int s = e / F, j = e - s * F;
-            dst[e] = s_tile[s * (LF + 1) + l * F + j];
-        }
-    }
+    PieceOut *out = reinterpret_cast<PieceOut *>(gT);
+    for (int l = 0; l < L; ++l)
+        if ((int)threadIdx.x < ns) out[(int64_t)l * N + s0 + threadIdx.x] = s_tile[threadIdx.x * pitch + l];
 }
 
 // ------------------------------------------------------------------------------------------------- pass A
@@ -623,17 +624,16 @@ template <int DIM, int F>
 static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                           const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s) {
     const int L = lt.num_lods;
-    const int LF = L * F;
     // pass T over the whole batch
     {
-        const uint32_t blocks = (uint32_t)((n + kTransposeSamples - 1) / kTransposeSamples);
-        const size_t shmem = (size_t)kTransposeSamples * (LF + 1) * sizeof(float);
+        const uint32_t blocks = (uint32_t)((n + 255) / 256);
+        const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
         if (dtype == SHACIRA_F32)
-            hipLaunchKernelGGL(transpose_grad_kernel<float>, dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const float *>(grad_out), w.gT, n, LF, F);
+            hipLaunchKernelGGL((transpose_grad_kernel<float, F>), dim3(blocks), dim3(256), shmem, s,
+                               static_cast<const float *>(grad_out), w.gT, n, L);
         else
-            hipLaunchKernelGGL(transpose_grad_kernel<__half>, dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const __half *>(grad_out), w.gT, n, LF, F);
+            hipLaunchKernelGGL((transpose_grad_kernel<__half, F>), dim3(blocks), dim3(256), shmem, s,
+                               static_cast<const __half *>(grad_out), w.gT, n, L);
         SHACIRA_CHECK_LAUNCH();
     }
     // direct levels: one pass over the whole batch, no items
@@ -695,6 +695,10 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (e != hipSuccess) attr_err = e;
         };
+        set(reinterpret_cast<const void *>(&transpose_grad_kernel<float, 2>), 140 * 1024);
+        set(reinterpret_cast<const void *>(&transpose_grad_kernel<float, 4>), 140 * 1024);
+        set(reinterpret_cast<const void *>(&transpose_grad_kernel<__half, 2>), 140 * 1024);
+        set(reinterpret_cast<const void *>(&transpose_grad_kernel<__half, 4>), 140 * 1024);
         set(reinterpret_cast<const void *>(&direct_accumulate_kernel<2, 2>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&direct_accumulate_kernel<2, 4>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&direct_accumulate_kernel<3, 2>), 16384 * sizeof(double));

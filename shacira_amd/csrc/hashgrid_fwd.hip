@@ -10,6 +10,8 @@
 //   - coords are fetched once per sample by L neighbouring lanes (same address -> one request);
 //   - each corner row (F scalars) is fetched by ONE vector load of F*sizeof(T) bytes.
 // HBM-bound: algorithmic bytes per sample = 4*DIM + L*2^DIM*F*s + L*F*s.
+#include <mutex>
+
 #include "internal.h"
 
 namespace shacira {
@@ -428,30 +430,26 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
     }
 }
 
-// [L][N][F] -> [N][L*F] through LDS: both sides coalesced. Block: 64 samples.
-template <typename T>
+// [L][N][F] -> [N][L*F] through LDS: both sides coalesced. Block: 256 samples; every access is one 8-byte
+// (fp32, F == 2) or F*sizeof(T)-byte piece per lane, lanes consecutive.
+template <typename T, int F>
 __global__ __launch_bounds__(256) void untranspose_feats_kernel(const T *__restrict__ src, T *__restrict__ dst,
-                                                                int64_t N, int L, int F) {
+                                                                int64_t N, int L) {
+    struct alignas(sizeof(T) * F) Piece { T v[F]; };
     extern __shared__ __align__(16) unsigned char s_raw_t[];
-    T *s_tile = reinterpret_cast<T *>(s_raw_t);  // [64][LF + 2]
-    const int LF = L * F;
-    const int pitch = LF + 2;
-    const int64_t s0 = (int64_t)blockIdx.x * 64;
-    const int ns = (int)((N - s0 < 64) ? (N - s0) : 64);
-    const int per_level = ns * F;
-    for (int l = 0; l < L; ++l) {
-        const T *p = src + ((int64_t)l * N + s0) * F;
-        for (int e = threadIdx.x; e < per_level; e += 256) {
-            const int sm = e / F, j = e - sm * F;
-            s_tile[sm * pitch + l * F + j] = p[e];
-        }
-    }
+    Piece *s_tile = reinterpret_cast<Piece *>(s_raw_t);  // [256][L + 1] pieces
+    const int pitch = L + 1;
+    const int64_t s0 = (int64_t)blockIdx.x * 256;
+    const int ns = (int)((N - s0 < 256) ? (N - s0) : 256);
+    const Piece *in = reinterpret_cast<const Piece *>(src);
+    for (int l = 0; l < L; ++l)
+        if ((int)threadIdx.x < ns) s_tile[threadIdx.x * pitch + l] = in[(int64_t)l * N + s0 + threadIdx.x];
     __syncthreads();
-    T *out = dst + s0 * LF;
-    const int total = ns * LF;
+    Piece *out = reinterpret_cast<Piece *>(dst) + s0 * L;
+    const int total = ns * L;
     for (int e = threadIdx.x; e < total; e += 256) {
-        const int sm = e / LF, c = e - sm * LF;
-        out[e] = s_tile[sm * pitch + c];
+        const int sm = e / L, l = e - sm * L;
+        out[e] = s_tile[sm * pitch + l];
     }
 }
 
@@ -470,11 +468,15 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
                                static_cast<T *>(workspace), num_coords, tiles);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
-            const int LF = lt.num_lods * F;
-            const size_t shmem = (size_t)64 * (LF + 2) * sizeof(T);
-            hipLaunchKernelGGL(untranspose_feats_kernel<T>, dim3((uint32_t)((num_coords + 63) / 64)), dim3(256), shmem,
-                               stream, static_cast<const T *>(workspace), static_cast<T *>(feats), num_coords,
-                               lt.num_lods, F);
+            const size_t shmem = (size_t)256 * (lt.num_lods + 1) * F * sizeof(T);
+            static std::once_flag once;  // per instantiation: allow > 64 KiB of dynamic LDS (L = 32, F = 4, fp32)
+            std::call_once(once, [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&untranspose_feats_kernel<T, F>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+            });
+            hipLaunchKernelGGL((untranspose_feats_kernel<T, F>), dim3((uint32_t)((num_coords + 255) / 256)), dim3(256),
+                               shmem, stream, static_cast<const T *>(workspace), static_cast<T *>(feats), num_coords,
+                               lt.num_lods);
             return hipGetLastError();
         }
         if (variant == 1) {

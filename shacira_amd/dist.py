@@ -25,7 +25,8 @@ def init_from_env(backend=None):
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # torchrun: join even a 1-rank group
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kwargs = {}

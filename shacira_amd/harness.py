@@ -176,7 +176,8 @@ class ImageFitter:
             stats = torch.stack([sq_sum.detach(), ((q(pred) - q(self.rgb)) ** 2).sum()]).double()
         if self.bucket is not None:
             self.bucket.allreduce()
-            dist.all_reduce(stats)
+            if dist.is_initialized():
+                dist.all_reduce(stats)
         self.optimizer.step()
         n = self.global_pixels * 3
         rgb_loss = float(stats[0]) / n

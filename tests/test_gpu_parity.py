@@ -127,6 +127,17 @@ def test_other_feature_dims(dev, dim, F):
     np.testing.assert_allclose(grad.cpu().numpy(), ref_g, rtol=RTOL, atol=RTOL * np.abs(ref_g).max())
 
 
+def test_max_levels_and_wide_features(dev):
+    """SHACIRA_MAX_LODS = 32 levels with F = 4 (largest staging tiles of the transposing passes), 3-D and 2-D."""
+    for dim, bw in ((3, 14), (2, 12)):
+        res = geo(8, 300, 32)
+        sizes, first, T, coords, table, go = _problem(dim, res, bw, 20_011, F=4)
+        feats, grad = _run(dev, dim, res, bw, coords, table, go, first)
+        assert np.array_equal(feats.cpu().numpy(), oc.forward(coords, table, first, res, bw))
+        ref_g = oc.backward(coords, go, (T, 4), first, res, bw)
+        np.testing.assert_allclose(grad.cpu().numpy(), ref_g, rtol=RTOL, atol=RTOL * np.abs(ref_g).max())
+
+
 def test_out_of_table_corner_is_memory_safe(dev):
     # dense 2-D level, res >= 258, coord == +1: the reference reads one row past the table with weight 0 (UB)
     res, bw = [300], 19
