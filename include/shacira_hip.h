@@ -156,6 +156,7 @@ SHACIRA_API int shacira_entropy_bits_backward(int64_t num_rows, int latent_dim, 
 /*
  * Tunables (process-wide, read at call time; for benchmarking and A/B only).
  *   "fwd_variant", "bwd_variant": integer algorithm selectors, -1 = automatic.
+ *   "bin_batch_mib": cap (MiB) of the backward's item array; larger batches are processed in sub-batches.
  */
 SHACIRA_API int shacira_set_option(const char *name, int value);
 SHACIRA_API int shacira_get_option(const char *name);

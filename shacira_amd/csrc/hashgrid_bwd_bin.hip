@@ -554,13 +554,13 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
     plan.chunk = (uint32_t)chunk;
 }
 
-// sub-batch so that the item array stays below ~1.5 GiB
+// sub-batch so that the item array stays below the cap (default 1.5 GiB, option "bin_batch_mib")
 static int64_t bin_batch_samples(int dim, const LevelTable &lt, int64_t n) {
     const size_t item = 8 + 4 * (size_t)lt.feature_dim;
     BinPlan plan;
     make_plan(dim, lt, kTile, plan);
     const size_t per_sample = (size_t)(plan.nbl ? plan.nbl : 1) * (1u << (dim - 1)) * item;
-    int64_t cap = (int64_t)(((size_t)1536 << 20) / per_sample);
+    int64_t cap = (int64_t)(((size_t)g_bin_batch_mib.load() << 20) / per_sample);
     cap = cap / kTile * kTile;
     if (cap < kTile) cap = kTile;
     return n < cap ? n : cap;

@@ -44,5 +44,6 @@ hipError_t entropy_dispatch(bool bwd, int ld, const EntropyArgs &a, hipStream_t 
 // api.hip: tunables
 extern std::atomic<int> g_fwd_variant;
 extern std::atomic<int> g_bwd_variant;
+extern std::atomic<int> g_bin_batch_mib;
 
 }  // namespace shacira

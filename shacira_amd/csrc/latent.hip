@@ -46,15 +46,23 @@ __device__ __forceinline__ void block_reduce_store(const float (&acc)[NRED], dou
     }
 }
 
-// out[q] = scale * sum_b partials[b][q]; the nred results are split over up to three fp32 outputs (NULL = skip)
-__global__ void finish_partials_kernel(const double *__restrict__ partials, int nblocks, int nred,
-                                       const float *__restrict__ scale, float *__restrict__ out0, int n0,
-                                       float *__restrict__ out1, int n1, float *__restrict__ out2, int n2) {
-    const double sc = scale ? (double)scale[0] : 1.0;
-    for (int q = threadIdx.x; q < nred; q += blockDim.x) {
-        double v = 0.0;
-        for (int b = 0; b < nblocks; ++b) v += partials[(size_t)b * nred + q];
-        v *= sc;
+// out[q] = scale * sum_b partials[b][q]; one workgroup per q (fixed summation tree -> bitwise reproducible).
+// The nred results are split over up to three fp32 outputs (NULL = skip).
+__global__ __launch_bounds__(256) void finish_partials_kernel(const double *__restrict__ partials, int nblocks,
+                                                              int nred, const float *__restrict__ scale,
+                                                              float *__restrict__ out0, int n0,
+                                                              float *__restrict__ out1, int n1,
+                                                              float *__restrict__ out2, int n2) {
+    __shared__ double s_w[4];
+    const int q = blockIdx.x;
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) v += partials[(size_t)b * nred + q];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        if (scale) v *= (double)scale[0];
         if (q < n0) {
             if (out0) out0[q] = (float)v;
         } else if (q < n0 + n1) {
@@ -179,8 +187,9 @@ template <int LD, int F> static hipError_t decode_launch(bool bwd, const DecodeA
                        a.matrix, a.colscale, a.shift, a.clampw, a.grad_decoded, a.grad_latent, a.partials, a.rows);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(128), 0, s, a.partials, blocks, LD * F + 2 * F,
-                       (const float *)nullptr, a.grad_matrix, LD * F, a.grad_colscale, F, a.grad_shift, F);
+    hipLaunchKernelGGL(finish_partials_kernel, dim3(LD * F + 2 * F), dim3(256), 0, s, a.partials, blocks,
+                       LD * F + 2 * F, (const float *)nullptr, a.grad_matrix, LD * F, a.grad_colscale, F, a.grad_shift,
+                       F);
     return hipGetLastError();
 }
 
@@ -345,7 +354,7 @@ template <int LD> static hipError_t entropy_launch(bool bwd, const EntropyArgs &
                            a.num_layers, a.partials, a.rows);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(64), 0, s, a.partials, blocks, 1,
+        hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(256), 0, s, a.partials, blocks, 1,
                            (const float *)nullptr, a.total_bits, 1, (float *)nullptr, 0, (float *)nullptr, 0);
         return hipGetLastError();
     }
@@ -354,8 +363,8 @@ template <int LD> static hipError_t entropy_launch(bool bwd, const EntropyArgs &
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.grad_params) {
-        hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(128), 0, s, a.partials, blocks, 12 * LD, a.grad_total,
-                           a.grad_params, 12 * LD, (float *)nullptr, 0, (float *)nullptr, 0);
+        hipLaunchKernelGGL(finish_partials_kernel, dim3(12 * LD), dim3(256), 0, s, a.partials, blocks, 12 * LD,
+                           a.grad_total, a.grad_params, 12 * LD, (float *)nullptr, 0, (float *)nullptr, 0);
         e = hipGetLastError();
     }
     return e;

@@ -81,11 +81,10 @@ class BitEstimator(nn.Module):
     # ------------------------------------------------------------------------------------------------------
     def packed_params(self):
         """[4, 3, channel] = (f1.h, f1.b, f1.a, ..., f4.h, f4.b, 0) -- the C-ABI's parameter block (differentiable)."""
-        rows = []
+        pieces = []
         for f in (self.f1, self.f2, self.f3, self.f4):
-            a = f.a if f.a is not None else torch.zeros_like(f.h)
-            rows.append(torch.stack((f.h[0], f.b[0], a[0]), dim=0))
-        return torch.stack(rows, dim=0)
+            pieces += [f.h, f.b, f.a if f.a is not None else torch.zeros_like(f.h)]
+        return torch.cat(pieces, dim=0).view(4, 3, -1)     # one cat kernel; its backward hands out row views
 
     def total_bits(self, latent, noise=None):
         """Entropy of the whole table in bits (scalar tensor). ``noise`` None means the validation rule round()."""

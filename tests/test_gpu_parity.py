@@ -127,6 +127,43 @@ def test_other_feature_dims(dev, dim, F):
     np.testing.assert_allclose(grad.cpu().numpy(), ref_g, rtol=RTOL, atol=RTOL * np.abs(ref_g).max())
 
 
+@pytest.mark.parametrize("kind", ["one_point", "clustered", "lattice"])
+def test_skewed_sample_distributions(dev, kind):
+    """All samples in one cell / a tight cluster / a regular pixel lattice: bucket loads are maximally uneven
+    (one bucket per level receives everything -> many chunks per bucket, atomic flush path)."""
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, 30_000, edge=False)
+    rng = np.random.default_rng(5)
+    if kind == "one_point":
+        coords[:] = np.array([0.123, -0.456, 0.789], np.float32)
+    elif kind == "clustered":
+        coords[:] = (np.array([0.3, 0.3, -0.2]) + rng.normal(0, 0.004, coords.shape)).astype(np.float32)
+    else:
+        dim, res, bw = CONFIGS["B"]
+        sizes, first, T, _, table, _ = _problem(dim, res, bw, 16, edge=False)
+        rr, cc = np.meshgrid((np.arange(192) / 192 - 0.5) * 2, (np.arange(256) / 256 - 0.5) * 2, indexing="ij")
+        coords = np.stack([rr, cc], -1).reshape(-1, 2).astype(np.float32)
+        go = rng.standard_normal((coords.shape[0], len(res) * 2)).astype(np.float32)
+    feats, grad = _run(dev, dim, res, bw, coords, table, go, first)
+    assert np.array_equal(feats.cpu().numpy(), oc.forward(coords, table, first, res, bw))
+    ref_g = oc.backward(coords, go, (T, 2), first, res, bw)
+    np.testing.assert_allclose(grad.cpu().numpy(), ref_g, rtol=RTOL, atol=RTOL * np.abs(ref_g).max())
+
+
+def test_backward_in_sub_batches(dev):
+    """Item array capped to 1 MiB: the backward walks the batch in many sub-batches and accumulates across them."""
+    from shacira_amd import _lib
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, 50_000)
+    _lib.set_option("bin_batch_mib", 1)
+    try:
+        _, grad = _run(dev, dim, res, bw, coords, table, go, first)
+    finally:
+        _lib.set_option("bin_batch_mib", 1536)
+    ref_g = oc.backward(coords, go, (T, 2), first, res, bw)
+    np.testing.assert_allclose(grad.cpu().numpy(), ref_g, rtol=RTOL, atol=RTOL * np.abs(ref_g).max())
+
+
 def test_max_levels_and_wide_features(dev):
     """SHACIRA_MAX_LODS = 32 levels with F = 4 (largest staging tiles of the transposing passes), 3-D and 2-D."""
     for dim, bw in ((3, 14), (2, 12)):
