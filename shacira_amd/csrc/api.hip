@@ -10,6 +10,8 @@ namespace shacira {
 
 std::atomic<int> g_fwd_variant{-1};
 std::atomic<int> g_bwd_variant{-1};
+std::atomic<int> g_bin_debug{0};          // timing experiments only (non-zero values give wrong results)
+std::atomic<int> g_bin_acc_kib{128};      // LDS accumulator image per consumer workgroup, KiB (64 or 128)
 std::atomic<int> g_bin_batch_mib{1536};   // cap of the backward's item array per sub-batch, MiB
 
 static int build_level_table(int dim, int num_lods, int feature_dim, int bw, const int32_t *res_host,
@@ -61,6 +63,12 @@ int shacira_set_option(const char *name, int value) {
     if (!name) return SHACIRA_EINVAL;
     if (!std::strcmp(name, "fwd_variant")) { g_fwd_variant = value; return 0; }
     if (!std::strcmp(name, "bwd_variant")) { g_bwd_variant = value; return 0; }
+    if (!std::strcmp(name, "bin_debug")) { g_bin_debug = value; return 0; }
+    if (!std::strcmp(name, "bin_acc_kib")) {
+        if (value != 64 && value != 128) return SHACIRA_EINVAL;
+        g_bin_acc_kib = value;
+        return 0;
+    }
     if (!std::strcmp(name, "bin_batch_mib")) {
         if (value < 1) return SHACIRA_EINVAL;
         g_bin_batch_mib = value;
@@ -74,6 +82,7 @@ int shacira_get_option(const char *name) {
     if (!std::strcmp(name, "fwd_variant")) return g_fwd_variant;
     if (!std::strcmp(name, "bwd_variant")) return g_bwd_variant;
     if (!std::strcmp(name, "bin_batch_mib")) return g_bin_batch_mib;
+    if (!std::strcmp(name, "bin_acc_kib")) return g_bin_acc_kib;
     return SHACIRA_EINVAL;
 }
 

@@ -206,33 +206,61 @@ __global__ __launch_bounds__(64) void bin_scan_tiles_kernel(uint32_t *__restrict
 }
 
 // single block: bucket bases (exclusive scan of totals) and the consumer work list
-//   base[b]        first item of bucket b in the item array
-//   unit_first[b]  first work unit of bucket b; unit_first[total_buckets] = number of units
+//   base[b]         first item of bucket b in the item array (base[nb] = total)
+//   unit_first[b]   first work unit of bucket b; unit_first[nb] = number of units
+//   unit_bucket[u]  bucket of work unit u
 __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *__restrict__ totals,
                                                                 uint64_t *__restrict__ base,
-                                                                uint32_t *__restrict__ unit_first, uint32_t nb,
+                                                                uint32_t *__restrict__ unit_first,
+                                                                uint32_t *__restrict__ unit_bucket, uint32_t nb,
                                                                 uint32_t chunk_items) {
-    __shared__ uint64_t s_items[kMaxBuckets];
-    __shared__ uint32_t s_units[kMaxBuckets];
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
-        const uint32_t c = totals[b];
-        s_items[b] = c;
-        s_units[b] = (c + chunk_items - 1) / chunk_items;
+    __shared__ uint64_t s_items[kMaxBuckets + 2];
+    __shared__ uint32_t s_units[kMaxBuckets + 2];
+    __shared__ uint64_t s_wave_items[16];
+    __shared__ uint32_t s_wave_units[16];
+    // each thread owns buckets 2t, 2t+1 (kMaxBuckets = 2 * 1024)
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint64_t c[2];
+    uint32_t u[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t b = 2 * t + k;
+        c[k] = (b < nb) ? totals[b] : 0u;
+        u[k] = (uint32_t)((c[k] + chunk_items - 1) / chunk_items);
+    }
+    uint64_t ci = c[0] + c[1];
+    uint32_t ui = u[0] + u[1];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t nc = __shfl_up(ci, off, 64);
+        const uint32_t nu = __shfl_up(ui, off, 64);
+        if (lane >= (uint32_t)off) { ci += nc; ui += nu; }
+    }
+    if (lane == 63) { s_wave_items[wave] = ci; s_wave_units[wave] = ui; }
+    __syncthreads();
+    uint64_t wc = 0;
+    uint32_t wu = 0;
+    for (uint32_t w = 0; w < wave; ++w) { wc += s_wave_items[w]; wu += s_wave_units[w]; }
+    const uint64_t ex_items = wc + ci - (c[0] + c[1]);
+    const uint32_t ex_units = wu + ui - (u[0] + u[1]);
+    s_items[2 * t] = ex_items;
+    s_items[2 * t + 1] = ex_items + c[0];
+    s_units[2 * t] = ex_units;
+    s_units[2 * t + 1] = ex_units + u[0];
+    if (t == 1023) {  // grand totals for nb == kMaxBuckets
+        s_items[kMaxBuckets] = ex_items + c[0] + c[1];
+        s_units[kMaxBuckets] = ex_units + u[0] + u[1];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {  // <= 2048 entries: a serial scan costs ~2 us and keeps this trivially correct
-        uint64_t acc = 0;
-        uint32_t u = 0;
-        for (uint32_t b = 0; b < nb; ++b) {
-            const uint64_t c = s_items[b];
-            const uint32_t n = s_units[b];
-            base[b] = acc;
-            unit_first[b] = u;
-            acc += c;
-            u += n;
-        }
-        base[nb] = acc;
-        unit_first[nb] = u;
+    for (uint32_t b = t; b <= nb; b += 1024) {
+        base[b] = s_items[b];          // entries >= nb hold the grand totals (zero counts beyond nb)
+        unit_first[b] = s_units[b];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t b = 2 * t + k;
+        if (b < nb)
+            for (uint32_t q = 0; q < u[k]; ++q) unit_bucket[s_units[b] + q] = b;
     }
 }
 
@@ -244,7 +272,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                                                                   const uint32_t *__restrict__ tile_off,
                                                                   const uint64_t *__restrict__ base,
                                                                   Item<F> *__restrict__ items, int64_t sample0,
-                                                                  int64_t N, int64_t Ntotal) {
+                                                                  int64_t N, int64_t Ntotal, int debug) {
     constexpr int NP = 1 << (DIM - 1);
     constexpr int SPT = kTile / kBinThreads;   // samples per thread
     constexpr int kStage = kTile * NP;         // staged items per block
@@ -293,13 +321,20 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t b = 0; b < bl.nb; ++b) {
-            s_start[b] = acc;
-            acc += s_hist[b];
+    if (threadIdx.x < 64) {  // wave 0: exclusive scan of the <= 128 bucket counts, two per lane
+        const uint32_t lane = threadIdx.x;
+        const uint32_t c0 = (2 * lane < bl.nb) ? s_hist[2 * lane] : 0u;
+        const uint32_t c1 = (2 * lane + 1 < bl.nb) ? s_hist[2 * lane + 1] : 0u;
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t nbr = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += nbr;
         }
-        s_start[bl.nb] = acc;
+        const uint32_t excl = incl - (c0 + c1);
+        if (2 * lane < bl.nb) s_start[2 * lane] = excl;
+        if (2 * lane + 1 < bl.nb) s_start[2 * lane + 1] = excl + c0;
+        if (lane == 63) s_start[bl.nb] = incl;
     }
     if (threadIdx.x < bl.nb) {
         const size_t gb = bl.bucket0 + threadIdx.x;
@@ -324,6 +359,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     }
     __syncthreads();
     const uint32_t staged = s_start[bl.nb];
+    if (debug == 2 && staged < 0x7FFFFFFFu) return;  // EXPERIMENT: price of the global stores (results invalid)
     for (uint32_t pos = threadIdx.x; pos < staged; pos += kBinThreads) {
         const uint32_t b = s_bucket[pos];
         items[s_gbase[b] + (pos - s_start[b])] = s_items[pos];
@@ -336,24 +372,15 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
                                                                       const int32_t *__restrict__ first_idx,
                                                                       const uint64_t *__restrict__ base,
                                                                       const uint32_t *__restrict__ unit_first,
+                                                                      const uint32_t *__restrict__ unit_bucket,
                                                                       const Item<F> *__restrict__ items,
                                                                       float *__restrict__ grad_table,
-                                                                      int force_atomic) {
+                                                                      int force_atomic, int debug) {
     extern __shared__ double s_acc[];  // [rows_pb][F]
-    __shared__ uint32_t s_bucket;
     const uint32_t nbk = plan.total_buckets;
     const uint32_t unit = blockIdx.x;
     if (unit >= unit_first[nbk]) return;
-    if (threadIdx.x == 0) {  // bucket of this unit: last b with unit_first[b] <= unit
-        uint32_t lo = 0, hi = nbk;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (unit_first[mid] <= unit) lo = mid; else hi = mid;
-        }
-        s_bucket = lo;
-    }
-    __syncthreads();
-    const uint32_t gb = s_bucket;
+    const uint32_t gb = unit_bucket[unit];
     // level of the bucket
     uint32_t lvl = plan.blevel[0];
     for (uint32_t q = 1; q < plan.nbl; ++q)
@@ -383,6 +410,10 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         for (int u = 0; u < UN; ++u) {
             const uint32_t ra = it[u].key & 0x1FFFu, rb = (it[u].key >> 13) & 0x1FFFu;
             const float gx = 1.0f - it[u].fx;
+            if (debug == 1) {  // EXPERIMENT: price of the LDS atomics (results invalid)
+                if (it[u].key == 0xFFFFFFFFu) s_acc[0] = gx;
+                continue;
+            }
             if (it[u].key & (1u << 26)) {
 #pragma unroll
                 for (int j = 0; j < F; ++j) atomicAdd(&s_acc[ra * F + j], (double)(it[u].a[j] * gx));
@@ -471,7 +502,7 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
 bool bin_supported(int dim, const LevelTable &lt) {
     const int F = lt.feature_dim;
     if (F != 2 && F != 4) return false;
-    const uint32_t BR = 16384u / (uint32_t)F;  // 128 KiB of fp64 accumulators
+    const uint32_t BR = (uint32_t)g_bin_acc_kib.load() * 128u / (uint32_t)F;  // LDS image of fp64 accumulators
     for (int l = 0; l < lt.num_lods; ++l) {
         const uint32_t res = (uint32_t)lt.res[l];
         if (lt.dense[l]) {
@@ -493,7 +524,7 @@ bool bin_supported(int dim, const LevelTable &lt) {
 
 static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan) {
     const int F = lt.feature_dim;
-    const uint32_t BR = 16384u / (uint32_t)F;
+    const uint32_t BR = (uint32_t)g_bin_acc_kib.load() * 128u / (uint32_t)F;
     uint32_t shift = 0;
     while ((1u << shift) < BR) ++shift;
     uint32_t nbk = 0;
@@ -573,6 +604,7 @@ struct BinWorkspace {
     uint32_t *totals;
     uint64_t *base;
     uint32_t *unit_first;
+    uint32_t *unit_bucket;
     float *acc32;  // fp32 accumulation image for fp16 tables
     size_t bytes;
 };
@@ -588,8 +620,10 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     const size_t o_items = take((size_t)nb * plan.nbl * plan.pairs * item);
     const size_t o_cnt = take((size_t)plan.total_buckets * plan.num_tiles * sizeof(uint32_t));
     const size_t o_tot = take((size_t)(plan.total_buckets + 1) * sizeof(uint32_t));
-    const size_t o_base = take((size_t)(plan.total_buckets + 1) * sizeof(uint64_t));
-    const size_t o_unit = take((size_t)(plan.total_buckets + 1) * sizeof(uint32_t));
+    const size_t o_base = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
+    const size_t o_unit = take((size_t)(kMaxBuckets + 2) * sizeof(uint32_t));
+    const uint64_t max_items_ws = (uint64_t)nb * plan.nbl * plan.pairs;
+    const size_t o_ub = take((size_t)(max_items_ws / plan.chunk + plan.total_buckets + 2) * sizeof(uint32_t));
     const size_t o_acc = take(dtype == SHACIRA_F16 ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0);
     BinWorkspace w{};
     unsigned char *p = static_cast<unsigned char *>(ws);
@@ -600,6 +634,7 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
         w.totals = reinterpret_cast<uint32_t *>(p + o_tot);
         w.base = reinterpret_cast<uint64_t *>(p + o_base);
         w.unit_first = reinterpret_cast<uint32_t *>(p + o_unit);
+        w.unit_bucket = reinterpret_cast<uint32_t *>(p + o_ub);
         w.acc32 = reinterpret_cast<float *>(p + o_acc);
     }
     w.bytes = off;
@@ -665,19 +700,19 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                            plan.num_tiles);
         SHACIRA_CHECK_LAUNCH();
         hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
-                           plan.total_buckets, plan.chunk);
+                           w.unit_bucket, plan.total_buckets, plan.chunk);
         SHACIRA_CHECK_LAUNCH();
         constexpr int NP = 1 << (DIM - 1);
         const size_t stage = (size_t)kTile * NP * (sizeof(Item<F>) + 1);
         hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,
-                           w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n);
+                           w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n, g_bin_debug.load());
         SHACIRA_CHECK_LAUNCH();
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NP;
         const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + plan.total_buckets + 1;
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         hipLaunchKernelGGL((bin_consume_kernel<F>), dim3(max_units), dim3(kConsumeThreads), acc_bytes, s, lt, plan,
-                           first_idx, w.base, w.unit_first, reinterpret_cast<const Item<F> *>(w.items), acc,
-                           multi ? 1 : 0);
+                           first_idx, w.base, w.unit_first, w.unit_bucket,
+                           reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, g_bin_debug.load());
         SHACIRA_CHECK_LAUNCH();
     }
     return hipSuccess;
