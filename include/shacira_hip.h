@@ -154,6 +154,17 @@ SHACIRA_API int shacira_entropy_bits_backward(int64_t num_rows, int latent_dim, 
                                   void *stream);
 
 /*
+ * Fused Adam step over a flat fp32 buffer ("next" row f1: the optimizer step that follows the backward in the
+ * reference's trainers, torch.optim.Adam built by wisp/trainers/base_trainer.py:206-266 and stepped at
+ * wisp/trainers/image_trainer.py:355-359). torch.optim.Adam semantics with amsgrad=False, maximize=False:
+ *     g' = grad + weight_decay*param ; m = beta1*m + (1-beta1)*g' ; v = beta2*v + (1-beta2)*g'^2
+ *     param -= lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps)
+ *   step counts from 1. zero_grad != 0 also clears `grad` in the same pass (saves the next step's memset).
+ */
+SHACIRA_API int shacira_adam_step(int64_t numel, float *param, float *grad, float *exp_avg, float *exp_avg_sq, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad, void *stream);
+
+/*
  * Tunables (process-wide, read at call time; for benchmarking and A/B only).
  *   "fwd_variant", "bwd_variant": integer algorithm selectors, -1 = automatic.
  *   "bin_batch_mib": cap (MiB) of the backward's item array; larger batches are processed in sub-batches.

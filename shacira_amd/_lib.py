@@ -35,6 +35,7 @@ SIGNATURES = {
     "shacira_entropy_bits_workspace_bytes": (_sz, [_i64, _i]),
     "shacira_entropy_bits_forward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "shacira_entropy_bits_backward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "shacira_adam_step": (_i, [_i64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _i, _p]),
 }
 
 

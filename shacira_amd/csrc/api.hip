@@ -197,4 +197,13 @@ int shacira_entropy_bits_backward(int64_t num_rows, int latent_dim, int num_laye
     return (int)entropy_dispatch(true, latent_dim, a, (hipStream_t)stream);
 }
 
+int shacira_adam_step(int64_t numel, float *param, float *grad, float *exp_avg, float *exp_avg_sq, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad, void *stream) {
+    if (numel < 0 || step < 1) return SHACIRA_EINVAL;
+    if (numel > 0 && (!param || !grad || !exp_avg || !exp_avg_sq)) return SHACIRA_EINVAL;
+    if (!(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f)) return SHACIRA_EINVAL;
+    return (int)adam_step_launch(param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, step,
+                                 zero_grad, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -41,6 +41,10 @@ hipError_t latent_decode_dispatch(bool bwd, int ld, int f, const DecodeArgs &a, 
 bool entropy_supported(int ld);
 hipError_t entropy_dispatch(bool bwd, int ld, const EntropyArgs &a, hipStream_t s);
 
+// adam.hip
+hipError_t adam_step_launch(float *p, float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps,
+                            float wd, int step, int zero_grad, hipStream_t s);
+
 // api.hip: tunables
 extern std::atomic<int> g_fwd_variant;
 extern std::atomic<int> g_bwd_variant;
