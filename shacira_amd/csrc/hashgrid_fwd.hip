@@ -424,7 +424,16 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
                     acc[j] = (k == 0) ? tv * w : fmaf(tv, w, acc[j]);
                 }
             }
-            if constexpr (TRANSPOSED) store_row<T, F>(feats + ((int64_t)lvl * N + idx[u]) * F, acc);
+            if constexpr (TRANSPOSED) {
+                T *dstT = feats + ((int64_t)lvl * N + idx[u]) * F;
+                if constexpr (sizeof(T) == 4 && F == 2) {   // staging stream: written once, read once
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 o = {acc[0], acc[1]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x2 *>(dstT));
+                } else {
+                    store_row<T, F>(dstT, acc);
+                }
+            }
             else store_row<T, F>(feats + (idx[u] * lt.num_lods + lvl) * F, acc);
         }
     }

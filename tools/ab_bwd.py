@@ -21,6 +21,6 @@ def bench(dim, N, opts):
     for _ in range(20): f()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / 20
-for dbg in (0, 1, 2):
+for dbg in (0, 4, 8, 12):
     print(f"dim=3 bin_debug={dbg}: bwd {bench(3, 1 << 20, {'bin_debug': dbg}):.3f} ms", flush=True)
 _lib.set_option("bin_debug", 0)
