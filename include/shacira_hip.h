@@ -164,6 +164,12 @@ SHACIRA_API int shacira_entropy_bits_backward(int64_t num_rows, int latent_dim, 
 SHACIRA_API int shacira_adam_step(int64_t numel, float *param, float *grad, float *exp_avg, float *exp_avg_sq, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad, void *stream);
 
+/* Same, with the step count read from DEVICE memory (int32, >= 1) so that the launch can be captured into a
+ * hipGraph and replayed while the count advances (the caller increments it on the stream). */
+SHACIRA_API int shacira_adam_step_capturable(int64_t numel, float *param, float *grad, float *exp_avg, float *exp_avg_sq,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 const int32_t *step_dev, int zero_grad, void *stream);
+
 /*
  * Tunables (process-wide, read at call time; for benchmarking and A/B only).
  *   "fwd_variant", "bwd_variant": integer algorithm selectors, -1 = automatic.

@@ -17,7 +17,13 @@ namespace shacira {
 __global__ __launch_bounds__(256) void adam_step_kernel(float *__restrict__ p, float *__restrict__ g,
                                                         float *__restrict__ m, float *__restrict__ v, int64_t n,
                                                         float lr_over_bc1, float b1, float b2, float inv_sqrt_bc2,
-                                                        float eps, float wd, int zero_grad) {
+                                                        float eps, float wd, int zero_grad, float lr,
+                                                        const int32_t *__restrict__ step_dev) {
+    if (step_dev) {  // graph-capturable form: the step count lives on the device, corrections computed here
+        const double t = (double)step_dev[0];
+        lr_over_bc1 = (float)((double)lr / (1.0 - pow((double)b1, t)));
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+    }
     const int64_t stride = (int64_t)gridDim.x * 256 * 4;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 4 <= n) {
@@ -54,15 +60,15 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float *__restrict__ p, f
 }
 
 hipError_t adam_step_launch(float *p, float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps,
-                            float wd, int step, int zero_grad, hipStream_t s) {
+                            float wd, int step, const int32_t *step_dev, int zero_grad, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    const double bc1 = 1.0 - std::pow((double)b1, (double)step);
-    const double bc2 = 1.0 - std::pow((double)b2, (double)step);
+    const double bc1 = step_dev ? 1.0 : 1.0 - std::pow((double)b1, (double)step);
+    const double bc2 = step_dev ? 1.0 : 1.0 - std::pow((double)b2, (double)step);
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_step_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, p, g, m, v, n, (float)(lr / bc1), b1,
-                       b2, (float)(1.0 / std::sqrt(bc2)), eps, wd, zero_grad);
+                       b2, (float)(1.0 / std::sqrt(bc2)), eps, wd, zero_grad, lr, step_dev);
     return hipGetLastError();
 }
 

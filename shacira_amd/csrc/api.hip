@@ -203,7 +203,17 @@ int shacira_adam_step(int64_t numel, float *param, float *grad, float *exp_avg, 
     if (numel > 0 && (!param || !grad || !exp_avg || !exp_avg_sq)) return SHACIRA_EINVAL;
     if (!(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f)) return SHACIRA_EINVAL;
     return (int)adam_step_launch(param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, step,
-                                 zero_grad, (hipStream_t)stream);
+                                 nullptr, zero_grad, (hipStream_t)stream);
+}
+
+int shacira_adam_step_capturable(int64_t numel, float *param, float *grad, float *exp_avg, float *exp_avg_sq, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, const int32_t *step_dev,
+                                 int zero_grad, void *stream) {
+    if (numel < 0 || !step_dev) return SHACIRA_EINVAL;
+    if (numel > 0 && (!param || !grad || !exp_avg || !exp_avg_sq)) return SHACIRA_EINVAL;
+    if (!(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f)) return SHACIRA_EINVAL;
+    return (int)adam_step_launch(param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, 1,
+                                 step_dev, zero_grad, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -43,7 +43,7 @@ hipError_t entropy_dispatch(bool bwd, int ld, const EntropyArgs &a, hipStream_t 
 
 // adam.hip
 hipError_t adam_step_launch(float *p, float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps,
-                            float wd, int step, int zero_grad, hipStream_t s);
+                            float wd, int step, const int32_t *step_dev, int zero_grad, hipStream_t s);
 
 // api.hip: tunables
 extern std::atomic<int> g_fwd_variant;

@@ -189,8 +189,65 @@ class ImageFitter:
         return rgb_loss, psnr, float(avg_bits.detach()) if torch.is_tensor(avg_bits) else float(avg_bits)
 
 
+class GraphedImageFitter(ImageFitter):
+    """The same step recorded ONCE into a HIP graph and replayed: the per-step work of the image configs is a few
+    hundred microseconds of GPU time behind ~150 launches, i.e. launch-bound when issued eagerly from Python.
+
+    Differences from the eager fitter, all forced by capture: the entropy noise is drawn with the device generator
+    (`grid.device_noise`), Adam keeps its step count on the device (`FusedAdam(capturable=True)`), the entropy weight
+    lambda(step) is a device scalar refreshed before each replay, and PSNR is evaluated on request (`psnr()`), not
+    every step. The `div` normaliser updates (iterations 1, 2, 5, 10 with norm_every = 10) happen in the eager
+    warm-up steps that precede the capture."""
+
+    def __init__(self, nef, coords, rgb, total_steps, cdec, cent, warmup_steps=11, **kw):
+        from .optim import FusedAdam
+        super().__init__(nef, coords, rgb, total_steps, cdec, cent, **kw)
+        assert coords.is_cuda and self.world == 1, "graph capture: single-GPU path"
+        groups = [{k: v for k, v in g.items() if k != "params"} | {"params": g["params"]}
+                  for g in self.optimizer.param_groups]
+        self.optimizer = FusedAdam(groups, eps=1e-8, capturable=True)
+        nef.grid.device_noise = True
+        self.lam = torch.zeros((), device=coords.device)
+        self.stats = torch.zeros(2, dtype=torch.float64, device=coords.device)
+        self.warmup_steps = warmup_steps
+        self.graph = None
+
+    def _body(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        pred = self.nef.rgb(self.coords)
+        sq_sum = ((pred - self.rgb) ** 2).sum()
+        avg_bits, _ = self.nef.grid.ent_loss(1, is_val=False)
+        loss = sq_sum / (self.global_pixels * 3) + self.lam * avg_bits
+        loss.backward()
+        self.optimizer.step()
+        with torch.no_grad():
+            q = lambda t: (torch.clamp(t, 0, 1) * 255).to(torch.uint8).float()
+            self.stats.copy_(torch.stack([sq_sum.detach(), ((q(pred) - q(self.rgb)) ** 2).sum()]).double())
+
+    def step(self):
+        self.iteration += 1
+        self.lam.fill_(float(self.lambda_sched(self.iteration - 1)))
+        if self.iteration <= self.warmup_steps:
+            with torch.no_grad():
+                self._update_div()
+            self._body()
+            return
+        if self.graph is None:
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._body()
+        else:
+            self.graph.replay()
+
+    def psnr(self):
+        n = self.global_pixels * 3
+        s = self.stats.tolist()
+        return 20 * math.log10(255.0) - 10 * math.log10(max(s[1] / n, 1e-12)), s[0] / n
+
+
 def fit_image(device, steps=1000, height=512, width=768, seed=0, num_lods=16, log_every=0, hidden_dim=16, rank=0,
-              world=1):
+              world=1, graphed=False):
     """Fit the procedural image with the config-B LatentGrid; returns dict(psnr, rgb_loss, avg_bits, bpp, history).
     With world > 1 the (shuffled) pixel batch is sharded over ranks; results are identical on every rank."""
     from .dist import shard_batch
@@ -201,14 +258,32 @@ def fit_image(device, steps=1000, height=512, width=768, seed=0, num_lods=16, lo
     perm = torch.randperm(height * width, generator=torch.Generator().manual_seed(seed))  # dataset shuffle_idx
     coords = shard_batch(image_coords(height, width)[perm], rank, world).contiguous().to(device)
     rgb = shard_batch(img[perm], rank, world).contiguous().to(device)
-    fitter = ImageFitter(nef, coords, rgb, steps, cdec, cent, world=world, global_pixels=height * width)
     history = []
     out = None
-    for it in range(steps):
-        out = fitter.step()
-        if log_every and (it + 1) % log_every == 0:
-            history.append((it + 1,) + out)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    import time
+    t_loop = time.perf_counter()
+    if graphed:
+        fitter = GraphedImageFitter(nef, coords, rgb, steps, cdec, cent, global_pixels=height * width)
+        for it in range(steps):
+            fitter.step()
+            if log_every and (it + 1) % log_every == 0:
+                ps, rl = fitter.psnr()
+                history.append((it + 1, rl, ps, float("nan")))
+        ps, rl = fitter.psnr()
+        out = (rl, ps, float("nan"))
+    else:
+        fitter = ImageFitter(nef, coords, rgb, steps, cdec, cent, world=world, global_pixels=height * width)
+        for it in range(steps):
+            out = fitter.step()
+            if log_every and (it + 1) % log_every == 0:
+                history.append((it + 1,) + out)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    t_loop = time.perf_counter() - t_loop
     ldec_bits, latent_bits = grid.size(use_torchac=False, use_prob_model=False)
     rest_bits = sum(p.numel() * 32 for n, p in nef.named_parameters() if "grid" not in n)
     bpp = (latent_bits + ldec_bits + rest_bits) / (height * width)
-    return dict(psnr=out[1], rgb_loss=out[0], avg_bits=out[2], bpp=bpp, steps=steps, history=history)
+    return dict(psnr=out[1], rgb_loss=out[0], avg_bits=out[2], bpp=bpp, steps=steps, history=history,
+                ms_per_step=t_loop / steps * 1e3)

@@ -16,11 +16,16 @@ from . import _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, zero_grad_in_step=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, zero_grad_in_step=False,
+                 capturable=False):
+        """capturable=True keeps the step count in device memory (like torch's ``capturable``) so that ``step()`` can
+        be recorded into a HIP graph; GPU fp32 parameters only."""
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.zero_grad_in_step = zero_grad_in_step
+        self.capturable = capturable
+        self._step_dev = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -29,6 +34,11 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = None
+        if self.capturable:
+            if self._step_dev is None:
+                dev = next(p for g in self.param_groups for p in g["params"]).device
+                self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._step_dev += 1          # on the stream: part of the captured graph
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -39,9 +49,20 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                g, m, v = p.grad, st["exp_avg"], st["exp_avg_sq"]
+                if self.capturable:
+                    L = L or _lib.lib()
+                    with torch.cuda.device(p.device):
+                        rc = L.shacira_adam_step_capturable(
+                            p.numel(), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.contiguous().data_ptr()),
+                            ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(v.data_ptr()), float(group["lr"]), float(b1),
+                            float(b2), float(group["eps"]), float(group["weight_decay"]),
+                            ctypes.c_void_p(self._step_dev.data_ptr()), int(self.zero_grad_in_step),
+                            ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
+                    _lib.check(rc, "adam_step_capturable")
+                    continue
                 st["step"] += 1
                 t = int(st["step"])
-                g, m, v = p.grad, st["exp_avg"], st["exp_avg_sq"]
                 if (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous()
                         and g.dtype == torch.float32 and not g.is_sparse):
                     L = L or _lib.lib()

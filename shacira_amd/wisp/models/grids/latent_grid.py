@@ -52,9 +52,13 @@ class LatentGrid(_MultiLevelTable):
             self.noise_freq = conf_entropy_reg["noise_freq"]
 
     # ---------------------------------------------------------------------------------------------- entropy
+    device_noise = False   # opt-in: draw the entropy noise with the device generator (graph-capturable, no H2D copy)
+
     def _draw_noise(self):
         # U(-1/2, 1/2) drawn with the CPU generator and moved to the table's device, exactly as the reference
         # does (latent_grid.py:128-131), so a given torch.manual_seed reproduces the reference's noise stream.
+        if self.device_noise:
+            return torch.rand(self.codebook.shape, device=self.codebook.device, dtype=self.codebook.dtype) - 0.5
         return torch.rand(self.codebook.shape).to(self.codebook) - 0.5
 
     def ent_loss(self, idx, is_val=False):
