@@ -12,6 +12,7 @@ _ALIASES = [
     "ops", "ops.grid", "ops.image", "ops.image.metrics", "core", "accelstructs", "models", "models.grids",
     "models.grids.blas_grid", "models.grids.hash_grid", "models.grids.latent_grid", "models.latent_decoders",
     "models.latent_decoders.basic_latent_decoder", "models.latent_decoders.hierarchical_latent_decoder",
+    "models.latent_decoders.multi_latent_decoder",
     "models.prob_models", "models.prob_models.bit_estimator", "utils", "utils.schedulers",
 ]
 

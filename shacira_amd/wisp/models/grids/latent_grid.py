@@ -16,7 +16,7 @@ from typing import Any, Dict, List
 
 import torch
 
-from ..latent_decoders import DecoderIdentity, HierarchicalLatentDecoder, LatentDecoder
+from ..latent_decoders import DecoderIdentity, HierarchicalLatentDecoder, LatentDecoder, MultiLatentDecoder
 from ..prob_models import BitEstimator
 from .hash_grid import _MultiLevelTable, geometric_resolutions
 
@@ -105,7 +105,10 @@ class LatentGrid(_MultiLevelTable):
             offsets = torch.cat((self.codebook_lod_first_idx, self.codebook_lod_sizes[-1:]))
             return HierarchicalLatentDecoder(self.num_lods, offsets, decoder_cfg)
         if kind == "multi":
-            raise NotImplementedError("ldecode_type='multi' (MultiLatentDecoder) is a 'next' row (SURVEY.md 8 f4)")
+            decoder_cfg["num_entries"] = self.codebook.size(0)
+            decoder = MultiLatentDecoder(**decoder_cfg)
+            del decoder_cfg["num_entries"]
+            return decoder
         if kind == "single":
             return LatentDecoder(**decoder_cfg)
 

@@ -4,6 +4,7 @@
 Run:  python tests/golden/make_golden.py            (needs /root/reference; writes tests/golden/*.npz|json)
 
 What is pinned by the real reference code (executed, not restated):
+  multi_decoder.npz   MultiLatentDecoder.forward/backward/size ('sq'/'dft', soft vs straight-through alpha)   multi_latent_decoder.py:27-210
   latent_decoder.npz  LatentDecoder.forward/backward ('sq'/'dft', shift on/off, div != 1, clamp)   basic_latent_decoder.py:97-198
   bit_estimator.npz   BitEstimator CDF + gradients for num_layers 1..4                               bit_estimator.py:9-65
   latent_grid.npz     LatentGrid.from_geometric tables/buffers/param names, ent_loss (train + val),
@@ -155,6 +156,38 @@ def main():
         out[f"dft_{a}_{b}"] = ldec.get_dft_matrix(a, b).numpy()
     out["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, "latent_decoder.npz"), **out)
+
+    # ------------------------------------------------------------------ MultiLatentDecoder (row f4)
+    mout = {}
+    mcases = []
+    for ci, (ld, fd, mat, shift, K, st) in enumerate([(2, 2, "sq", True, 3, True), (2, 2, "sq", True, 3, False),
+                                                      (2, 4, "dft", True, 2, True), (1, 2, "dft", False, 4, False)]):
+        torch.manual_seed(500 + ci)
+        dec = ldec.MultiLatentDecoder(latent_dim=ld, feature_dim=fd, norm="none", ldecode_matrix=mat, use_shift=shift,
+                                      num_entries=97, ldec_std=0.1, num_decoders=K, alpha_std=1.0)
+        dec.straight_through = st
+        dec.temperature = 0.7
+        with torch.no_grad():
+            dec.div.fill_(1.3)
+            if shift:
+                dec.layers[0].use_shift.copy_(torch.randn(dec.layers[0].use_shift.shape, generator=g) * 0.01)
+        lat = ((torch.rand(97, ld, generator=g) - 0.5) * 7.0).requires_grad_(True)
+        y = dec(lat)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        pre = f"m{ci}_"
+        mout[pre + "latent"] = lat.detach().numpy()
+        mout[pre + "out"] = y.detach().numpy()
+        mout[pre + "grad_out"] = gy.numpy()
+        mout[pre + "grad_latent"] = lat.grad.numpy()
+        for n, p_ in dec.named_parameters():
+            mout[pre + "p_" + n] = p_.detach().numpy()
+            mout[pre + "g_" + n] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy()
+        mout[pre + "size"] = np.float64(dec.size())
+        mcases.append(dict(latent_dim=ld, feature_dim=fd, ldecode_matrix=mat, use_shift=shift, num_decoders=K,
+                           straight_through=st, state_keys=sorted(dec.state_dict().keys())))
+    mout["cases_json"] = np.frombuffer(json.dumps(mcases).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "multi_decoder.npz"), **mout)
 
     # ------------------------------------------------------------------ (iii) BitEstimator
     out = {}

@@ -13,7 +13,7 @@ from oracle import hashgrid_c as oc
 from shacira_amd import hip_ops
 from shacira_amd.wisp.models.grids import HashGrid, LatentGrid
 from shacira_amd.wisp.models.latent_decoders import (DecoderIdentity, HierarchicalLatentDecoder, LatentDecoder,
-                                                      get_dft_matrix)
+                                                      MultiLatentDecoder, get_dft_matrix)
 from shacira_amd.wisp.models.prob_models import BitEstimator
 from shacira_amd.wisp.ops import grid as grid_ops
 from shacira_amd.wisp.ops.image.metrics import clamped_psnr, psnr
@@ -180,10 +180,41 @@ def test_freeze_and_hierarchical():
     assert all(d.temperature == 0.3 and d.use_sga for d in grid.latent_dec.decoders)
     grid.freeze()
     assert not any(p.requires_grad for p in grid.parameters())
-    with pytest.raises(NotImplementedError):
-        LatentGrid.from_geometric(feature_dim=2, num_lods=3, latent_dim=1, resolution_dim=2, codebook_bitwidth=6,
-                                  min_grid_res=4, max_grid_res=16, blas_level=2,
-                                  conf_latent_decoder=conf(1, ltype="multi")[0], conf_entropy_reg=cent)
+    cm = conf(2, ltype="multi")[0]
+    cm["num_decoders"] = 3
+    gm = LatentGrid.from_geometric(feature_dim=2, num_lods=3, latent_dim=2, resolution_dim=2, codebook_bitwidth=6,
+                                   min_grid_res=4, max_grid_res=16, blas_level=2, multiscale_type="cat",
+                                   conf_latent_decoder=cm, conf_entropy_reg=cent)
+    assert isinstance(gm.latent_dec, MultiLatentDecoder) and gm.latent_dec.alpha.shape == (3, gm.codebook.shape[0])
+    assert "num_entries" not in cm and gm.latent_dec(gm.codebook).shape == (gm.codebook.shape[0], 2)
+
+
+def test_multi_latent_decoder_module(golden):
+    """Row f4: MultiLatentDecoder against vectors produced by the reference's own module (incl. its double-mixing
+    quirk in the 'sq' branch), same seed -> same alpha / scale init."""
+    g = golden("multi_decoder.npz")
+    for ci, case in enumerate(npz_json(g["cases_json"])):
+        p = f"m{ci}_"
+        torch.manual_seed(500 + ci)
+        dec = MultiLatentDecoder(latent_dim=case["latent_dim"], feature_dim=case["feature_dim"], norm="none",
+                                 ldecode_matrix=case["ldecode_matrix"], use_shift=case["use_shift"], num_entries=97,
+                                 ldec_std=0.1, num_decoders=case["num_decoders"], alpha_std=1.0)
+        assert sorted(dec.state_dict().keys()) == case["state_keys"]
+        assert (dec.alpha.detach().numpy() == g[p + "p_alpha"]).all()                 # same RNG draw order
+        assert (dec.layers[0].scale.detach().numpy() == g[p + "p_layers.0.scale"]).all()
+        dec.load_state_dict({k[len(p) + 2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(p + "p_")})
+        dec.straight_through = case["straight_through"]
+        dec.temperature = 0.7
+        lat = torch.from_numpy(g[p + "latent"]).requires_grad_(True)
+        y = dec(lat)
+        np.testing.assert_allclose(y.detach().numpy(), g[p + "out"], rtol=1e-5, atol=1e-7)
+        y.backward(torch.from_numpy(g[p + "grad_out"]))
+        np.testing.assert_allclose(lat.grad.numpy(), g[p + "grad_latent"], rtol=1e-5, atol=1e-7)
+        for n, prm in dec.named_parameters():
+            want = g[p + "g_" + n]
+            got = prm.grad.numpy() if prm.grad is not None else np.zeros_like(want)
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6, err_msg=n)
+        assert dec.size() == pytest.approx(float(g[p + "size"]), rel=1e-6)
 
 
 # ------------------------------------------------------------------------------------------------ decoder / CDF
