@@ -154,6 +154,24 @@ SHACIRA_API int shacira_entropy_bits_backward(int64_t num_rows, int latent_dim, 
                                   void *stream);
 
 /*
+ * Fused decoder MLP (row a14): BasicDecoder.forward of the reference (wisp/models/decoders/basic_decoders.py:74-101)
+ * as NeuralImage uses it (wisp/models/nefs/image.py:107-116, :152): `num_hidden` Linear(+bias)+ReLU layers of width
+ * `hidden_dim`, then the linear `lout`; fp32.
+ *   params / grad_params: one flat buffer  W1 [H, IN] (nn.Linear.weight layout), b1 [H], W2 [H, H], b2 [H], ...,
+ *                         Wout [OUT, H], bout [OUT]
+ *   x [num_rows, in_dim], y / grad_y [num_rows, out_dim], grad_x [num_rows, in_dim] (may be NULL)
+ * Only a fixed set of shapes is compiled (shacira_mlp_supported); others return SHACIRA_EDTYPE and the caller keeps
+ * using its own Linear layers. The backward recomputes the hidden activations (nothing is saved by the forward).
+ */
+SHACIRA_API int shacira_mlp_supported(int in_dim, int hidden_dim, int num_hidden, int out_dim);
+SHACIRA_API size_t shacira_mlp_backward_workspace_bytes(int in_dim, int hidden_dim, int num_hidden, int out_dim);
+SHACIRA_API int shacira_mlp_forward(int64_t num_rows, int in_dim, int hidden_dim, int num_hidden, int out_dim, const float *x,
+                        const float *params, float *y, void *stream);
+SHACIRA_API int shacira_mlp_backward(int64_t num_rows, int in_dim, int hidden_dim, int num_hidden, int out_dim, const float *x,
+                         const float *params, const float *grad_y, float *grad_x, float *grad_params, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
+/*
  * Fused Adam step over a flat fp32 buffer ("next" row f1: the optimizer step that follows the backward in the
  * reference's trainers, torch.optim.Adam built by wisp/trainers/base_trainer.py:206-266 and stepped at
  * wisp/trainers/image_trainer.py:355-359). torch.optim.Adam semantics with amsgrad=False, maximize=False:

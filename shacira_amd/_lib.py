@@ -35,6 +35,10 @@ SIGNATURES = {
     "shacira_entropy_bits_workspace_bytes": (_sz, [_i64, _i]),
     "shacira_entropy_bits_forward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "shacira_entropy_bits_backward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "shacira_mlp_supported": (_i, [_i, _i, _i, _i]),
+    "shacira_mlp_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "shacira_mlp_forward": (_i, [_i64, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "shacira_mlp_backward": (_i, [_i64, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "shacira_adam_step": (_i, [_i64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _i, _p]),
     "shacira_adam_step_capturable": (_i, [_i64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _p, _i, _p]),
 }

@@ -216,4 +216,35 @@ int shacira_adam_step_capturable(int64_t numel, float *param, float *grad, float
                                  step_dev, zero_grad, (hipStream_t)stream);
 }
 
+int shacira_mlp_supported(int in_dim, int hidden_dim, int num_hidden, int out_dim) {
+    return mlp_supported(in_dim, hidden_dim, num_hidden, out_dim) ? 1 : 0;
+}
+
+size_t shacira_mlp_backward_workspace_bytes(int in_dim, int hidden_dim, int num_hidden, int out_dim) {
+    return mlp_supported(in_dim, hidden_dim, num_hidden, out_dim)
+               ? mlp_workspace_bytes(in_dim, hidden_dim, num_hidden, out_dim) : 0;
+}
+
+int shacira_mlp_forward(int64_t num_rows, int in_dim, int hidden_dim, int num_hidden, int out_dim, const float *x,
+                        const float *params, float *y, void *stream) {
+    if (num_rows < 0) return SHACIRA_EINVAL;
+    if (!mlp_supported(in_dim, hidden_dim, num_hidden, out_dim)) return SHACIRA_EDTYPE;
+    if (num_rows == 0) return 0;
+    if (!x || !params || !y) return SHACIRA_EINVAL;
+    return (int)mlp_dispatch(false, in_dim, hidden_dim, num_hidden, out_dim, num_rows, x, params, y, nullptr, nullptr,
+                             nullptr, nullptr, (hipStream_t)stream);
+}
+
+int shacira_mlp_backward(int64_t num_rows, int in_dim, int hidden_dim, int num_hidden, int out_dim, const float *x,
+                         const float *params, const float *grad_y, float *grad_x, float *grad_params, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+    if (num_rows < 0) return SHACIRA_EINVAL;
+    if (!mlp_supported(in_dim, hidden_dim, num_hidden, out_dim)) return SHACIRA_EDTYPE;
+    if (!workspace || workspace_bytes < mlp_workspace_bytes(in_dim, hidden_dim, num_hidden, out_dim))
+        return SHACIRA_EWORKSPACE;
+    if (!params || !grad_params || (num_rows > 0 && (!x || !grad_y))) return SHACIRA_EINVAL;
+    return (int)mlp_dispatch(true, in_dim, hidden_dim, num_hidden, out_dim, num_rows, x, params, nullptr, grad_y,
+                             grad_x, grad_params, static_cast<double *>(workspace), (hipStream_t)stream);
+}
+
 }  // extern "C"

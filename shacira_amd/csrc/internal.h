@@ -45,6 +45,13 @@ hipError_t entropy_dispatch(bool bwd, int ld, const EntropyArgs &a, hipStream_t 
 hipError_t adam_step_launch(float *p, float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps,
                             float wd, int step, const int32_t *step_dev, int zero_grad, hipStream_t s);
 
+// mlp.hip
+bool mlp_supported(int in, int h, int nh, int out);
+int mlp_num_params(int in, int h, int nh, int out);
+size_t mlp_workspace_bytes(int in, int h, int nh, int out);
+hipError_t mlp_dispatch(bool bwd, int in, int h, int nh, int out, int64_t N, const float *x, const float *params,
+                        float *y, const float *gy, float *gx, float *gparams, double *partials, hipStream_t s);
+
 // api.hip: tunables
 extern std::atomic<int> g_fwd_variant;
 extern std::atomic<int> g_bwd_variant;

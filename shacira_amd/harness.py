@@ -3,7 +3,7 @@
 
 Restated from the reference (behaviour only):
   NeuralImage.rgb            wisp/models/nefs/image.py:127-154      feats = grid.interpolate(coords) -> decoder_color
-  BasicDecoder               wisp/models/decoders/basic_decoders.py:17-101  (num_layers+1 hidden Linear+ReLU, then `lout`)
+  BasicDecoder               -> shacira_amd/wisp/models/decoders (mirror; fused HIP MLP on the GPU)
   ImageTrainer.step          wisp/trainers/image_trainer.py:269-359  MSE + lambda(epoch) * avg_bits, `div` normaliser
                              update at iterations where norm_every % iteration == 0 (sic), Adam step
   optimizer parameter groups wisp/trainers/base_trainer.py:206-266   by parameter-NAME substring
@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .wisp.models.decoders import BasicDecoder
 from .wisp.models.grids import LatentGrid
 from .wisp.models.latent_decoders import LatentDecoder
 from .wisp.ops.image.metrics import clamped_psnr
@@ -53,21 +54,6 @@ def image_coords(height, width):
     return torch.stack([rr, cc], -1).reshape(-1, 2)
 
 
-class BasicDecoder(nn.Module):
-    """Linear(+ReLU) x num_layers, then `lout` (same attribute names as the reference's BasicDecoder)."""
-
-    def __init__(self, input_dim, output_dim, num_layers=1, hidden_dim=128, bias=True):
-        super().__init__()
-        dims = [input_dim] + [hidden_dim] * num_layers
-        self.layers = nn.ModuleList([nn.Linear(a, b, bias=bias) for a, b in zip(dims[:-1], dims[1:])])
-        self.lout = nn.Linear(hidden_dim, output_dim, bias=bias)
-
-    def forward(self, x):
-        for layer in self.layers:
-            x = torch.relu(layer(x))
-        return self.lout(x)
-
-
 class NeuralImage(nn.Module):
     """coords [N,2] -> rgb [N,3]: grid lookup then `decoder_color` MLP (num_layers+1 hidden layers of hidden_dim)."""
 
@@ -75,7 +61,8 @@ class NeuralImage(nn.Module):
         super().__init__()
         self.grid = grid
         feat = grid.feature_dim * grid.num_lods if grid.multiscale_type == "cat" else grid.feature_dim
-        self.decoder_color = BasicDecoder(feat, 3, num_layers=num_layers + 1, hidden_dim=hidden_dim)
+        # image.py:107-116: BasicDecoder(in, 3, relu, bias=True, nn.Linear, num_layers + 1, hidden_dim, skip=[])
+        self.decoder_color = BasicDecoder(feat, 3, torch.relu, True, nn.Linear, num_layers + 1, hidden_dim, [])
 
     def rgb(self, coords, lod_idx=None):
         if lod_idx is None:

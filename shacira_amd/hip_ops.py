@@ -190,3 +190,33 @@ def entropy_bits_backward(latent, noise, params, num_layers, grad_total, need_la
                                                       _stream(latent))
     _lib.check(rc, "entropy_bits_backward")
     return g_lat, g_par
+
+
+# ------------------------------------------------------------------------------------------------ decoder MLP (a14)
+def mlp_supported(in_dim, hidden_dim, num_hidden, out_dim):
+    return bool(_lib.lib().shacira_mlp_supported(int(in_dim), int(hidden_dim), int(num_hidden), int(out_dim)))
+
+
+def mlp_forward(x, params, in_dim, hidden_dim, num_hidden, out_dim):
+    _need_gpu(x, params)
+    y = torch.empty((x.shape[0], out_dim), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().shacira_mlp_forward(x.shape[0], in_dim, hidden_dim, num_hidden, out_dim, _ptr(x), _ptr(params),
+                                            _ptr(y), _stream(x))
+    _lib.check(rc, "mlp_forward")
+    return y
+
+
+def mlp_backward(x, params, grad_y, in_dim, hidden_dim, num_hidden, out_dim, need_grad_x=True):
+    _need_gpu(x, params, grad_y)
+    dev = x.device
+    gx = torch.empty_like(x) if need_grad_x else None
+    gp = torch.empty_like(params)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        n = L.shacira_mlp_backward_workspace_bytes(in_dim, hidden_dim, num_hidden, out_dim)
+        ws = torch.empty((n,), dtype=torch.uint8, device=dev)
+        rc = L.shacira_mlp_backward(x.shape[0], in_dim, hidden_dim, num_hidden, out_dim, _ptr(x), _ptr(params),
+                                    _ptr(grad_y), _ptr(gx), _ptr(gp), _ptr(ws), n, _stream(x))
+    _lib.check(rc, "mlp_backward")
+    return gx, gp
