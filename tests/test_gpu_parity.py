@@ -400,3 +400,41 @@ def test_autocast_runs_the_half_instantiation(dev):
     assert grid.codebook.grad is not None and grid.codebook.grad.dtype == torch.float32
     f32 = grid.interpolate(coords, 0)
     assert float((f.float() - f32).abs().max()) < 5e-4
+
+
+def test_config_c_full_size_properties(dev):
+    """BASELINE config C: 24 Kodak-sized pixel lattices in one batch (N = 9 437 184), 16-level 2-D grid (bw 19 table:
+    the backward runs in sub-batches). Size-independent properties at full size + an oracle slice."""
+    ops = _ops()
+    dim, res, bw = CONFIGS["Bp"]
+    sizes, first, T = table_layout(res, bw, dim)
+    H, W, IM = 512, 768, 24
+    rows = (torch.arange(H, dtype=torch.float32) / H - 0.5) * 2
+    cols = (torch.arange(W, dtype=torch.float32) / W - 0.5) * 2
+    rr, cc = torch.meshgrid(rows, cols, indexing="ij")
+    lattice = torch.stack([rr, cc], -1).reshape(-1, 2)
+    g = torch.Generator().manual_seed(0)
+    coords = torch.cat([lattice[torch.randperm(H * W, generator=g)] for _ in range(IM)]).to(dev)
+    N = coords.shape[0]
+    assert N == 9_437_184
+    tf = torch.from_numpy(first).to(dev)
+    table = (torch.randn(T, 2, generator=g) * 0.01).to(dev)
+    go = torch.randn(N, 32, generator=g).to(dev)
+    feats = ops.hashgrid_interpolate2d_cuda(coords, table, tf, res, bw)
+    grad = ops.hashgrid_backward(2, coords, go, T, torch.float32, tf, res, bw, 2)
+    sl = slice(4_000_000, 4_002_048)
+    assert np.array_equal(feats[sl].cpu().numpy(), oc.forward(coords[sl].cpu().numpy(), table.cpu().numpy(), first, res, bw))
+    lhs = float((feats.double() * go.double()).sum())
+    rhs = float((table.double() * grad.double()).sum())
+    assert lhs == pytest.approx(rhs, rel=1e-4)                      # adjointness <F t, go> == <t, F^T go>
+    for l in (0, 8, 15):
+        lo, hi = int(first[l]), int(first[l]) + sizes[l]
+        np.testing.assert_allclose(grad[lo:hi].double().sum(0).cpu().numpy(),
+                                   go[:, 2 * l:2 * l + 2].double().sum(0).cpu().numpy(), rtol=1e-3, atol=0.5)
+    # every lattice point is sampled 24 times: the gradient of one image's samples, times 24 with the same go, matches
+    one = slice(0, H * W)
+    g1 = ops.hashgrid_backward(2, coords[one].contiguous(), go[one].contiguous(), T, torch.float32, tf, res, bw, 2)
+    ref = oc.backward(coords[one].cpu().numpy()[:5000], go[one].cpu().numpy()[:5000], (T, 2), first, res, bw)
+    g5k = ops.hashgrid_backward(2, coords[:5000].contiguous(), go[:5000].contiguous(), T, torch.float32, tf, res, bw, 2)
+    np.testing.assert_allclose(g5k.cpu().numpy(), ref, rtol=RTOL, atol=RTOL * np.abs(ref).max())
+    assert torch.isfinite(g1).all()
