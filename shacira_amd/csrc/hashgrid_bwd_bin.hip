@@ -484,11 +484,13 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
 // Levels whose whole (used) row range fits one LDS image need no partitioning at all: a workgroup keeps a private
 // fp64 image of a GROUP of such levels, walks its share of the samples adding every corner with ds_add_f64, and
 // adds the image to the (zeroed) gradient table with coalesced float atomics at the end.
-template <int DIM, int F>
+// GT = float: gradients come from the transposed image gT [L][N][F]; otherwise (T = table scalar) straight from
+// grad_output [N, L*F] -- used when no level needs binning, which makes the transposing pass unnecessary.
+template <int DIM, int F, typename GT, bool TRANSPOSED>
 __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(LevelTable lt, BinPlan plan,
                                                                             const int32_t *__restrict__ first_idx,
                                                                             const float *__restrict__ coords,
-                                                                            const float *__restrict__ gT,
+                                                                            const GT *__restrict__ gT,
                                                                             float *__restrict__ grad_table,
                                                                             int64_t N) {
     constexpr int NC = 1 << DIM;
@@ -508,10 +510,10 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
             const BinLevel bl = plan.lv[l];
             Corners<DIM> c;
             compute_corners<DIM>(t, lt.res[l], lt.hi[l], lt.dense[l] != 0, lt.mask, c);
-            const float *gp = gT + ((int64_t)l * N + i) * F;
+            const GT *gp = TRANSPOSED ? gT + ((int64_t)l * N + i) * F : gT + (i * lt.num_lods + l) * F;
             float g[F];
 #pragma unroll
-            for (int j = 0; j < F; ++j) g[j] = gp[j];
+            for (int j = 0; j < F; ++j) g[j] = Scalar<GT>::load(gp + j);
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 if (c.row[k] < bl.used) {
@@ -701,8 +703,11 @@ template <int DIM, int F>
 static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                           const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s) {
     const int L = lt.num_lods;
-    // pass T over the whole batch
-    {
+    BinPlan whole;
+    make_plan(DIM, lt, n, whole);
+    const bool need_T = whole.nbl > 0;   // only binned levels consume the transposed gradients
+    if (need_T) {
+        // pass T over the whole batch
         const uint32_t blocks = (uint32_t)((n + 255) / 256);
         const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
         if (dtype == SHACIRA_F32)
@@ -714,21 +719,26 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         SHACIRA_CHECK_LAUNCH();
     }
     // direct levels: one pass over the whole batch, no items
-    {
-        BinPlan plan;
-        make_plan(DIM, lt, n, plan);
-        if (plan.ngroups > 0) {
-            uint32_t bpg = 512u / plan.ngroups;                       // ~512 workgroups in total
-            const uint32_t need = (uint32_t)((n + 2047) / 2048);      // at least ~2 samples per thread each
-            if (bpg > need) bpg = need;
-            if (bpg < 1) bpg = 1;
-            const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
-            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F>), dim3(bpg, plan.ngroups), dim3(kConsumeThreads),
-                               acc_bytes, s, lt, plan, first_idx, coords, w.gT, acc, n);
-            SHACIRA_CHECK_LAUNCH();
-        }
-        if (plan.nbl == 0) return hipSuccess;
+    if (whole.ngroups > 0) {
+        const BinPlan &plan = whole;
+        uint32_t bpg = 512u / plan.ngroups;                       // ~512 workgroups in total
+        const uint32_t need = (uint32_t)((n + 2047) / 2048);      // at least ~2 samples per thread each
+        if (bpg > need) bpg = need;
+        if (bpg < 1) bpg = 1;
+        const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
+        const dim3 grid(bpg, plan.ngroups);
+        if (need_T)
+            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true>), grid, dim3(kConsumeThreads), acc_bytes,
+                               s, lt, plan, first_idx, coords, w.gT, acc, n);
+        else if (dtype == SHACIRA_F32)
+            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, false>), grid, dim3(kConsumeThreads), acc_bytes,
+                               s, lt, plan, first_idx, coords, static_cast<const float *>(grad_out), acc, n);
+        else
+            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, __half, false>), grid, dim3(kConsumeThreads),
+                               acc_bytes, s, lt, plan, first_idx, coords, static_cast<const __half *>(grad_out), acc, n);
+        SHACIRA_CHECK_LAUNCH();
     }
+    if (whole.nbl == 0) return hipSuccess;
     const int64_t nb = bin_batch_samples(DIM, lt, n);
     const bool multi = nb < n;
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
@@ -776,10 +786,12 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&transpose_grad_kernel<float, 4>), 140 * 1024);
         set(reinterpret_cast<const void *>(&transpose_grad_kernel<__half, 2>), 140 * 1024);
         set(reinterpret_cast<const void *>(&transpose_grad_kernel<__half, 4>), 140 * 1024);
-        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<2, 2>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<2, 4>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<3, 2>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<3, 4>), 16384 * sizeof(double));
+#define SHACIRA_DIRECT_ATTR(D, FF)                                                                              \
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, float, true>), 16384 * sizeof(double));   \
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, float, false>), 16384 * sizeof(double));  \
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, __half, false>), 16384 * sizeof(double));
+        SHACIRA_DIRECT_ATTR(2, 2) SHACIRA_DIRECT_ATTR(2, 4) SHACIRA_DIRECT_ATTR(3, 2) SHACIRA_DIRECT_ATTR(3, 4)
+#undef SHACIRA_DIRECT_ATTR
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
