@@ -38,8 +38,45 @@ WORKLOADS = {
     "S1_nerf_hash_3d_L16_F2_bw19_N2^20": (3, geo(16, 2048, 16), 19, 2, 1 << 20),
     "S2_kodak_2d_L16_F2_bw19_N2^20": (2, geo(16, 2048, 16), 19, 2, 1 << 20),
     "B_kodak_2d_L16_F2_bw11_N393216": (2, geo(16, 512, 16), 11, 2, 393216),
+    "C_kodak24_2d_L16_F2_bw11_N9437184": (2, geo(16, 512, 16), 11, 2, 24 * 393216),
     "D_nerf_lego_3d_L16_F2_bw19_N65536": (3, geo(16, 2048, 16), 19, 2, 65536),
 }
+SECONDARY = ["S2_kodak_2d_L16_F2_bw19_N2^20", "B_kodak_2d_L16_F2_bw11_N393216", "C_kodak24_2d_L16_F2_bw11_N9437184",
+             "D_nerf_lego_3d_L16_F2_bw19_N65536"]
+
+
+def quick_measure(name, device, iters=10):
+    """fwd / bwd operator times of another BASELINE config (same protocol, fewer iterations); not the headline."""
+    from shacira_amd import hip_ops
+    dim, res, bw, F, n = WORKLOADS[name]
+    L = len(res)
+    sizes = [min(2 ** bw, r ** dim) for r in res]
+    first = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)).to(device)
+    T = int(sum(sizes))
+    g = torch.Generator().manual_seed(7)
+    table = (torch.randn(T, F, generator=g) * 0.01).to(device)
+    coords = (torch.rand(n, dim, generator=g) * 2 - 1).to(device)
+    go = torch.randn(n, L * F, generator=g).to(device)
+    fwd = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for _ in range(3):
+        fwd(coords, table, first, res, bw)
+        hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F)
+    torch.cuda.synchronize()
+    tf = tb = 0.0
+    for _ in range(iters):
+        ev[0].record()
+        fwd(coords, table, first, res, bw)
+        ev[1].record()
+        hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F)
+        ev[2].record()
+        torch.cuda.synchronize()
+        tf += ev[0].elapsed_time(ev[1]) / iters
+        tb += ev[1].elapsed_time(ev[2]) / iters
+    bf, bb = algorithmic_bytes_per_sample(dim, L, F)
+    gbs = (bf + bb) * n / ((tf + tb) * 1e-3) / 1e9
+    return {"samples_per_s": n / ((tf + tb) * 1e-3), "ms_forward": tf, "ms_backward": tb, "samples": n,
+            "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS}
 
 
 def algorithmic_bytes_per_sample(dim, L, F, s=4):
@@ -86,6 +123,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="S1_nerf_hash_3d_L16_F2_bw19_N2^20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the quick figures for the other BASELINE configs")
     ap.add_argument("--psnr-steps", type=int, default=1000, help="image-fit steps for the PSNR figure (0 = skip)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 17)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
@@ -166,6 +204,12 @@ def main():
                           "Adam (kodak.yaml learning rates)", "bpp": fit["bpp"], "rgb_loss": fit["rgb_loss"],
                 "seconds": time.perf_counter() - tp, "n_gpus": world}
 
+    secondary = None
+    if rank == 0 and not args.no_secondary:
+        del coords, grad_out
+        torch.cuda.empty_cache()
+        secondary = {name: quick_measure(name, device) for name in SECONDARY if name != args.workload}
+
     if rank == 0:
         ms_fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
         ms_bwd = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
@@ -203,6 +247,7 @@ def main():
                                           "bytes_per_sample": b_fwd + b_bwd}},
             "ms": {"forward": ms_fwd, "backward": ms_bwd, "allreduce": ms_ar},
             "psnr": psnr,
+            "other_configs_1gpu": secondary,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, res, bw, F, first_np, T, min(args.cpu_samples, n_local),
