@@ -274,3 +274,98 @@ def fit_image(device, steps=1000, height=512, width=768, seed=0, num_lods=16, lo
     bpp = (latent_bits + ldec_bits + rest_bits) / (height * width)
     return dict(psnr=out[1], rgb_loss=out[0], avg_bits=out[2], bpp=bpp, steps=steps, history=history,
                 ms_per_step=t_loop / steps * 1e3)
+
+
+# =====================================================================================================================
+# 3-D: NeRF-like ray points against an analytic field (configs D / E of SURVEY.md section 8)
+# =====================================================================================================================
+def analytic_field(points):
+    """Smooth + sharp analytic colour field on [-1,1]^3 -> rgb in [0,1]. points [N,3]."""
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    r = torch.sqrt(x * x + y * y + z * z + 1e-12)
+    shell = torch.sigmoid((0.6 - r) * 40.0)                                  # a sphere with a soft edge
+    rgb = torch.stack([0.5 + 0.5 * torch.sin(6.0 * x + 2.0 * y) * shell,
+                       0.5 + 0.5 * torch.cos(5.0 * y - 3.0 * z) * shell,
+                       0.25 + 0.5 * shell * (0.5 + 0.5 * torch.sin(9.0 * z))], -1)
+    box = ((x.abs() < 0.3) & (y.abs() < 0.15) & (z.abs() < 0.45)).float().unsqueeze(-1)   # a hard-edged box inside
+    box_rgb = torch.stack([torch.full_like(x, 0.9), torch.full_like(x, 0.2), torch.full_like(x, 0.1)], -1)
+    return torch.clamp(rgb * (1 - box) + box * box_rgb, 0.0, 1.0)
+
+
+def ray_points(num_rays, samples_per_ray, generator, jitter=True):
+    """NeRF-like sample positions: origins on the radius-3 sphere, directions toward a jittered point in
+    [-0.5,0.5]^3, `samples_per_ray` stratified samples on the chord inside [-1,1]^3. -> [num_rays*samples_per_ray, 3]"""
+    o = torch.randn(num_rays, 3, generator=generator)
+    o = 3.0 * o / o.norm(dim=1, keepdim=True)
+    target = torch.rand(num_rays, 3, generator=generator) - 0.5
+    d = target - o
+    d = d / d.norm(dim=1, keepdim=True)
+    # slab intersection with the cube [-1,1]^3
+    inv = 1.0 / torch.where(d.abs() < 1e-9, torch.full_like(d, 1e-9), d)
+    t0, t1 = (-1.0 - o) * inv, (1.0 - o) * inv
+    tnear = torch.minimum(t0, t1).max(dim=1)[0]
+    tfar = torch.maximum(t0, t1).min(dim=1)[0]
+    u = (torch.arange(samples_per_ray, dtype=torch.float32).unsqueeze(0)
+         + (torch.rand(num_rays, samples_per_ray, generator=generator) if jitter else 0.5)) / samples_per_ray
+    t = tnear.unsqueeze(1) + (tfar - tnear).unsqueeze(1) * u
+    pts = o.unsqueeze(1) + d.unsqueeze(1) * t.unsqueeze(-1)
+    return pts.reshape(-1, 3).clamp(-1.0, 1.0)
+
+
+class NeuralField3D(nn.Module):
+    """positions [N,3] -> rgb [N,3]: HashGrid (nerf_hash.yaml: 16 levels, F=2, bw 19, res 16..2048) + small MLP."""
+
+    def __init__(self, grid, hidden_dim=64):
+        super().__init__()
+        self.grid = grid
+        self.decoder_color = BasicDecoder(grid.feature_dim * grid.num_lods, 3, torch.relu, True, nn.Linear, 1,
+                                          hidden_dim, [])
+
+    def rgb(self, coords):
+        feats = self.grid.interpolate(coords, len(self.grid.active_lods) - 1).reshape(coords.shape[0], -1)
+        return torch.sigmoid(self.decoder_color(feats))
+
+
+def fit_field_3d(device, steps=500, rays=4096, samples_per_ray=16, seed=0, codebook_bitwidth=19, max_grid_res=2048,
+                 num_lods=16, rank=0, world=1, val_points=65536):
+    """Config D/E: every step draws `rays` x `samples_per_ray` fresh ray points (global batch, sharded over ranks),
+    L1 loss to the analytic field, Adam; returns dict(psnr on a fixed validation set, ms_per_step)."""
+    import time
+    from .dist import FlatGradients, shard_batch
+    from .optim import FusedAdam
+    from .wisp.models.grids import HashGrid
+    from .wisp.ops.image.metrics import psnr as psnr_fn
+    torch.manual_seed(seed)
+    grid = HashGrid.from_geometric(feature_dim=2, num_lods=num_lods, multiscale_type="cat", resolution_dim=3,
+                                   feature_std=0.01, codebook_bitwidth=codebook_bitwidth, min_grid_res=16,
+                                   max_grid_res=max_grid_res, blas_level=3)
+    nef = NeuralField3D(grid).to(device)
+    groups = [g for g in param_groups(nef, lr=1e-3, grid_lr=1e-2) if g["params"]]
+    opt = FusedAdam(groups, eps=1e-15) if device.type == "cuda" else torch.optim.Adam(groups, eps=1e-15)
+    bucket = FlatGradients([p for g in groups for p in g["params"]]) if world > 1 else None
+    gen = torch.Generator().manual_seed(seed + 1)                     # the SAME sample stream on every rank
+    n_global = rays * samples_per_ray
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pts = ray_points(rays, samples_per_ray, gen)
+        local = shard_batch(pts, rank, world).contiguous().to(device)
+        target = analytic_field(local)
+        if bucket is not None:
+            bucket.zero_()
+        else:
+            opt.zero_grad(set_to_none=True)
+        loss = (nef.rgb(local) - target).abs().sum() / (n_global * 3)     # global-mean L1 (multiview_trainer.py:105-108)
+        loss.backward()
+        if bucket is not None:
+            bucket.allreduce()
+        opt.step()
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    with torch.no_grad():
+        vp = (torch.rand(val_points, 3, generator=torch.Generator().manual_seed(99)) * 2 - 1).to(device)
+        pred = nef.rgb(vp)
+        val = psnr_fn(pred.clamp(0, 1), analytic_field(vp))
+    return dict(psnr=val, ms_per_step=ms, steps=steps, samples_per_step=n_global)

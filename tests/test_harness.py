@@ -88,3 +88,27 @@ def test_graph_captured_step_reaches_the_same_psnr():
     tail_g = float(np.mean([h[2] for h in graphed["history"][-2:]]))
     assert abs(tail_e - tail_g) <= 0.3, (tail_e, tail_g)
     assert abs(graphed["bpp"] - eager["bpp"]) / eager["bpp"] < 0.05
+
+
+def test_ray_points_and_field():
+    g = torch.Generator().manual_seed(0)
+    pts = harness.ray_points(64, 16, g)
+    assert pts.shape == (1024, 3) and float(pts.abs().max()) <= 1.0
+    rgb = harness.analytic_field(pts)
+    assert rgb.shape == (1024, 3) and 0.0 <= float(rgb.min()) and float(rgb.max()) <= 1.0 and float(rgb.std()) > 0.05
+
+
+def test_field_fit_3d_on_cpu_restatement(oracle_op):
+    r = harness.fit_field_3d(torch.device("cpu"), steps=40, rays=128, samples_per_ray=8, codebook_bitwidth=10,
+                             max_grid_res=64, num_lods=6, val_points=2048)
+    assert r["psnr"] > 11.0 and r["samples_per_step"] == 1024
+
+
+@pytest.mark.gpu
+def test_field_fit_3d_gpu_matches_cpu_restatement(oracle_op, monkeypatch):
+    kw = dict(steps=120, rays=256, samples_per_ray=16, codebook_bitwidth=12, max_grid_res=128, num_lods=8,
+              val_points=8192)
+    cpu = harness.fit_field_3d(torch.device("cpu"), **kw)
+    monkeypatch.undo()
+    gpu = harness.fit_field_3d(torch.device("cuda:0"), **kw)
+    assert abs(gpu["psnr"] - cpu["psnr"]) <= 0.1, (gpu["psnr"], cpu["psnr"])
