@@ -188,6 +188,13 @@ SHACIRA_API int shacira_adam_step_capturable(int64_t numel, float *param, float 
                                  float lr, float beta1, float beta2, float eps, float weight_decay,
                                  const int32_t *step_dev, int zero_grad, void *stream);
 
+/* Multi-tensor form: up to 32 parameters (HOST arrays of device pointers, sizes, per-tensor lr / weight decay) in
+ * one launch. `step_dev` non-NULL: step count read from device memory (graph-capturable), else `step` is used. */
+SHACIRA_API int shacira_adam_step_multi(int num_tensors, const int64_t *numel_host, float *const *param, float *const *grad,
+                            float *const *exp_avg, float *const *exp_avg_sq, const float *lr_host,
+                            const float *weight_decay_host, float beta1, float beta2, float eps, int step,
+                            const int32_t *step_dev, int zero_grad, void *stream);
+
 /*
  * Tunables (process-wide, read at call time; for benchmarking and A/B only).
  *   "fwd_variant", "bwd_variant": integer algorithm selectors, -1 = automatic.

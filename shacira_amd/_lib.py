@@ -40,6 +40,7 @@ SIGNATURES = {
     "shacira_mlp_forward": (_i, [_i64, _i, _i, _i, _i, _p, _p, _p, _p]),
     "shacira_mlp_backward": (_i, [_i64, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "shacira_adam_step": (_i, [_i64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _i, _p]),
+    "shacira_adam_step_multi": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _i, _p, _i, _p]),
     "shacira_adam_step_capturable": (_i, [_i64, _p, _p, _p, _p, _f, _f, _f, _f, _f, _p, _i, _p]),
 }
 

@@ -216,6 +216,24 @@ int shacira_adam_step_capturable(int64_t numel, float *param, float *grad, float
                                  step_dev, zero_grad, (hipStream_t)stream);
 }
 
+int shacira_adam_step_multi(int num_tensors, const int64_t *numel_host, float *const *param, float *const *grad,
+                            float *const *exp_avg, float *const *exp_avg_sq, const float *lr_host,
+                            const float *weight_decay_host, float beta1, float beta2, float eps, int step,
+                            const int32_t *step_dev, int zero_grad, void *stream) {
+    if (num_tensors < 0 || num_tensors > 32) return SHACIRA_EINVAL;
+    if (num_tensors == 0) return 0;
+    if (!numel_host || !param || !grad || !exp_avg || !exp_avg_sq || !lr_host || !weight_decay_host)
+        return SHACIRA_EINVAL;
+    if (!step_dev && step < 1) return SHACIRA_EINVAL;
+    if (!(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f)) return SHACIRA_EINVAL;
+    for (int t = 0; t < num_tensors; ++t)
+        if (numel_host[t] < 0 || (numel_host[t] > 0 && (!param[t] || !grad[t] || !exp_avg[t] || !exp_avg_sq[t])))
+            return SHACIRA_EINVAL;
+    return (int)adam_multi_launch(num_tensors, param, grad, exp_avg, exp_avg_sq, numel_host, lr_host,
+                                  weight_decay_host, beta1, beta2, eps, step, step_dev, zero_grad,
+                                  (hipStream_t)stream);
+}
+
 int shacira_mlp_supported(int in_dim, int hidden_dim, int num_hidden, int out_dim) {
     return mlp_supported(in_dim, hidden_dim, num_hidden, out_dim) ? 1 : 0;
 }

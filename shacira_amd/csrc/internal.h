@@ -45,6 +45,10 @@ hipError_t entropy_dispatch(bool bwd, int ld, const EntropyArgs &a, hipStream_t 
 hipError_t adam_step_launch(float *p, float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps,
                             float wd, int step, const int32_t *step_dev, int zero_grad, hipStream_t s);
 
+hipError_t adam_multi_launch(int count, float *const *p, float *const *g, float *const *m, float *const *v,
+                             const int64_t *n, const float *lr, const float *wd, float b1, float b2, float eps,
+                             int step, const int32_t *step_dev, int zero_grad, hipStream_t s);
+
 // mlp.hip
 bool mlp_supported(int in, int h, int nh, int out);
 int mlp_num_params(int in, int h, int nh, int out);

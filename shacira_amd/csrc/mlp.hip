@@ -111,11 +111,10 @@ __global__ __launch_bounds__(kMlpTile) void mlp_backward_kernel(const float *__r
     constexpr int P = kMlpTile + 4;  // row pitch of the element-major images (conflict-free ds_read_b128)
     // images: input of every layer (x, h_0 .. h_{NH-1}) and pre-activation gradient of every layer (d_0 .. d_{NH-1}, dy)
     constexpr int kInRows = IN + NH * H;
-    constexpr int kGradRows = NH * H + OUT;
     extern __shared__ __align__(16) float smem[];
     float *sw = smem;                                   // [n_params]
     float *s_in = smem + (S::n_params + 3) / 4 * 4;     // [kInRows][P]
-    float *s_g = s_in + kInRows * P;                    // [kGradRows][P]
+    float *s_g = s_in + kInRows * P;                    // [NH * H + OUT][P]
     for (int e = threadIdx.x; e < S::n_params; e += kMlpTile) sw[e] = params[e];
 
     // each thread owns up to EPT weight/bias elements e = threadIdx.x + k*256
@@ -279,10 +278,11 @@ static hipError_t mlp_run(bool bwd, int64_t N, const float *x, const float *para
     constexpr int P = kMlpTile + 4;
     const size_t shmem = ((size_t)(S::n_params + 3) / 4 * 4 + (size_t)(IN + NH * H + NH * H + OUT) * P) * sizeof(float);
     static std::once_flag once;
-    std::call_once(once, [shmem] {
-        if (shmem > 64 * 1024)
+    std::call_once(once, [] {
+        constexpr size_t need = ((size_t)(S::n_params + 3) / 4 * 4 + (size_t)(IN + NH * H + NH * H + OUT) * P) * sizeof(float);
+        if (need > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_backward_kernel<IN, H, NH, OUT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
     });
     hipLaunchKernelGGL((mlp_backward_kernel<IN, H, NH, OUT>), dim3((uint32_t)blocks), dim3(kMlpTile), shmem, s, x,
                        params, gy, gx, partials, N, tpb);

@@ -1,11 +1,13 @@
 """Fused Adam for the hash-grid path's parameters ("next" row f1 of SURVEY.md section 8).
 
 Drop-in for ``torch.optim.Adam`` (the optimiser the reference's trainers build, wisp/trainers/base_trainer.py:206-266)
-restricted to what those configs use: amsgrad=False, maximize=False, L2 ``weight_decay``, per-group ``lr``. Every
-fp32 GPU parameter is stepped by ONE HIP kernel (``shacira_adam_step``) instead of torch's ~10-kernel foreach chain;
-with ``zero_grad_in_step=True`` the same pass clears ``.grad`` (useful with ``dist.FlatGradients``, whose gradient
-buffer is persistent). State dict keys (``step``, ``exp_avg``, ``exp_avg_sq``) match torch's, so checkpoints
-interchange. Parameters that are not fp32-contiguous-on-GPU are stepped with the same formula in torch ops.
+restricted to what those configs use: amsgrad=False, maximize=False, L2 ``weight_decay``, per-group ``lr``. All fp32
+GPU parameters that share (betas, eps) are stepped by ONE multi-tensor HIP launch (``shacira_adam_step_multi``, up to
+32 tensors per launch) instead of torch's ~10-kernel foreach chain; with ``zero_grad_in_step=True`` the same pass
+clears ``.grad`` (useful with ``dist.FlatGradients``, whose gradient buffer is persistent); ``capturable=True`` keeps
+the step count on the device so ``step()`` can be recorded into a HIP graph. State dict keys (``step``, ``exp_avg``,
+``exp_avg_sq``) match torch's. Parameters that are not fp32-contiguous-on-GPU are stepped with the same formula in
+torch ops.
 """
 import ctypes
 import math
@@ -14,18 +16,36 @@ import torch
 
 from . import _lib
 
+_MAX = 32
+
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, zero_grad_in_step=False,
                  capturable=False):
-        """capturable=True keeps the step count in device memory (like torch's ``capturable``) so that ``step()`` can
-        be recorded into a HIP graph; GPU fp32 parameters only."""
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.zero_grad_in_step = zero_grad_in_step
         self.capturable = capturable
         self._step_dev = None
+        self._step_host = 0
+
+    def _launch(self, batch, b1, b2, eps, device):
+        k = len(batch)
+        PtrArr, I64Arr, FArr = ctypes.c_void_p * k, ctypes.c_int64 * k, ctypes.c_float * k
+        ps = PtrArr(*[p.data_ptr() for p, _, _, _, _, _ in batch])
+        gs = PtrArr(*[g.data_ptr() for _, g, _, _, _, _ in batch])
+        ms = PtrArr(*[m.data_ptr() for _, _, m, _, _, _ in batch])
+        vs = PtrArr(*[v.data_ptr() for _, _, _, v, _, _ in batch])
+        ns = I64Arr(*[p.numel() for p, _, _, _, _, _ in batch])
+        lrs = FArr(*[float(lr) for _, _, _, _, lr, _ in batch])
+        wds = FArr(*[float(wd) for _, _, _, _, _, wd in batch])
+        step_dev = ctypes.c_void_p(self._step_dev.data_ptr()) if self.capturable else None
+        with torch.cuda.device(device):
+            rc = _lib.lib().shacira_adam_step_multi(k, ns, ps, gs, ms, vs, lrs, wds, float(b1), float(b2), float(eps),
+                                                    int(self._step_host), step_dev, int(self.zero_grad_in_step),
+                                                    ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+        _lib.check(rc, "adam_step_multi")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -33,12 +53,13 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        L = None
+        self._step_host += 1
         if self.capturable:
             if self._step_dev is None:
                 dev = next(p for g in self.param_groups for p in g["params"]).device
-                self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+                self._step_dev = torch.full((1,), self._step_host - 1, dtype=torch.int32, device=dev)
             self._step_dev += 1          # on the stream: part of the captured graph
+        pending = {}                      # (device, b1, b2, eps) -> list of tensors for the fused launch
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -50,35 +71,25 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 g, m, v = p.grad, st["exp_avg"], st["exp_avg_sq"]
-                if self.capturable:
-                    L = L or _lib.lib()
-                    with torch.cuda.device(p.device):
-                        rc = L.shacira_adam_step_capturable(
-                            p.numel(), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.contiguous().data_ptr()),
-                            ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(v.data_ptr()), float(group["lr"]), float(b1),
-                            float(b2), float(group["eps"]), float(group["weight_decay"]),
-                            ctypes.c_void_p(self._step_dev.data_ptr()), int(self.zero_grad_in_step),
-                            ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
-                    _lib.check(rc, "adam_step_capturable")
+                if not self.capturable:
+                    st["step"] += 1
+                fused = (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous()
+                         and g.dtype == torch.float32 and not g.is_sparse)
+                if fused:
+                    key = (p.device, b1, b2, group["eps"])
+                    pending.setdefault(key, []).append((p, g, m, v, group["lr"], group["weight_decay"]))
                     continue
-                st["step"] += 1
+                if self.capturable:
+                    raise RuntimeError("FusedAdam(capturable=True) handles fp32 contiguous GPU parameters only")
                 t = int(st["step"])
-                if (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous()
-                        and g.dtype == torch.float32 and not g.is_sparse):
-                    L = L or _lib.lib()
-                    with torch.cuda.device(p.device):
-                        rc = L.shacira_adam_step(p.numel(), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.data_ptr()),
-                                                 ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(v.data_ptr()),
-                                                 float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                                 float(group["weight_decay"]), t, int(self.zero_grad_in_step),
-                                                 ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
-                    _lib.check(rc, "adam_step")
-                else:
-                    gr = g.add(p, alpha=group["weight_decay"]) if group["weight_decay"] else g
-                    m.mul_(b1).add_(gr, alpha=1 - b1)
-                    v.mul_(b2).addcmul_(gr, gr, value=1 - b2)
-                    denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(group["eps"])
-                    p.addcdiv_(m, denom, value=-group["lr"] / (1 - b1 ** t))
-                    if self.zero_grad_in_step:
-                        g.zero_()
+                gr = g.add(p, alpha=group["weight_decay"]) if group["weight_decay"] else g
+                m.mul_(b1).add_(gr, alpha=1 - b1)
+                v.mul_(b2).addcmul_(gr, gr, value=1 - b2)
+                denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(group["eps"])
+                p.addcdiv_(m, denom, value=-group["lr"] / (1 - b1 ** t))
+                if self.zero_grad_in_step:
+                    g.zero_()
+        for (device, b1, b2, eps), items in pending.items():
+            for i in range(0, len(items), _MAX):
+                self._launch(items[i:i + _MAX], b1, b2, eps, device)
         return loss
