@@ -10,7 +10,6 @@ namespace shacira {
 
 std::atomic<int> g_fwd_variant{-1};
 std::atomic<int> g_bwd_variant{-1};
-std::atomic<int> g_bin_debug{0};          // timing experiments only (non-zero values give wrong results)
 std::atomic<int> g_bin_acc_kib{128};      // LDS accumulator image per consumer workgroup, KiB (64 or 128)
 std::atomic<int> g_bin_batch_mib{1536};   // cap of the backward's item array per sub-batch, MiB
 
@@ -63,7 +62,6 @@ int shacira_set_option(const char *name, int value) {
     if (!name) return SHACIRA_EINVAL;
     if (!std::strcmp(name, "fwd_variant")) { g_fwd_variant = value; return 0; }
     if (!std::strcmp(name, "bwd_variant")) { g_bwd_variant = value; return 0; }
-    if (!std::strcmp(name, "bin_debug")) { g_bin_debug = value; return 0; }
     if (!std::strcmp(name, "bin_acc_kib")) {
         if (value != 64 && value != 128) return SHACIRA_EINVAL;
         g_bin_acc_kib = value;

@@ -68,20 +68,6 @@ template <int F> struct alignas(F == 2 ? 16 : 8) Item {
 };
 
 // Items are written once and read once: stream them past the caches (non-temporal).
-template <int F> __device__ __forceinline__ Item<F> load_item_nt(const Item<F> *p) {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    Item<F> it;
-    if constexpr (sizeof(Item<F>) == 16) {
-        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-        __builtin_memcpy(&it, &v, 16);
-    } else {
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
-        uint32_t *d = reinterpret_cast<uint32_t *>(&it);
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(Item<F>) / 4); ++k) d[k] = __builtin_nontemporal_load(q + k);
-    }
-    return it;
-}
 template <int F> __device__ __forceinline__ void store_item_nt(Item<F> *p, const Item<F> &it) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     if constexpr (sizeof(Item<F>) == 16) {
@@ -313,7 +299,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                                                                   const uint32_t *__restrict__ tile_off,
                                                                   const uint64_t *__restrict__ base,
                                                                   Item<F> *__restrict__ items, int64_t sample0,
-                                                                  int64_t N, int64_t Ntotal, int debug) {
+                                                                  int64_t N, int64_t Ntotal) {
     constexpr int NP = 1 << (DIM - 1);
     constexpr int SPT = kTile / kBinThreads;   // samples per thread
     constexpr int kStage = kTile * NP;         // staged items per block
@@ -400,7 +386,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     }
     __syncthreads();
     const uint32_t staged = s_start[bl.nb];
-    if (debug == 2 && staged < 0x7FFFFFFFu) return;  // EXPERIMENT: price of the global stores (results invalid)
     for (uint32_t pos = threadIdx.x; pos < staged; pos += kBinThreads) {
         const uint32_t b = s_bucket[pos];
         // write-once / read-once stream: non-temporal stores (measured -7 % on the whole backward)
@@ -417,7 +402,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
                                                                       const uint32_t *__restrict__ unit_bucket,
                                                                       const Item<F> *__restrict__ items,
                                                                       float *__restrict__ grad_table,
-                                                                      int force_atomic, int debug) {
+                                                                      int force_atomic) {
     extern __shared__ double s_acc[];  // [rows_pb][F]
     const uint32_t nbk = plan.total_buckets;
     const uint32_t unit = blockIdx.x;
@@ -445,17 +430,13 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const uint64_t p = p0 + (uint64_t)u * kConsumeThreads;
-            if (p < end) it[u] = (debug & 4) ? load_item_nt<F>(items + p) : items[p];
+            if (p < end) it[u] = items[p];
             else it[u].key = 0;
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const uint32_t ra = it[u].key & 0x1FFFu, rb = (it[u].key >> 13) & 0x1FFFu;
             const float gx = 1.0f - it[u].fx;
-            if (debug == 1) {  // EXPERIMENT: price of the LDS atomics (results invalid)
-                if (it[u].key == 0xFFFFFFFFu) s_acc[0] = gx;
-                continue;
-            }
             if (it[u].key & (1u << 26)) {
 #pragma unroll
                 for (int j = 0; j < F; ++j) atomicAdd(&s_acc[ra * F + j], (double)(it[u].a[j] * gx));
@@ -757,14 +738,14 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         constexpr int NP = 1 << (DIM - 1);
         const size_t stage = (size_t)kTile * NP * (sizeof(Item<F>) + 1);
         hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,
-                           w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n, g_bin_debug.load());
+                           w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n);
         SHACIRA_CHECK_LAUNCH();
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NP;
         const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + plan.total_buckets + 1;
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         hipLaunchKernelGGL((bin_consume_kernel<F>), dim3(max_units), dim3(kConsumeThreads), acc_bytes, s, lt, plan,
                            first_idx, w.base, w.unit_first, w.unit_bucket,
-                           reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, g_bin_debug.load());
+                           reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0);
         SHACIRA_CHECK_LAUNCH();
     }
     return hipSuccess;

@@ -510,14 +510,6 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
                 return hipGetLastError();
             }
         }
-        if (variant == 96) {  // EXPERIMENT ONLY: level-major output layout (wrong for callers), to price the stores
-            const uint32_t groups = (uint32_t)((lt.num_lods + 7) / 8);
-            const uint32_t tiles = (uint32_t)((num_coords + 127) / 128);
-            hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true>), dim3(8u * tiles * groups),
-                               dim3(256), 0, stream, lt, first_idx, coords, static_cast<const T *>(table),
-                               static_cast<T *>(feats), num_coords, tiles);
-            return hipGetLastError();
-        }
         if (variant == 4 || variant == 5) {
             const uint32_t groups = (uint32_t)((lt.num_lods + 7) / 8);
             if (variant == 4) {

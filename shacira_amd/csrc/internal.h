@@ -61,6 +61,5 @@ extern std::atomic<int> g_fwd_variant;
 extern std::atomic<int> g_bwd_variant;
 extern std::atomic<int> g_bin_batch_mib;
 extern std::atomic<int> g_bin_acc_kib;
-extern std::atomic<int> g_bin_debug;
 
 }  // namespace shacira
