@@ -4,11 +4,16 @@
 // (wisp/csrc/ops/hashgrid_interpolate.cpp:44-66, :130-152; kernels hashgrid_interpolate_cuda.cu:47-109 and
 // hashgrid_interpolate2d_cuda.cu:44-99). One launch covers every level (the reference launches L kernels).
 //
-// Work decomposition ("lane = (sample, level)"): work item w = sample * L + level, one per lane, so that
-//   - the feats store is one contiguous F*sizeof(T)-byte piece per lane, consecutive lanes consecutive addresses
-//     (a wave writes 64*F*sizeof(T) contiguous bytes; the reference strides lanes by L*F*sizeof(T));
-//   - coords are fetched once per sample by L neighbouring lanes (same address -> one request);
-//   - each corner row (F scalars) is fetched by ONE vector load of F*sizeof(T) bytes.
+// What bounds it (measured): a wave-level gather costs ~20 clk + 2 clk per distinct 128-byte line
+// it touches, and lines fetched from beyond the XCD's L2 cost a full Infinity-Cache request. The kernels below differ
+// in how they keep that count down; all of them produce bit-identical results (same fp64 coordinate scale, same
+// corner order, same fmaf chain as the reference):
+//   variant 0  lane = (sample, level)                                     (round-1 first version, kept for A/B)
+//   variant 1  thread = sample, rolled loop over levels, LDS-staged rows
+//   variant 2  block = (level, tile), one level per XCD at a time
+//   variant 3  lane pair = sample (x / x+1 corners merge into one request), sample-major   [default: 2-D, small N]
+//   variant 4/5 variant 2's schedule + variant 3's lane pairing, feats written in place
+//   variant 6  variant 4 writing a level-major staging buffer + transposing copy             [default: 3-D, N >= 16 K]
 // HBM-bound: algorithmic bytes per sample = 4*DIM + L*2^DIM*F*s + L*F*s.
 #include <mutex>
 
@@ -118,8 +123,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(LevelTable lt, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Variant 1 ("sample per thread"): a thread walks the levels of ONE sample, keeps the L*F results in registers and
-// writes its feats row with full-width vector stores. All waves of the chip advance through the levels at about
+// Variant 1 ("sample per thread"): a thread walks the levels of ONE sample, stages the L*F results in wave-private
+// LDS and the wave writes its 64 feats rows with full-width vector stores. All waves of the chip advance through the levels at about
 // the same pace, so at any moment the gathers of the whole chip target one or two level tables (<= 4 MiB each:
 // L2-resident) instead of all of them (48.8 MiB: Infinity-Cache bound, profiles/r01_microbench2_lds_gather.txt).
 // Level parameters are wave-uniform (scalar registers). MAXL bounds the register array.
