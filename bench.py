@@ -123,12 +123,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="S1_nerf_hash_3d_L16_F2_bw19_N2^20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ar-chunks", type=int, default=1,
+                    help="N > 1: build the gradient in this many level groups and all-reduce each group's rows "
+                         "asynchronously while the next group is computed. Default 1: measured on one GPU the split "
+                         "costs ~0.11 ms per extra group, about what it can hide at 8 GPUs; kept opt-in until it "
+                         "has been measured on a multi-GPU node")
     ap.add_argument("--no-secondary", action="store_true", help="skip the quick figures for the other BASELINE configs")
     ap.add_argument("--psnr-steps", type=int, default=1000, help="image-fit steps for the PSNR figure (0 = skip)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 17)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()
 
+    from shacira_amd import _lib
     from shacira_amd import dist as sdist
     from shacira_amd import hip_ops
     rank, world, device = sdist.init_from_env()
@@ -155,17 +161,44 @@ def main():
     first = torch.from_numpy(first_np).to(device)
     fwd = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
 
+    # N > 1: the codebook gradient is still reduced exactly once per step, but in `chunks` row ranges: the backward
+    # is issued per level group and each group's (contiguous) rows start their all-reduce on RCCL's stream while
+    # the next group is computed (xGMI transfer hidden behind compute). N = 1: one call, no collective.
+    chunks = max(1, min(args.ar_chunks, L))
+    if chunks == 1:
+        groups = [(0, L)]
+    else:
+        cuts = [0] + [max(1, min(L - 1, round(L * (5 + 3 * k / (chunks - 1)) / 8))) for k in range(chunks - 1)] + [L]
+        cuts = sorted(set(cuts))
+        groups = list(zip(cuts[:-1], cuts[1:]))
+    row_of = lambda l: int(first_np[l]) if l < L else T
+
     def step(ev=None):
         if ev:
             ev[0].record()
         feats = fwd(coords, table, first, res, bw)
         if ev:
             ev[1].record()
-        grad = hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F)
-        if ev:
-            ev[2].record()
-        if dist.is_initialized():
-            dist.all_reduce(grad)                                          # one RCCL all-reduce (sum) per step
+        if len(groups) == 1:
+            grad = hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F)
+            if ev:
+                ev[2].record()
+            if dist.is_initialized():
+                dist.all_reduce(grad)                                      # one RCCL all-reduce (sum) per step
+        else:
+            grad = torch.empty((T, F), dtype=table.dtype, device=device)
+            ws = hip_ops.backward_workspace(dim, n_local, T, table.dtype, res, bw, F, device)
+            pending = []
+            for gi, (lb, le) in enumerate(groups):
+                hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F, levels=(lb, le),
+                                          out=grad, workspace=ws,
+                                          flags=_lib.BWD_STAGE_ALL_LEVELS if gi == 0 else _lib.BWD_REUSE_STAGED)
+                if dist.is_initialized():
+                    pending.append(dist.all_reduce(grad[row_of(lb):row_of(le)], async_op=True))
+            if ev:
+                ev[2].record()
+            for wk in pending:
+                wk.wait()
         if ev:
             ev[3].record()
         return feats, grad
@@ -234,7 +267,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "dim": dim, "levels": L, "feature_dim": F, "bitwidth": bw,
                        "table_rows": T, "samples_per_gpu": n_local,
-                       "parallelism": f"dp{world}" + ("+allreduce(grad_codebook)" if world > 1 else "")},
+                       "parallelism": f"dp{world}" + (f"+allreduce(grad_codebook, {len(groups)} level groups "
+                                                      f"{groups}, overlapped with the backward)" if world > 1 else "")},
             "roofline": {"bound": "hbm",
                          "kernel": (f"hashgrid_{dom[0]} operator = one C-ABI call, HIP events on its stream; kernels: "
                                     + ("transpose_grad + bin_count + 2 scans + bin_scatter + bin_consume + "

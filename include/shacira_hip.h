@@ -97,6 +97,24 @@ SHACIRA_API int shacira_hashgrid_backward(int dim, int64_t num_coords, int num_l
                               void *grad_codebook, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Same, restricted to levels [level_begin, level_end): writes (completely) only the rows of those levels,
+ * [codebook_first_idx[level_begin], codebook_first_idx[level_end]) (to table_rows for level_end == num_lods), and leaves
+ * the rest of grad_codebook untouched. Lets a data-parallel caller start the all-reduce of the finished rows while the
+ * remaining levels are still being computed. fp32 tables only; same workspace size as the full call.
+ *   flags: SHACIRA_BWD_STAGE_ALL_LEVELS  stage (transpose) the gradients of ALL levels into the workspace, not only
+ *                                        this call's, so that later calls on the SAME workspace can skip that pass;
+ *          SHACIRA_BWD_REUSE_STAGED      the workspace already holds them (set by an earlier call with the flag above,
+ *                                        same arguments, same workspace, same stream order).
+ */
+#define SHACIRA_BWD_STAGE_ALL_LEVELS 1
+#define SHACIRA_BWD_REUSE_STAGED 2
+SHACIRA_API int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                     int codebook_bitwidth, const int32_t *resolutions_host,
+                                     const int32_t *codebook_first_idx, int64_t table_rows, const float *coords,
+                                     const void *grad_output, int dtype, void *grad_codebook, int level_begin,
+                                     int level_end, int flags, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Latent decode, deterministic (non-SGA) path of LatentDecoder.forward with num_layers_dec == 0
  * (basic_latent_decoder.py:192-198 with DecoderLayer.forward :86-91):
  *     q        = rint(latent)                       round-half-to-even, torch.round (StraightThrough :28-36)

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libshacira_hip.so")
 
 F32, F16 = 0, 1
 EINVAL, EDTYPE, EODD, EWORKSPACE = -1, -2, -3, -4
+BWD_STAGE_ALL_LEVELS, BWD_REUSE_STAGED = 1, 2
 
 _lock = threading.Lock()
 _lib = None
@@ -29,6 +30,8 @@ SIGNATURES = {
     "shacira_hashgrid_forward": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p]),
     "shacira_hashgrid_backward_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i, _p, _i64, _i]),
     "shacira_hashgrid_backward": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p]),
+    "shacira_hashgrid_backward_levels": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _i, _i, _i, _p, _sz,
+                                              _p]),
     "shacira_latent_decode_forward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "shacira_latent_decode_backward_workspace_bytes": (_sz, [_i64, _i, _i]),
     "shacira_latent_decode_backward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -60,6 +63,11 @@ def lib():
                     fn = getattr(handle, name)
                     fn.restype = res
                     fn.argtypes = args
+                # A/B without code changes: SHACIRA_OPTIONS="bin_acc_kib=64,fwd_variant=3"
+                for item in filter(None, os.environ.get("SHACIRA_OPTIONS", "").split(",")):
+                    name, _, value = item.partition("=")
+                    if handle.shacira_set_option(name.strip().encode(), int(value)) != 0:
+                        raise RuntimeError(f"SHACIRA_OPTIONS: unknown option or bad value: {item!r}")
                 _lib = handle
     return _lib
 

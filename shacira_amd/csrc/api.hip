@@ -34,6 +34,9 @@ static int build_level_table(int dim, int num_lods, int feature_dim, int bw, con
     lt.num_lods = num_lods;
     lt.feature_dim = feature_dim;
     lt.table_rows = table_rows;
+    lt.level_begin = 0;
+    lt.level_end = num_lods;
+    lt.stage_flags = 0;
     return 0;
 }
 
@@ -121,9 +124,25 @@ int shacira_hashgrid_backward(int dim, int64_t num_coords, int num_lods, int fea
                               const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
                               const float *coords, const void *grad_output, int dtype, void *grad_codebook,
                               void *workspace, size_t workspace_bytes, void *stream) {
+    return shacira_hashgrid_backward_levels(dim, num_coords, num_lods, feature_dim, codebook_bitwidth, resolutions_host,
+                                            codebook_first_idx, table_rows, coords, grad_output, dtype, grad_codebook,
+                                            0, num_lods, 0, workspace, workspace_bytes, stream);
+}
+
+int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                                     const int32_t *resolutions_host, const int32_t *codebook_first_idx,
+                                     int64_t table_rows, const float *coords, const void *grad_output, int dtype,
+                                     void *grad_codebook, int level_begin, int level_end, int flags, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
     LevelTable lt;
     int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
     if (rc) return rc;
+    if (level_begin < 0 || level_end > num_lods || level_begin >= level_end) return SHACIRA_EINVAL;
+    const bool partial = !(level_begin == 0 && level_end == num_lods);
+    if (partial && dtype != SHACIRA_F32) return SHACIRA_EDTYPE;   // level ranges: fp32 tables only
+    lt.level_begin = level_begin;
+    lt.level_end = level_end;
+    lt.stage_flags = flags & (SHACIRA_BWD_STAGE_ALL_LEVELS | SHACIRA_BWD_REUSE_STAGED);
     if (dtype != SHACIRA_F32 && dtype != SHACIRA_F16) return SHACIRA_EDTYPE;
     if (num_coords < 0 || !grad_codebook) return SHACIRA_EINVAL;
     if (num_coords > 0 && (!codebook_first_idx || !coords || !grad_output)) return SHACIRA_EINVAL;

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(LevelTable lt,
     for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < num_items; w += stride) {
         const uint32_t s = w / L;
         const uint32_t lvl = w - s * L;
+        if ((int32_t)lvl < lt.level_begin || (int32_t)lvl >= lt.level_end) continue;
         const int64_t i = sample0 + s;
         double t[DIM];
 #pragma unroll
@@ -73,6 +74,16 @@ __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float *__restrict
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) dst[i] = __float2half_rn(src[i]);
+}
+
+// zeroes the rows of levels [level_begin, level_end) (first_idx lives on the device)
+__global__ __launch_bounds__(256) void zero_level_rows_kernel(float *__restrict__ acc,
+                                                              const int32_t *__restrict__ first_idx, int level_begin,
+                                                              int level_end, int num_lods, int64_t table_rows, int F) {
+    const int64_t lo = (int64_t)first_idx[level_begin] * F;
+    const int64_t hi = ((level_end < num_lods) ? (int64_t)first_idx[level_end] : table_rows) * F;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; e < hi; e += stride) acc[e] = 0.0f;
 }
 
 template <int DIM, typename T, int F>
@@ -134,7 +145,14 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
     if (dtype == SHACIRA_F16) {
         acc = bin ? bin_acc32(dim, dtype, lt, n, workspace) : static_cast<float *>(workspace);
     }
-    hipError_t e = hipMemsetAsync(acc, 0, (size_t)numel * sizeof(float), s);  // at::zeros_like, .cpp:81/:167
+    hipError_t e = hipSuccess;
+    if (lt.level_begin == 0 && lt.level_end == lt.num_lods) {
+        e = hipMemsetAsync(acc, 0, (size_t)numel * sizeof(float), s);  // at::zeros_like, .cpp:81/:167
+    } else {
+        hipLaunchKernelGGL(zero_level_rows_kernel, dim3(2048), dim3(256), 0, s, acc, first_idx, lt.level_begin,
+                           lt.level_end, lt.num_lods, lt.table_rows, lt.feature_dim);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) return e;
     if (bin) {
         e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s);

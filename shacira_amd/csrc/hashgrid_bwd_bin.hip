@@ -142,7 +142,7 @@ __device__ __forceinline__ void enumerate_pairs(const double (&t)[DIM], int32_t 
 // grad_output [N, L*F] (T) -> gT [L][N][F] fp32, through LDS, F scalars per lane per access. Block: 256 samples.
 template <typename T, int F>
 __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict__ go, float *__restrict__ gT,
-                                                             int64_t N, int L) {
+                                                             int64_t N, int L, int lb, int le) {
     struct alignas(sizeof(T) * F) PieceIn { T v[F]; };
     struct alignas(sizeof(float) * F) PieceOut { float v[F]; };
     extern __shared__ __align__(16) unsigned char s_raw_g[];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
     }
     __syncthreads();
     PieceOut *out = reinterpret_cast<PieceOut *>(gT);
-    for (int l = 0; l < L; ++l) {
+    for (int l = lb; l < le; ++l) {
         if ((int)threadIdx.x < ns) {
             const PieceOut q = s_tile[threadIdx.x * pitch + l];
             float *dst = reinterpret_cast<float *>(out + (int64_t)l * N + s0 + threadIdx.x);
@@ -562,6 +562,15 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
         bl.shift = shift;
         bl.dgroup = -1;
         bl.drow0 = 0;
+        if (l < lt.level_begin || l >= lt.level_end) {  // not part of this call
+            bl.nb = 0;
+            bl.used = 0;
+            bl.rows_pb = 0;
+            bl.G = 1;
+            bl.magicG = 0;
+            bl.bucket0 = 0xFFFFFFFFu;
+            continue;
+        }
         if (lt.dense[l]) {
             const uint64_t lines = (dim == 3) ? res * res : res;
             bl.used = (uint32_t)(lines * res);
@@ -601,10 +610,9 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
     plan.BR = BR;
     plan.num_tiles = (uint32_t)((n_batch + kTile - 1) / kTile);
     plan.pairs = 1u << (dim - 1);
-    // work-unit size: ~1/768 of the items so that an evenly loaded hashed bucket (1/64 of a level) is ONE unit
-    // (plain-store flush) while over-full coarse buckets split into equal chunks that keep all 256 CUs busy
-    uint64_t items = (uint64_t)n_batch * plan.nbl * plan.pairs;
-    uint64_t chunk = items / 768 + 1024;
+    // work-unit size: 1/48 of ONE level's items, so that an evenly loaded hashed bucket (1/64 of a level) is ONE unit
+    // (plain-store flush) with 33 % slack, while over-full coarse buckets split into equal chunks that keep all CUs busy
+    uint64_t chunk = (uint64_t)n_batch * plan.pairs / 48 + 1024;
     if (chunk < 8192) chunk = 8192;
     if (chunk > (1u << 22)) chunk = 1u << 22;
     plan.chunk = (uint32_t)chunk;
@@ -686,17 +694,21 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     const int L = lt.num_lods;
     BinPlan whole;
     make_plan(DIM, lt, n, whole);
-    const bool need_T = whole.nbl > 0;   // only binned levels consume the transposed gradients
-    if (need_T) {
+    const bool stage_all = (lt.stage_flags & SHACIRA_BWD_STAGE_ALL_LEVELS) != 0;
+    const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
+    // only binned levels consume the transposed gradients (a later call on this workspace may, too: stage_all)
+    const bool need_T = whole.nbl > 0 || stage_all || staged;
+    if (need_T && !staged) {
+        const int t_lb = stage_all ? 0 : lt.level_begin, t_le = stage_all ? L : lt.level_end;
         // pass T over the whole batch
         const uint32_t blocks = (uint32_t)((n + 255) / 256);
         const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
         if (dtype == SHACIRA_F32)
             hipLaunchKernelGGL((transpose_grad_kernel<float, F>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const float *>(grad_out), w.gT, n, L);
+                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le);
         else
             hipLaunchKernelGGL((transpose_grad_kernel<__half, F>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const __half *>(grad_out), w.gT, n, L);
+                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le);
         SHACIRA_CHECK_LAUNCH();
     }
     // direct levels: one pass over the whole batch, no items

@@ -26,6 +26,9 @@ struct LevelTable {
     int32_t num_lods;
     int32_t feature_dim;
     int64_t table_rows;
+    int32_t level_begin;              // backward only: levels [level_begin, level_end) are processed
+    int32_t level_end;
+    int32_t stage_flags;              // SHACIRA_BWD_STAGE_ALL_LEVELS / SHACIRA_BWD_REUSE_STAGED
 };
 
 // Host-side replica of the kernel's int32 dense test (.cu:27-29 / 2d.cu:26-27), short-circuit, wraparound.

@@ -62,8 +62,13 @@ def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, cod
 
 
 def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codebook_first_idx, resolution,
-                      codebook_bitwidth, feature_dim):
-    """grad_codebook [table_rows, feature_dim] of ``table_dtype`` (the codebook's values are not needed)."""
+                      codebook_bitwidth, feature_dim, levels=None, out=None, workspace=None, flags=0):
+    """grad_codebook [table_rows, feature_dim] of ``table_dtype`` (the codebook's values are not needed).
+
+    ``levels=(begin, end)`` computes (and overwrites) only the rows of those levels inside ``out`` (an existing
+    gradient buffer) -- used to overlap the all-reduce of finished rows with the remaining levels. A series of such
+    calls can share ``workspace`` (see ``backward_workspace``) with ``flags`` BWD_STAGE_ALL_LEVELS on the first and
+    BWD_REUSE_STAGED on the following ones, so the gradients are transposed once."""
     _need_gpu(coords, grad_output, codebook_first_idx)
     res = tuple(int(r) for r in resolution)
     N, T, F = coords.shape[0], int(table_rows), int(feature_dim)
@@ -73,17 +78,41 @@ def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codeboo
     if grad_output.dtype != table_dtype:
         grad_output = grad_output.to(table_dtype)
     device = grad_output.device
-    grad_codebook = torch.empty((T, F), dtype=table_dtype, device=device)
+    if out is not None:
+        if tuple(out.shape) != (T, F) or out.dtype != table_dtype or not out.is_contiguous():
+            raise RuntimeError("out must be a contiguous [table_rows, feature_dim] tensor of the table dtype")
+        grad_codebook = out
+    else:
+        if levels is not None and tuple(levels) != (0, len(res)):
+            raise RuntimeError("a level range needs an existing `out` buffer (other rows are left untouched)")
+        grad_codebook = torch.empty((T, F), dtype=table_dtype, device=device)
+    lb, le = (0, len(res)) if levels is None else (int(levels[0]), int(levels[1]))
     L = _lib.lib()
     with torch.cuda.device(device):
         nbytes = L.shacira_hashgrid_backward_workspace_bytes(dim, N, len(res), F, int(codebook_bitwidth),
                                                              _res_array(res), T, dt)
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
-        rc = L.shacira_hashgrid_backward(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
-                                         _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
-                                         _ptr(grad_codebook), _ptr(ws), nbytes, _stream(grad_output))
+        if workspace is not None:
+            if workspace.numel() * workspace.element_size() < nbytes:
+                raise RuntimeError("workspace too small")
+            ws = workspace
+        else:
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
+        rc = L.shacira_hashgrid_backward_levels(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
+                                                _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
+                                                _ptr(grad_codebook), lb, le, int(flags), _ptr(ws), nbytes,
+                                                _stream(grad_output))
     _lib.check(rc, "hashgrid_interpolate_backward")
     return grad_codebook
+
+
+def backward_workspace(dim, num_coords, table_rows, table_dtype, resolution, codebook_bitwidth, feature_dim, device):
+    """Scratch buffer a caller can share between several ``hashgrid_backward(..., levels=...)`` calls."""
+    res = tuple(int(r) for r in resolution)
+    with torch.cuda.device(device):
+        n = _lib.lib().shacira_hashgrid_backward_workspace_bytes(dim, int(num_coords), len(res), int(feature_dim),
+                                                                 int(codebook_bitwidth), _res_array(res),
+                                                                 int(table_rows), _DTYPES[table_dtype])
+    return torch.empty((max(n, 1),), dtype=torch.uint8, device=device)
 
 
 def hashgrid_interpolate_cuda(coords, codebook, codebook_first_idx, resolution, codebook_bitwidth):

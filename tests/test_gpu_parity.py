@@ -164,6 +164,41 @@ def test_backward_in_sub_batches(dev):
     np.testing.assert_allclose(grad.cpu().numpy(), ref_g, rtol=RTOL, atol=RTOL * np.abs(ref_g).max())
 
 
+@pytest.mark.parametrize("name,bvar", [("D", -1), ("Bp", -1), ("B", -1), ("D", 0)])
+def test_backward_by_level_ranges(dev, name, bvar):
+    """Gradient built in two calls over disjoint level ranges (the hook for overlapping the all-reduce of finished
+    rows with the remaining levels) == one call over all levels; rows outside a call's range are left untouched."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw = CONFIGS[name]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, 30_001)
+    tc, tg, tf = (torch.from_numpy(a).to(dev) for a in (coords, go, first))
+    _lib.set_option("bwd_variant", bvar)
+    try:
+        full = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2)
+        out = torch.full((T, 2), 7.0, device=dev)
+        split = 9
+        ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, levels=(split, len(res)), out=out)
+        lo = int(first[split])
+        assert float((out[:lo] - 7.0).abs().max()) == 0.0                      # untouched
+        ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, levels=(0, split), out=out)
+    finally:
+        _lib.set_option("bwd_variant", -1)
+    ref = oc.backward(coords, go, (T, 2), first, res, bw)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=RTOL * np.abs(ref).max())
+    np.testing.assert_allclose(out.cpu().numpy(), full.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(full.abs().max()))
+    with pytest.raises(RuntimeError):
+        ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, levels=(0, 3))   # needs `out`
+    # shared workspace: gradients staged once by the first call, reused by the second
+    ws = ops.backward_workspace(dim, coords.shape[0], T, torch.float32, res, bw, 2, dev)
+    out2 = torch.full((T, 2), -3.0, device=dev)
+    ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, levels=(0, split), out=out2, workspace=ws,
+                          flags=_lib.BWD_STAGE_ALL_LEVELS)
+    ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, levels=(split, len(res)), out=out2,
+                          workspace=ws, flags=_lib.BWD_REUSE_STAGED)
+    np.testing.assert_allclose(out2.cpu().numpy(), ref, rtol=RTOL, atol=RTOL * np.abs(ref).max())
+
+
 def test_max_levels_and_wide_features(dev):
     """SHACIRA_MAX_LODS = 32 levels with F = 4 (largest staging tiles of the transposing passes), 3-D and 2-D."""
     for dim, bw in ((3, 14), (2, 12)):
