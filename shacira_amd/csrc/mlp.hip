@@ -24,7 +24,7 @@
 
 namespace shacira {
 
-constexpr int kMlpTile = 256;  // samples per tile == threads per block
+constexpr int kMlpTile = 128;  // samples per tile == threads per block
 
 template <int IN, int H, int NH, int OUT> struct MlpShape {
     static constexpr int w_off(int layer) {  // offset of W of hidden layer `layer` (0-based); layer == NH: output layer
