@@ -448,7 +448,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
 // (fp32, F == 2) or F*sizeof(T)-byte piece per lane, lanes consecutive.
 template <typename T, int F>
 __global__ __launch_bounds__(256) void untranspose_feats_kernel(const T *__restrict__ src, T *__restrict__ dst,
-                                                                int64_t N, int L) {
+                                                                int64_t N, int L,
+                                                                const uint32_t *__restrict__ perm) {
     struct alignas(sizeof(T) * F) Piece { T v[F]; };
     extern __shared__ __align__(16) unsigned char s_raw_t[];
     Piece *s_tile = reinterpret_cast<Piece *>(s_raw_t);  // [256][L + 1] pieces
@@ -459,12 +460,25 @@ __global__ __launch_bounds__(256) void untranspose_feats_kernel(const T *__restr
     for (int l = 0; l < L; ++l)
         if ((int)threadIdx.x < ns) s_tile[threadIdx.x * pitch + l] = in[(int64_t)l * N + s0 + threadIdx.x];
     __syncthreads();
-    Piece *out = reinterpret_cast<Piece *>(dst) + s0 * L;
     const int total = ns * L;
+    if (perm) {   // staged rows are in cell-sorted order: row j belongs to sample perm[j] (whole rows stay contiguous)
+        Piece *out = reinterpret_cast<Piece *>(dst);
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const int sm = e / L, l = e - sm * L;
+            out[(int64_t)perm[s0 + sm] * L + l] = s_tile[sm * pitch + l];
+        }
+        return;
+    }
+    Piece *out = reinterpret_cast<Piece *>(dst) + s0 * L;
     for (int e = threadIdx.x; e < total; e += 256) {
         const int sm = e / L, l = e - sm * L;
         out[e] = s_tile[sm * pitch + l];
     }
+}
+
+static bool use_sorted(int dim, const LevelTable &lt, int64_t n);
+template <typename T> static size_t staged_bytes(const LevelTable &lt, int64_t n) {
+    return ((size_t)n * lt.num_lods * lt.feature_dim * sizeof(T) + 255) / 256 * 256;
 }
 
 template <int DIM, typename T, int F>
@@ -477,10 +491,22 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
             // then one transposing copy into the caller's [N, L*F] layout
             const uint32_t groups = (uint32_t)((lt.num_lods + 7) / 8);
             const uint32_t tiles = (uint32_t)((num_coords + 127) / 128);
+            const uint32_t *perm = nullptr;
+            hipError_t e;
+            if (use_sorted(DIM, lt, num_coords)) {
+                // variant 7: the same kernels walking the samples in cell-sorted order (cell_sort.hip)
+                uint32_t *perm_w;
+                float *sorted;
+                unsigned char *sort_ws = static_cast<unsigned char *>(workspace) + staged_bytes<T>(lt, num_coords);
+                e = cell_sort(DIM, coords, num_coords, sort_ws, &perm_w, &sorted, stream);
+                if (e != hipSuccess) return e;
+                perm = perm_w;
+                coords = sorted;
+            }
             hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true>), dim3(8u * tiles * groups),
                                dim3(256), 0, stream, lt, first_idx, coords, static_cast<const T *>(table),
                                static_cast<T *>(workspace), num_coords, tiles);
-            hipError_t e = hipGetLastError();
+            e = hipGetLastError();
             if (e != hipSuccess) return e;
             const size_t shmem = (size_t)256 * (lt.num_lods + 1) * F * sizeof(T);
             static std::once_flag once;  // per instantiation: allow > 64 KiB of dynamic LDS (L = 32, F = 4, fp32)
@@ -490,7 +516,7 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
             });
             hipLaunchKernelGGL((untranspose_feats_kernel<T, F>), dim3((uint32_t)((num_coords + 255) / 256)), dim3(256),
                                shmem, stream, static_cast<const T *>(workspace), static_cast<T *>(feats), num_coords,
-                               lt.num_lods);
+                               lt.num_lods, perm);
             return hipGetLastError();
         }
         if (variant == 1) {
@@ -564,18 +590,25 @@ static hipError_t dispatch_f(const LevelTable &lt, const int32_t *first_idx, con
     }
 }
 
-// level-major staging buffer [L][N][F] of the table's scalar type (variant 6)
+// level-major staging buffer [L][N][F] of the table's scalar type (variants 6 and 7)
 static bool use_staged(int dim, const LevelTable &lt, int64_t n) {
     const int v = g_fwd_variant.load();
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return false;
-    if (v == 6) return true;
+    if (v == 6 || v == 7) return true;
     return v < 0 && dim == 3 && n >= 16384;   // measured: 3-D large batches; 2-D and small batches: variant 3
+}
+
+static bool use_sorted(int dim, const LevelTable &lt, int64_t n) {
+    (void)dim;
+    (void)lt;
+    return g_fwd_variant.load() == 7 && n > 0;
 }
 
 size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return 0;
-    (void)dim;
-    return (size_t)n * lt.num_lods * lt.feature_dim * (dtype == SHACIRA_F32 ? 4 : 2);
+    size_t b = ((size_t)n * lt.num_lods * lt.feature_dim * (dtype == SHACIRA_F32 ? 4 : 2) + 255) / 256 * 256;
+    if (use_sorted(dim, lt, n)) b += cell_sort_workspace_bytes(dim, n);
+    return b;
 }
 
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,

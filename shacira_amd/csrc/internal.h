@@ -2,6 +2,7 @@
 #pragma once
 
 #include <atomic>
+#include <mutex>
 
 #include "hashgrid_device.h"
 
@@ -12,6 +13,10 @@ size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int6
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                      const float *coords, const void *table, void *feats, void *workspace, int64_t n,
                                      hipStream_t s);
+// cell_sort.hip
+size_t cell_sort_workspace_bytes(int dim, int64_t n);
+hipError_t cell_sort(int dim, const float *coords, int64_t n, void *ws, uint32_t **perm_out, float **sorted_out,
+                     hipStream_t s);
 // hashgrid_bwd.hip
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
 hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,

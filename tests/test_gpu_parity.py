@@ -63,7 +63,7 @@ def _run(dev, dim, res, bw, coords, table, go, first, dtype=torch.float32):
 
 
 @pytest.mark.parametrize("name", ["A", "B", "Bp", "D"])
-@pytest.mark.parametrize("variant", [(-1, -1), (0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1)])
+@pytest.mark.parametrize("variant", [(-1, -1), (0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1)])
 def test_forward_bit_exact_backward_within_tolerance(dev, name, variant):
     from shacira_amd import _lib
     dim, res, bw = CONFIGS[name]
