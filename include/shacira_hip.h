@@ -217,6 +217,9 @@ SHACIRA_API int shacira_adam_step_multi(int num_tensors, const int64_t *numel_ho
  * Tunables (process-wide, read at call time; for benchmarking and A/B only).
  *   "fwd_variant", "bwd_variant": integer algorithm selectors, -1 = automatic.
  *   "bin_batch_mib": cap (MiB) of the backward's item array; larger batches are processed in sub-batches.
+ *   "bin_acc_kib": LDS accumulator image per consumer workgroup (64 or 128).
+ *   "bwd_fork": 1 (default) = the backward's count + scan passes are issued on a library-owned side stream, forked
+ *               from and joined back into the caller's stream with events (stream semantics unchanged); 0 = one stream.
  */
 SHACIRA_API int shacira_set_option(const char *name, int value);
 SHACIRA_API int shacira_get_option(const char *name);

@@ -688,12 +688,64 @@ float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *work
         if (e_ != hipSuccess) return e_;       \
     } while (0)
 
+// Side stream for the passes that do not depend on the transposed gradient (count + scans): they are compute/LDS
+// bound while the transpose and the direct levels are memory/LDS bound, so they share the chip well. One per host
+// thread and device; fork/join with events keeps the caller's stream semantics (and is capturable in a HIP graph once
+// the objects exist -- they are created on the first eager call).
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static hipError_t side_stream(SideStream **out) {
+    static thread_local SideStream per_device[16];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    SideStream &ss = per_device[dev];
+    if (!ss.stream) {
+        hipStream_t st;
+        hipEvent_t a, b;
+        if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&a, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&b, hipEventDisableTiming)) != hipSuccess) return e;
+        ss.fork = a;
+        ss.join = b;
+        ss.stream = st;
+    }
+    *out = &ss;
+    return hipSuccess;
+}
+
 template <int DIM, int F>
 static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                           const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s) {
     const int L = lt.num_lods;
     BinPlan whole;
     make_plan(DIM, lt, n, whole);
+    const int64_t nb = bin_batch_samples(DIM, lt, n);
+    const bool multi = nb < n;
+    // single sub-batch (the usual case): count + scans run on the side stream next to transpose + direct levels
+    SideStream *ss = nullptr;
+    if (whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 && n >= (1 << 18)) {   // measured: a loss at 64 K samples
+        hipError_t e = side_stream(&ss);
+        if (e != hipSuccess) return e;
+        if ((e = hipEventRecord(ss->fork, s)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(ss->stream, ss->fork, 0)) != hipSuccess) return e;
+        BinPlan plan;
+        make_plan(DIM, lt, n, plan);
+        const dim3 grid(plan.num_tiles, plan.nbl);
+        hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, ss->stream, lt, plan, coords, w.cnt,
+                           (int64_t)0, n);
+        SHACIRA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, ss->stream, w.cnt, w.totals,
+                           plan.num_tiles);
+        SHACIRA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, ss->stream, w.totals, w.base,
+                           w.unit_first, w.unit_bucket, plan.total_buckets, plan.chunk);
+        SHACIRA_CHECK_LAUNCH();
+        if ((e = hipEventRecord(ss->join, ss->stream)) != hipSuccess) return e;
+    }
     const bool stage_all = (lt.stage_flags & SHACIRA_BWD_STAGE_ALL_LEVELS) != 0;
     const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
     // only binned levels consume the transposed gradients (a later call on this workspace may, too: stage_all)
@@ -732,21 +784,25 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         SHACIRA_CHECK_LAUNCH();
     }
     if (whole.nbl == 0) return hipSuccess;
-    const int64_t nb = bin_batch_samples(DIM, lt, n);
-    const bool multi = nb < n;
+    if (ss) {
+        hipError_t e = hipStreamWaitEvent(s, ss->join, 0);
+        if (e != hipSuccess) return e;
+    }
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
         BinPlan plan;
         make_plan(DIM, lt, hi - s0, plan);
         const dim3 grid(plan.num_tiles, plan.nbl);
-        hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, s, lt, plan, coords, w.cnt, s0, hi);
-        SHACIRA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, s, w.cnt, w.totals,
-                           plan.num_tiles);
-        SHACIRA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
-                           w.unit_bucket, plan.total_buckets, plan.chunk);
-        SHACIRA_CHECK_LAUNCH();
+        if (!ss) {
+            hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, s, lt, plan, coords, w.cnt, s0, hi);
+            SHACIRA_CHECK_LAUNCH();
+            hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, s, w.cnt, w.totals,
+                               plan.num_tiles);
+            SHACIRA_CHECK_LAUNCH();
+            hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
+                               w.unit_bucket, plan.total_buckets, plan.chunk);
+            SHACIRA_CHECK_LAUNCH();
+        }
         constexpr int NP = 1 << (DIM - 1);
         const size_t stage = (size_t)kTile * NP * (sizeof(Item<F>) + 1);
         hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,

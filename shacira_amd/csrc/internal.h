@@ -66,5 +66,6 @@ extern std::atomic<int> g_fwd_variant;
 extern std::atomic<int> g_bwd_variant;
 extern std::atomic<int> g_bin_batch_mib;
 extern std::atomic<int> g_bin_acc_kib;
+extern std::atomic<int> g_bwd_fork;
 
 }  // namespace shacira

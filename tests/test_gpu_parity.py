@@ -199,6 +199,45 @@ def test_backward_by_level_ranges(dev, name, bvar):
     np.testing.assert_allclose(out2.cpu().numpy(), ref, rtol=RTOL, atol=RTOL * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("name", ["D", "Bp"])
+def test_backward_side_stream_fork(dev, name):
+    """N >= 2^18: count + scans run on the library's side stream. Same gradient as the single-stream order and as
+    the oracle; the forked call is also capturable into a HIP graph (after one eager call) and replays correctly."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw = CONFIGS[name]
+    N = 1 << 18
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, N, seed=11)
+    tc, tg, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(go).to(dev), torch.from_numpy(first).to(dev)
+    ref = oc.backward(coords, go, (T, 2), first, res, bw)
+    scale = np.abs(ref).max()
+    grads = {}
+    try:
+        for fork in (0, 1):
+            _lib.set_option("bwd_fork", fork)
+            assert _lib.get_option("bwd_fork") == fork
+            grads[fork] = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2)
+            np.testing.assert_allclose(grads[fork].cpu().numpy(), ref, rtol=RTOL, atol=RTOL * scale)
+        # graph capture of the forked call (side stream joins back into the capturing stream)
+        out = torch.empty((T, 2), device=dev)
+        ws = ops.backward_workspace(dim, N, T, torch.float32, res, bw, 2, dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, out=out, workspace=ws)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, out=out, workspace=ws)
+        tg.mul_(2.0)
+        out.fill_(7.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), 2.0 * ref, rtol=RTOL, atol=2 * RTOL * scale)
+    finally:
+        _lib.set_option("bwd_fork", 1)
+
+
 def test_max_levels_and_wide_features(dev):
     """SHACIRA_MAX_LODS = 32 levels with F = 4 (largest staging tiles of the transposing passes), 3-D and 2-D."""
     for dim, bw in ((3, 14), (2, 12)):
