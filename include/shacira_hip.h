@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SHACIRA_ABI_VERSION 2
+#define SHACIRA_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define SHACIRA_API __attribute__((visibility("default")))
@@ -212,6 +212,34 @@ SHACIRA_API int shacira_adam_step_multi(int num_tensors, const int64_t *numel_ho
                             float *const *exp_avg, float *const *exp_avg_sq, const float *lr_host,
                             const float *weight_decay_host, float beta1, float beta2, float eps, int step,
                             const int32_t *step_dev, int zero_grad, void *stream);
+
+/*
+ * Symbol statistics and entropy coding of the rounded latents -- replaces the per-channel
+ * `torch.round(...).long()` + `torch.unique(return_counts=True)` of LatentGrid.size
+ * (wisp/models/grids/latent_grid.py:141-143) and the torchac.encode_float_cdf call (:155-172).
+ *
+ *   shacira_latent_symbol_range      minmax[c] = {min, max} over rows of (int)rint(latent[r, c])   (device int32 [ld][2];
+ *                                    {INT32_MAX, INT32_MIN} when num_rows == 0). rint = round-half-even = torch.round.
+ *   shacira_latent_symbol_histogram  counts[c][k] = #rows with rint(latent[r, c]) == minmax[c][0] + k, 0 <= k < nbins
+ *                                    (device uint64 [ld][nbins], overwritten). `minmax` is the device array written by
+ *                                    shacira_latent_symbol_range; nbins >= max_c (max - min + 1).
+ *   latent_dim <= 16, else SHACIRA_EDTYPE.
+ *
+ * Range coder (HOST buffers, runs on the calling thread; the reference codes on the CPU as well):
+ *   static model = freq_host[num_symbols] with sum exactly 65536 and freq >= 1 for every symbol that occurs.
+ *   shacira_rc_encode  symbols (indices into the model) -> bytes; *out_len = bytes produced; SHACIRA_EWORKSPACE if
+ *                      `capacity` < *out_len (nothing valid written); shacira_rc_encode_bound(n) is always enough.
+ *   shacira_rc_decode  exact inverse: reproduces the n symbols.
+ */
+SHACIRA_API int shacira_latent_symbol_range(int64_t num_rows, int latent_dim, const float *latent, int32_t *minmax,
+                                void *stream);
+SHACIRA_API int shacira_latent_symbol_histogram(int64_t num_rows, int latent_dim, const float *latent, const int32_t *minmax,
+                                    int nbins, uint64_t *counts, void *stream);
+SHACIRA_API size_t shacira_rc_encode_bound(int64_t num_symbols_to_code);
+SHACIRA_API int shacira_rc_encode(const int32_t *symbols_host, int64_t n, const uint32_t *freq_host, int num_symbols,
+                      uint8_t *out_host, size_t capacity, size_t *out_len);
+SHACIRA_API int shacira_rc_decode(const uint8_t *in_host, size_t len, const uint32_t *freq_host, int num_symbols, int64_t n,
+                      int32_t *symbols_host);
 
 /*
  * Tunables (process-wide, read at call time; for benchmarking and A/B only).

@@ -38,6 +38,11 @@ SIGNATURES = {
     "shacira_entropy_bits_workspace_bytes": (_sz, [_i64, _i]),
     "shacira_entropy_bits_forward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "shacira_entropy_bits_backward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "shacira_latent_symbol_range": (_i, [_i64, _i, _p, _p, _p]),
+    "shacira_latent_symbol_histogram": (_i, [_i64, _i, _p, _p, _i, _p, _p]),
+    "shacira_rc_encode_bound": (_sz, [_i64]),
+    "shacira_rc_encode": (_i, [_p, _i64, _p, _i, _p, _sz, _p]),
+    "shacira_rc_decode": (_i, [_p, _sz, _p, _i, _i64, _p]),
     "shacira_mlp_supported": (_i, [_i, _i, _i, _i]),
     "shacira_mlp_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "shacira_mlp_forward": (_i, [_i64, _i, _i, _i, _i, _p, _p, _p, _p]),

@@ -187,6 +187,32 @@ int shacira_latent_decode_backward(int64_t num_rows, int latent_dim, int feature
     return (int)latent_decode_dispatch(true, latent_dim, feature_dim, a, (hipStream_t)stream);
 }
 
+int shacira_latent_symbol_range(int64_t num_rows, int latent_dim, const float *latent, int32_t *minmax, void *stream) {
+    if (num_rows < 0 || latent_dim < 1 || !minmax || (num_rows > 0 && !latent)) return SHACIRA_EINVAL;
+    if (!symbols_supported(latent_dim)) return SHACIRA_EDTYPE;
+    return (int)symbol_range_launch(latent, num_rows, latent_dim, minmax, (hipStream_t)stream);
+}
+
+int shacira_latent_symbol_histogram(int64_t num_rows, int latent_dim, const float *latent, const int32_t *minmax,
+                                    int nbins, uint64_t *counts, void *stream) {
+    if (num_rows < 0 || latent_dim < 1 || nbins < 1 || !minmax || !counts || (num_rows > 0 && !latent))
+        return SHACIRA_EINVAL;
+    if (!symbols_supported(latent_dim)) return SHACIRA_EDTYPE;
+    return (int)symbol_histogram_launch(latent, num_rows, latent_dim, minmax, nbins, counts, (hipStream_t)stream);
+}
+
+size_t shacira_rc_encode_bound(int64_t n) { return rc_encode_bound(n < 0 ? 0 : n); }
+
+int shacira_rc_encode(const int32_t *symbols_host, int64_t n, const uint32_t *freq_host, int num_symbols,
+                      uint8_t *out_host, size_t capacity, size_t *out_len) {
+    return rc_encode(symbols_host, n, freq_host, num_symbols, out_host, capacity, out_len);
+}
+
+int shacira_rc_decode(const uint8_t *in_host, size_t len, const uint32_t *freq_host, int num_symbols, int64_t n,
+                      int32_t *symbols_host) {
+    return rc_decode(in_host, len, freq_host, num_symbols, n, symbols_host);
+}
+
 size_t shacira_entropy_bits_workspace_bytes(int64_t, int) { return latent_workspace_bytes(); }
 
 int shacira_entropy_bits_forward(int64_t num_rows, int latent_dim, int num_layers, const float *latent,

@@ -46,6 +46,15 @@ hipError_t latent_decode_dispatch(bool bwd, int ld, int f, const DecodeArgs &a, 
 bool entropy_supported(int ld);
 hipError_t entropy_dispatch(bool bwd, int ld, const EntropyArgs &a, hipStream_t s);
 
+// symbols.hip
+bool symbols_supported(int ld);
+hipError_t symbol_range_launch(const float *latent, int64_t rows, int ld, int32_t *minmax, hipStream_t s);
+hipError_t symbol_histogram_launch(const float *latent, int64_t rows, int ld, const int32_t *minmax, int nbins,
+                                   uint64_t *counts, hipStream_t s);
+size_t rc_encode_bound(int64_t n);
+int rc_encode(const int32_t *sym, int64_t n, const uint32_t *freq, int nsym, uint8_t *out, size_t cap, size_t *len);
+int rc_decode(const uint8_t *in, size_t len, const uint32_t *freq, int nsym, int64_t n, int32_t *sym);
+
 // adam.hip
 hipError_t adam_step_launch(float *p, float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps,
                             float wd, int step, const int32_t *step_dev, int zero_grad, hipStream_t s);

@@ -249,3 +249,35 @@ def mlp_backward(x, params, grad_y, in_dim, hidden_dim, num_hidden, out_dim, nee
                                     _ptr(grad_y), _ptr(gx), _ptr(gp), _ptr(ws), n, _stream(x))
     _lib.check(rc, "mlp_backward")
     return gx, gp
+
+
+# ---------------------------------------------------------------------------------------------- symbol statistics
+def symbols_supported(latent_dim):
+    return 1 <= latent_dim <= 16
+
+
+def latent_symbol_counts(latent):
+    """Per-channel histogram of ``round(latent)`` (half to even, as ``torch.round``).
+
+    Returns ``(lo, counts)``: ``lo`` int64 [ld] on the host = smallest symbol per channel, ``counts`` int64
+    [ld, nbins] on the device with ``counts[c, k]`` = rows whose rounded value in channel c is ``lo[c] + k``
+    (trailing bins of narrower channels are 0). Replaces ``torch.unique(return_counts=True)`` of
+    LatentGrid.size (reference latent_grid.py:141-143); one host read-back of 2*ld integers sizes the bins."""
+    _need_gpu(latent)
+    if latent.dtype != torch.float32 or latent.dim() != 2:
+        raise RuntimeError("latent_symbol_counts: expected an fp32 [rows, latent_dim] tensor")
+    latent = latent.detach().contiguous()
+    rows, ld = latent.shape
+    L = _lib.lib()
+    with torch.cuda.device(latent.device):
+        minmax = torch.empty((ld, 2), dtype=torch.int32, device=latent.device)
+        _lib.check(L.shacira_latent_symbol_range(rows, ld, _ptr(latent), _ptr(minmax), _stream(latent)),
+                   "shacira_latent_symbol_range")
+        mm = minmax.cpu()
+        if rows == 0:
+            return torch.zeros(ld, dtype=torch.int64), torch.zeros((ld, 1), dtype=torch.int64, device=latent.device)
+        nbins = int((mm[:, 1].long() - mm[:, 0].long()).max().item()) + 1
+        counts = torch.empty((ld, nbins), dtype=torch.int64, device=latent.device)  # kernel writes uint64, < 2^63
+        _lib.check(L.shacira_latent_symbol_histogram(rows, ld, _ptr(latent), _ptr(minmax), nbins, _ptr(counts),
+                                                     _stream(latent)), "shacira_latent_symbol_histogram")
+    return mm[:, 0].long(), counts

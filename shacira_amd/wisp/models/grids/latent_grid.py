@@ -75,24 +75,46 @@ class LatentGrid(_MultiLevelTable):
         return total_bits / self.codebook.shape[0], total_bits
 
     def size(self, use_torchac=False, use_prob_model=False):
-        """(decoder bits, latent bits): empirical (or model) entropy of the rounded latents per channel."""
+        """(decoder bits, latent bits): empirical (or model) entropy of the rounded latents per channel, or -- with
+        ``use_torchac`` -- the bits of the arithmetic-coded payload. Same formula as reference latent_grid.py:138-174;
+        the sorted ``torch.unique`` per channel is replaced by one histogram pass (HIP kernel for device tables), and
+        the byte stream comes from this package's range coder (shacira_amd/codec.py) instead of torchac, coding with
+        the empirical distribution exactly as the reference's torchac branch does."""
+        from .... import codec
         ldec_size = self.latent_dec.size(use_torchac)
-        if use_torchac:
-            raise NotImplementedError("torchac arithmetic coding is not available (un-pinned third-party dependency "
-                                      "of the reference, latent_grid.py:154-172); use use_torchac=False")
         codebook_bits = 0
+        lo, hist = codec.symbol_counts(self.codebook)
+        device = self.codebook.device
         for dim in range(self.codebook.size(1)):
-            weight = torch.round(self.codebook[:, dim]).long()
-            unique_vals, counts = torch.unique(weight, return_counts=True)
+            present = hist[dim].nonzero()[0]
+            unique_vals = torch.as_tensor(lo[dim] + present, dtype=torch.long, device=device)
+            counts = torch.as_tensor(hist[dim][present], dtype=torch.long, device=device)
             if not use_prob_model:
                 probs = counts / torch.sum(counts)
             else:
                 assert self.prob_model is not None
                 probs = self.prob_model(unique_vals + 0.5, single_channel=dim) \
                     - self.prob_model(unique_vals - 0.5, single_channel=dim)
-            information_bits = torch.clamp(-1.0 * torch.log(probs + 1e-10) / math.log(2.0), 0, 1000)
-            codebook_bits += torch.sum(information_bits * counts).item()
+            if not use_torchac:
+                information_bits = torch.clamp(-1.0 * torch.log(probs + 1e-10) / math.log(2.0), 0, 1000)
+                codebook_bits += torch.sum(information_bits * counts).item()
+            else:
+                codebook_bits += codec.payload_bits(codec.compress_latents(self.codebook[:, dim:dim + 1]))
         return ldec_size, codebook_bits
+
+    def compress(self) -> bytes:
+        """Entropy-coded container of the rounded latents (what ``size`` estimates), see shacira_amd/codec.py."""
+        from .... import codec
+        return codec.compress_latents(self.codebook)
+
+    def load_compressed(self, data: bytes) -> None:
+        """Overwrite the latents with the (integer) values stored by ``compress``."""
+        from .... import codec
+        values = codec.decompress_latents(data, device=self.codebook.device)
+        if tuple(values.shape) != tuple(self.codebook.shape):
+            raise ValueError(f"container holds {tuple(values.shape)} latents, the grid {tuple(self.codebook.shape)}")
+        with torch.no_grad():
+            self.codebook.copy_(values)
 
     def setup_decoders(self, decoder_cfg):
         if not decoder_cfg["ldecode_enabled"]:

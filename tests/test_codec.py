@@ -1,0 +1,105 @@
+"""Range coder + container of the rounded latents (shacira_amd/codec.py, C-ABI shacira_rc_*): host-side, runs
+without a GPU. Integer work: round trips must be exact."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from shacira_amd import _lib, codec
+
+
+def _entropy_bits(sym):
+    _, c = np.unique(sym, return_counts=True)
+    p = c / c.sum()
+    return float(-(c * np.log2(p)).sum())
+
+
+@pytest.mark.parametrize("kind", ["gauss", "two", "skew", "wide", "single", "tiny"])
+def test_range_coder_round_trip_and_rate(kind):
+    rng = np.random.default_rng(3)
+    if kind == "gauss":
+        sym = np.round(rng.standard_normal(200_000) * 4).astype(np.int64)
+    elif kind == "two":
+        sym = rng.integers(0, 2, 50_000)
+    elif kind == "skew":
+        sym = (rng.random(300_000) < 0.001).astype(np.int64) * rng.integers(1, 50, 300_000)
+    elif kind == "wide":
+        sym = rng.integers(0, 30_000, 100_000)   # many distinct symbols, most of them seen a few times
+    elif kind == "single":
+        sym = np.full(10_000, 7)
+    else:
+        sym = np.array([3, 1, 2])
+    sym = sym - sym.min()
+    counts = np.bincount(sym)
+    freq = codec.normalise_frequencies(counts)
+    assert freq.sum() == 65536 and np.all(freq[counts > 0] >= 1) and np.all(freq[counts == 0] == 0)
+    data = codec.rc_encode(sym.astype(np.int32), freq)
+    back = codec.rc_decode(data, freq, sym.size)
+    assert np.array_equal(back, sym)
+    # rate: cross-entropy under the 16-bit model + 5 flush bytes, with 0.1 % slack for the range truncation
+    model_bits = float(-(counts[counts > 0] * np.log2(freq[counts > 0] / 65536.0)).sum())
+    assert 8 * len(data) <= model_bits * 1.0001 + 56
+    if kind in ("gauss", "two"):
+        assert 8 * len(data) <= _entropy_bits(sym) * 1.005 + 56
+
+
+def test_range_coder_argument_checks():
+    L = _lib.lib()
+    freq = np.array([65535, 1], dtype=np.uint32)
+    bad = np.array([65535, 2], dtype=np.uint32)
+    sym = np.array([0, 1, 0], dtype=np.int32)
+    out = np.zeros(64, dtype=np.uint8)
+    n = ctypes.c_size_t(0)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert L.shacira_rc_encode(p(sym), 3, p(bad), 2, p(out), 64, ctypes.byref(n)) == _lib.EINVAL      # sum != 2^16
+    assert L.shacira_rc_encode(p(np.array([2], np.int32)), 1, p(freq), 2, p(out), 64, ctypes.byref(n)) == _lib.EINVAL
+    zero = np.array([65536, 0], dtype=np.uint32)
+    assert L.shacira_rc_encode(p(np.array([1], np.int32)), 1, p(zero), 2, p(out), 64, ctypes.byref(n)) == _lib.EINVAL
+    assert L.shacira_rc_encode(p(sym), 3, p(freq), 2, p(out), 2, ctypes.byref(n)) == _lib.EWORKSPACE   # too small
+    assert n.value > 2
+    assert L.shacira_rc_encode(p(sym), 3, p(freq), 2, p(out), 64, ctypes.byref(n)) == 0
+    assert L.shacira_rc_encode(None, 0, p(freq), 2, p(out), 64, ctypes.byref(n)) == 0 and n.value == 6  # empty
+    assert L.shacira_rc_encode_bound(10) >= 10 * 2
+
+
+@pytest.mark.parametrize("shape,scale", [((5000, 1), 2.0), ((4096, 2), 0.3), ((777, 3), 25.0), ((0, 2), 1.0),
+                                         ((1, 1), 1.0)])
+def test_container_restores_rounded_latents(shape, scale):
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(shape, generator=g) * scale
+    if shape[0] > 10:
+        lat[3] = 0.5          # ties: torch.round is half-to-even
+        lat[4] = 1.5
+        lat[5] = -2.5
+    blob = codec.compress_latents(lat)
+    back = codec.decompress_latents(blob)
+    assert back.dtype == torch.float32 and tuple(back.shape) == tuple(shape)
+    assert torch.equal(back, torch.round(lat))
+    if shape[0] > 100:
+        lo, counts = codec.symbol_counts(lat)
+        est = sum(codec.entropy_bits(counts[c]) for c in range(shape[1]))
+        assert est <= codec.payload_bits(blob) <= est * 1.02 + 48 * shape[1]
+    with pytest.raises(ValueError):
+        codec.decompress_latents(b"nope" + blob)
+
+
+def test_symbol_counts_match_torch_unique():
+    g = torch.Generator().manual_seed(6)
+    lat = torch.randn((20_000, 3), generator=g) * torch.tensor([0.2, 3.0, 40.0])
+    lo, counts = codec.symbol_counts(lat)
+    for c in range(3):
+        vals, cnt = torch.unique(torch.round(lat[:, c]).long(), return_counts=True)
+        nz = counts[c].nonzero()[0]
+        assert np.array_equal(lo[c] + nz, vals.numpy()) and np.array_equal(counts[c][nz], cnt.numpy())
+
+
+def test_range_coder_fuzz_round_trip():
+    """Random models and lengths (carry propagation, renormalisation, symbols of frequency 1): exact round trips."""
+    rng = np.random.default_rng(1)
+    for it in range(150):
+        nsym, n = int(rng.integers(1, 400)), int(rng.integers(1, 3000))
+        w = rng.random(nsym) ** int(rng.integers(1, 8))
+        sym = rng.choice(nsym, size=n, p=w / w.sum())
+        freq = codec.normalise_frequencies(np.bincount(sym, minlength=nsym))
+        assert np.array_equal(codec.rc_decode(codec.rc_encode(sym.astype(np.int32), freq), freq, n), sym), it

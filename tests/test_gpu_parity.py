@@ -457,7 +457,37 @@ def test_latent_grid_module_on_gpu_matches_reference_run(dev, golden, name):
             np.testing.assert_allclose(prm.grad.cpu().numpy(), g[p + "ent_g_" + n], rtol=1e-3, atol=1e-3)
     _, totv = grid.ent_loss(1, is_val=True)
     assert totv.item() == pytest.approx(float(g[p + "ent_total_val"]), rel=RTOL)
-    np.testing.assert_allclose(list(grid.size()), g[p + "size"][:2], rtol=1e-5)
+    np.testing.assert_allclose(list(grid.size()), g[p + "size"][:2], rtol=1e-5)   # histogram kernel inside
+    _, pm_bits = grid.size(use_prob_model=True)
+    assert pm_bits == pytest.approx(float(g[p + "size"][2]), rel=1e-5)
+    blob = grid.compress()                                   # device histogram -> host range coder -> container
+    rounded = torch.round(grid.codebook.detach())
+    grid.load_compressed(blob)
+    assert torch.equal(grid.codebook.detach(), rounded)
+
+
+@pytest.mark.parametrize("rows,ld,scale", [(1, 1, 1.0), (1000, 1, 0.2), (100_003, 2, 5.0), (1 << 20, 1, 30.0),
+                                           (300_000, 3, 3000.0), (50_000, 8, 2.0), (4096, 16, 1.0)])
+def test_symbol_histogram_is_exact(dev, rows, ld, scale):
+    """Integer work: per-channel counts of round(latent) identical to torch.unique on the host (ties half-to-even,
+    LDS-private and global-atomic bin paths, every supported latent_dim)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + ld)
+    lat = torch.randn((rows, ld), generator=g) * scale
+    if rows >= 1000:
+        lat[0] = 0.5
+        lat[1] = 1.5
+        lat[2] = -2.5
+        lat[3] = -0.5
+    lo, counts = ops.latent_symbol_counts(lat.to(dev))
+    counts = counts.cpu().numpy()
+    assert counts.sum() == rows * ld
+    for c in range(ld):
+        vals, cnt = torch.unique(torch.round(lat[:, c]).long(), return_counts=True)
+        nz = counts[c].nonzero()[0]
+        assert np.array_equal(int(lo[c]) + nz, vals.numpy()) and np.array_equal(counts[c][nz], cnt.numpy())
+    with pytest.raises(RuntimeError):
+        ops.latent_symbol_counts(lat)                        # host tensor: no CPU fallback in the operator layer
 
 
 def test_autocast_runs_the_half_instantiation(dev):
