@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SHACIRA_ABI_VERSION 3
+#define SHACIRA_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define SHACIRA_API __attribute__((visibility("default")))
@@ -240,6 +240,57 @@ SHACIRA_API int shacira_rc_encode(const int32_t *symbols_host, int64_t n, const 
                       uint8_t *out_host, size_t capacity, size_t *out_len);
 SHACIRA_API int shacira_rc_decode(const uint8_t *in_host, size_t len, const uint32_t *freq_host, int num_symbols, int64_t n,
                       int32_t *symbols_host);
+
+/*
+ * Volume integration over variable-length sample packs and sample generation on a dense occupancy grid -- the steps
+ * either side of the hash-grid lookup in the NeRF pipeline. The reference runs them through kaolin 0.13 (un-vendored):
+ * `spc_render.exponential_integration` / `sum_reduce` (call sites wisp/tracers/packed_rf_tracer.py:131-151),
+ * `OctreeAS._raymarch_ray` / `_raymarch_voxel` (wisp/accelstructs/octree_as.py:171-290) on `unbatched_query` /
+ * `unbatched_raytrace`.
+ *
+ * Packs: the samples of ray r are rows [pack_start[r], pack_start[r+1]) (device int64 [num_packs + 1], ascending).
+ *   shacira_pack_integrate_forward   weights[i] = exp(-sum_{j<i in pack} tau[j]) * (1 - exp(-tau[i]))
+ *                                    ray_feats[r, c] = sum_i weights[i] * feats[i, c]
+ *                                    (= exponential_integration(feats, tau, boundary, exclusive=True))
+ *   shacira_pack_integrate_backward  gradients of both outputs w.r.t. feats and tau; grad_weights may be NULL (zero)
+ *   shacira_pack_sum                 out[r, c] = sum_i x[i, c]                  (= sum_reduce)
+ *   shacira_pack_broadcast           out[i, c] = per_pack[r(i), c]              (its gradient)
+ *   channels <= 16, else SHACIRA_EDTYPE.
+ *
+ * Occupancy: uint8 [G][G][G], G = 2^level, indexed [x][y][z]; a point p in [-1,1]^3 lies in cell
+ * floor(clamp(G*(p+1)/2, 0, G-1)) (kaolin quantize_points). Both generators are two-pass (count, host/device scan of
+ * the counts by the caller, emit at offsets [num_rays + 1]).
+ *   shacira_raymarch_ray_{count,emit}    `num_samples` stratified depths per ray:
+ *                                        depth = (lin[j] + jitter[r, j] / num_samples) * (dist_max - dist_min) + dist_min
+ *                                        (lin = torch.linspace(0, 1, num_samples), jitter ~ U[0,1) supplied by the caller),
+ *                                        kept when the cell of origin + dir * depth is occupied. emit writes, in order,
+ *                                        ridx int64, samples [.,3], depth, deltas (depth - previous depth of the ray,
+ *                                        dist_min before the first), boundary uint8 (1 at a ray's first kept sample).
+ *   shacira_raytrace_dense_{count,emit}  every (ray, occupied cell) crossing in depth order: ridx int32, pidx int32
+ *                                        (Morton index of the cell, x most significant), depth [., 2] = entry (>= 0), exit.
+ */
+SHACIRA_API int shacira_pack_integrate_forward(int64_t num_samples, int64_t num_packs, int channels, const float *feats,
+                                   const float *tau, const int64_t *pack_start, float *ray_feats, float *weights,
+                                   void *stream);
+SHACIRA_API int shacira_pack_integrate_backward(int64_t num_samples, int64_t num_packs, int channels, const float *feats,
+                                    const float *tau, const int64_t *pack_start, const float *grad_ray_feats,
+                                    const float *grad_weights, float *grad_feats, float *grad_tau, void *stream);
+SHACIRA_API int shacira_pack_sum(int64_t num_samples, int64_t num_packs, int channels, const float *x,
+                     const int64_t *pack_start, float *out, void *stream);
+SHACIRA_API int shacira_pack_broadcast(int64_t num_samples, int64_t num_packs, int channels, const float *per_pack,
+                           const int64_t *pack_start, float *out, void *stream);
+SHACIRA_API int shacira_raymarch_ray_count(int64_t num_rays, int num_samples, const float *origins, const float *dirs,
+                               float dist_min, float dist_max, const float *lin, const float *jitter,
+                               const uint8_t *occupancy, int level, int32_t *counts, void *stream);
+SHACIRA_API int shacira_raymarch_ray_emit(int64_t num_rays, int num_samples, const float *origins, const float *dirs,
+                              float dist_min, float dist_max, const float *lin, const float *jitter,
+                              const uint8_t *occupancy, int level, const int64_t *offsets, int64_t *ridx,
+                              float *samples, float *depth, float *deltas, uint8_t *boundary, void *stream);
+SHACIRA_API int shacira_raytrace_dense_count(int64_t num_rays, const float *origins, const float *dirs,
+                                 const uint8_t *occupancy, int level, int32_t *counts, void *stream);
+SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origins, const float *dirs,
+                                const uint8_t *occupancy, int level, const int64_t *offsets, int32_t *ridx,
+                                int32_t *pidx, float *depth, void *stream);
 
 /*
  * Tunables (process-wide, read at call time; for benchmarking and A/B only).

@@ -43,6 +43,14 @@ SIGNATURES = {
     "shacira_rc_encode_bound": (_sz, [_i64]),
     "shacira_rc_encode": (_i, [_p, _i64, _p, _i, _p, _sz, _p]),
     "shacira_rc_decode": (_i, [_p, _sz, _p, _i, _i64, _p]),
+    "shacira_pack_integrate_forward": (_i, [_i64, _i64, _i, _p, _p, _p, _p, _p, _p]),
+    "shacira_pack_integrate_backward": (_i, [_i64, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "shacira_pack_sum": (_i, [_i64, _i64, _i, _p, _p, _p, _p]),
+    "shacira_pack_broadcast": (_i, [_i64, _i64, _i, _p, _p, _p, _p]),
+    "shacira_raymarch_ray_count": (_i, [_i64, _i, _p, _p, _f, _f, _p, _p, _p, _i, _p, _p]),
+    "shacira_raymarch_ray_emit": (_i, [_i64, _i, _p, _p, _f, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "shacira_raytrace_dense_count": (_i, [_i64, _p, _p, _p, _i, _p, _p]),
+    "shacira_raytrace_dense_emit": (_i, [_i64, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "shacira_mlp_supported": (_i, [_i, _i, _i, _i]),
     "shacira_mlp_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "shacira_mlp_forward": (_i, [_i64, _i, _i, _i, _i, _p, _p, _p, _p]),

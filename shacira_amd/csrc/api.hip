@@ -213,6 +213,92 @@ int shacira_rc_decode(const uint8_t *in_host, size_t len, const uint32_t *freq_h
     return rc_decode(in_host, len, freq_host, num_symbols, n, symbols_host);
 }
 
+static int pack_args_ok(int64_t S, int64_t R, int C) {
+    if (S < 0 || R < 0 || C < 1) return SHACIRA_EINVAL;
+    if (C > 16) return SHACIRA_EDTYPE;
+    return 0;
+}
+
+int shacira_pack_integrate_forward(int64_t num_samples, int64_t num_packs, int channels, const float *feats,
+                                   const float *tau, const int64_t *pack_start, float *ray_feats, float *weights,
+                                   void *stream) {
+    if (int rc = pack_args_ok(num_samples, num_packs, channels)) return rc;
+    if (num_packs == 0) return 0;
+    if (!pack_start || !ray_feats || (num_samples > 0 && (!feats || !tau || !weights))) return SHACIRA_EINVAL;
+    return (int)pack_integrate_launch(false, num_packs, channels, feats, tau, pack_start, ray_feats, weights, nullptr,
+                                      nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int shacira_pack_integrate_backward(int64_t num_samples, int64_t num_packs, int channels, const float *feats,
+                                    const float *tau, const int64_t *pack_start, const float *grad_ray_feats,
+                                    const float *grad_weights, float *grad_feats, float *grad_tau, void *stream) {
+    if (int rc = pack_args_ok(num_samples, num_packs, channels)) return rc;
+    if (num_packs == 0 || num_samples == 0) return 0;
+    if (!pack_start || !feats || !tau || !grad_ray_feats || !grad_feats || !grad_tau) return SHACIRA_EINVAL;
+    return (int)pack_integrate_launch(true, num_packs, channels, feats, tau, pack_start, nullptr, nullptr,
+                                      grad_ray_feats, grad_weights, grad_feats, grad_tau, (hipStream_t)stream);
+}
+
+int shacira_pack_sum(int64_t num_samples, int64_t num_packs, int channels, const float *x, const int64_t *pack_start,
+                     float *out, void *stream) {
+    if (int rc = pack_args_ok(num_samples, num_packs, channels)) return rc;
+    if (num_packs == 0) return 0;
+    if (!pack_start || !out || (num_samples > 0 && !x)) return SHACIRA_EINVAL;
+    return (int)pack_sum_launch(false, num_packs, channels, x, pack_start, out, (hipStream_t)stream);
+}
+
+int shacira_pack_broadcast(int64_t num_samples, int64_t num_packs, int channels, const float *per_pack,
+                           const int64_t *pack_start, float *out, void *stream) {
+    if (int rc = pack_args_ok(num_samples, num_packs, channels)) return rc;
+    if (num_packs == 0 || num_samples == 0) return 0;
+    if (!pack_start || !out || !per_pack) return SHACIRA_EINVAL;
+    return (int)pack_sum_launch(true, num_packs, channels, per_pack, pack_start, out, (hipStream_t)stream);
+}
+
+static int march_args_ok(int64_t num_rays, const float *origins, const float *dirs, const uint8_t *occ, int level) {
+    if (num_rays < 0 || level < 0 || level > 10) return SHACIRA_EINVAL;
+    if (num_rays > 0 && (!origins || !dirs || !occ)) return SHACIRA_EINVAL;
+    return 0;
+}
+
+int shacira_raymarch_ray_count(int64_t num_rays, int num_samples, const float *origins, const float *dirs,
+                               float dist_min, float dist_max, const float *lin, const float *jitter,
+                               const uint8_t *occupancy, int level, int32_t *counts, void *stream) {
+    if (int rc = march_args_ok(num_rays, origins, dirs, occupancy, level)) return rc;
+    if (num_samples < 1 || (num_rays > 0 && (!lin || !jitter || !counts))) return SHACIRA_EINVAL;
+    return (int)raymarch_ray_launch(false, num_rays, num_samples, origins, dirs, dist_min, dist_max, lin, jitter,
+                                    occupancy, level, counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    (hipStream_t)stream);
+}
+
+int shacira_raymarch_ray_emit(int64_t num_rays, int num_samples, const float *origins, const float *dirs,
+                              float dist_min, float dist_max, const float *lin, const float *jitter,
+                              const uint8_t *occupancy, int level, const int64_t *offsets, int64_t *ridx,
+                              float *samples, float *depth, float *deltas, uint8_t *boundary, void *stream) {
+    if (int rc = march_args_ok(num_rays, origins, dirs, occupancy, level)) return rc;
+    if (num_samples < 1 || (num_rays > 0 && (!lin || !jitter || !offsets))) return SHACIRA_EINVAL;
+    return (int)raymarch_ray_launch(true, num_rays, num_samples, origins, dirs, dist_min, dist_max, lin, jitter,
+                                    occupancy, level, nullptr, offsets, ridx, samples, depth, deltas, boundary,
+                                    (hipStream_t)stream);
+}
+
+int shacira_raytrace_dense_count(int64_t num_rays, const float *origins, const float *dirs, const uint8_t *occupancy,
+                                 int level, int32_t *counts, void *stream) {
+    if (int rc = march_args_ok(num_rays, origins, dirs, occupancy, level)) return rc;
+    if (num_rays > 0 && !counts) return SHACIRA_EINVAL;
+    return (int)raytrace_dense_launch(false, num_rays, origins, dirs, occupancy, level, counts, nullptr, nullptr,
+                                      nullptr, nullptr, (hipStream_t)stream);
+}
+
+int shacira_raytrace_dense_emit(int64_t num_rays, const float *origins, const float *dirs, const uint8_t *occupancy,
+                                int level, const int64_t *offsets, int32_t *ridx, int32_t *pidx, float *depth,
+                                void *stream) {
+    if (int rc = march_args_ok(num_rays, origins, dirs, occupancy, level)) return rc;
+    if (num_rays > 0 && !offsets) return SHACIRA_EINVAL;
+    return (int)raytrace_dense_launch(true, num_rays, origins, dirs, occupancy, level, nullptr, offsets, ridx, pidx,
+                                      depth, (hipStream_t)stream);
+}
+
 size_t shacira_entropy_bits_workspace_bytes(int64_t, int) { return latent_workspace_bytes(); }
 
 int shacira_entropy_bits_forward(int64_t num_rows, int latent_dim, int num_layers, const float *latent,

@@ -55,6 +55,20 @@ size_t rc_encode_bound(int64_t n);
 int rc_encode(const int32_t *sym, int64_t n, const uint32_t *freq, int nsym, uint8_t *out, size_t cap, size_t *len);
 int rc_decode(const uint8_t *in, size_t len, const uint32_t *freq, int nsym, int64_t n, int32_t *sym);
 
+// render.hip
+hipError_t pack_integrate_launch(bool bwd, int64_t R, int C, const float *feats, const float *tau,
+                                 const int64_t *pack_start, float *ray_feats, float *weights, const float *g_ray,
+                                 const float *g_w, float *g_feats, float *g_tau, hipStream_t s);
+hipError_t pack_sum_launch(bool broadcast, int64_t R, int C, const float *in, const int64_t *pack_start, float *out,
+                           hipStream_t s);
+hipError_t raymarch_ray_launch(bool emit, int64_t num_rays, int ns, const float *origins, const float *dirs,
+                               float dist_min, float dist_max, const float *lin, const float *jitter,
+                               const uint8_t *occ, int level, int32_t *counts, const int64_t *offsets, int64_t *ridx,
+                               float *samples, float *depth, float *deltas, uint8_t *boundary, hipStream_t s);
+hipError_t raytrace_dense_launch(bool emit, int64_t num_rays, const float *origins, const float *dirs,
+                                 const uint8_t *occ, int level, int32_t *counts, const int64_t *offsets, int32_t *ridx,
+                                 int32_t *pidx, float *depth, hipStream_t s);
+
 // adam.hip
 hipError_t adam_step_launch(float *p, float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps,
                             float wd, int step, const int32_t *step_dev, int zero_grad, hipStream_t s);

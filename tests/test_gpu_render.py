@@ -1,0 +1,132 @@
+"""Volume integration and sample generation kernels (render.hip) against the CPU restatement in oracle/render.py,
+through the C-ABI. fp32: tolerance 1e-5 relative (north_star); ids, counts and boundaries exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import render as orr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from shacira_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _packs(rng, R, max_len, allow_long=True):
+    lens = rng.integers(1, max_len, R)
+    if allow_long and R > 3:
+        lens[1] = 1
+        lens[2] = 64
+        lens[3] = 257
+    boundary = np.zeros(lens.sum(), dtype=bool)
+    boundary[np.concatenate([[0], np.cumsum(lens)[:-1]])] = True
+    return torch.from_numpy(boundary)
+
+
+@pytest.mark.parametrize("C", [1, 3, 4, 7])
+@pytest.mark.parametrize("R,max_len", [(1, 5), (37, 40), (300, 200)])
+def test_exponential_integration_forward_backward(dev, C, R, max_len):
+    from shacira_amd import render
+    rng = np.random.default_rng(C * 100 + R)
+    boundary = _packs(rng, R, max_len)
+    S = boundary.shape[0]
+    feats = torch.from_numpy(rng.random((S, C)).astype(np.float32))
+    tau = torch.from_numpy((rng.random((S, 1)) ** 3 * 2.0).astype(np.float32))
+    g_ray = torch.from_numpy(rng.standard_normal((R, C)).astype(np.float32))
+    g_w = torch.from_numpy(rng.standard_normal((S, 1)).astype(np.float32))
+    # oracle (fp64 autograd of the published formula)
+    f64, t64 = feats.double().requires_grad_(), tau.double().requires_grad_()
+    ray_o, w_o = orr.exponential_integration(f64, t64, boundary)
+    (ray_o * g_ray.double()).sum().add((w_o * g_w.double()).sum()).backward()
+    # HIP
+    fd, td = feats.to(dev).requires_grad_(), tau.to(dev).requires_grad_()
+    ray, w = render.exponential_integration(fd, td, boundary.to(dev))
+    assert tuple(ray.shape) == (R, C) and tuple(w.shape) == (S, 1)
+    np.testing.assert_allclose(ray.detach().cpu().numpy(), ray_o.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(w.detach().cpu().numpy(), w_o.detach().numpy(), rtol=1e-5, atol=1e-7)
+    ((ray * g_ray.to(dev)).sum() + (w * g_w.to(dev)).sum()).backward()
+    np.testing.assert_allclose(fd.grad.cpu().numpy(), f64.grad.numpy(), rtol=1e-5, atol=1e-6)
+    scale = float(t64.grad.abs().max())
+    np.testing.assert_allclose(td.grad.cpu().numpy(), t64.grad.numpy(), rtol=1e-4, atol=2e-6 * scale)
+    # sum_reduce + its gradient, and the alpha / depth uses of the tracer
+    xs = torch.from_numpy(rng.standard_normal((S, C)).astype(np.float32))
+    xd = xs.to(dev).requires_grad_()
+    out = render.sum_reduce(xd, boundary.to(dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), orr.sum_reduce(xs, boundary).numpy(), rtol=1e-5, atol=1e-5)
+    (out * g_ray.to(dev)).sum().backward()
+    pid = torch.cumsum(boundary.long(), 0) - 1
+    assert torch.equal(xd.grad.cpu(), g_ray[pid])
+    with pytest.raises(RuntimeError):
+        render.exponential_integration(feats, tau, boundary)   # host tensors: no CPU fallback
+
+
+def _rays(rng, n):
+    o = rng.standard_normal((n, 3))
+    o = 3.0 * o / np.linalg.norm(o, axis=1, keepdims=True)
+    d = (rng.random((n, 3)) - 0.5) - o
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    return torch.from_numpy(o.astype(np.float32)), torch.from_numpy(d.astype(np.float32))
+
+
+@pytest.mark.parametrize("level,ns", [(3, 16), (5, 64), (7, 200)])
+def test_raymarch_ray_matches_reference_python(dev, level, ns):
+    from shacira_amd import render
+    rng = np.random.default_rng(level)
+    N, G = 500, 1 << level
+    o, d = _rays(rng, N)
+    occ = torch.from_numpy(rng.random((G, G, G)) < 0.3)
+    jit = torch.from_numpy(rng.random((N, ns)).astype(np.float32))
+    near, far = 1.5, 4.5
+    full = torch.ones((G, G, G), dtype=torch.bool)
+    # all cells occupied: every sample is emitted -> positions / depths / deltas of the whole lattice
+    r_all, s_all, dep_all, del_all, b_all = [t.cpu() for t in render.raymarch_ray(o.to(dev), d.to(dev), near, far,
+                                                                                 full.to(dev), level, ns, jit.to(dev))]
+    assert r_all.shape[0] == N * ns and torch.equal(r_all, torch.arange(N).repeat_interleave(ns))
+    ro, so, do, dlo, bo = orr.raymarch_ray(o, d, near, far, full, level, ns, jit)
+    np.testing.assert_allclose(dep_all.numpy(), do.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(del_all.numpy(), dlo.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(s_all.numpy(), so.numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(b_all, bo)
+    # real occupancy: exactly the reference's filter applied to the very same positions
+    r, s, dep, dl, b = [t.cpu() for t in render.raymarch_ray(o.to(dev), d.to(dev), near, far, occ.to(dev), level, ns,
+                                                             jit.to(dev))]
+    r2, s2, dep2, dl2, b2 = orr.filter_samples(s_all, dep_all, del_all, occ, level, N, ns)
+    assert torch.equal(r, r2) and torch.equal(b, b2)
+    assert torch.equal(s, s2) and torch.equal(dep, dep2) and torch.equal(dl, dl2)
+    # nothing occupied -> nothing emitted
+    none = render.raymarch_ray(o.to(dev), d.to(dev), near, far, torch.zeros_like(full).to(dev), level, ns, jit.to(dev))
+    assert none[0].numel() == 0 and none[4].numel() == 0
+
+
+@pytest.mark.parametrize("level", [2, 4, 6])
+def test_raytrace_dense_matches_brute_force(dev, level):
+    from shacira_amd import render
+    rng = np.random.default_rng(10 + level)
+    N, G = 200, 1 << level
+    o, d = _rays(rng, N)
+    o[0] = torch.tensor([0.05, 0.02, -0.03])           # a ray that starts inside the volume
+    o[1], d[1] = torch.tensor([0.3, 0.3, -3.0]), torch.tensor([0.0, 0.0, 1.0])   # axis aligned
+    o[2], d[2] = torch.tensor([5.0, 5.0, 5.0]), torch.tensor([0.0, 1.0, 0.0])    # misses
+    occ = torch.from_numpy(rng.random((G, G, G)) < 0.4)
+    q0 = orr.quantize_points(o[0:1], level)[0]
+    occ[q0[0], q0[1], q0[2]] = True                   # ... inside an occupied cell: entry depth clipped to 0
+    ridx, pidx, depth = [t.cpu() for t in render.raytrace_dense(o.to(dev), d.to(dev), occ.to(dev), level)]
+    ro, co, do = orr.raytrace_dense(o, d, occ, level)
+    # drop grazing contacts (shorter than 1e-4) on both sides, then compare run by run
+    keep = (depth[:, 1] - depth[:, 0]) > 1e-4
+    keep_o = (do[:, 1] - do[:, 0]) > 1e-4
+    ridx, pidx, depth = ridx[keep], pidx[keep], depth[keep]
+    ro, co, do = ro[keep_o], co[keep_o], do[keep_o]
+    assert torch.equal(ridx.long(), ro)
+    morton = torch.zeros(co.shape[0], dtype=torch.long)
+    for b in range(level):
+        morton |= (((co[:, 0] >> b) & 1) << (3 * b + 2)) | (((co[:, 1] >> b) & 1) << (3 * b + 1)) \
+            | (((co[:, 2] >> b) & 1) << (3 * b))
+    assert torch.equal(pidx.long(), morton)
+    np.testing.assert_allclose(depth.numpy(), do.numpy(), rtol=1e-4, atol=2e-5)
+    assert not (ridx == 2).any() and (ridx == 0).any() and float(depth[ridx == 0][0, 0]) == 0.0
