@@ -369,3 +369,92 @@ def fit_field_3d(device, steps=500, rays=4096, samples_per_ray=16, seed=0, codeb
         pred = nef.rgb(vp)
         val = psnr_fn(pred.clamp(0, 1), analytic_field(vp))
     return dict(psnr=val, ms_per_step=ms, steps=steps, samples_per_step=n_global)
+
+
+# ------------------------------------------------------------------------------------------------ NeRF render-and-fit
+def analytic_scene(points):
+    """Closed-form radiance field inside [-1,1]^3: density = three soft blobs (particles per unit length), colour =
+    a smooth position-dependent albedo. -> (density [N, 1], rgb [N, 3])."""
+    centers = torch.tensor([[0.35, 0.0, 0.1], [-0.3, 0.25, -0.2], [0.0, -0.4, 0.3]], device=points.device)
+    radii = torch.tensor([0.32, 0.26, 0.22], device=points.device)
+    d2 = ((points[:, None, :] - centers[None]) ** 2).sum(-1)
+    density = (40.0 * torch.sigmoid((radii[None] ** 2 - d2) * 60.0)).sum(-1, keepdim=True)
+    rgb = 0.5 + 0.5 * torch.stack([torch.sin(3.0 * points[:, 0] + 0.5), torch.sin(4.0 * points[:, 1] - 1.0),
+                                   torch.cos(3.5 * points[:, 2] + 0.3)], -1)
+    return density, rgb
+
+
+def camera_rays(num_rays, generator, device):
+    """Unit-direction rays from the radius-3 sphere toward a jittered point near the origin."""
+    o = torch.randn(num_rays, 3, generator=generator)
+    o = 3.0 * o / o.norm(dim=1, keepdim=True)
+    d = (torch.rand(num_rays, 3, generator=generator) - 0.5) * 1.4 - o
+    d = d / d.norm(dim=1, keepdim=True)
+    return o.to(device), d.to(device)
+
+
+class _AnalyticNef:
+    """The closed-form scene behind the radiance-field interface, so the SAME tracer renders the targets."""
+
+    def __init__(self, grid):
+        self.grid = grid
+
+    def __call__(self, coords, ray_d, lod_idx=None, channels=None):
+        density, rgb = analytic_scene(coords)
+        return dict(rgb=rgb, density=density)
+
+
+def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwidth=19, max_grid_res=2048,
+             num_lods=16, blas_level=5, prune_every=100, val_rays=8192, hidden_dim=64):
+    """NeRF-style fit of the analytic scene through the full pipeline the reference runs per step
+    (multiview_trainer.py:88-150): ray marching on the occupancy grid ('ray' sampler) -> hash-grid lookup -> density /
+    colour decoders -> volume integration -> L1 to the target pixels -> Adam; occupancy pruned every `prune_every` steps.
+    Targets are rendered from the closed-form scene by the same tracer with 4x the samples.
+    Returns dict(psnr on held-out rays, ms_per_step, samples_per_step)."""
+    import time
+    from .optim import FusedAdam
+    from .wisp.core import Rays
+    from .wisp.models.grids import HashGrid
+    from .wisp.models.nefs import NeuralRadianceField
+    from .wisp.ops.image.metrics import psnr as psnr_fn
+    from .wisp.tracers import PackedRFTracer
+    torch.manual_seed(seed)
+    grid = HashGrid.from_geometric(feature_dim=2, num_lods=num_lods, multiscale_type="cat", resolution_dim=3,
+                                   feature_std=0.01, codebook_bitwidth=codebook_bitwidth, min_grid_res=16,
+                                   max_grid_res=max_grid_res, blas_level=blas_level)
+    nef = NeuralRadianceField(grid, view_embedder="positional", view_multires=4, hidden_dim=hidden_dim, num_layers=1,
+                              prune_density_decay=0.95, prune_min_density=0.01 * 512 / 3 ** 0.5).to(device)
+    truth = _AnalyticNef(HashGrid.from_geometric(feature_dim=2, num_lods=2, multiscale_type="cat", resolution_dim=3,
+                                                 feature_std=0.0, codebook_bitwidth=4, min_grid_res=2,
+                                                 max_grid_res=4, blas_level=blas_level))   # carries the occupancy only
+    tracer = PackedRFTracer(raymarch_type="ray", num_steps=num_steps, bg_color="white")
+    gt_tracer = PackedRFTracer(raymarch_type="ray", num_steps=4 * num_steps, bg_color="white")
+    groups = [g for g in param_groups(nef, lr=1e-3, grid_lr=1e-2) if g["params"]]
+    opt = FusedAdam(groups, eps=1e-15)
+    gen = torch.Generator().manual_seed(seed + 1)
+    near, far = 1.2, 4.8
+    samples_seen = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        o, d = camera_rays(rays, gen, device)
+        batch = Rays(o, d, dist_min=near, dist_max=far)
+        with torch.no_grad():
+            target = gt_tracer(truth, batch).rgb
+        opt.zero_grad(set_to_none=True)
+        rb = tracer(nef, batch)
+        loss = torch.abs(rb.rgb[..., :3] - target[..., :3]).mean()
+        loss.backward()
+        opt.step()
+        samples_seen += rays * num_steps
+        if prune_every and (it + 1) % prune_every == 0:
+            nef.prune()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    with torch.no_grad():
+        o, d = camera_rays(val_rays, torch.Generator().manual_seed(4242), device)
+        batch = Rays(o, d, dist_min=near, dist_max=far)
+        val = psnr_fn(tracer(nef, batch).rgb.clamp(0, 1), gt_tracer(truth, batch).rgb)
+    occupied = int(nef.grid.blas.points.shape[0])
+    return dict(psnr=val, ms_per_step=ms, steps=steps, rays_per_step=rays, candidate_samples_per_step=rays * num_steps,
+                occupied_cells=occupied, total_cells=int(grid.num_cells))

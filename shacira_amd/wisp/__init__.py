@@ -13,7 +13,8 @@ _ALIASES = [
     "models.grids.blas_grid", "models.grids.hash_grid", "models.grids.latent_grid", "models.latent_decoders",
     "models.latent_decoders.basic_latent_decoder", "models.latent_decoders.hierarchical_latent_decoder",
     "models.latent_decoders.multi_latent_decoder",
-    "models.prob_models", "models.prob_models.bit_estimator", "models.decoders", "models.decoders.basic_decoders", "utils", "utils.schedulers",
+    "models.prob_models", "models.prob_models.bit_estimator", "models.decoders", "models.decoders.basic_decoders",
+    "models.embedders", "models.nefs", "models.nefs.nerf", "tracers", "tracers.packed_rf_tracer", "utils", "utils.schedulers",
 ]
 
 

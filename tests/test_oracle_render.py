@@ -1,0 +1,101 @@
+"""The CPU restatement of the volume-integration / sample-generation steps (oracle/render.py) against naive per-ray
+loops written from the formulas, and the host-side occupancy mirror. No golden vectors exist for these steps in the
+reference (kaolin is not vendored): the restatement is "parity unpinned" and anchored on the published formula."""
+import numpy as np
+import torch
+
+from oracle import render as orr
+from shacira_amd.wisp.accelstructs import OctreeAS, _morton_points
+
+
+def _boundary(lens):
+    b = np.zeros(sum(lens), dtype=bool)
+    b[np.concatenate([[0], np.cumsum(lens)[:-1]])] = True
+    return torch.from_numpy(b)
+
+
+def test_exponential_integration_equals_per_ray_loop():
+    rng = np.random.default_rng(0)
+    lens = [1, 7, 64, 3, 130]
+    boundary = _boundary(lens)
+    S = sum(lens)
+    feats = torch.from_numpy(rng.random((S, 3)))
+    tau = torch.from_numpy(rng.random((S, 1)) * 1.5)
+    ray, w = orr.exponential_integration(feats, tau, boundary)
+    i = 0
+    for r, n in enumerate(lens):
+        T, acc = 1.0, np.zeros(3)
+        for k in range(n):
+            a = 1.0 - np.exp(-tau[i + k, 0].item())
+            wk = T * a
+            assert abs(w[i + k, 0].item() - wk) < 1e-12
+            acc += wk * feats[i + k].numpy()
+            T *= np.exp(-tau[i + k, 0].item())
+        np.testing.assert_allclose(ray[r].numpy(), acc, rtol=1e-12)
+        i += n
+    np.testing.assert_allclose(orr.sum_reduce(feats, boundary).numpy(),
+                               np.stack([feats[s:s + n].sum(0).numpy() for s, n in zip(np.cumsum([0] + lens[:-1]), lens)]))
+    assert torch.equal(orr.mark_pack_boundaries(torch.tensor([4, 4, 7, 9, 9, 9])),
+                       torch.tensor([True, False, True, True, False, False]))
+
+
+def test_raymarch_ray_keeps_exactly_the_occupied_samples():
+    rng = np.random.default_rng(1)
+    level, ns, N = 3, 12, 40
+    G = 1 << level
+    o = torch.from_numpy(rng.uniform(-0.9, 0.9, (N, 3)).astype(np.float32))
+    d = torch.from_numpy(rng.standard_normal((N, 3)).astype(np.float32))
+    d = d / d.norm(dim=1, keepdim=True)
+    occ = torch.from_numpy(rng.random((G, G, G)) < 0.5)
+    jit = torch.from_numpy(rng.random((N, ns)).astype(np.float32))
+    ridx, samples, depth, deltas, boundary = orr.raymarch_ray(o, d, 0.0, 0.8, occ, level, ns, jit)
+    assert orr.query_dense(occ, samples, level).all()
+    np.testing.assert_allclose(samples.numpy(), (o[ridx] + d[ridx] * depth).numpy(), rtol=1e-6, atol=1e-6)
+    assert (deltas > 0).all() and (ridx[1:] >= ridx[:-1]).all() and boundary.sum() == ridx.unique().numel()
+    # the first sample of a ray measures its delta from dist_min, the others from the previous (kept or not) sample
+    all_depth = (torch.linspace(0, 1.0, ns)[None] + jit / ns) * 0.8
+    first = torch.isclose(depth[:, 0], all_depth[ridx, 0])
+    np.testing.assert_allclose(deltas[first, 0].numpy(), depth[first, 0].numpy(), rtol=1e-6)
+
+
+def test_raytrace_and_voxel_sampling_are_consistent():
+    rng = np.random.default_rng(2)
+    level, N, ns = 3, 30, 4
+    G = 1 << level
+    o = torch.from_numpy(rng.standard_normal((N, 3)).astype(np.float32))
+    o = 3.0 * o / o.norm(dim=1, keepdim=True)
+    d = -o / o.norm(dim=1, keepdim=True) + torch.from_numpy(rng.normal(0, 0.1, (N, 3)).astype(np.float32))
+    d = d / d.norm(dim=1, keepdim=True)
+    occ = torch.from_numpy(rng.random((G, G, G)) < 0.5)
+    ridx, cells, depth = orr.raytrace_dense(o, d, occ, level)
+    assert (depth[:, 1] > depth[:, 0]).all() and occ[cells[:, 0], cells[:, 1], cells[:, 2]].all()
+    mid = o[ridx] + d[ridx] * depth.mean(1, keepdim=True)
+    assert torch.equal(orr.quantize_points(mid, level), cells)          # interval midpoints lie in the reported cell
+    for r in ridx.unique():                                              # per ray: sorted, non-overlapping intervals
+        dr = depth[ridx == r]
+        assert (dr[1:, 0] >= dr[:-1, 1] - 1e-5).all()
+    jit = torch.from_numpy(rng.random((ridx.shape[0], ns)).astype(np.float32))
+    rs, samples, ds, deltas, boundary = orr.raymarch_voxel(o, d, ridx, depth, ns, jit)
+    assert samples.shape[0] == ridx.shape[0] * ns and boundary.sum() == ridx.unique().numel()
+    long_enough = (depth[:, 1] - depth[:, 0] > 1e-3).repeat_interleave(ns)
+    assert torch.equal(orr.quantize_points(samples, level)[long_enough], cells.repeat_interleave(ns, 0)[long_enough])
+    np.testing.assert_allclose(deltas.reshape(-1, ns).sum(1).numpy(), (ds.reshape(-1, ns)[:, -1] - depth[:, 0]).numpy(),
+                               rtol=1e-4, atol=1e-6)
+
+
+def test_occupancy_mirror_query_and_pruned_set():
+    level = 3
+    dense = OctreeAS.make_dense(level)
+    assert dense.points.shape == (512, 3) and torch.equal(dense.points, _morton_points(level))
+    pts = torch.tensor([[-1.0, -1.0, -1.0], [0.99, 0.99, 0.99], [0.0, 0.0, 0.0], [5.0, -5.0, 0.1]])
+    pidx = dense.query(pts).pidx
+    assert pidx[0] == 0 and pidx[1] == 511 and (pidx >= 0).all()       # out-of-range points clamp to border cells
+    assert torch.equal(dense.points[pidx[2]].long(), torch.tensor([4, 4, 4]))
+    kept = torch.tensor([[4, 4, 4], [0, 0, 0], [7, 0, 3]])
+    pruned = OctreeAS.from_quantized_points(kept, level)
+    assert pruned.points.shape == (3, 3) and pruned.occupancy_grid.sum() == 3
+    q = pruned.query(pts).pidx
+    assert q[0] == 0 and q[1] == -1 and q[2] >= 0
+    # points come back in Morton order
+    codes = [int(c) for c in (pruned.points.long() * torch.tensor([1, 1, 1])).sum(1)]
+    assert torch.equal(pruned.points[0].long(), torch.tensor([0, 0, 0])) and len(codes) == 3
