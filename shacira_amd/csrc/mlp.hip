@@ -260,6 +260,16 @@ __global__ __launch_bounds__(256) void mlp_finish_kernel(const double *__restric
 
 constexpr int kMlpMaxBlocks = 512;
 
+hipError_t mlp_finish_launch(const double *partials, int nblocks, int n, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(mlp_finish_kernel, dim3(n), dim3(256), 0, s, partials, nblocks, n, out);
+    return hipGetLastError();
+}
+
+// mlp_mfma.hip: hidden widths that are multiples of 32 run on the fp32 matrix cores
+template <int IN, int H, int NH, int OUT>
+hipError_t wide_mlp_run(bool bwd, int64_t N, const float *x, const float *params, float *y, const float *gy, float *gx,
+                        float *gparams, double *partials, hipStream_t s);
+
 template <int IN, int H, int NH, int OUT>
 static hipError_t mlp_run(bool bwd, int64_t N, const float *x, const float *params, float *y, const float *gy,
                           float *gx, float *gparams, double *partials, hipStream_t s) {
@@ -306,6 +316,13 @@ static mlp_fn mlp_lookup(int in, int h, int nh, int out) {
     SHACIRA_MLP(32, 16, 3, 3)
     SHACIRA_MLP(32, 16, 2, 4)
 #undef SHACIRA_MLP
+#define SHACIRA_WIDE(IN, H, NH, OUT) \
+    if (in == IN && h == H && nh == NH && out == OUT) return &wide_mlp_run<IN, H, NH, OUT>;
+    SHACIRA_WIDE(32, 64, 1, 16)  // NeRF density decoder: 16 levels x F=2 -> 64 -> 16   (nerf.py:121-130, hidden_dim 64)
+    SHACIRA_WIDE(43, 64, 2, 3)   // NeRF colour decoder: 16 + 27 (view embedding) -> 64 -> 64 -> rgb   (nerf.py:132-140)
+    SHACIRA_WIDE(32, 64, 2, 3)   // image / 3-D field decoders with hidden_dim 64
+    SHACIRA_WIDE(16, 64, 2, 3)
+#undef SHACIRA_WIDE
     return nullptr;
 }
 

@@ -30,7 +30,9 @@ def test_basic_decoder_host_logic_and_names():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dims", [(32, 16, 2, 3), (24, 16, 2, 3), (16, 16, 2, 3), (48, 16, 2, 3), (32, 16, 1, 3),
-                                  (32, 16, 3, 3), (32, 16, 2, 4)])
+                                  (32, 16, 3, 3), (32, 16, 2, 4),
+                                  # hidden width 64: the fp32-MFMA kernels (NeRF density / colour decoders)
+                                  (32, 64, 1, 16), (43, 64, 2, 3), (32, 64, 2, 3), (16, 64, 2, 3)])
 @pytest.mark.parametrize("n", [1, 255, 256, 70_001])
 def test_fused_mlp_matches_torch_layers(dims, n):
     from shacira_amd import hip_ops
@@ -41,20 +43,33 @@ def test_fused_mlp_matches_torch_layers(dims, n):
     dec = BasicDecoder(IN, OUT, torch.relu, True, nn.Linear, NH, H, []).to(dev)
     with torch.no_grad():
         for p in dec.parameters():
-            p.mul_(3.0)                                   # enough dynamic range for the ReLUs to gate both ways
-    x = torch.randn(n, IN, device=dev, requires_grad=True)
-    gy = torch.randn(n, OUT, device=dev)
-    y = dec(x)                                            # fused path
-    y.backward(gy)
-    got = [x.grad.clone()] + [p.grad.clone() for p in dec.parameters()]
-    # reference: the same layers in float64 on the same parameters
+            p.mul_(3.0 if H < 64 else 1.5)                # enough dynamic range for the ReLUs to gate both ways
     dec64 = BasicDecoder(IN, OUT, torch.relu, True, nn.Linear, NH, H, []).to(dev).double()
     dec64.load_state_dict({k: v.double() for k, v in dec.state_dict().items()})
-    x64 = x.detach().double().requires_grad_(True)
-    y64 = _torch_mlp(dec64, x64)
-    y64.backward(gy.double())
-    want = [x64.grad] + [p.grad for p in dec64.parameters()]
+
+    def both(x0, gy):
+        dec.zero_grad(); dec64.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        y = dec(x)                                        # fused path
+        y.backward(gy)
+        got = [x.grad.clone()] + [p.grad.clone() for p in dec.parameters()]
+        x64 = x0.double().requires_grad_(True)            # reference: the same layers in float64, same parameters
+        y64 = _torch_mlp(dec64, x64)
+        y64.backward(gy.double())
+        return y, y64, got, [x64.grad] + [p.grad for p in dec64.parameters()]
+
+    x0 = torch.randn(n, IN, device=dev)
+    gy = torch.randn(n, OUT, device=dev)
+    y, y64, got, want = both(x0, gy)
     torch.testing.assert_close(y.double(), y64, rtol=1e-5, atol=1e-5)
+    # A sample whose pre-activation sits within rounding of 0 may take the other ReLU branch than the fp64 evaluation
+    # (its input-gradient row and its contribution to every weight gradient then differ): at most a couple per 100 k
+    # samples; they are dropped and the comparison repeated without them.
+    gx, gx64 = got[0].double(), want[0]
+    bad_rows = ((gx - gx64).abs() > 1e-5 * gx64.abs() + 1e-5 * float(gx64.abs().max()) + 1e-9).any(dim=1)
+    assert int(bad_rows.sum()) <= n // 30_000, int(bad_rows.sum())
+    if bad_rows.any():
+        y, y64, got, want = both(x0[~bad_rows], gy[~bad_rows])
     for a, b in zip(got, want):
         torch.testing.assert_close(a.double(), b, rtol=1e-5, atol=1e-5 * float(b.abs().max()) + 1e-9)
 
@@ -85,4 +100,36 @@ def test_fused_mlp_speed_on_image_batch():
         y = _torch_mlp(dec, x); y.backward(gy)
     tf, tl = run(fused), run(layers)
     print(f"decoder MLP fwd+bwd on 393216 px: fused {tf:.3f} ms vs torch Linear layers {tl:.3f} ms")
+    assert tf < tl
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(32, 64, 1, 16), (43, 64, 2, 3)])
+def test_mfma_mlp_speed_on_nerf_batch(dims):
+    dev = torch.device("cuda:0")
+    IN, H, NH, OUT = dims
+    dec = BasicDecoder(IN, OUT, torch.relu, True, nn.Linear, NH, H, []).to(dev)
+    n = 1 << 19
+    x = torch.randn(n, IN, device=dev, requires_grad=True)
+    gy = torch.randn(n, OUT, device=dev)
+
+    def run(fn, iters=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters
+
+    def fused():
+        y = dec(x); y.backward(gy)
+
+    def layers():
+        y = _torch_mlp(dec, x); y.backward(gy)
+    tf, tl = run(fused), run(layers)
+    print(f"NeRF decoder {dims} fwd+bwd on {n} samples: MFMA kernels {tf:.3f} ms vs torch Linear layers {tl:.3f} ms")
     assert tf < tl
