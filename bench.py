@@ -55,7 +55,12 @@ def quick_measure(name, device, iters=10):
     T = int(sum(sizes))
     g = torch.Generator().manual_seed(7)
     table = (torch.randn(T, F, generator=g) * 0.01).to(device)
-    coords = (torch.rand(n, dim, generator=g) * 2 - 1).to(device)
+    if name.startswith("D_"):
+        # NeRF-like ray points -- 4096 rays from the radius-3 sphere, 16 stratified samples inside the cube
+        from shacira_amd import harness
+        coords = harness.ray_points(n // 16, 16, g).contiguous().to(device)
+    else:
+        coords = (torch.rand(n, dim, generator=g) * 2 - 1).to(device)
     go = torch.randn(n, L * F, generator=g).to(device)
     fwd = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -130,6 +135,8 @@ def main():
                          "has been measured on a multi-GPU node")
     ap.add_argument("--no-secondary", action="store_true", help="skip the quick figures for the other BASELINE configs")
     ap.add_argument("--psnr-steps", type=int, default=1000, help="image-fit steps for the PSNR figure (0 = skip)")
+    ap.add_argument("--nerf-steps", type=int, default=500,
+                    help="steps of the NeRF-style render-and-fit on the analytic scene for the second PSNR figure (0 = skip)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 17)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()
@@ -237,6 +244,38 @@ def main():
                           "Adam (kodak.yaml learning rates)", "bpp": fit["bpp"], "rgb_loss": fit["rgb_loss"],
                 "seconds": time.perf_counter() - tp, "n_gpus": world}
 
+    # second PSNR figure (rank 0 only, outside the timed region): the reference's per-step NeRF pipeline -- ray marching
+    # on the occupancy grid, hash-grid lookup, MFMA decoders, volume integration, L1, fused Adam -- on a closed-form scene
+    psnr_nerf = None
+    if rank == 0 and args.nerf_steps > 0:
+        from shacira_amd import harness
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        fit = harness.fit_nerf(device, steps=args.nerf_steps)
+        psnr_nerf = {"value": fit["psnr"], "unit": "dB (psnr, held-out rays)", "step": args.nerf_steps,
+                     "config": "D: 3-D HashGrid L16 F2 bw19 res16..2048, 4096 rays x 128 candidate samples ('ray' "
+                               "marcher, occupancy level 5 pruned every 100 steps), density 32-64-16 + colour 43-64-64-3 "
+                               "decoders, analytic scene", "ms_per_step": fit["ms_per_step"],
+                     "occupied_cells": fit["occupied_cells"], "seconds": time.perf_counter() - tp}
+
+    # the optimiser pass that follows the backward in training (SURVEY 8d "second figure"): fused Adam over the table
+    ms_adam = None
+    if rank == 0:
+        from shacira_amd.optim import FusedAdam
+        ptab = torch.nn.Parameter(table.clone())
+        ptab.grad = torch.randn_like(ptab)
+        opt = FusedAdam([ptab], lr=1e-2, eps=1e-15)
+        for _ in range(3):
+            opt.step()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        for _ in range(20):
+            opt.step()
+        eb.record()
+        torch.cuda.synchronize()
+        ms_adam = ea.elapsed_time(eb) / 20
+        del ptab, opt
+
     secondary = None
     if rank == 0 and not args.no_secondary:
         del coords, grad_out
@@ -279,8 +318,11 @@ def main():
                          "ms_per_launch": dom[1],
                          "fwd_bwd_path": {"achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS,
                                           "bytes_per_sample": b_fwd + b_bwd}},
-            "ms": {"forward": ms_fwd, "backward": ms_bwd, "allreduce": ms_ar},
+            "ms": {"forward": ms_fwd, "backward": ms_bwd, "allreduce": ms_ar, "adam_table": ms_adam,
+                   "samples_per_s_with_adam": (n_local / ((ms_fwd + ms_bwd + ms_ar + ms_adam) * 1e-3)
+                                               if ms_adam is not None else None)},
             "psnr": psnr,
+            "psnr_nerf": psnr_nerf,
             "other_configs_1gpu": secondary,
         }
         if world == 1 and not args.no_cpu_baseline:
