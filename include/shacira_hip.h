@@ -296,7 +296,7 @@ SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origi
  * Tunables (process-wide, read at call time; for benchmarking and A/B only).
  *   "fwd_variant", "bwd_variant": integer algorithm selectors, -1 = automatic.
  *   "bin_batch_mib": cap (MiB) of the backward's item array; larger batches are processed in sub-batches.
- *   "bin_acc_kib": LDS accumulator image per consumer workgroup (64 or 128).
+ *   "bin_acc_kib": LDS accumulator image per consumer workgroup: 64, 128, or 0 = chosen from the batch size (default).
  *   "bwd_fork": 1 (default) = the backward's count + scan passes are issued on a library-owned side stream, forked
  *               from and joined back into the caller's stream with events (stream semantics unchanged); 0 = one stream.
  */

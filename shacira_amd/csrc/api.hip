@@ -11,7 +11,7 @@ namespace shacira {
 std::atomic<int> g_fwd_variant{-1};
 std::atomic<int> g_bwd_variant{-1};
 std::atomic<int> g_bwd_fork{1};           // 1: count + scans of the backward on a side stream next to the transpose
-std::atomic<int> g_bin_acc_kib{128};      // LDS accumulator image per consumer workgroup, KiB (64 or 128)
+std::atomic<int> g_bin_acc_kib{0};        // LDS accumulator image per consumer workgroup, KiB: 64, 128, 0 = by batch size
 std::atomic<int> g_bin_batch_mib{1536};   // cap of the backward's item array per sub-batch, MiB
 
 static int build_level_table(int dim, int num_lods, int feature_dim, int bw, const int32_t *res_host,
@@ -67,7 +67,7 @@ int shacira_set_option(const char *name, int value) {
     if (!std::strcmp(name, "fwd_variant")) { g_fwd_variant = value; return 0; }
     if (!std::strcmp(name, "bwd_variant")) { g_bwd_variant = value; return 0; }
     if (!std::strcmp(name, "bin_acc_kib")) {
-        if (value != 64 && value != 128) return SHACIRA_EINVAL;
+        if (value != 0 && value != 64 && value != 128) return SHACIRA_EINVAL;
         g_bin_acc_kib = value;
         return 0;
     }

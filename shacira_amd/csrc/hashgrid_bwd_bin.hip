@@ -522,12 +522,13 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
 // ------------------------------------------------------------------------------------------------- host side
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan);
+static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib);
 
-bool bin_supported(int dim, const LevelTable &lt) {
+// can the table be partitioned with an LDS accumulator image of `acc_kib` KiB per consumer workgroup?
+static bool bin_feasible(int dim, const LevelTable &lt, int acc_kib) {
     const int F = lt.feature_dim;
     if (F != 2 && F != 4) return false;
-    const uint32_t BR = (uint32_t)g_bin_acc_kib.load() * 128u / (uint32_t)F;  // LDS image of fp64 accumulators
+    const uint32_t BR = (uint32_t)acc_kib * 128u / (uint32_t)F;  // rows of the fp64 image
     for (int l = 0; l < lt.num_lods; ++l) {
         const uint32_t res = (uint32_t)lt.res[l];
         if (lt.dense[l]) {
@@ -540,16 +541,32 @@ bool bin_supported(int dim, const LevelTable &lt) {
         }
     }
     BinPlan plan;
-    make_plan(dim, lt, kTile, plan);
+    make_plan(dim, lt, kTile, plan, acc_kib);
     if (plan.total_buckets > (uint32_t)kMaxBuckets) return false;
     for (int l = 0; l < lt.num_lods; ++l)
         if (plan.lv[l].nb > (uint32_t)kMaxLevelBuckets) return false;
     return true;
 }
 
-static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan) {
+// Image size per call, from the TOTAL batch (one choice per call so that every plan of the call classifies the levels
+// alike). Option "bin_acc_kib": 64 / 128 force it, 0 (default) = measured rule: 64 KiB images (two consumer workgroups
+// per CU overlap their zero / stream / flush phases) win up to 2^19 3-D samples, 128 KiB (half as many buckets) beyond.
+static int choose_acc_kib(int dim, const LevelTable &lt, int64_t n) {
+    const int opt = g_bin_acc_kib.load();
+    if (opt != 0) return opt;
+    const int64_t pairs = (int64_t)1 << (dim - 1);
+    if (n * pairs <= ((int64_t)1 << 21) && bin_feasible(dim, lt, 64)) return 64;
+    return 128;
+}
+
+bool bin_supported(int dim, const LevelTable &lt) {
+    const int opt = g_bin_acc_kib.load();
+    return bin_feasible(dim, lt, opt ? opt : 128);
+}
+
+static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib) {
     const int F = lt.feature_dim;
-    const uint32_t BR = (uint32_t)g_bin_acc_kib.load() * 128u / (uint32_t)F;
+    const uint32_t BR = (uint32_t)acc_kib * 128u / (uint32_t)F;
     uint32_t shift = 0;
     while ((1u << shift) < BR) ++shift;
     uint32_t nbk = 0;
@@ -622,7 +639,7 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
 static int64_t bin_batch_samples(int dim, const LevelTable &lt, int64_t n) {
     const size_t item = 8 + 4 * (size_t)lt.feature_dim;
     BinPlan plan;
-    make_plan(dim, lt, kTile, plan);
+    make_plan(dim, lt, kTile, plan, choose_acc_kib(dim, lt, n));
     const size_t per_sample = (size_t)(plan.nbl ? plan.nbl : 1) * (1u << (dim - 1)) * item;
     int64_t cap = (int64_t)(((size_t)g_bin_batch_mib.load() << 20) / per_sample);
     cap = cap / kTile * kTile;
@@ -645,7 +662,7 @@ struct BinWorkspace {
 static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, void *ws) {
     BinPlan plan;
     const int64_t nb = bin_batch_samples(dim, lt, n);
-    make_plan(dim, lt, nb, plan);
+    make_plan(dim, lt, nb, plan, choose_acc_kib(dim, lt, n));
     const size_t item = 8 + 4 * (size_t)lt.feature_dim;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -722,7 +739,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                           const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s) {
     const int L = lt.num_lods;
     BinPlan whole;
-    make_plan(DIM, lt, n, whole);
+    const int acc_kib = choose_acc_kib(DIM, lt, n);
+    make_plan(DIM, lt, n, whole, acc_kib);
     const int64_t nb = bin_batch_samples(DIM, lt, n);
     const bool multi = nb < n;
     // single sub-batch (the usual case): count + scans run on the side stream next to transpose + direct levels
@@ -733,7 +751,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         if ((e = hipEventRecord(ss->fork, s)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(ss->stream, ss->fork, 0)) != hipSuccess) return e;
         BinPlan plan;
-        make_plan(DIM, lt, n, plan);
+        make_plan(DIM, lt, n, plan, acc_kib);
         const dim3 grid(plan.num_tiles, plan.nbl);
         hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, ss->stream, lt, plan, coords, w.cnt,
                            (int64_t)0, n);
@@ -791,7 +809,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
         BinPlan plan;
-        make_plan(DIM, lt, hi - s0, plan);
+        make_plan(DIM, lt, hi - s0, plan, acc_kib);
         const dim3 grid(plan.num_tiles, plan.nbl);
         if (!ss) {
             hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, s, lt, plan, coords, w.cnt, s0, hi);
