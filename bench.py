@@ -306,8 +306,11 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "dim": dim, "levels": L, "feature_dim": F, "bitwidth": bw,
                        "table_rows": T, "samples_per_gpu": n_local,
-                       "parallelism": f"dp{world}" + (f"+allreduce(grad_codebook, {len(groups)} level groups "
-                                                      f"{groups}, overlapped with the backward)" if world > 1 else "")},
+                       "parallelism": f"dp{world}" + ("" if world == 1 else
+                                                      "+one allreduce(grad_codebook) after the backward"
+                                                      if len(groups) == 1 else
+                                                      f"+allreduce(grad_codebook) in {len(groups)} level groups "
+                                                      f"{groups}, overlapped with the backward")},
             "roofline": {"bound": "hbm",
                          "kernel": (f"hashgrid_{dom[0]} operator = one C-ABI call, HIP events on its stream; kernels: "
                                     + ("transpose_grad + bin_count + 2 scans + bin_scatter + bin_consume + "

@@ -22,6 +22,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     use_gpu = torch.cuda.is_available()
+    # SHACIRA_TEST_SINGLE_GPU=1: every rank on cuda:0 with the gloo backend -- only to exercise the multi-rank control
+    # flow of bench.py / the harness on a one-GPU box (RCCL refuses two ranks on one device)
+    single = use_gpu and os.environ.get("SHACIRA_TEST_SINGLE_GPU") == "1"
+    if single:
+        local, backend = 0, backend or "gloo"
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
@@ -30,7 +35,7 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kwargs = {}
-        if use_gpu:
+        if use_gpu and not single:
             kwargs["device_id"] = device
         dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world, **kwargs)
     return rank, world, device
