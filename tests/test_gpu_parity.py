@@ -542,3 +542,46 @@ def test_config_c_full_size_properties(dev):
     g5k = ops.hashgrid_backward(2, coords[:5000].contiguous(), go[:5000].contiguous(), T, torch.float32, tf, res, bw, 2)
     np.testing.assert_allclose(g5k.cpu().numpy(), ref, rtol=RTOL, atol=RTOL * np.abs(ref).max())
     assert torch.isfinite(g1).all()
+
+
+def test_concurrent_calls_from_two_threads(dev):
+    """The boundary is reentrant (the backward runs on autograd worker threads): two host threads, each on its own
+    stream and its own problem, interleave forward / backward calls (batches above and below the side-stream
+    threshold); every result equals the single-threaded one."""
+    import threading
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T = table_layout(res, bw, dim)
+    tf = torch.from_numpy(first).to(dev)
+    problems = []
+    for seed, n in ((1, 1 << 18), (2, 50_000)):
+        g = torch.Generator().manual_seed(seed)
+        coords = (torch.rand(n, 3, generator=g) * 2 - 1).to(dev)
+        table = (torch.randn(T, 2, generator=g) * 0.01).to(dev)
+        go = torch.randn(n, 32, generator=g).to(dev)
+        f = ops.hashgrid_interpolate_cuda(coords, table, tf, res, bw)
+        gr = ops.hashgrid_interpolate_backward_cuda(coords, go, table, tf, res, bw, 2, False)
+        problems.append((coords, table, go, f, gr))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        coords, table, go, f_ref, g_ref = problems[k]
+        stream = torch.cuda.Stream()
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(10):
+                    f = ops.hashgrid_interpolate_cuda(coords, table, tf, res, bw)
+                    gr = ops.hashgrid_interpolate_backward_cuda(coords, go, table, tf, res, bw, 2, False)
+                    stream.synchronize()
+                    if not torch.equal(f, f_ref):
+                        errors.append(f"thread {k}: forward differs")
+                    if not torch.allclose(gr, g_ref, rtol=1e-5, atol=1e-5 * float(g_ref.abs().max())):
+                        errors.append(f"thread {k}: backward differs")
+        except Exception as exc:                     # noqa: BLE001 - reported to the main thread
+            errors.append(f"thread {k}: {exc!r}")
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors[:3]
