@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SHACIRA_ABI_VERSION 4
+#define SHACIRA_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define SHACIRA_API __attribute__((visibility("default")))
@@ -212,6 +212,31 @@ SHACIRA_API int shacira_adam_step_multi(int num_tensors, const int64_t *numel_ho
                             float *const *exp_avg, float *const *exp_avg_sq, const float *lr_host,
                             const float *weight_decay_host, float beta1, float beta2, float eps, int step,
                             const int32_t *step_dev, int zero_grad, void *stream);
+
+/*
+ * Latent decode with stochastic Gumbel annealing (SGA) instead of rounding -- the `use_sga` branch of
+ * LatentDecoder.forward (wisp/models/latent_decoders/basic_latent_decoder.py:183-191), the training mode of the
+ * reference's shipped configs (kodak.yaml / nerf_lego.yaml: use_sga, diff_sampling) until `decay_period`:
+ *     wf = floor(w), wc = wf + 1
+ *     logits = -tanh(clamp(w - wf, +-(1 - 1e-6))) / T ,  -tanh(clamp(wc - w, +-(1 - 1e-6))) / T
+ *     (s0, s1) = RelaxedOneHotCategorical(T, logits).rsample()      [diff_sampling]  /  .sample()  [otherwise]
+ *              = softmax((logits + g) / T),  g = -log(-log(clamp(u, eps, 1 - eps)))
+ *     q = wf * s0 + wc * s1 ;  then the decode of shacira_latent_decode_forward on q instead of round(w).
+ * `uniforms` [num_rows, latent_dim, 2] fp32 in [0, 1) are supplied by the caller (torch.rand on the device: the one
+ * draw the reference's sampler makes), so the operator is deterministic. Backward: grad_latent through rsample() when
+ * diff_sampling (floor carries no gradient), through a straight-through floor otherwise; other outputs as in
+ * shacira_latent_decode_backward.
+ */
+SHACIRA_API int shacira_latent_decode_sga_forward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,
+                                      const float *uniforms, float temperature, int diff_sampling, const float *div,
+                                      const float *matrix, const float *colscale, const float *shift,
+                                      float clamp_weights, float *decoded, void *stream);
+SHACIRA_API int shacira_latent_decode_sga_backward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,
+                                       const float *uniforms, float temperature, int diff_sampling, const float *div,
+                                       const float *matrix, const float *colscale, const float *shift,
+                                       float clamp_weights, const float *grad_decoded, float *grad_latent,
+                                       float *grad_matrix, float *grad_colscale, float *grad_shift, void *workspace,
+                                       size_t workspace_bytes, void *stream);
 
 /*
  * Symbol statistics and entropy coding of the rounded latents -- replaces the per-channel

@@ -5,6 +5,9 @@ Follows (reference file:line):
   wisp/models/latent_decoders/basic_latent_decoder.py:28-36   StraightThrough (round forward, identity backward)
   wisp/models/latent_decoders/basic_latent_decoder.py:86-91   DecoderLayer.forward ('sq' and 'dft')
   wisp/models/latent_decoders/basic_latent_decoder.py:192-198 LatentDecoder.forward, non-SGA path
+  wisp/models/latent_decoders/basic_latent_decoder.py:183-191 LatentDecoder.forward, SGA path (stochastic Gumbel annealing;
+      the sampler is torch.distributions RelaxedOneHotCategorical = exp(ExpRelaxedCategorical.rsample()):
+      u = clamp(rand, eps, 1-eps); g = -log(-log u); score = (logits + g)/T; sample = exp(score - logsumexp(score)))
   wisp/models/prob_models/bit_estimator.py:27-44, :58-65      Bitparm / BitEstimator forward
   wisp/models/grids/latent_grid.py:122-136                    LatentGrid.ent_loss
 
@@ -54,6 +57,65 @@ def decode_backward(latent, div, matrix, colscale, shift, clamp_weights, grad_ou
         colscale=(gy * zm.astype(np.float64)).sum(0).astype(f32),
         shift=gy.sum(0).astype(f32),
     )
+
+
+def sga_quantise(latent, uniforms, temperature, diff_sampling=True):
+    """SGA sample between floor(w) and floor(w)+1 and its derivative w.r.t. w. uniforms: [T, ld, 2] in [0, 1).
+    float64 inside; -> (q [T, ld] float32, dq_dw [T, ld] float64).
+    diff_sampling: rsample() through the relaxed categorical, floor without gradient; otherwise sample() (no gradient
+    through the sampler) and a straight-through floor (dq/dw = s0 + s1)."""
+    w = latent.astype(np.float64)
+    T = float(temperature)
+    lim = 1.0 - 1e-6
+    wf = np.floor(w)
+    wc = wf + 1.0
+    df = np.clip(w - wf, -lim, lim)
+    dc = np.clip(wc - w, -lim, lim)
+    lf, lc = -np.tanh(df) / T, -np.tanh(dc) / T
+    eps = float(np.finfo(np.float32).eps)
+    u = np.clip(uniforms.astype(np.float64), eps, 1.0 - eps)
+    g = -np.log(-np.log(u))
+    z0, z1 = (lf + g[..., 0]) / T, (lc + g[..., 1]) / T
+    m = np.maximum(z0, z1)
+    lse = m + np.log(np.exp(z0 - m) + np.exp(z1 - m))
+    s0, s1 = np.exp(z0 - lse), np.exp(z1 - lse)
+    q = wf * s0 + wc * s1
+    if diff_sampling:
+        in_f = (w - wf > -lim) & (w - wf < lim)
+        in_c = (wc - w > -lim) & (wc - w < lim)
+        dz = ((1.0 - np.tanh(dc) ** 2) * in_c + (1.0 - np.tanh(df) ** 2) * in_f) / (T * T)   # d(z1 - z0)/dw
+        dq = (wc - wf) * s0 * s1 * dz
+    else:
+        dq = s0 + s1
+    return q.astype(f32), dq
+
+
+def decode_sga_forward(latent, uniforms, temperature, diff_sampling, div, matrix, colscale=None, shift=None,
+                       clamp_weights=0.0):
+    q, _ = sga_quantise(latent, uniforms, temperature, diff_sampling)
+    z = (q / div.astype(f32)).astype(f32)
+    zm = (z @ matrix.astype(f32)).astype(f32)
+    y = zm
+    if colscale is not None:
+        y = (y * colscale.reshape(1, -1).astype(f32)).astype(f32)
+    if shift is not None:
+        y = (y + shift.reshape(1, -1).astype(f32)).astype(f32)
+    return (np.clip(y, -clamp_weights, clamp_weights).astype(f32) if clamp_weights > 0 else y), (z, zm, y)
+
+
+def decode_sga_backward(latent, uniforms, temperature, diff_sampling, div, matrix, colscale, shift, clamp_weights,
+                        grad_out):
+    _, dq = sga_quantise(latent, uniforms, temperature, diff_sampling)
+    _, (z, zm, y) = decode_sga_forward(latent, uniforms, temperature, diff_sampling, div, matrix, colscale, shift,
+                                       clamp_weights)
+    gy = grad_out.astype(np.float64).copy()
+    if clamp_weights > 0:
+        gy[(y < -clamp_weights) | (y > clamp_weights)] = 0.0
+    cs = np.ones(matrix.shape[1]) if colscale is None else colscale.reshape(-1).astype(np.float64)
+    gs = gy * cs.reshape(1, -1)
+    gq = (gs @ matrix.astype(np.float64).T) / div.astype(np.float64).reshape(1, -1)
+    return dict(latent=(gq * dq).astype(f32), matrix=(z.astype(np.float64).T @ gs).astype(f32),
+                colscale=(gy * zm.astype(np.float64)).sum(0).astype(f32), shift=gy.sum(0).astype(f32))
 
 
 def _softplus(h):

@@ -38,6 +38,9 @@ SIGNATURES = {
     "shacira_entropy_bits_workspace_bytes": (_sz, [_i64, _i]),
     "shacira_entropy_bits_forward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "shacira_entropy_bits_backward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "shacira_latent_decode_sga_forward": (_i, [_i64, _i, _i, _p, _p, _f, _i, _p, _p, _p, _p, _f, _p, _p]),
+    "shacira_latent_decode_sga_backward": (_i, [_i64, _i, _i, _p, _p, _f, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p,
+                                                _p, _sz, _p]),
     "shacira_latent_symbol_range": (_i, [_i64, _i, _p, _p, _p]),
     "shacira_latent_symbol_histogram": (_i, [_i64, _i, _p, _p, _i, _p, _p]),
     "shacira_rc_encode_bound": (_sz, [_i64]),

@@ -187,6 +187,40 @@ int shacira_latent_decode_backward(int64_t num_rows, int latent_dim, int feature
     return (int)latent_decode_dispatch(true, latent_dim, feature_dim, a, (hipStream_t)stream);
 }
 
+int shacira_latent_decode_sga_forward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,
+                                      const float *uniforms, float temperature, int diff_sampling, const float *div,
+                                      const float *matrix, const float *colscale, const float *shift,
+                                      float clamp_weights, float *decoded, void *stream) {
+    if (num_rows < 0 || latent_dim < 1 || feature_dim < 1 || !(temperature > 0.0f)) return SHACIRA_EINVAL;
+    if (!latent_decode_supported(latent_dim, feature_dim)) return SHACIRA_EDTYPE;
+    if (num_rows == 0) return 0;
+    if (!latent || !uniforms || !div || !matrix || !decoded) return SHACIRA_EINVAL;
+    DecodeArgs a{};
+    a.latent = latent; a.div = div; a.matrix = matrix; a.colscale = colscale; a.shift = shift;
+    a.clampw = clamp_weights; a.decoded = decoded; a.rows = num_rows;
+    a.uniforms = uniforms; a.temperature = temperature; a.diff_sampling = diff_sampling;
+    return (int)latent_decode_dispatch(false, latent_dim, feature_dim, a, (hipStream_t)stream);
+}
+
+int shacira_latent_decode_sga_backward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,
+                                       const float *uniforms, float temperature, int diff_sampling, const float *div,
+                                       const float *matrix, const float *colscale, const float *shift,
+                                       float clamp_weights, const float *grad_decoded, float *grad_latent,
+                                       float *grad_matrix, float *grad_colscale, float *grad_shift, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
+    if (num_rows < 0 || latent_dim < 1 || feature_dim < 1 || !(temperature > 0.0f)) return SHACIRA_EINVAL;
+    if (!latent_decode_supported(latent_dim, feature_dim)) return SHACIRA_EDTYPE;
+    if (!workspace || workspace_bytes < latent_workspace_bytes()) return SHACIRA_EWORKSPACE;
+    if (num_rows > 0 && (!latent || !uniforms || !div || !matrix || !grad_decoded)) return SHACIRA_EINVAL;
+    DecodeArgs a{};
+    a.latent = latent; a.div = div; a.matrix = matrix; a.colscale = colscale; a.shift = shift;
+    a.clampw = clamp_weights; a.grad_decoded = grad_decoded; a.grad_latent = grad_latent;
+    a.grad_matrix = grad_matrix; a.grad_colscale = grad_colscale; a.grad_shift = grad_shift;
+    a.partials = static_cast<double *>(workspace); a.rows = num_rows;
+    a.uniforms = uniforms; a.temperature = temperature; a.diff_sampling = diff_sampling;
+    return (int)latent_decode_dispatch(true, latent_dim, feature_dim, a, (hipStream_t)stream);
+}
+
 int shacira_latent_symbol_range(int64_t num_rows, int latent_dim, const float *latent, int32_t *minmax, void *stream) {
     if (num_rows < 0 || latent_dim < 1 || !minmax || (num_rows > 0 && !latent)) return SHACIRA_EINVAL;
     if (!symbols_supported(latent_dim)) return SHACIRA_EDTYPE;

@@ -32,6 +32,9 @@ struct DecodeArgs {
     float *grad_latent, *grad_matrix, *grad_colscale, *grad_shift;
     double *partials;
     int64_t rows;
+    const float *uniforms;   // non-NULL: stochastic Gumbel annealing instead of rounding ([rows, ld, 2] uniforms)
+    float temperature;
+    int diff_sampling;
 };
 struct EntropyArgs {
     const float *latent, *noise, *params, *grad_total;

@@ -100,11 +100,52 @@ template <int LD, int F> struct DecodeConsts {
     }
 };
 
-template <int LD, int F>
+// Stochastic Gumbel annealing (basic_latent_decoder.py:183-191): relaxed one-hot choice between floor(w) and floor(w)+1
+// with logits -tanh(distance)/T, sampled as torch's RelaxedOneHotCategorical(T) does from two uniforms per latent:
+// u = clamp(rand, eps, 1-eps); g = -log(-log u); score = (logit + g)/T; sample = exp(score - logsumexp(score)).
+// dq = d(sample)/dw: rsample() path when `diff` (floor carries no gradient), else straight-through floor (s0 + s1).
+struct SgaArgs {
+    const float *uniforms;  // [rows, LD, 2]
+    float temperature;
+    int diff;
+};
+__device__ __forceinline__ void sga_quantise(float w, float u0, float u1, float T, bool diff, float &q, float &dq) {
+    const float lim = 1.0f - 1e-6f, eps = 1.1920929e-07f;
+    const float wf = floorf(w), wc = wf + 1.0f;
+    const float a = w - wf, b = wc - w;
+    const float tf_ = tanhf(fminf(fmaxf(a, -lim), lim)), tc = tanhf(fminf(fmaxf(b, -lim), lim));
+    const float lf = -tf_ / T, lc = -tc / T;
+    u0 = fminf(fmaxf(u0, eps), 1.0f - eps);
+    u1 = fminf(fmaxf(u1, eps), 1.0f - eps);
+    const float z0 = (lf + -logf(-logf(u0))) / T, z1 = (lc + -logf(-logf(u1))) / T;
+    const float m = fmaxf(z0, z1);
+    const float lse = m + logf(expf(z0 - m) + expf(z1 - m));
+    const float s0 = expf(z0 - lse), s1 = expf(z1 - lse);
+    q = wf * s0 + wc * s1;
+    if (diff) {
+        const float in_f = (a > -lim && a < lim) ? 1.0f : 0.0f, in_c = (b > -lim && b < lim) ? 1.0f : 0.0f;
+        dq = s0 * s1 * ((1.0f - tc * tc) * in_c + (1.0f - tf_ * tf_) * in_f) / (T * T);
+    } else {
+        dq = s0 + s1;
+    }
+}
+
+template <int LD, int F, bool SGA>
 __device__ __forceinline__ void decode_row(const DecodeConsts<LD, F> &p, const float *__restrict__ latent, int64_t r,
-                                           float (&z)[LD], float (&zm)[F], float (&y)[F]) {
+                                           const SgaArgs &sga, float (&z)[LD], float (&dq)[LD], float (&zm)[F],
+                                           float (&y)[F]) {
 #pragma unroll
-    for (int c = 0; c < LD; ++c) z[c] = rintf(latent[r * LD + c]) / p.div[c];  // torch.round: half to even
+    for (int c = 0; c < LD; ++c) {
+        if constexpr (SGA) {
+            float q;
+            const float2 u = *reinterpret_cast<const float2 *>(sga.uniforms + (r * LD + c) * 2);
+            sga_quantise(latent[r * LD + c], u.x, u.y, sga.temperature, sga.diff != 0, q, dq[c]);
+            z[c] = q / p.div[c];
+        } else {
+            z[c] = rintf(latent[r * LD + c]) / p.div[c];  // torch.round: half to even
+            dq[c] = 1.0f;                                  // straight-through rounding
+        }
+    }
 #pragma unroll
     for (int j = 0; j < F; ++j) {
         float s = z[0] * p.mat[j];
@@ -115,17 +156,17 @@ __device__ __forceinline__ void decode_row(const DecodeConsts<LD, F> &p, const f
     }
 }
 
-template <int LD, int F>
+template <int LD, int F, bool SGA>
 __global__ __launch_bounds__(kThreads) void latent_decode_fwd_kernel(
     const float *__restrict__ latent, const float *__restrict__ div, const float *__restrict__ matrix,
     const float *__restrict__ colscale, const float *__restrict__ shift, float clampw, float *__restrict__ decoded,
-    int64_t rows) {
+    int64_t rows, SgaArgs sga) {
     DecodeConsts<LD, F> p;
     p.load(div, matrix, colscale, shift, clampw);
     const int64_t stride = (int64_t)gridDim.x * kThreads;
     for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < rows; r += stride) {
-        float z[LD], zm[F], y[F];
-        decode_row<LD, F>(p, latent, r, z, zm, y);
+        float z[LD], dq[LD], zm[F], y[F];
+        decode_row<LD, F, SGA>(p, latent, r, sga, z, dq, zm, y);
 #pragma unroll
         for (int j = 0; j < F; ++j) {
             float v = y[j];
@@ -136,12 +177,12 @@ __global__ __launch_bounds__(kThreads) void latent_decode_fwd_kernel(
 }
 
 // reductions: [LD*F] grad_matrix, [F] grad_colscale, [F] grad_shift
-template <int LD, int F>
+template <int LD, int F, bool SGA>
 __global__ __launch_bounds__(kThreads) void latent_decode_bwd_kernel(
     const float *__restrict__ latent, const float *__restrict__ div, const float *__restrict__ matrix,
     const float *__restrict__ colscale, const float *__restrict__ shift, float clampw,
     const float *__restrict__ grad_decoded, float *__restrict__ grad_latent, double *__restrict__ partials,
-    int64_t rows) {
+    int64_t rows, SgaArgs sga) {
     constexpr int NRED = LD * F + 2 * F;
     DecodeConsts<LD, F> p;
     p.load(div, matrix, colscale, shift, clampw);
@@ -150,8 +191,8 @@ __global__ __launch_bounds__(kThreads) void latent_decode_bwd_kernel(
     for (int q = 0; q < NRED; ++q) acc[q] = 0.0f;
     const int64_t stride = (int64_t)gridDim.x * kThreads;
     for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < rows; r += stride) {
-        float z[LD], zm[F], y[F], gy[F];
-        decode_row<LD, F>(p, latent, r, z, zm, y);
+        float z[LD], dq[LD], zm[F], y[F], gy[F];
+        decode_row<LD, F, SGA>(p, latent, r, sga, z, dq, zm, y);
 #pragma unroll
         for (int j = 0; j < F; ++j) {
             float g = grad_decoded[r * F + j];
@@ -170,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void latent_decode_bwd_kernel(
                 acc[c * F + j] += z[c] * gs;  // grad_matrix
                 gl = fmaf(gs, p.mat[c * F + j], gl);
             }
-            if (grad_latent) grad_latent[r * LD + c] = gl / p.div[c];  // straight-through rounding
+            if (grad_latent) grad_latent[r * LD + c] = gl / p.div[c] * dq[c];  // dq = 1: straight-through rounding
         }
     }
     block_reduce_store<NRED>(acc, partials);
@@ -178,13 +219,24 @@ __global__ __launch_bounds__(kThreads) void latent_decode_bwd_kernel(
 
 template <int LD, int F> static hipError_t decode_launch(bool bwd, const DecodeArgs &a, hipStream_t s) {
     const int blocks = grid_for(a.rows);
+    const SgaArgs sga{a.uniforms, a.temperature, a.diff_sampling};
     if (!bwd) {
-        hipLaunchKernelGGL((latent_decode_fwd_kernel<LD, F>), dim3(blocks), dim3(kThreads), 0, s, a.latent, a.div,
-                           a.matrix, a.colscale, a.shift, a.clampw, a.decoded, a.rows);
+        if (a.uniforms)
+            hipLaunchKernelGGL((latent_decode_fwd_kernel<LD, F, true>), dim3(blocks), dim3(kThreads), 0, s, a.latent,
+                               a.div, a.matrix, a.colscale, a.shift, a.clampw, a.decoded, a.rows, sga);
+        else
+            hipLaunchKernelGGL((latent_decode_fwd_kernel<LD, F, false>), dim3(blocks), dim3(kThreads), 0, s, a.latent,
+                               a.div, a.matrix, a.colscale, a.shift, a.clampw, a.decoded, a.rows, sga);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((latent_decode_bwd_kernel<LD, F>), dim3(blocks), dim3(kThreads), 0, s, a.latent, a.div,
-                       a.matrix, a.colscale, a.shift, a.clampw, a.grad_decoded, a.grad_latent, a.partials, a.rows);
+    if (a.uniforms)
+        hipLaunchKernelGGL((latent_decode_bwd_kernel<LD, F, true>), dim3(blocks), dim3(kThreads), 0, s, a.latent, a.div,
+                           a.matrix, a.colscale, a.shift, a.clampw, a.grad_decoded, a.grad_latent, a.partials, a.rows,
+                           sga);
+    else
+        hipLaunchKernelGGL((latent_decode_bwd_kernel<LD, F, false>), dim3(blocks), dim3(kThreads), 0, s, a.latent,
+                           a.div, a.matrix, a.colscale, a.shift, a.clampw, a.grad_decoded, a.grad_latent, a.partials,
+                           a.rows, sga);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(finish_partials_kernel, dim3(LD * F + 2 * F), dim3(256), 0, s, a.partials, blocks,

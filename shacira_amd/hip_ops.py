@@ -189,6 +189,43 @@ def latent_decode_backward(latent, div, matrix, colscale, shift, clamp_weights, 
     return g_lat, g_mat, g_cs, g_sh
 
 
+def latent_decode_sga_forward(latent, uniforms, temperature, diff_sampling, div, matrix, colscale, shift, clamp_weights):
+    """SGA sample (reference basic_latent_decoder.py:183-191) + decode in one kernel; ``uniforms`` [T, ld, 2]."""
+    _need_gpu(latent, uniforms, div, matrix, colscale, shift)
+    T, ld = latent.shape
+    F = matrix.shape[1]
+    if tuple(uniforms.shape) != (T, ld, 2) or uniforms.dtype != torch.float32 or not uniforms.is_contiguous():
+        raise RuntimeError("uniforms must be a contiguous fp32 [rows, latent_dim, 2] tensor")
+    out = torch.empty((T, F), dtype=torch.float32, device=latent.device)
+    with torch.cuda.device(latent.device):
+        rc = _lib.lib().shacira_latent_decode_sga_forward(T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature),
+                                                          int(bool(diff_sampling)), _ptr(div), _ptr(matrix),
+                                                          _ptr(colscale), _ptr(shift), float(clamp_weights), _ptr(out),
+                                                          _stream(latent))
+    _lib.check(rc, "latent_decode_sga_forward")
+    return out
+
+
+def latent_decode_sga_backward(latent, uniforms, temperature, diff_sampling, div, matrix, colscale, shift, clamp_weights,
+                               grad_decoded, need_colscale):
+    _need_gpu(latent, uniforms, grad_decoded)
+    T, ld = latent.shape
+    F = matrix.shape[1]
+    dev = latent.device
+    g_lat = torch.empty_like(latent)
+    g_mat = torch.empty((ld, F), dtype=torch.float32, device=dev)
+    g_cs = torch.empty((F,), dtype=torch.float32, device=dev) if need_colscale else None
+    g_sh = torch.empty((F,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _latent_workspace(dev)
+        rc = _lib.lib().shacira_latent_decode_sga_backward(
+            T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature), int(bool(diff_sampling)), _ptr(div),
+            _ptr(matrix), _ptr(colscale), _ptr(shift), float(clamp_weights), _ptr(grad_decoded), _ptr(g_lat),
+            _ptr(g_mat), _ptr(g_cs), _ptr(g_sh), _ptr(ws), ws.numel(), _stream(latent))
+    _lib.check(rc, "latent_decode_sga_backward")
+    return g_lat, g_mat, g_cs, g_sh
+
+
 def entropy_supported(latent_dim):
     return latent_dim in (1, 2, 3, 4, 8)
 

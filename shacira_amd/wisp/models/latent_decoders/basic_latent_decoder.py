@@ -3,11 +3,12 @@ arguments, parameter names (``div``, ``layers.0.scale``, ``layers.0.shift``, ``l
 (``use_sga``, ``temperature``, ``diff_sampling``) -- reference wisp/models/latent_decoders/basic_latent_decoder.py:97-228.
 
 Execution:
-  * deterministic path (``use_sga`` False, no hidden layers, identity activations -- what every shipped config runs
-    after the SGA warm-up, at validation, and whenever SGA is off): ONE fused HIP kernel forward and one fused kernel
-    + a tiny finishing kernel backward (``decode_layer._FusedLatentDecode``) when the table lives on the GPU;
-  * SGA sampling (Gumbel noise from torch's generator), hidden layers and non-identity activations stay torch ops
-    (SURVEY.md section 7 "hard parts"), as do tensors that live on the host.
+  * no hidden layers, identity activations (every shipped config), table on the GPU: ONE fused HIP kernel forward and
+    one fused kernel + a tiny finishing kernel backward -- ``decode_layer._FusedLatentDecode`` for the rounding path
+    (after the SGA warm-up, at validation, whenever SGA is off) and ``_FusedLatentDecodeSGA`` for the SGA path (the
+    two uniforms per latent come from ``torch.rand`` on the device: the single draw the reference's
+    RelaxedOneHotCategorical makes, so a seeded run consumes the generator exactly like the reference);
+  * hidden layers and non-identity activations stay torch ops, as do tensors that live on the host.
 """
 import torch
 import torch.nn as nn
@@ -15,7 +16,7 @@ from torch import Tensor
 from torch.nn.modules.utils import _ntuple
 
 from .... import hip_ops
-from .decode_layer import DecoderLayer, _FusedLatentDecode, get_dft_matrix  # noqa: F401  (re-exported)
+from .decode_layer import DecoderLayer, _FusedLatentDecode, _FusedLatentDecodeSGA, get_dft_matrix  # noqa: F401
 from .quantizers import StraightThrough, StraightThroughFloor, epsilon, sga_sample  # noqa: F401
 
 
@@ -98,12 +99,16 @@ class LatentDecoder(nn.Module):
     # -- forward ----------------------------------------------------------------------------------------------
     def _fusable(self, weight: Tensor) -> bool:
         return (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2
-                and not self.use_sga and self.num_layers_dec == 0 and self._identity_acts
+                and self.num_layers_dec == 0 and self._identity_acts
                 and hip_ops.latent_decode_supported(self.latent_dim, self.channels))
 
     def forward(self, weight: Tensor) -> Tensor:
         if self._fusable(weight):
             matrix, colscale, shift = self._decoder_layers()[0].fused_operands()
+            if self.use_sga:
+                uniforms = torch.rand(weight.shape + (2,), dtype=weight.dtype, device=weight.device)
+                return _FusedLatentDecodeSGA.apply(weight, uniforms, float(self.temperature), bool(self.diff_sampling),
+                                                   self.div, matrix, colscale, shift, float(self.clamp_weights))
             return _FusedLatentDecode.apply(weight, self.div, matrix, colscale, shift, float(self.clamp_weights))
         if self.use_sga:
             weight = sga_sample(weight, self.temperature, self.diff_sampling)

@@ -47,6 +47,30 @@ class _FusedLatentDecode(torch.autograd.Function):
                 g_sh.reshape(shift.shape) if (shift is not None and ctx.needs_input_grad[4]) else None, None)
 
 
+class _FusedLatentDecodeSGA(torch.autograd.Function):
+    """SGA sample between floor and ceil (uniforms drawn by the caller) -> /div -> decode, one HIP kernel each way."""
+
+    @staticmethod
+    def forward(ctx, latent, uniforms, temperature, diff_sampling, div, matrix, colscale, shift, clamp_weights):
+        latent = latent.contiguous()
+        ctx.save_for_backward(latent, uniforms, div, matrix, colscale, shift)
+        ctx.opts = (float(temperature), bool(diff_sampling), clamp_weights)
+        return hip_ops.latent_decode_sga_forward(latent, uniforms, temperature, diff_sampling, div, matrix.contiguous(),
+                                                 colscale, shift, clamp_weights)
+
+    @staticmethod
+    def backward(ctx, grad_decoded):
+        latent, uniforms, div, matrix, colscale, shift = ctx.saved_tensors
+        temperature, diff_sampling, clamp_weights = ctx.opts
+        g_lat, g_mat, g_cs, g_sh = hip_ops.latent_decode_sga_backward(
+            latent, uniforms, temperature, diff_sampling, div, matrix.contiguous(), colscale, shift, clamp_weights,
+            grad_decoded.contiguous(), need_colscale=colscale is not None)
+        return (g_lat if ctx.needs_input_grad[0] else None, None, None, None, None,
+                g_mat if ctx.needs_input_grad[5] else None,
+                g_cs.reshape(colscale.shape) if (colscale is not None and ctx.needs_input_grad[6]) else None,
+                g_sh.reshape(shift.shape) if (shift is not None and ctx.needs_input_grad[7]) else None, None)
+
+
 class DecoderLayer(Module):
     """One affine decode layer: 'sq' learns the full [in, out] matrix; 'dft*' fixes a DCT basis and learns a
     per-output scale. ``shift`` exists only with ``bias=True``."""

@@ -6,6 +6,9 @@ Run:  python tests/golden/make_golden.py            (needs /root/reference; writ
 What is pinned by the real reference code (executed, not restated):
   multi_decoder.npz   MultiLatentDecoder.forward/backward/size ('sq'/'dft', soft vs straight-through alpha)   multi_latent_decoder.py:27-210
   latent_decoder.npz  LatentDecoder.forward/backward ('sq'/'dft', shift on/off, div != 1, clamp)   basic_latent_decoder.py:97-198
+  latent_decoder_sga.npz  LatentDecoder.forward/backward on the SGA path (use_sga, diff_sampling on/off), with the
+                      uniforms the reference's RelaxedOneHotCategorical drew                            basic_latent_decoder.py:183-191
+                      (written by `python tests/golden/make_golden.py sga`, leaves the other files untouched)
   bit_estimator.npz   BitEstimator CDF + gradients for num_layers 1..4                               bit_estimator.py:9-65
   latent_grid.npz     LatentGrid.from_geometric tables/buffers/param names, ent_loss (train + val),
                       size(), interpolate() glue ('cat'/'sum', rep trick, [B,S,d] flattening)         latent_grid.py:32-382
@@ -356,7 +359,59 @@ def main():
     print("golden vectors written to", HERE)
 
 
+def make_sga():
+    """SGA path of the reference's LatentDecoder, executed; the uniform numbers its sampler consumed are recovered by
+    re-seeding (RelaxedOneHotCategorical.rsample draws ONE torch.rand of shape [rows, ld, 2])."""
+    _install_shims()
+    import importlib
+    core_mod = importlib.import_module("wisp.core.wisp_module")
+    sys.modules["wisp.core"].WispModule = core_mod.WispModule
+    ldec = importlib.import_module("wisp.models.latent_decoders")
+    out, cases = {}, []
+    g = torch.Generator().manual_seed(4321)
+    for ci, (ld, fd, mat, temp, diff, divv) in enumerate([
+            (1, 2, "sq", 0.5, True, 1.0), (2, 2, "sq", 0.2, True, 2.5), (2, 4, "dft", 1.0, True, 0.8),
+            (1, 2, "sq", 0.3, False, 1.0), (3, 2, "sq", 0.05, True, 1.5)]):
+        torch.manual_seed(200 + ci)
+        dec = ldec.LatentDecoder(latent_dim=ld, feature_dim=fd, norm="none", ldecode_matrix=mat, use_shift=True,
+                                 ldec_std=0.1, use_sga=True, diff_sampling=diff)
+        dec.temperature = temp
+        with torch.no_grad():
+            dec.div.fill_(divv)
+            dec.layers[0].shift.copy_(torch.randn(1, fd, generator=g) * 0.01)
+        lat = ((torch.rand(301, ld, generator=g) - 0.5) * 9.0)
+        lat[0] = 0.0; lat[1] = 2.0; lat[2] = -3.0; lat[3] = 0.5; lat[4] = -1.999999     # integers, ties, near-integers
+        lat.requires_grad_(True)
+        seed = 900 + ci
+        torch.manual_seed(seed)
+        y = dec(lat)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        torch.manual_seed(seed)
+        uniforms = torch.rand(301, ld, 2)
+        pre = f"c{ci}_"
+        out[pre + "latent"] = lat.detach().numpy()
+        out[pre + "uniforms"] = uniforms.numpy()
+        out[pre + "div"] = dec.div.detach().numpy()
+        out[pre + "scale"] = dec.layers[0].scale.detach().numpy()
+        out[pre + "shift"] = dec.layers[0].shift.detach().numpy()
+        if "dft" in mat:
+            out[pre + "dft"] = dec.layers[0].dft.detach().numpy()
+        out[pre + "out"] = y.detach().numpy()
+        out[pre + "grad_out"] = gy.numpy()
+        out[pre + "grad_latent"] = lat.grad.numpy()
+        out[pre + "grad_scale"] = dec.layers[0].scale.grad.numpy()
+        out[pre + "grad_shift"] = dec.layers[0].shift.grad.numpy()
+        cases.append(dict(latent_dim=ld, feature_dim=fd, ldecode_matrix=mat, temperature=temp, diff_sampling=diff))
+    out["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "latent_decoder_sga.npz"), **out)
+    print("SGA golden vectors written")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; goldens can only be regenerated in the dev container")
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "sga":
+        make_sga()
+    else:
+        main()

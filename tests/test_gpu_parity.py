@@ -585,3 +585,43 @@ def test_concurrent_calls_from_two_threads(dev):
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errors, errors[:3]
+
+
+def test_sga_latent_decode_against_reference_vectors(dev, golden):
+    """SGA path (reference basic_latent_decoder.py:183-191) fused: fed the uniforms the reference's sampler drew, the
+    kernel reproduces the reference module's outputs and gradients; and the module takes the same path on the GPU,
+    consuming torch's generator exactly like the reference (one torch.rand of [rows, ld, 2])."""
+    ops = _ops()
+    from shacira_amd.wisp.models.latent_decoders import LatentDecoder
+    g = golden("latent_decoder_sga.npz")
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for ci, case in enumerate(npz_json(g["cases_json"])):
+        p = f"c{ci}_"
+        dft = "dft" in case["ldecode_matrix"]
+        matrix = to(g[p + "dft"] if dft else g[p + "scale"])
+        colscale = to(g[p + "scale"]) if dft else None
+        lat, uni, div, shift = to(g[p + "latent"]), to(g[p + "uniforms"]), to(g[p + "div"]), to(g[p + "shift"])
+        T, diff = case["temperature"], case["diff_sampling"]
+        out = ops.latent_decode_sga_forward(lat, uni, T, diff, div, matrix, colscale, shift, 0.0)
+        np.testing.assert_allclose(out.cpu().numpy(), g[p + "out"], rtol=RTOL, atol=2e-6)
+        gl, gm, gc, gs = ops.latent_decode_sga_backward(lat, uni, T, diff, div, matrix, colscale, shift, 0.0,
+                                                        to(g[p + "grad_out"]), need_colscale=dft)
+        gmax = float(np.abs(g[p + "grad_latent"]).max())
+        np.testing.assert_allclose(gl.cpu().numpy(), g[p + "grad_latent"], rtol=2e-4, atol=5e-5 * gmax)
+        gscale = gc.reshape(1, -1) if dft else gm
+        np.testing.assert_allclose(gscale.cpu().numpy(), g[p + "grad_scale"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(gs.reshape(1, -1).cpu().numpy(), g[p + "grad_shift"], rtol=1e-4, atol=2e-5)
+        # the module: same generator consumption as the reference -> same sample given the same device RNG state
+        dec = LatentDecoder(case["latent_dim"], case["feature_dim"], "none", case["ldecode_matrix"], True, use_sga=True,
+                            diff_sampling=diff).to(dev)
+        dec.temperature = T
+        with torch.no_grad():
+            dec.div.copy_(div)
+            dec.layers[0].scale.copy_(to(g[p + "scale"]))
+            dec.layers[0].shift.copy_(shift)
+        torch.manual_seed(77)
+        y_mod = dec(lat)
+        torch.manual_seed(77)
+        u_dev = torch.rand(lat.shape + (2,), device=dev)
+        y_op = ops.latent_decode_sga_forward(lat, u_dev, T, diff, div, matrix, colscale, shift, 0.0)
+        assert torch.equal(y_mod, y_op)

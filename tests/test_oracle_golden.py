@@ -84,3 +84,23 @@ def test_ent_loss_and_size(golden, name):
             if key in g:
                 np.testing.assert_allclose(gpar[k, s_i], g[key].reshape(-1), rtol=1e-3, atol=1e-3, err_msg=key)
     assert ol.size_bits(lat) == pytest.approx(float(g[p + "size"][1]), rel=1e-5)
+
+
+def test_sga_decode_restatement_against_reference_run(golden):
+    """SGA path of LatentDecoder (use_sga, diff_sampling on/off): the numpy restatement, fed the uniforms the reference's
+    sampler drew, reproduces the reference's outputs and gradients (vectors from `make_golden.py sga`)."""
+    g = golden("latent_decoder_sga.npz")
+    for ci, case in enumerate(npz_json(g["cases_json"])):
+        p = f"c{ci}_"
+        dft = "dft" in case["ldecode_matrix"]
+        matrix = g[p + "dft"] if dft else g[p + "scale"]
+        cs = g[p + "scale"] if dft else None
+        args = (g[p + "latent"], g[p + "uniforms"], case["temperature"], case["diff_sampling"], g[p + "div"], matrix, cs,
+                g[p + "shift"])
+        out, _ = ol.decode_sga_forward(*args)
+        np.testing.assert_allclose(out, g[p + "out"], rtol=1e-5, atol=1e-6)
+        bw = ol.decode_sga_backward(*args, 0.0, g[p + "grad_out"])
+        np.testing.assert_allclose(bw["latent"], g[p + "grad_latent"], rtol=2e-4, atol=5e-5 * np.abs(g[p + "grad_latent"]).max())   # fp32 reference, 1/T^2 up to 400
+        gscale = bw["colscale"].reshape(1, -1) if dft else bw["matrix"]
+        np.testing.assert_allclose(gscale, g[p + "grad_scale"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(bw["shift"].reshape(1, -1), g[p + "grad_shift"], rtol=1e-4, atol=2e-5)
