@@ -132,6 +132,13 @@ class ImageFitter:
             self.bucket = FlatGradients([p for g in groups for p in g["params"]])
         self.lambda_sched = DecayScheduler(total_steps, cent["entropy_reg_sched"], cent["entropy_reg"],
                                            cent["entropy_reg_end"])
+        # SGA warm-up of the shipped configs (base_trainer.py:155-157, image_trainer.py:132-137): temperature decays
+        # exponentially from 1 to `temperature`, SGA is switched off after `decay_period` of the run
+        self.temperature_sched = None
+        if cdec.get("use_sga"):
+            self.temperature_sched = DecayScheduler(total_steps, "exp", 1.0, cdec["temperature"],
+                                                    {"temperature": cdec["temperature"],
+                                                     "decay_period": cdec["decay_period"]})
 
     def _update_div(self):
         grid = self.nef.grid
@@ -152,6 +159,11 @@ class ImageFitter:
             self.optimizer.zero_grad(set_to_none=True)
         with torch.no_grad():
             self._update_div()
+        if self.temperature_sched is not None:
+            dec = self.nef.grid.latent_dec
+            dec.temperature = self.temperature_sched(self.iteration)
+            if self.iteration / self.total_steps > self.cdec["decay_period"]:
+                dec.use_sga = False
         pred = self.nef.rgb(self.coords)
         # mean over the GLOBAL batch: local sum / global element count (gradients are summed over ranks)
         sq_sum = ((pred - self.rgb) ** 2).sum()
@@ -234,12 +246,14 @@ class GraphedImageFitter(ImageFitter):
 
 
 def fit_image(device, steps=1000, height=512, width=768, seed=0, num_lods=16, log_every=0, hidden_dim=16, rank=0,
-              world=1, graphed=False):
+              world=1, graphed=False, use_sga=False):
     """Fit the procedural image with the config-B LatentGrid; returns dict(psnr, rgb_loss, avg_bits, bpp, history).
     With world > 1 the (shuffled) pixel batch is sharded over ranks; results are identical on every rank."""
     from .dist import shard_batch
     torch.manual_seed(seed)
-    grid, cdec, cent = kodak_like_grid(num_lods=num_lods)
+    if use_sga and graphed:
+        raise ValueError("the SGA temperature changes every step; the graphed fitter replays a fixed step")
+    grid, cdec, cent = kodak_like_grid(num_lods=num_lods, use_sga=use_sga)
     nef = NeuralImage(grid, hidden_dim=hidden_dim, num_layers=1).to(device)
     img = torch.from_numpy(make_test_image(height, width, seed)).reshape(-1, 3)
     perm = torch.randperm(height * width, generator=torch.Generator().manual_seed(seed))  # dataset shuffle_idx

@@ -90,6 +90,21 @@ def test_graph_captured_step_reaches_the_same_psnr():
     assert abs(graphed["bpp"] - eager["bpp"]) / eager["bpp"] < 0.05
 
 
+@pytest.mark.gpu
+def test_sga_warm_up_schedule_trains_and_switches_off():
+    """kodak.yaml's mode: stochastic Gumbel annealing (fused SGA decode kernels) with the exponential temperature
+    schedule until decay_period, rounding afterwards; lands at the same quality level as rounding throughout."""
+    dev = torch.device("cuda:0")
+    ste = harness.fit_image(dev, steps=400, height=96, width=128, seed=2, log_every=1)
+    sga = harness.fit_image(dev, steps=400, height=96, width=128, seed=2, log_every=1, use_sga=True)
+    tail = lambda r: float(np.mean([h[2] for h in r["history"][-20:]]))
+    assert abs(tail(ste) - tail(sga)) <= 1.5, (tail(ste), tail(sga))
+    assert tail(sga) > sga["history"][0][2] + 5.0            # it did train
+    assert 0.3 < sga["bpp"] / ste["bpp"] < 3.0
+    with pytest.raises(ValueError):
+        harness.fit_image(dev, steps=10, height=32, width=32, use_sga=True, graphed=True)
+
+
 def test_ray_points_and_field():
     g = torch.Generator().manual_seed(0)
     pts = harness.ray_points(64, 16, g)
