@@ -247,7 +247,8 @@ def main():
         torch.cuda.synchronize()
         psnr = {"value": fit["psnr"], "unit": "dB (clamped_psnr)", "step": args.psnr_steps,
                 "config": "B: 2-D LatentGrid L16 F2 ld1 bw11 res16..512, quant+entropy on, 512x768 procedural image, "
-                          "Adam (kodak.yaml learning rates)", "bpp": fit["bpp"], "rgb_loss": fit["rgb_loss"],
+                          "Adam (kodak.yaml learning rates)", "bpp": fit["bpp"], "bpp_file": fit["bpp_file"],
+                "file_bytes": fit["file_bytes"], "rgb_loss": fit["rgb_loss"],
                 "seconds": time.perf_counter() - tp, "n_gpus": world}
 
     # second PSNR figure (rank 0 only, outside the timed region): the reference's per-step NeRF pipeline -- ray marching

@@ -160,3 +160,66 @@ def payload_bits(data):
     (hl,) = struct.unpack_from("<I", data, len(MAGIC))
     header = json.loads(data[len(MAGIC) + 4:len(MAGIC) + 4 + hl].decode())
     return 8 * sum(ch["payload"] for ch in header["channels"])
+
+
+# ------------------------------------------------------------------------------------------------- whole-model files
+MODEL_MAGIC = b"SHCM\x01\x00"
+
+
+def save_model(module, path=None, latent_key_suffix="grid.codebook"):
+    """Serialise a neural field that owns a LatentGrid: the latent table goes through `compress_latents` (entropy
+    coded, restores round(latent)); every other entry of the state dict is stored raw (fp32 / int as is).
+    Returns the bytes (and writes them to `path` when given). The reference only ever `torch.save`s the fp32 state
+    (image_trainer.py:477-483), so its reported sizes are estimates; this file IS the size."""
+    state = module.state_dict()
+    entries, blobs, off = [], [], 0
+    for name, t in state.items():
+        if name.endswith(latent_key_suffix) and t.dim() == 2 and t.is_floating_point():
+            blob, kind = compress_latents(t), "latents"
+            meta = {"shape": list(t.shape)}
+        else:
+            arr = t.detach().cpu().contiguous().numpy()
+            blob, kind = arr.tobytes(), "raw"
+            meta = {"shape": list(arr.shape), "dtype": str(arr.dtype)}
+        entries.append({"name": name, "kind": kind, "offset": off, "nbytes": len(blob), **meta})
+        blobs.append(blob)
+        off += len(blob)
+    hj = json.dumps({"entries": entries}, separators=(",", ":")).encode()
+    data = MODEL_MAGIC + struct.pack("<I", len(hj)) + hj + b"".join(blobs)
+    if path is not None:
+        with open(path, "wb") as fh:
+            fh.write(data)
+    return data
+
+
+def load_model(module, data):
+    """Inverse of save_model (`data`: bytes or a path). Parameters are overwritten in place; the latent table receives
+    the stored integers, i.e. exactly what the decoder sees at validation time (round(latent))."""
+    if isinstance(data, (str, bytes)) and not isinstance(data, bytes):
+        with open(data, "rb") as fh:
+            data = fh.read()
+    if data[:len(MODEL_MAGIC)] != MODEL_MAGIC:
+        raise ValueError("not a SHCM model file")
+    (hl,) = struct.unpack_from("<I", data, len(MODEL_MAGIC))
+    base = len(MODEL_MAGIC) + 4 + hl
+    header = json.loads(data[len(MODEL_MAGIC) + 4:base].decode())
+    state = module.state_dict()
+    seen = set()
+    with torch.no_grad():
+        for e in header["entries"]:
+            if e["name"] not in state:
+                raise KeyError(f"file entry {e['name']} has no counterpart in the module")
+            dst = state[e["name"]]
+            blob = data[base + e["offset"]:base + e["offset"] + e["nbytes"]]
+            if e["kind"] == "latents":
+                val = decompress_latents(blob, device=dst.device)
+            else:
+                val = torch.from_numpy(np.frombuffer(blob, dtype=np.dtype(e["dtype"])).reshape(e["shape"]).copy())
+            if tuple(val.shape) != tuple(dst.shape):
+                raise ValueError(f"{e['name']}: file holds {tuple(val.shape)}, module {tuple(dst.shape)}")
+            dst.copy_(val.to(dst.device).to(dst.dtype))
+            seen.add(e["name"])
+    missing = [k for k in state if k not in seen]
+    if missing:
+        raise KeyError(f"module entries missing from the file: {missing[:5]}")
+    return module

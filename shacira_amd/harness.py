@@ -286,8 +286,10 @@ def fit_image(device, steps=1000, height=512, width=768, seed=0, num_lods=16, lo
     ldec_bits, latent_bits = grid.size(use_torchac=False, use_prob_model=False)
     rest_bits = sum(p.numel() * 32 for n, p in nef.named_parameters() if "grid" not in n)
     bpp = (latent_bits + ldec_bits + rest_bits) / (height * width)
-    return dict(psnr=out[1], rgb_loss=out[0], avg_bits=out[2], bpp=bpp, steps=steps, history=history,
-                ms_per_step=t_loop / steps * 1e3)
+    from . import codec
+    file_bytes = len(codec.save_model(nef))     # the real thing: range-coded latents + raw fp32 for everything else
+    return dict(psnr=out[1], rgb_loss=out[0], avg_bits=out[2], bpp=bpp, bpp_file=8.0 * file_bytes / (height * width),
+                file_bytes=file_bytes, steps=steps, history=history, ms_per_step=t_loop / steps * 1e3)
 
 
 # =====================================================================================================================

@@ -103,3 +103,27 @@ def test_range_coder_fuzz_round_trip():
         sym = rng.choice(nsym, size=n, p=w / w.sum())
         freq = codec.normalise_frequencies(np.bincount(sym, minlength=nsym))
         assert np.array_equal(codec.rc_decode(codec.rc_encode(sym.astype(np.int32), freq), freq, n), sym), it
+
+
+def test_model_file_round_trip_of_a_latent_grid_state():
+    """Whole-model container: latents entropy-coded (restored as round(latent)), every other state entry bit-exact."""
+    from shacira_amd import harness
+    torch.manual_seed(3)
+    grid, _, _ = harness.kodak_like_grid(num_lods=6, max_grid_res=64)
+    nef = harness.NeuralImage(grid, hidden_dim=16, num_layers=1)
+    with torch.no_grad():
+        grid.codebook.mul_(2.5)
+    before = {k: v.clone() for k, v in nef.state_dict().items()}
+    data = codec.save_model(nef)
+    raw_bytes = sum(v.numel() * v.element_size() for v in before.values())
+    assert len(data) < raw_bytes                                   # the coded table is smaller than fp32
+    with torch.no_grad():
+        for p in nef.parameters():
+            p.add_(1.0)                                            # scramble, then restore from the file
+    codec.load_model(nef, data)
+    after = nef.state_dict()
+    for k, v in before.items():
+        want = torch.round(v) if k.endswith("grid.codebook") else v
+        assert torch.equal(after[k], want), k
+    with pytest.raises(ValueError):
+        codec.load_model(nef, b"junk" + data)

@@ -625,3 +625,27 @@ def test_sga_latent_decode_against_reference_vectors(dev, golden):
         u_dev = torch.rand(lat.shape + (2,), device=dev)
         y_op = ops.latent_decode_sga_forward(lat, u_dev, T, diff, div, matrix, colscale, shift, 0.0)
         assert torch.equal(y_mod, y_op)
+
+
+def test_saved_model_reproduces_the_validation_output(dev):
+    """save_model -> load_model on the GPU: the restored field (integer latents from the range coder, raw fp32 rest)
+    evaluates bit-identically to the original in validation mode (which decodes round(latent))."""
+    from shacira_amd import codec, harness
+    torch.manual_seed(5)
+    grid, _, _ = harness.kodak_like_grid(num_lods=8, max_grid_res=128)
+    nef = harness.NeuralImage(grid, hidden_dim=16, num_layers=1).to(dev)
+    with torch.no_grad():
+        grid.codebook.mul_(3.0)
+    coords = harness.image_coords(64, 96).to(dev)
+    nef.eval()
+    with torch.no_grad():
+        want = nef.rgb(coords).clone()
+    data = codec.save_model(nef)
+    twin_grid, _, _ = harness.kodak_like_grid(num_lods=8, max_grid_res=128)
+    twin = harness.NeuralImage(twin_grid, hidden_dim=16, num_layers=1).to(dev).eval()
+    codec.load_model(twin, data)
+    with torch.no_grad():
+        got = twin.rgb(coords)
+    assert torch.equal(got, want)
+    est_bits = sum(grid.size(use_torchac=False)) + sum(p.numel() * 32 for n, p in nef.named_parameters() if "grid" not in n)
+    assert 8 * len(data) < 1.2 * est_bits + 8 * 4096          # the file is what the size estimate promises (+ header)
