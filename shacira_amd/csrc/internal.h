@@ -80,7 +80,9 @@ hipError_t adam_multi_launch(int count, float *const *p, float *const *g, float 
                              const int64_t *n, const float *lr, const float *wd, float b1, float b2, float eps,
                              int step, const int32_t *step_dev, int zero_grad, hipStream_t s);
 
-// mlp.hip
+// mlp.hip / mlp_mfma.hip
+constexpr int kMlpMaxBlocks = 512;        // backward grid (= rows of the fp64 partial-gradient workspace), VALU and wide MFMA
+constexpr int kMlpNarrowMaxBlocks = 512; // same for the narrow (16x16x4) MFMA decoders (measured: 256 / 1024 / 2048 slower)
 bool mlp_supported(int in, int h, int nh, int out);
 int mlp_num_params(int in, int h, int nh, int out);
 size_t mlp_workspace_bytes(int in, int h, int nh, int out);
@@ -93,5 +95,6 @@ extern std::atomic<int> g_bwd_variant;
 extern std::atomic<int> g_bin_batch_mib;
 extern std::atomic<int> g_bin_acc_kib;
 extern std::atomic<int> g_bwd_fork;
+extern std::atomic<int> g_mlp_variant;
 
 }  // namespace shacira

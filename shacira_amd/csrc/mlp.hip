@@ -258,15 +258,15 @@ __global__ __launch_bounds__(256) void mlp_finish_kernel(const double *__restric
     if (threadIdx.x == 0) out[q] = (float)((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
 }
 
-constexpr int kMlpMaxBlocks = 512;
 
 hipError_t mlp_finish_launch(const double *partials, int nblocks, int n, float *out, hipStream_t s) {
     hipLaunchKernelGGL(mlp_finish_kernel, dim3(n), dim3(256), 0, s, partials, nblocks, n, out);
     return hipGetLastError();
 }
 
-// mlp_mfma.hip: hidden widths that are multiples of 32 run on the fp32 matrix cores
-template <int IN, int H, int NH, int OUT>
+// mlp_mfma.hip: the same decoders on the fp32 matrix cores (MB = 32: width-64 NeRF decoders, MB = 16: width-16 image
+// decoders). Option "mlp_variant": -1 (default) = MFMA wherever instantiated, 0 = the VALU kernels of this file.
+template <int MB, int IN, int H, int NH, int OUT>
 hipError_t wide_mlp_run(bool bwd, int64_t N, const float *x, const float *params, float *y, const float *gy, float *gx,
                         float *gparams, double *partials, hipStream_t s);
 
@@ -306,6 +306,21 @@ typedef hipError_t (*mlp_fn)(bool, int64_t, const float *, const float *, float 
                              double *, hipStream_t);
 
 static mlp_fn mlp_lookup(int in, int h, int nh, int out) {
+    const bool valu_only = g_mlp_variant.load() == 0;
+#define SHACIRA_WIDE(MB, IN, H, NH, OUT) \
+    if (!valu_only && in == IN && h == H && nh == NH && out == OUT) return &wide_mlp_run<MB, IN, H, NH, OUT>;
+    SHACIRA_WIDE(32, 32, 64, 1, 16)  // NeRF density decoder: 16 levels x F=2 -> 64 -> 16   (nerf.py:121-130, hidden_dim 64)
+    SHACIRA_WIDE(32, 43, 64, 2, 3)   // NeRF colour decoder: 16 + 27 (view embedding) -> 64 -> 64 -> rgb   (nerf.py:132-140)
+    SHACIRA_WIDE(32, 32, 64, 2, 3)   // image / 3-D field decoders with hidden_dim 64
+    SHACIRA_WIDE(32, 16, 64, 2, 3)
+    SHACIRA_WIDE(32, 32, 64, 1, 3)
+    SHACIRA_WIDE(16, 32, 16, 2, 3)   // config B image decoder on 16x16x4 MFMA
+    SHACIRA_WIDE(16, 24, 16, 2, 3)
+    SHACIRA_WIDE(16, 16, 16, 2, 3)
+    SHACIRA_WIDE(16, 48, 16, 2, 3)
+    SHACIRA_WIDE(16, 32, 16, 1, 3)
+    SHACIRA_WIDE(16, 32, 16, 2, 4)
+#undef SHACIRA_WIDE
 #define SHACIRA_MLP(IN, H, NH, OUT) \
     if (in == IN && h == H && nh == NH && out == OUT) return &mlp_run<IN, H, NH, OUT>;
     SHACIRA_MLP(32, 16, 2, 3)   // config B: 16 levels x F=2 -> 16 -> 16 -> rgb
@@ -316,13 +331,6 @@ static mlp_fn mlp_lookup(int in, int h, int nh, int out) {
     SHACIRA_MLP(32, 16, 3, 3)
     SHACIRA_MLP(32, 16, 2, 4)
 #undef SHACIRA_MLP
-#define SHACIRA_WIDE(IN, H, NH, OUT) \
-    if (in == IN && h == H && nh == NH && out == OUT) return &wide_mlp_run<IN, H, NH, OUT>;
-    SHACIRA_WIDE(32, 64, 1, 16)  // NeRF density decoder: 16 levels x F=2 -> 64 -> 16   (nerf.py:121-130, hidden_dim 64)
-    SHACIRA_WIDE(43, 64, 2, 3)   // NeRF colour decoder: 16 + 27 (view embedding) -> 64 -> 64 -> rgb   (nerf.py:132-140)
-    SHACIRA_WIDE(32, 64, 2, 3)   // image / 3-D field decoders with hidden_dim 64
-    SHACIRA_WIDE(16, 64, 2, 3)
-#undef SHACIRA_WIDE
     return nullptr;
 }
 
@@ -335,7 +343,8 @@ int mlp_num_params(int in, int h, int nh, int out) {
 }
 
 size_t mlp_workspace_bytes(int in, int h, int nh, int out) {
-    return (size_t)kMlpMaxBlocks * mlp_num_params(in, h, nh, out) * sizeof(double);
+    const int rows = h < 32 ? kMlpNarrowMaxBlocks : kMlpMaxBlocks;
+    return (size_t)rows * mlp_num_params(in, h, nh, out) * sizeof(double);
 }
 
 hipError_t mlp_dispatch(bool bwd, int in, int h, int nh, int out, int64_t N, const float *x, const float *params,

@@ -1,4 +1,5 @@
-// mlp_mfma.hip -- the NeRF decoders (hidden width 64) on the fp32 matrix cores (gfx950).
+// mlp_mfma.hip -- the decoder MLPs on the fp32 matrix cores (gfx950): NeRF decoders (hidden width 64) on
+// v_mfma_f32_32x32x2f32, image decoders (hidden width 16) on v_mfma_f32_16x16x4f32 -- one templated implementation.
 //
 // Row a14 of SURVEY.md section 8, NeRF half: NeuralRadianceField's density decoder 32 -> 64 -> 16 and colour decoder
 // (16 + 27) -> 64 -> 64 -> 3 (wisp/models/nefs/nerf.py:121-147, BasicDecoder basic_decoders.py:74-101): Linear + bias +
@@ -6,15 +7,17 @@
 // 64x64 outputs) take ~2.2 ms of a 3.8 ms NeRF step. Here each way is one kernel built on v_mfma_f32_32x32x2f32 (fp32
 // in, fp32 accumulate: same precision class as the reference's fp32 GEMMs; bf16 MFMA would break fp32 parity).
 //
-// A wave owns a tile of 32 samples and computes TRANSPOSED activations  H^T [features x samples] = W [out x in] . X^T :
-//   A operand = weights from LDS (lane = output row), B operand = activations (lane = sample), C = 32x32 block whose
-//   accumulator layout is  row = 8*(v/4) + 4*(lane/32) + v%4,  col = lane%32  (v = accumulator register 0..15).
-// Chaining trick: the dot product may run over k in any order, so step (b, v) of the next layer takes k = 32b + row(v, h):
+// A wave owns a tile of MB samples (MB = 32 or 16 = the MFMA block) and computes TRANSPOSED activations
+// H^T [features x samples] = W [out x in] . X^T :
+//   A operand = weights from LDS (lane = output row), B operand = activations (lane = sample), C = MB x MB block whose
+//   accumulator layout is  row = (v/4)*(4*NQ) + 4*(lane/MB) + v%4,  col = lane%MB  (v = accumulator register, NQ = 64/MB;
+//   both layouts probed on the chip: tools/mfma_probe.hip, tools/mfma_probe16.hip).
+// Chaining trick: the dot product may run over k in any order, so step (b, v) of the next layer takes k = MB*b + row(v, q):
 // then accumulator register v of the previous layer's block b IS the B operand of that step -- activations never leave
 // the registers between layers, forward or backward (dH^T = W^T . dZ^T chains the same way).
 // Weight gradients contract over SAMPLES (dW = dZ^T . In), which needs both operands with the lane on the other
-// index: the wave stages dZ^T and In through a private LDS region per layer (bank-conflict-free pitches), 16 MFMA steps
-// per 32x32 block of dW, accumulators persistent across the wave's tiles; bias gradients fall out of the same LDS reads.
+// index: the wave stages dZ^T and In through a private LDS region per layer (bank-conflict-free pitches), MB/NQ MFMA
+// steps per block of dW, accumulators persistent across the wave's tiles; bias gradients fall out of the same LDS reads.
 // Block partials in fp64 + the finishing kernel of mlp.hip (reproducible for a fixed grid).
 #include <mutex>
 
@@ -23,27 +26,46 @@
 namespace shacira {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMfmaWaves = 4;          // waves (= 32-sample tiles in flight) per workgroup
+constexpr int kMfmaWaves = 4;          // waves (= sample tiles in flight) per workgroup
 constexpr int kMfmaMaxBlocks = 256;    // persistent grid: one workgroup per CU
 
-__device__ __forceinline__ int crow(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
+// MB = rows / columns of the MFMA block, NA = accumulator registers per lane, NQ = 64 / MB = k values per instruction
+template <int MB> struct Mma;
+template <> struct Mma<32> {
+    typedef f32x16 acc_t;
+    static constexpr int NA = 16, NQ = 2;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<16> {
+    typedef f32x4 acc_t;
+    static constexpr int NA = 4, NQ = 4;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+template <int MB> __device__ __forceinline__ constexpr int crow(int v, int q) {
+    return (v >> 2) * (4 * Mma<MB>::NQ) + 4 * q + (v & 3);
+}
 
-template <int IN, int H, int NH, int OUT> struct WideShape {
-    static_assert(H % 32 == 0 && OUT <= 32 && IN <= 64 && NH >= 1, "shape not covered by the MFMA kernels");
-    static constexpr int KB0 = (IN + 31) / 32;   // 32-wide k blocks of the first layer
-    static constexpr int HB = H / 32;
+template <int MB, int IN, int H, int NH, int OUT> struct WideShape {
+    static_assert(H % MB == 0 && OUT <= MB && IN <= 64 && NH >= 1 && NH <= 2, "shape not covered by the MFMA kernels");
+    static constexpr int KB0 = (IN + MB - 1) / MB;   // MB-wide k blocks of the first layer
+    static constexpr int HB = H / MB;
     static constexpr int fan_in(int l) { return l == 0 ? IN : H; }
     static constexpr int fan_out(int l) { return l == NH ? OUT : H; }
     static constexpr int kblocks(int l) { return l == 0 ? KB0 : HB; }
     static constexpr int oblocks(int l) { return l == NH ? 1 : HB; }
-    static constexpr int pitch(int l) { return 32 * kblocks(l) + 4; }          // LDS row pitch of W_l (floats)
+    static constexpr int pitch(int l) { return MB * kblocks(l) + 4; }          // LDS row pitch of W_l (floats)
     static constexpr int lds_w_off(int l) {                                       // padded W_l, then its padded bias
         int off = 0;
-        for (int q = 0; q < l; ++q) off += 32 * oblocks(q) * pitch(q) + 32 * oblocks(q);
+        for (int q = 0; q < l; ++q) off += MB * oblocks(q) * pitch(q) + MB * oblocks(q);
         return off;
     }
-    static constexpr int lds_b_off(int l) { return lds_w_off(l) + 32 * oblocks(l) * pitch(l); }
+    static constexpr int lds_b_off(int l) { return lds_w_off(l) + MB * oblocks(l) * pitch(l); }
     static constexpr int lds_weights = lds_w_off(NH + 1);
     static constexpr int p_off(int l) {   // offset of W_l in the flat parameter buffer (mlp.hip layout)
         int off = 0;
@@ -52,8 +74,8 @@ template <int IN, int H, int NH, int OUT> struct WideShape {
     }
     static constexpr int n_params = p_off(NH + 1);
     static constexpr int max_kb = KB0 > HB ? KB0 : HB;
-    static constexpr int stage_in_pitch = 32 * max_kb + 1;
-    static constexpr int stage_floats = 32 * stage_in_pitch + 32 * HB * 33;     // In [sample][k] + dZ [o][sample]
+    static constexpr int stage_in_pitch = MB * max_kb + 1;
+    static constexpr int stage_floats = MB * stage_in_pitch + MB * HB * (MB + 1);   // In [sample][k] + dZ [o][sample]
 };
 
 // zero-padded copy of the parameters into LDS
@@ -71,67 +93,74 @@ template <class S, int NH> __device__ __forceinline__ void load_weights(float *s
     __syncthreads();
 }
 
-// out^T[ob] = W[32ob.., :] . in^T + b   (A = W rows from LDS as float4 over 4 consecutive k, B = in[b][v])
-template <int KB, int OB, bool RELU>
+// out^T[ob] = W[MB*ob.., :] . in^T + b   (A = W rows from LDS as float4 over 4 consecutive k, B = in[b][v])
+template <int MB, int KB, int OB, bool RELU>
 __device__ __forceinline__ void layer_forward(const float *__restrict__ sW, int pitch, const float *__restrict__ sB,
-                                              const f32x16 (&in)[KB], f32x16 (&out)[OB], int i, int h) {
+                                              const typename Mma<MB>::acc_t (&in)[KB],
+                                              typename Mma<MB>::acc_t (&out)[OB], int i, int q) {
+    using M = Mma<MB>;
 #pragma unroll
     for (int ob = 0; ob < OB; ++ob) {
-        f32x16 acc;
+        typename M::acc_t acc;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = sB[32 * ob + crow(v, h)];
+        for (int v = 0; v < M::NA; ++v) acc[v] = sB[MB * ob + crow<MB>(v, q)];
 #pragma unroll
         for (int b = 0; b < KB; ++b) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 a = *reinterpret_cast<const float4 *>(sW + (32 * ob + i) * pitch + 32 * b + 8 * g + 4 * h);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, in[b][4 * g + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, in[b][4 * g + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, in[b][4 * g + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, in[b][4 * g + 3], acc, 0, 0, 0);
+            for (int g = 0; g < M::NA / 4; ++g) {
+                const float4 a = *reinterpret_cast<const float4 *>(sW + (MB * ob + i) * pitch + MB * b +
+                                                                   4 * M::NQ * g + 4 * q);
+                acc = M::mma(a.x, in[b][4 * g + 0], acc);
+                acc = M::mma(a.y, in[b][4 * g + 1], acc);
+                acc = M::mma(a.z, in[b][4 * g + 2], acc);
+                acc = M::mma(a.w, in[b][4 * g + 3], acc);
             }
         }
         if (RELU) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[v] = fmaxf(acc[v], 0.0f);
+            for (int v = 0; v < M::NA; ++v) acc[v] = fmaxf(acc[v], 0.0f);
         }
         out[ob] = acc;
     }
 }
 
-// din^T[kb] = W^T[32kb.., :] . dz^T   (A = W[o = 32ob + row(v, h)][k = 32kb + i] from LDS, B = dz[ob][v])
-template <int KB, int OB>
-__device__ __forceinline__ void layer_backward(const float *__restrict__ sW, int pitch, const f32x16 (&dz)[OB],
-                                               f32x16 (&din)[KB], int i, int h, int out_rows) {
+// din^T[kb] = W^T[MB*kb.., :] . dz^T   (A = W[o = MB*ob + row(v, q)][k = MB*kb + i] from LDS, B = dz[ob][v])
+template <int MB, int KB, int OB>
+__device__ __forceinline__ void layer_backward(const float *__restrict__ sW, int pitch,
+                                               const typename Mma<MB>::acc_t (&dz)[OB],
+                                               typename Mma<MB>::acc_t (&din)[KB], int i, int q, int out_rows) {
+    using M = Mma<MB>;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-        f32x16 acc;
+        typename M::acc_t acc;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+        for (int v = 0; v < M::NA; ++v) acc[v] = 0.0f;
 #pragma unroll
         for (int ob = 0; ob < OB; ++ob) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                if (32 * ob + crow(v, 0) >= out_rows) continue;   // rows beyond fan_out are zero in both halves
-                const float a = sW[(32 * ob + crow(v, h)) * pitch + 32 * kb + i];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dz[ob][v], acc, 0, 0, 0);
+            for (int v = 0; v < M::NA; ++v) {
+                if (MB * ob + crow<MB>(v, 0) >= out_rows) continue;   // rows beyond fan_out are zero for every lane
+                const float a = sW[(MB * ob + crow<MB>(v, q)) * pitch + MB * kb + i];
+                acc = M::mma(a, dz[ob][v], acc);
             }
         }
         din[kb] = acc;
     }
 }
 
-template <int IN, int KB0>
-__device__ __forceinline__ void load_input(const float *__restrict__ x, int64_t s, bool live, f32x16 (&in)[KB0], int h) {
+template <int MB, int IN, int KB0>
+__device__ __forceinline__ void load_input(const float *__restrict__ x, int64_t s, bool live,
+                                           typename Mma<MB>::acc_t (&in)[KB0], int q) {
+    using M = Mma<MB>;
 #pragma unroll
     for (int b = 0; b < KB0; ++b) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 32 * b + 8 * g + 4 * h;
+        for (int g = 0; g < M::NA / 4; ++g) {
+            const int f0 = MB * b + 4 * M::NQ * g + 4 * q;
             if constexpr (IN % 4 == 0) {
-                float4 q = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (live && f0 < IN) q = *reinterpret_cast<const float4 *>(x + s * IN + f0);
-                in[b][4 * g] = q.x; in[b][4 * g + 1] = q.y; in[b][4 * g + 2] = q.z; in[b][4 * g + 3] = q.w;
+                float4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (live && f0 < IN) t = *reinterpret_cast<const float4 *>(x + s * IN + f0);
+                in[b][4 * g] = t.x; in[b][4 * g + 1] = t.y; in[b][4 * g + 2] = t.z; in[b][4 * g + 3] = t.w;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) in[b][4 * g + r] = (live && f0 + r < IN) ? x[s * IN + f0 + r] : 0.0f;
@@ -141,14 +170,16 @@ __device__ __forceinline__ void load_input(const float *__restrict__ x, int64_t 
 }
 
 // rows [0, ROWS) of a transposed block set -> out[s, ROWS] (sample-major rows of the caller's tensor)
-template <int ROWS, int NB>
-__device__ __forceinline__ void store_rows(float *__restrict__ out, int64_t s, bool live, const f32x16 (&t)[NB], int h) {
+template <int MB, int ROWS, int NB>
+__device__ __forceinline__ void store_rows(float *__restrict__ out, int64_t s, bool live,
+                                           const typename Mma<MB>::acc_t (&t)[NB], int q) {
+    using M = Mma<MB>;
     if (!live) return;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 32 * b + 8 * g + 4 * h;
+        for (int g = 0; g < M::NA / 4; ++g) {
+            const int f0 = MB * b + 4 * M::NQ * g + 4 * q;
             if constexpr (ROWS % 4 == 0) {
                 if (f0 < ROWS)
                     *reinterpret_cast<float4 *>(out + s * ROWS + f0) =
@@ -162,106 +193,112 @@ __device__ __forceinline__ void store_rows(float *__restrict__ out, int64_t s, b
     }
 }
 
-template <int IN, int H, int NH, int OUT>
+template <int MB, int IN, int H, int NH, int OUT>
 __global__ __launch_bounds__(64 * kMfmaWaves) void wide_mlp_forward_kernel(const float *__restrict__ x,
                                                                             const float *__restrict__ params,
                                                                             float *__restrict__ y, int64_t N) {
-    using S = WideShape<IN, H, NH, OUT>;
+    using S = WideShape<MB, IN, H, NH, OUT>;
+    using A = typename Mma<MB>::acc_t;
     extern __shared__ __align__(16) float smem[];
     load_weights<S, NH>(smem, params);
-    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
-    const int64_t tiles = (N + 31) / 32;
+    const int lane = threadIdx.x & 63, i = lane % MB, q = lane / MB, wave = threadIdx.x >> 6;
+    const int64_t tiles = (N + MB - 1) / MB;
     for (int64_t t = (int64_t)blockIdx.x * kMfmaWaves + wave; t < tiles; t += (int64_t)gridDim.x * kMfmaWaves) {
-        const int64_t s = t * 32 + i;
+        const int64_t s = t * MB + i;
         const bool live = s < N;
-        f32x16 in0[S::KB0], ha[S::HB], hb[S::HB], yo[1];
-        load_input<IN, S::KB0>(x, s, live, in0, h);
-        layer_forward<S::KB0, S::HB, true>(smem + S::lds_w_off(0), S::pitch(0), smem + S::lds_b_off(0), in0, ha, i, h);
+        A in0[S::KB0], ha[S::HB], hb[S::HB], yo[1];
+        load_input<MB, IN, S::KB0>(x, s, live, in0, q);
+        layer_forward<MB, S::KB0, S::HB, true>(smem + S::lds_w_off(0), S::pitch(0), smem + S::lds_b_off(0), in0, ha, i, q);
 #pragma unroll
         for (int l = 1; l < NH; ++l) {
-            layer_forward<S::HB, S::HB, true>(smem + S::lds_w_off(l), S::pitch(l), smem + S::lds_b_off(l), ha, hb, i, h);
+            layer_forward<MB, S::HB, S::HB, true>(smem + S::lds_w_off(l), S::pitch(l), smem + S::lds_b_off(l), ha, hb, i,
+                                                  q);
 #pragma unroll
             for (int b = 0; b < S::HB; ++b) ha[b] = hb[b];
         }
-        layer_forward<S::HB, 1, false>(smem + S::lds_w_off(NH), S::pitch(NH), smem + S::lds_b_off(NH), ha, yo, i, h);
-        store_rows<OUT, 1>(y, s, live, yo, h);
+        layer_forward<MB, S::HB, 1, false>(smem + S::lds_w_off(NH), S::pitch(NH), smem + S::lds_b_off(NH), ha, yo, i, q);
+        store_rows<MB, OUT, 1>(y, s, live, yo, q);
     }
 }
 
-// dW block (ob, kb) += dZ^T[32ob.., samples] . In[samples, 32kb..] from the wave's LDS stage; also the bias partial
-template <int KB, int OB>
+// dW block (ob, kb) += dZ^T[MB*ob.., samples] . In[samples, MB*kb..] from the wave's LDS stage; also the bias partial
+template <int MB, int KB, int OB>
 __device__ __forceinline__ void accumulate_dw(const float *__restrict__ s_in, int in_pitch, const float *__restrict__ s_dz,
-                                              f32x16 (&dw)[OB][KB], float (&db)[OB], int i, int h) {
+                                              typename Mma<MB>::acc_t (&dw)[OB][KB], float (&db)[OB], int i, int q) {
+    using M = Mma<MB>;
 #pragma unroll
     for (int ob = 0; ob < OB; ++ob) {
-        float a[16];
+        float a[M::NA];
         float bsum = 0.0f;
 #pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            a[st] = s_dz[(32 * ob + i) * 33 + 2 * st + h];
+        for (int st = 0; st < M::NA; ++st) {
+            a[st] = s_dz[(MB * ob + i) * (MB + 1) + M::NQ * st + q];
             bsum += a[st];
         }
         db[ob] += bsum;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-            for (int st = 0; st < 16; ++st) {
-                const float b = s_in[(2 * st + h) * in_pitch + 32 * kb + i];
-                dw[ob][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], b, dw[ob][kb], 0, 0, 0);
+            for (int st = 0; st < M::NA; ++st) {
+                const float b = s_in[(M::NQ * st + q) * in_pitch + MB * kb + i];
+                dw[ob][kb] = M::mma(a[st], b, dw[ob][kb]);
             }
         }
     }
 }
 
-template <int NB> __device__ __forceinline__ void stage_in(float *s_in, int in_pitch, const f32x16 (&t)[NB], int j, int h) {
+template <int MB, int NB>
+__device__ __forceinline__ void stage_in(float *s_in, int in_pitch, const typename Mma<MB>::acc_t (&t)[NB], int j, int q) {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) s_in[j * in_pitch + 32 * b + crow(v, h)] = t[b][v];
+        for (int v = 0; v < Mma<MB>::NA; ++v) s_in[j * in_pitch + MB * b + crow<MB>(v, q)] = t[b][v];
 }
-template <int NB> __device__ __forceinline__ void stage_dz(float *s_dz, const f32x16 (&t)[NB], int j, int h) {
+template <int MB, int NB>
+__device__ __forceinline__ void stage_dz(float *s_dz, const typename Mma<MB>::acc_t (&t)[NB], int j, int q) {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) s_dz[(32 * b + crow(v, h)) * 33 + j] = t[b][v];
+        for (int v = 0; v < Mma<MB>::NA; ++v) s_dz[(MB * b + crow<MB>(v, q)) * (MB + 1) + j] = t[b][v];
 }
 
 // dW block -> the block's fp32 parameter-gradient image in LDS
-template <int KB, int OB>
-__device__ __forceinline__ void flush_dw(float *s_gp, int p_off, int fan_in, int fan_out, const f32x16 (&dw)[OB][KB],
-                                         const float (&db)[OB], int j, int h) {
+template <int MB, int KB, int OB>
+__device__ __forceinline__ void flush_dw(float *s_gp, int p_off, int fan_in, int fan_out,
+                                         const typename Mma<MB>::acc_t (&dw)[OB][KB], const float (&db)[OB], int j, int q) {
 #pragma unroll
     for (int ob = 0; ob < OB; ++ob) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int o = 32 * ob + crow(v, h), k = 32 * kb + j;
+            for (int v = 0; v < Mma<MB>::NA; ++v) {
+                const int o = MB * ob + crow<MB>(v, q), k = MB * kb + j;
                 if (o < fan_out && k < fan_in) atomicAdd(&s_gp[p_off + o * fan_in + k], dw[ob][kb][v]);
             }
         }
-        // bias: lane (i, h) holds the sum over its 16 samples of row 32ob + i
-        const int o = 32 * ob + j;
+        // bias: lane (i, q) holds the sum over its MB / NQ samples of row MB*ob + i
+        const int o = MB * ob + j;
         if (o < fan_out) atomicAdd(&s_gp[p_off + fan_in * fan_out + o], db[ob]);
     }
 }
 
-template <int IN, int H, int NH, int OUT>
+template <int MB, int IN, int H, int NH, int OUT>
 __global__ __launch_bounds__(64 * kMfmaWaves) void wide_mlp_backward_kernel(
     const float *__restrict__ x, const float *__restrict__ params, const float *__restrict__ gy,
     float *__restrict__ gx, double *__restrict__ partials, int64_t N) {
-    using S = WideShape<IN, H, NH, OUT>;
-    static_assert(NH <= 2, "register plan covers one or two hidden layers");
+    using S = WideShape<MB, IN, H, NH, OUT>;
+    using M = Mma<MB>;
+    using A = typename M::acc_t;
     extern __shared__ __align__(16) float smem[];
     float *s_gp = smem + S::lds_weights;                        // [n_params] block gradient image
-    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, i = lane % MB, q = lane / MB, wave = threadIdx.x >> 6;
     float *s_in = s_gp + (S::n_params + 3) / 4 * 4 + wave * S::stage_floats;   // wave-private stage
-    float *s_dz = s_in + 32 * S::stage_in_pitch;
+    float *s_dz = s_in + MB * S::stage_in_pitch;
     for (int e = threadIdx.x; e < S::n_params; e += 64 * kMfmaWaves) s_gp[e] = 0.0f;
     load_weights<S, NH>(smem, params);
 
     // persistent weight-gradient accumulators
-    f32x16 dw0[S::HB][S::KB0], dw1[S::HB][S::HB], dwo[1][S::HB];
+    A dw0[S::HB][S::KB0], dw1[S::HB][S::HB], dwo[1][S::HB];
     float db0[S::HB], db1[S::HB], dbo[1];
 #pragma unroll
     for (int a = 0; a < S::HB; ++a) {
@@ -269,76 +306,77 @@ __global__ __launch_bounds__(64 * kMfmaWaves) void wide_mlp_backward_kernel(
 #pragma unroll
         for (int b = 0; b < S::KB0; ++b)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) dw0[a][b][v] = 0.0f;
+            for (int v = 0; v < M::NA; ++v) dw0[a][b][v] = 0.0f;
 #pragma unroll
         for (int b = 0; b < S::HB; ++b)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) { dw1[a][b][v] = 0.0f; }
+            for (int v = 0; v < M::NA; ++v) { dw1[a][b][v] = 0.0f; }
 #pragma unroll
-        for (int v = 0; v < 16; ++v) dwo[0][a][v] = 0.0f;
+        for (int v = 0; v < M::NA; ++v) dwo[0][a][v] = 0.0f;
     }
     dbo[0] = 0.0f;
 
-    const int64_t tiles = (N + 31) / 32;
+    const int64_t tiles = (N + MB - 1) / MB;
     for (int64_t t = (int64_t)blockIdx.x * kMfmaWaves + wave; t < tiles; t += (int64_t)gridDim.x * kMfmaWaves) {
-        const int64_t s = t * 32 + i;
+        const int64_t s = t * MB + i;
         const bool live = s < N;
         // forward recompute, hidden activations kept in registers
-        f32x16 in0[S::KB0], h0[S::HB], h1[S::HB];
-        load_input<IN, S::KB0>(x, s, live, in0, h);
-        layer_forward<S::KB0, S::HB, true>(smem + S::lds_w_off(0), S::pitch(0), smem + S::lds_b_off(0), in0, h0, i, h);
+        A in0[S::KB0], h0[S::HB], h1[S::HB];
+        load_input<MB, IN, S::KB0>(x, s, live, in0, q);
+        layer_forward<MB, S::KB0, S::HB, true>(smem + S::lds_w_off(0), S::pitch(0), smem + S::lds_b_off(0), in0, h0, i, q);
         if constexpr (NH == 2)
-            layer_forward<S::HB, S::HB, true>(smem + S::lds_w_off(1), S::pitch(1), smem + S::lds_b_off(1), h0, h1, i, h);
+            layer_forward<MB, S::HB, S::HB, true>(smem + S::lds_w_off(1), S::pitch(1), smem + S::lds_b_off(1), h0, h1, i,
+                                                  q);
         // upstream gradient in accumulator layout
-        f32x16 dzo[1];
+        A dzo[1];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int o = crow(v, h);
+        for (int v = 0; v < M::NA; ++v) {
+            const int o = crow<MB>(v, q);
             dzo[0][v] = (live && o < OUT) ? gy[s * OUT + o] : 0.0f;
         }
-        const f32x16 (&hlast)[S::HB] = (NH == 2) ? h1 : h0;
+        const A (&hlast)[S::HB] = (NH == 2) ? h1 : h0;
         // output layer: dW_out, then dH_last
-        stage_in<S::HB>(s_in, S::stage_in_pitch, hlast, i, h);
-        stage_dz<1>(s_dz, dzo, i, h);
+        stage_in<MB, S::HB>(s_in, S::stage_in_pitch, hlast, i, q);
+        stage_dz<MB, 1>(s_dz, dzo, i, q);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // stage written by all lanes before any lane reads it
-        accumulate_dw<S::HB, 1>(s_in, S::stage_in_pitch, s_dz, dwo, dbo, i, h);
+        accumulate_dw<MB, S::HB, 1>(s_in, S::stage_in_pitch, s_dz, dwo, dbo, i, q);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        f32x16 dcur[S::HB];
-        layer_backward<S::HB, 1>(smem + S::lds_w_off(NH), S::pitch(NH), dzo, dcur, i, h, OUT);
+        A dcur[S::HB];
+        layer_backward<MB, S::HB, 1>(smem + S::lds_w_off(NH), S::pitch(NH), dzo, dcur, i, q, OUT);
 #pragma unroll
         for (int b = 0; b < S::HB; ++b)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) dcur[b][v] = (hlast[b][v] > 0.0f) ? dcur[b][v] : 0.0f;
+            for (int v = 0; v < M::NA; ++v) dcur[b][v] = (hlast[b][v] > 0.0f) ? dcur[b][v] : 0.0f;
         if constexpr (NH == 2) {
             // hidden layer 1: dW_1 = dZ_1^T . H_0, then dH_0
-            stage_in<S::HB>(s_in, S::stage_in_pitch, h0, i, h);
-            stage_dz<S::HB>(s_dz, dcur, i, h);
+            stage_in<MB, S::HB>(s_in, S::stage_in_pitch, h0, i, q);
+            stage_dz<MB, S::HB>(s_dz, dcur, i, q);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            accumulate_dw<S::HB, S::HB>(s_in, S::stage_in_pitch, s_dz, dw1, db1, i, h);
+            accumulate_dw<MB, S::HB, S::HB>(s_in, S::stage_in_pitch, s_dz, dw1, db1, i, q);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            f32x16 dprev[S::HB];
-            layer_backward<S::HB, S::HB>(smem + S::lds_w_off(1), S::pitch(1), dcur, dprev, i, h, H);
+            A dprev[S::HB];
+            layer_backward<MB, S::HB, S::HB>(smem + S::lds_w_off(1), S::pitch(1), dcur, dprev, i, q, H);
 #pragma unroll
             for (int b = 0; b < S::HB; ++b)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) dcur[b][v] = (h0[b][v] > 0.0f) ? dprev[b][v] : 0.0f;
+                for (int v = 0; v < M::NA; ++v) dcur[b][v] = (h0[b][v] > 0.0f) ? dprev[b][v] : 0.0f;
         }
         // first layer: dW_0 = dZ_0^T . X, then dX
-        stage_in<S::KB0>(s_in, S::stage_in_pitch, in0, i, h);
-        stage_dz<S::HB>(s_dz, dcur, i, h);
+        stage_in<MB, S::KB0>(s_in, S::stage_in_pitch, in0, i, q);
+        stage_dz<MB, S::HB>(s_dz, dcur, i, q);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        accumulate_dw<S::KB0, S::HB>(s_in, S::stage_in_pitch, s_dz, dw0, db0, i, h);
+        accumulate_dw<MB, S::KB0, S::HB>(s_in, S::stage_in_pitch, s_dz, dw0, db0, i, q);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (gx != nullptr) {
-            f32x16 dx[S::KB0];
-            layer_backward<S::KB0, S::HB>(smem + S::lds_w_off(0), S::pitch(0), dcur, dx, i, h, H);
-            store_rows<IN, S::KB0>(gx, s, live, dx, h);
+            A dx[S::KB0];
+            layer_backward<MB, S::KB0, S::HB>(smem + S::lds_w_off(0), S::pitch(0), dcur, dx, i, q, H);
+            store_rows<MB, IN, S::KB0>(gx, s, live, dx, q);
         }
     }
     // wave accumulators -> block image (LDS float atomics: once per kernel) -> fp64 block partial
-    flush_dw<S::KB0, S::HB>(s_gp, S::p_off(0), IN, H, dw0, db0, i, h);
-    if constexpr (NH == 2) flush_dw<S::HB, S::HB>(s_gp, S::p_off(1), H, H, dw1, db1, i, h);
-    flush_dw<S::HB, 1>(s_gp, S::p_off(NH), H, OUT, dwo, dbo, i, h);
+    flush_dw<MB, S::KB0, S::HB>(s_gp, S::p_off(0), IN, H, dw0, db0, i, q);
+    if constexpr (NH == 2) flush_dw<MB, S::HB, S::HB>(s_gp, S::p_off(1), H, H, dw1, db1, i, q);
+    flush_dw<MB, S::HB, 1>(s_gp, S::p_off(NH), H, OUT, dwo, dbo, i, q);
     __syncthreads();
     for (int e = threadIdx.x; e < S::n_params; e += 64 * kMfmaWaves)
         partials[(size_t)blockIdx.x * S::n_params + e] = (double)s_gp[e];
@@ -347,13 +385,18 @@ __global__ __launch_bounds__(64 * kMfmaWaves) void wide_mlp_backward_kernel(
 // finishing pass (mlp.hip): fp64 block partials -> fp32 gradient, fixed summation tree
 hipError_t mlp_finish_launch(const double *partials, int nblocks, int n, float *out, hipStream_t s);
 
-template <int IN, int H, int NH, int OUT>
+template <int MB, int IN, int H, int NH, int OUT>
 hipError_t wide_mlp_run(bool bwd, int64_t N, const float *x, const float *params, float *y, const float *gy, float *gx,
                         float *gparams, double *partials, hipStream_t s) {
-    using S = WideShape<IN, H, NH, OUT>;
-    const int64_t tiles = (N + 31) / 32;
+    using S = WideShape<MB, IN, H, NH, OUT>;
+    const int64_t tiles = (N + MB - 1) / MB;
     int64_t blocks = (tiles + kMfmaWaves - 1) / kMfmaWaves;
-    if (blocks > kMfmaMaxBlocks) blocks = kMfmaMaxBlocks;
+    // narrow decoders are memory-bound: several workgroups per CU hide the load latency; wide ones fill the registers
+    // forward: no per-block epilogue, so many small workgroups; backward: every workgroup pays the weight load, the
+    // gradient flush and one partial row for the finishing pass
+    const int64_t max_blocks = (MB == 16) ? (bwd ? kMlpNarrowMaxBlocks : 2048) : kMfmaMaxBlocks;
+    static_assert(kMfmaMaxBlocks <= kMlpMaxBlocks, "the partial-gradient workspace has kMlpMaxBlocks rows");
+    if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     constexpr size_t fwd_lds = (size_t)S::lds_weights * sizeof(float);
     constexpr size_t bwd_lds =
@@ -364,34 +407,41 @@ hipError_t wide_mlp_run(bool bwd, int64_t N, const float *x, const float *params
     std::call_once(once, [] {
         hipError_t e = hipSuccess;
         if (fwd_lds > 64 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_mlp_forward_kernel<IN, H, NH, OUT>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_mlp_forward_kernel<MB, IN, H, NH, OUT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds);
         if (e == hipSuccess && bwd_lds > 64 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_mlp_backward_kernel<IN, H, NH, OUT>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_mlp_backward_kernel<MB, IN, H, NH, OUT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
         attr_err = e;
     });
     if (attr_err != hipSuccess) return attr_err;
     if (!bwd) {
-        hipLaunchKernelGGL((wide_mlp_forward_kernel<IN, H, NH, OUT>), dim3((uint32_t)blocks), dim3(64 * kMfmaWaves),
+        hipLaunchKernelGGL((wide_mlp_forward_kernel<MB, IN, H, NH, OUT>), dim3((uint32_t)blocks), dim3(64 * kMfmaWaves),
                            fwd_lds, s, x, params, y, N);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((wide_mlp_backward_kernel<IN, H, NH, OUT>), dim3((uint32_t)blocks), dim3(64 * kMfmaWaves), bwd_lds,
-                       s, x, params, gy, gx, partials, N);
+    hipLaunchKernelGGL((wide_mlp_backward_kernel<MB, IN, H, NH, OUT>), dim3((uint32_t)blocks), dim3(64 * kMfmaWaves),
+                       bwd_lds, s, x, params, gy, gx, partials, N);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return mlp_finish_launch(partials, (int)blocks, S::n_params, gparams, s);
 }
 
 // the instantiations mlp.hip's lookup table refers to
-template hipError_t wide_mlp_run<32, 64, 1, 16>(bool, int64_t, const float *, const float *, float *, const float *,
-                                                 float *, float *, double *, hipStream_t);
-template hipError_t wide_mlp_run<43, 64, 2, 3>(bool, int64_t, const float *, const float *, float *, const float *,
-                                                float *, float *, double *, hipStream_t);
-template hipError_t wide_mlp_run<32, 64, 2, 3>(bool, int64_t, const float *, const float *, float *, const float *,
-                                                float *, float *, double *, hipStream_t);
-template hipError_t wide_mlp_run<16, 64, 2, 3>(bool, int64_t, const float *, const float *, float *, const float *,
-                                                float *, float *, double *, hipStream_t);
+#define SHACIRA_WIDE_INST(MB, IN, H, NH, OUT)                                                                        \
+    template hipError_t wide_mlp_run<MB, IN, H, NH, OUT>(bool, int64_t, const float *, const float *, float *,       \
+                                                         const float *, float *, float *, double *, hipStream_t);
+SHACIRA_WIDE_INST(32, 32, 64, 1, 16)
+SHACIRA_WIDE_INST(32, 43, 64, 2, 3)
+SHACIRA_WIDE_INST(32, 32, 64, 2, 3)
+SHACIRA_WIDE_INST(32, 16, 64, 2, 3)
+SHACIRA_WIDE_INST(32, 32, 64, 1, 3)
+SHACIRA_WIDE_INST(16, 32, 16, 2, 3)
+SHACIRA_WIDE_INST(16, 24, 16, 2, 3)
+SHACIRA_WIDE_INST(16, 16, 16, 2, 3)
+SHACIRA_WIDE_INST(16, 48, 16, 2, 3)
+SHACIRA_WIDE_INST(16, 32, 16, 1, 3)
+SHACIRA_WIDE_INST(16, 32, 16, 2, 4)
+#undef SHACIRA_WIDE_INST
 
 }  // namespace shacira

@@ -34,9 +34,24 @@ def test_basic_decoder_host_logic_and_names():
                                   # hidden width 64: the fp32-MFMA kernels (NeRF density / colour decoders)
                                   (32, 64, 1, 16), (43, 64, 2, 3), (32, 64, 2, 3), (16, 64, 2, 3)])
 @pytest.mark.parametrize("n", [1, 255, 256, 70_001])
-def test_fused_mlp_matches_torch_layers(dims, n):
-    from shacira_amd import hip_ops
+@pytest.mark.parametrize("variant", [-1, 0])
+def test_fused_mlp_matches_torch_layers(dims, n, variant):
+    """variant -1: the MFMA kernels wherever a shape has one (16x16x4 for width 16, 32x32x2 for width 64), 0: the VALU
+    kernels (width 16 only)."""
+    from shacira_amd import _lib, hip_ops
     dev = torch.device("cuda:0")
+    IN, H, NH, OUT = dims
+    if variant == 0 and H != 16:
+        pytest.skip("width-64 decoders exist as MFMA kernels only")
+    _lib.set_option("mlp_variant", variant)
+    try:
+        _check_fused_mlp(dims, n, dev)
+    finally:
+        _lib.set_option("mlp_variant", -1)
+
+
+def _check_fused_mlp(dims, n, dev):
+    from shacira_amd import hip_ops
     IN, H, NH, OUT = dims
     assert hip_ops.mlp_supported(*dims)
     torch.manual_seed(IN + NH + n % 7)
@@ -98,8 +113,15 @@ def test_fused_mlp_speed_on_image_batch():
 
     def layers():
         y = _torch_mlp(dec, x); y.backward(gy)
+    from shacira_amd import _lib
     tf, tl = run(fused), run(layers)
-    print(f"decoder MLP fwd+bwd on 393216 px: fused {tf:.3f} ms vs torch Linear layers {tl:.3f} ms")
+    _lib.set_option("mlp_variant", 0)
+    try:
+        tv = run(fused)
+    finally:
+        _lib.set_option("mlp_variant", -1)
+    print(f"decoder MLP fwd+bwd on 393216 px: MFMA 16x16x4 {tf:.3f} ms, VALU kernels {tv:.3f} ms, torch Linear layers "
+          f"{tl:.3f} ms")
     assert tf < tl
 
 
