@@ -555,8 +555,12 @@ static int choose_acc_kib(int dim, const LevelTable &lt, int64_t n) {
     const int opt = g_bin_acc_kib.load();
     if (opt != 0) return opt;
     const int64_t pairs = (int64_t)1 << (dim - 1);
-    if (n * pairs <= ((int64_t)1 << 21) && bin_feasible(dim, lt, 64)) return 64;
-    return 128;
+    if (n * pairs > ((int64_t)1 << 21) || !bin_feasible(dim, lt, 64)) return 128;
+    // tables whose levels are all "direct" (config B: every level fits an LDS image) want the big image: fewer level
+    // groups, hence fewer walks over the samples (measured 82 vs 124 us on the 393 216-pixel batch)
+    BinPlan big;
+    make_plan(dim, lt, kTile, big, 128);
+    return big.nbl == 0 ? 128 : 64;
 }
 
 bool bin_supported(int dim, const LevelTable &lt) {
