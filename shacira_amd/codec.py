@@ -110,6 +110,10 @@ def entropy_bits(counts):
 def compress_latents(latent):
     """[T, ld] float latents -> container bytes holding round(latent) exactly."""
     T, ld = latent.shape
+    if not bool(torch.isfinite(latent).all()):
+        raise ValueError("latents must be finite to be entropy coded")
+    if T and float(latent.detach().abs().max()) >= 2.0 ** 30:
+        raise ValueError("latents beyond +-2^30 are outside the coder's symbol range")
     lo, counts = symbol_counts(latent)
     sym = torch.round(latent.detach().float()).to(torch.int64).cpu().numpy()
     header = {"rows": int(T), "latent_dim": int(ld), "channels": []}

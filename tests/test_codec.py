@@ -82,6 +82,11 @@ def test_container_restores_rounded_latents(shape, scale):
         assert est <= codec.payload_bits(blob) <= est * 1.02 + 48 * shape[1]
     with pytest.raises(ValueError):
         codec.decompress_latents(b"nope" + blob)
+    if shape[0] > 1:
+        bad = lat.clone()
+        bad[1, 0] = float("nan")
+        with pytest.raises(ValueError):
+            codec.compress_latents(bad)
 
 
 def test_symbol_counts_match_torch_unique():
