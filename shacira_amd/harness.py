@@ -421,11 +421,15 @@ class _AnalyticNef:
 
 
 def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwidth=19, max_grid_res=2048,
-             num_lods=16, blas_level=5, prune_every=100, val_rays=8192, hidden_dim=64):
+             num_lods=16, blas_level=5, prune_every=100, val_rays=8192, hidden_dim=64, latent=False,
+             entropy_reg=1.0e-4):
     """NeRF-style fit of the analytic scene through the full pipeline the reference runs per step
     (multiview_trainer.py:88-150): ray marching on the occupancy grid ('ray' sampler) -> hash-grid lookup -> density /
     colour decoders -> volume integration -> L1 to the target pixels -> Adam; occupancy pruned every `prune_every` steps.
     Targets are rendered from the closed-form scene by the same tracer with 4x the samples.
+    `latent=True`: the compressed variant the reference's nerf_lego.yaml trains -- a 3-D LatentGrid (latent_dim 1, SGA
+    warm-up with temperature 1.0 until decay_period 0.9, entropy model with one layer, lambda = `entropy_reg`); the
+    result then also carries the size estimate and the bytes of the entropy-coded model file.
     Returns dict(psnr on held-out rays, ms_per_step, samples_per_step)."""
     import time
     from .optim import FusedAdam
@@ -435,9 +439,26 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
     from .wisp.ops.image.metrics import psnr as psnr_fn
     from .wisp.tracers import PackedRFTracer
     torch.manual_seed(seed)
-    grid = HashGrid.from_geometric(feature_dim=2, num_lods=num_lods, multiscale_type="cat", resolution_dim=3,
-                                   feature_std=0.01, codebook_bitwidth=codebook_bitwidth, min_grid_res=16,
-                                   max_grid_res=max_grid_res, blas_level=blas_level)
+    cdec = None
+    if latent:
+        cdec = dict(ldecode_enabled=True, ldecode_type="single", use_sga=True, diff_sampling=True, use_shift=True,
+                    ldecode_matrix="sq", latent_dim=1, norm="none", norm_every=10, ldec_std=0.1, decay_period=0.9,
+                    temperature=1.0, num_layers_dec=0, hidden_dim_dec=0, activation="none", final_activation="none",
+                    clamp_weights=0.0, num_decoders=1, alpha_std=1.0)
+        cent = dict(num_prob_layers=1, entropy_reg=entropy_reg, entropy_reg_end=entropy_reg,
+                    entropy_reg_sched="cosine", noise_freq=1)
+        grid = LatentGrid.from_geometric(feature_dim=2, num_lods=num_lods, latent_dim=1, multiscale_type="cat",
+                                         resolution_dim=3, feature_std=0.02, feature_bias=0.0,
+                                         codebook_bitwidth=codebook_bitwidth, min_grid_res=16,
+                                         max_grid_res=max_grid_res, blas_level=blas_level, init_grid="normal",
+                                         conf_latent_decoder=cdec, conf_entropy_reg=cent)
+        temperature_sched = DecayScheduler(steps, "exp", 1.0, cdec["temperature"],
+                                           {"temperature": cdec["temperature"], "decay_period": cdec["decay_period"]})
+        grid.device_noise = True   # 6.1 M uniforms per step: drawn on the device (the reference draws on the host + H2D)
+    else:
+        grid = HashGrid.from_geometric(feature_dim=2, num_lods=num_lods, multiscale_type="cat", resolution_dim=3,
+                                       feature_std=0.01, codebook_bitwidth=codebook_bitwidth, min_grid_res=16,
+                                       max_grid_res=max_grid_res, blas_level=blas_level)
     nef = NeuralRadianceField(grid, view_embedder="positional", view_multires=4, hidden_dim=hidden_dim, num_layers=1,
                               prune_density_decay=0.95, prune_min_density=0.01 * 512 / 3 ** 0.5).to(device)
     truth = _AnalyticNef(HashGrid.from_geometric(feature_dim=2, num_lods=2, multiscale_type="cat", resolution_dim=3,
@@ -458,8 +479,15 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
         with torch.no_grad():
             target = gt_tracer(truth, batch).rgb
         opt.zero_grad(set_to_none=True)
+        if latent:
+            grid.latent_dec.temperature = temperature_sched(it + 1)
+            if (it + 1) / steps > cdec["decay_period"]:
+                grid.latent_dec.use_sga = False
         rb = tracer(nef, batch)
         loss = torch.abs(rb.rgb[..., :3] - target[..., :3]).mean()
+        if latent and entropy_reg > 0:
+            avg_bits, _ = grid.ent_loss(it, is_val=False)       # multiview_trainer.py:109-113
+            loss = loss + entropy_reg * avg_bits
         loss.backward()
         opt.step()
         samples_seen += rays * num_steps
@@ -472,5 +500,11 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
         batch = Rays(o, d, dist_min=near, dist_max=far)
         val = psnr_fn(tracer(nef, batch).rgb.clamp(0, 1), gt_tracer(truth, batch).rgb)
     occupied = int(nef.grid.blas.points.shape[0])
-    return dict(psnr=val, ms_per_step=ms, steps=steps, rays_per_step=rays, candidate_samples_per_step=rays * num_steps,
-                occupied_cells=occupied, total_cells=int(grid.num_cells))
+    out = dict(psnr=val, ms_per_step=ms, steps=steps, rays_per_step=rays, candidate_samples_per_step=rays * num_steps,
+               occupied_cells=occupied, total_cells=int(grid.num_cells))
+    if latent:
+        from . import codec
+        ldec_bits, latent_bits = grid.size(use_torchac=False, use_prob_model=False)
+        out.update(table_bytes_fp32=grid.codebook.numel() * 4, latent_bytes_estimate=latent_bits / 8,
+                   file_bytes=len(codec.save_model(nef)))
+    return out

@@ -180,3 +180,14 @@ def test_nerf_fit_learns_the_scene(dev):
                          prune_every=100, val_rays=4096)
     assert r["psnr"] > 17.5, r                                 # an all-background render scores ~11 dB
     assert 0 < r["occupied_cells"] < r["total_cells"], r      # pruning removed the empty space, kept the blobs
+
+
+def test_compressed_nerf_fit_trains_and_codes(dev):
+    """nerf_lego.yaml's mode end to end: 3-D LatentGrid (fused SGA decode, entropy model, device noise), marcher,
+    MFMA decoders, volume integration; the model file is a small fraction of the fp32 table and the fit learns."""
+    from shacira_amd import harness
+    r = harness.fit_nerf(dev, steps=300, rays=2048, num_steps=96, codebook_bitwidth=16, max_grid_res=512,
+                         prune_every=100, val_rays=4096, latent=True)
+    assert r["psnr"] > 15.0, r
+    assert r["file_bytes"] < 0.25 * r["table_bytes_fp32"], r
+    assert 0.5 < r["file_bytes"] / (r["latent_bytes_estimate"] + 60_000) < 2.0, r   # + decoders stored raw
