@@ -138,11 +138,72 @@ __device__ __forceinline__ void enumerate_pairs(const double (&t)[DIM], int32_t 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fixed point
+// LDS integer atomics run 1.6x faster than ds_add_f64 (2.1-2.5 vs 1.3-1.4 T op/s, profiles/r01_microbench2), so the
+// accumulator images hold 64-bit fixed-point numbers. Scale per level: gmax[l] = max |grad_output| over the level's
+// columns (bit pattern of the float, gathered by pass T or by grad_absmax_kernel; integer max on the bits orders
+// finite < inf < NaN). Every contribution is |g * weight| <= gmax < 2^e, so with scale 2^(headroom - e) a contribution
+// stays below 2^headroom and n_max of them below 2^62: headroom = min(50, 62 - ceil(log2(n_max))). Conversion is one
+// fp64 fma with the 1.5 * 2^52 constant (the integer appears in the low mantissa bits) -- exact to the scale's LSB, i.e.
+// 2^-headroom relative to gmax (>= 41 bits here vs 24 of the reference's fp32 atomics) and order-independent.
+// A level whose gmax is inf / NaN falls back to the fp64 image so that non-finite gradients propagate as before.
+struct FxScale {
+    double scale, inv;   // 2^k, 2^-k
+    bool fixed;          // false: accumulate in fp64 (non-finite gradients)
+};
+__device__ __forceinline__ FxScale fx_scale_of(uint32_t gmax_bits, int headroom) {
+    FxScale f;
+    f.fixed = gmax_bits < 0x7F800000u;
+    int e = (int)((gmax_bits >> 23) & 0xFFu) - 126;   // |g| < 2^e for normal floats; denormals / zero: e = -126
+    if (e < -126) e = -126;
+    const int k = headroom - e;
+    f.scale = __longlong_as_double((long long)(1023 + k) << 52);
+    f.inv = __longlong_as_double((long long)(1023 - k) << 52);
+    return f;
+}
+__device__ __forceinline__ unsigned long long fx_encode(float c, double scale) {
+    const double magic = 6755399441055744.0;   // 1.5 * 2^52
+    return (unsigned long long)(__double_as_longlong(fma((double)c, scale, magic)) - __double_as_longlong(magic));
+}
+__device__ __forceinline__ float fx_decode(unsigned long long v, double inv) { return (float)((double)(long long)v * inv); }
+static inline int fx_headroom(uint64_t n_max) {
+    int bits = 0;
+    while (((uint64_t)1 << bits) < n_max) ++bits;
+    const int h = 62 - bits;
+    return h > 50 ? 50 : (h < 24 ? 24 : h);
+}
+
+// max |grad_output| per level (bit patterns) for calls that do not transpose: thread-local running max, one LDS and
+// one global atomic per thread / level. The grid is a multiple of L blocks so a thread stays on one level.
+template <typename T, int F>
+__global__ __launch_bounds__(256) void grad_absmax_kernel(const T *__restrict__ go, int64_t N, int L,
+                                                          uint32_t *__restrict__ gmax) {
+    __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
+    if (threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t total = N * L, stride = (int64_t)gridDim.x * 256;
+    const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t m = 0;
+    for (int64_t e = e0; e < total; e += stride) {
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            const uint32_t b = __float_as_uint(fabsf(Scalar<T>::load(go + e * F + j)));
+            m = b > m ? b : m;
+        }
+    }
+    if (e0 < total) atomicMax(&s_max[(int)(e0 % L)], m);
+    __syncthreads();
+    if ((int)threadIdx.x < L && s_max[threadIdx.x]) atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
+}
+
 // ------------------------------------------------------------------------------------------------- pass T
 // grad_output [N, L*F] (T) -> gT [L][N][F] fp32, through LDS, F scalars per lane per access. Block: 256 samples.
 template <typename T, int F>
 __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict__ go, float *__restrict__ gT,
-                                                             int64_t N, int L, int lb, int le) {
+                                                             int64_t N, int L, int lb, int le,
+                                                             uint32_t *__restrict__ gmax) {
+    __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
+    if (threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
     struct alignas(sizeof(T) * F) PieceIn { T v[F]; };
     struct alignas(sizeof(float) * F) PieceOut { float v[F]; };
     extern __shared__ __align__(16) unsigned char s_raw_g[];
@@ -163,8 +224,14 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
     __syncthreads();
     PieceOut *out = reinterpret_cast<PieceOut *>(gT);
     for (int l = lb; l < le; ++l) {
+        uint32_t m = 0;
         if ((int)threadIdx.x < ns) {
             const PieceOut q = s_tile[threadIdx.x * pitch + l];
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                const uint32_t b = __float_as_uint(fabsf(q.v[j]));
+                m = b > m ? b : m;
+            }
             float *dst = reinterpret_cast<float *>(out + (int64_t)l * N + s0 + threadIdx.x);
             if constexpr (F == 2) {
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -175,7 +242,16 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
                 for (int j = 0; j < F; ++j) __builtin_nontemporal_store(q.v[j], dst + j);
             }
         }
+        // wave max -> one LDS atomic per wave and level
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_xor(m, off, 64);
+            m = o > m ? o : m;
+        }
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_max[l], m);
     }
+    __syncthreads();
+    if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x]) atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------- pass A
@@ -402,8 +478,10 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
                                                                       const uint32_t *__restrict__ unit_bucket,
                                                                       const Item<F> *__restrict__ items,
                                                                       float *__restrict__ grad_table,
-                                                                      int force_atomic) {
-    extern __shared__ double s_acc[];  // [rows_pb][F]
+                                                                      int force_atomic,
+                                                                      const uint32_t *__restrict__ gmax,
+                                                                      int headroom) {
+    extern __shared__ double s_acc[];  // [rows_pb][F]: fp64, or 64-bit fixed point (same size)
     const uint32_t nbk = plan.total_buckets;
     const uint32_t unit = blockIdx.x;
     if (unit >= unit_first[nbk]) return;
@@ -417,8 +495,10 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     const uint32_t row0 = b * bl.rows_pb;
     const uint32_t nrows = (bl.used - row0 < bl.rows_pb) ? (bl.used - row0) : bl.rows_pb;
 
-    for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) s_acc[e] = 0.0;
+    for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) s_acc[e] = 0.0;   // all-zero bits either way
     __syncthreads();
+    const FxScale fx = fx_scale_of(gmax[lvl], headroom);
+    unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
 
     const uint32_t chunk = unit - unit_first[gb];
     const uint64_t begin = base[gb] + (uint64_t)chunk * plan.chunk;
@@ -437,13 +517,24 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         for (int u = 0; u < UN; ++u) {
             const uint32_t ra = it[u].key & 0x1FFFu, rb = (it[u].key >> 13) & 0x1FFFu;
             const float gx = 1.0f - it[u].fx;
-            if (it[u].key & (1u << 26)) {
+            if (fx.fixed) {
+                if (it[u].key & (1u << 26)) {
 #pragma unroll
-                for (int j = 0; j < F; ++j) atomicAdd(&s_acc[ra * F + j], (double)(it[u].a[j] * gx));
-            }
-            if (it[u].key & (1u << 27)) {
+                    for (int j = 0; j < F; ++j) atomicAdd(&s_fix[ra * F + j], fx_encode(it[u].a[j] * gx, fx.scale));
+                }
+                if (it[u].key & (1u << 27)) {
 #pragma unroll
-                for (int j = 0; j < F; ++j) atomicAdd(&s_acc[rb * F + j], (double)(it[u].a[j] * it[u].fx));
+                    for (int j = 0; j < F; ++j) atomicAdd(&s_fix[rb * F + j], fx_encode(it[u].a[j] * it[u].fx, fx.scale));
+                }
+            } else {
+                if (it[u].key & (1u << 26)) {
+#pragma unroll
+                    for (int j = 0; j < F; ++j) atomicAdd(&s_acc[ra * F + j], (double)(it[u].a[j] * gx));
+                }
+                if (it[u].key & (1u << 27)) {
+#pragma unroll
+                    for (int j = 0; j < F; ++j) atomicAdd(&s_acc[rb * F + j], (double)(it[u].a[j] * it[u].fx));
+                }
             }
         }
     }
@@ -454,7 +545,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) {
         const int64_t grow = grow0 + e / F;
         if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
-        const float v = (float)s_acc[e];
+        const float v = fx.fixed ? fx_decode(s_fix[e], fx.inv) : (float)s_acc[e];
         float *dst = grad_table + grow * F + (e % F);
         if (single) *dst = v;
         else if (v != 0.0f) unsafeAtomicAdd(dst, v);
@@ -473,14 +564,28 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
                                                                             const float *__restrict__ coords,
                                                                             const GT *__restrict__ gT,
                                                                             float *__restrict__ grad_table,
-                                                                            int64_t N) {
+                                                                            int64_t N,
+                                                                            const uint32_t *__restrict__ gmax,
+                                                                            int headroom) {
     constexpr int NC = 1 << DIM;
     extern __shared__ double s_acc[];
+    __shared__ double s_scale[SHACIRA_MAX_LODS], s_inv[SHACIRA_MAX_LODS];
+    __shared__ int s_all_fixed;
     const uint32_t grp = blockIdx.y;
     const uint32_t rows = plan.grows[grp];
     const uint32_t mask = plan.gmask[grp];
+    if (threadIdx.x == 0) s_all_fixed = 1;
     for (uint32_t e = threadIdx.x; e < rows * F; e += kConsumeThreads) s_acc[e] = 0.0;
     __syncthreads();
+    if ((int)threadIdx.x < lt.num_lods && ((mask >> threadIdx.x) & 1u)) {
+        const FxScale f = fx_scale_of(gmax[threadIdx.x], headroom);
+        s_scale[threadIdx.x] = f.scale;
+        s_inv[threadIdx.x] = f.inv;
+        if (!f.fixed) s_all_fixed = 0;     // one non-finite level: the whole group accumulates in fp64
+    }
+    __syncthreads();
+    const bool fixed = s_all_fixed != 0;
+    unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
     const int64_t stride = (int64_t)gridDim.x * kConsumeThreads;
     for (int64_t i = (int64_t)blockIdx.x * kConsumeThreads + threadIdx.x; i < N; i += stride) {
         double t[DIM];
@@ -495,12 +600,18 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
             float g[F];
 #pragma unroll
             for (int j = 0; j < F; ++j) g[j] = Scalar<GT>::load(gp + j);
+            const double scale = s_scale[l];
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 if (c.row[k] < bl.used) {
-                    double *dst = s_acc + (size_t)(bl.drow0 + c.row[k]) * F;
+                    const size_t slot = (size_t)(bl.drow0 + c.row[k]) * F;
+                    if (fixed) {
 #pragma unroll
-                    for (int j = 0; j < F; ++j) atomicAdd(dst + j, (double)(g[j] * c.w[k]));
+                        for (int j = 0; j < F; ++j) atomicAdd(s_fix + slot + j, fx_encode(g[j] * c.w[k], scale));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < F; ++j) atomicAdd(s_acc + slot + j, (double)(g[j] * c.w[k]));
+                    }
                 }
             }
         }
@@ -513,7 +624,8 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
         for (uint32_t e = threadIdx.x; e < bl.used * F; e += kConsumeThreads) {
             const int64_t grow = grow0 + e / F;
             if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
-            const float v = (float)s_acc[(size_t)bl.drow0 * F + e];
+            const float v = fixed ? fx_decode(s_fix[(size_t)bl.drow0 * F + e], s_inv[l])
+                                  : (float)s_acc[(size_t)bl.drow0 * F + e];
             if (v != 0.0f) unsafeAtomicAdd(grad_table + grow * F + (e % F), v);
         }
     }
@@ -659,6 +771,7 @@ struct BinWorkspace {
     uint64_t *base;
     uint32_t *unit_first;
     uint32_t *unit_bucket;
+    uint32_t *gmax;  // [SHACIRA_MAX_LODS] bit patterns of max |grad_output| per level
     float *acc32;  // fp32 accumulation image for fp16 tables
     size_t bytes;
 };
@@ -670,7 +783,9 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     const size_t item = 8 + 4 * (size_t)lt.feature_dim;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    // gT and gmax first: their offsets must not depend on the level range of the call (REUSE_STAGED calls share them)
     const size_t o_gT = take((size_t)n * lt.num_lods * lt.feature_dim * sizeof(float));
+    const size_t o_gmax = take(SHACIRA_MAX_LODS * sizeof(uint32_t));
     const size_t o_items = take((size_t)nb * plan.nbl * plan.pairs * item);
     const size_t o_cnt = take((size_t)plan.total_buckets * plan.num_tiles * sizeof(uint32_t));
     const size_t o_tot = take((size_t)(plan.total_buckets + 1) * sizeof(uint32_t));
@@ -689,6 +804,7 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
         w.base = reinterpret_cast<uint64_t *>(p + o_base);
         w.unit_first = reinterpret_cast<uint32_t *>(p + o_unit);
         w.unit_bucket = reinterpret_cast<uint32_t *>(p + o_ub);
+        w.gmax = reinterpret_cast<uint32_t *>(p + o_gmax);
         w.acc32 = reinterpret_cast<float *>(p + o_acc);
     }
     w.bytes = off;
@@ -772,17 +888,33 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
     // only binned levels consume the transposed gradients (a later call on this workspace may, too: stage_all)
     const bool need_T = whole.nbl > 0 || stage_all || staged;
+    if (!staged) {   // per-level max |grad_output| for the fixed-point scales (kept in the workspace for REUSE_STAGED)
+        hipError_t e = hipMemsetAsync(w.gmax, 0, SHACIRA_MAX_LODS * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+    }
     if (need_T && !staged) {
         const int t_lb = stage_all ? 0 : lt.level_begin, t_le = stage_all ? L : lt.level_end;
-        // pass T over the whole batch
+        // pass T over the whole batch (also gathers gmax)
         const uint32_t blocks = (uint32_t)((n + 255) / 256);
         const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
         if (dtype == SHACIRA_F32)
             hipLaunchKernelGGL((transpose_grad_kernel<float, F>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le);
+                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax);
         else
             hipLaunchKernelGGL((transpose_grad_kernel<__half, F>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le);
+                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax);
+        SHACIRA_CHECK_LAUNCH();
+    } else if (!need_T) {
+        // nothing is transposed (every level is direct): one streaming read for gmax; grid = multiple of L blocks
+        int64_t blocks = (n * L + 256 * 16 - 1) / (256 * 16);
+        if (blocks > 2048) blocks = 2048;
+        blocks = (blocks + L - 1) / L * L;
+        if (dtype == SHACIRA_F32)
+            hipLaunchKernelGGL((grad_absmax_kernel<float, F>), dim3((uint32_t)blocks), dim3(256), 0, s,
+                               static_cast<const float *>(grad_out), n, L, w.gmax);
+        else
+            hipLaunchKernelGGL((grad_absmax_kernel<__half, F>), dim3((uint32_t)blocks), dim3(256), 0, s,
+                               static_cast<const __half *>(grad_out), n, L, w.gmax);
         SHACIRA_CHECK_LAUNCH();
     }
     // direct levels: one pass over the whole batch, no items
@@ -794,15 +926,19 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         if (bpg < 1) bpg = 1;
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         const dim3 grid(bpg, plan.ngroups);
+        // a row receives at most (samples walked by one workgroup) x (corners) contributions
+        const int headroom = fx_headroom(((uint64_t)n / bpg + kConsumeThreads) * (1u << DIM));
         if (need_T)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true>), grid, dim3(kConsumeThreads), acc_bytes,
-                               s, lt, plan, first_idx, coords, w.gT, acc, n);
+                               s, lt, plan, first_idx, coords, w.gT, acc, n, w.gmax, headroom);
         else if (dtype == SHACIRA_F32)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, false>), grid, dim3(kConsumeThreads), acc_bytes,
-                               s, lt, plan, first_idx, coords, static_cast<const float *>(grad_out), acc, n);
+                               s, lt, plan, first_idx, coords, static_cast<const float *>(grad_out), acc, n, w.gmax,
+                               headroom);
         else
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, __half, false>), grid, dim3(kConsumeThreads),
-                               acc_bytes, s, lt, plan, first_idx, coords, static_cast<const __half *>(grad_out), acc, n);
+                               acc_bytes, s, lt, plan, first_idx, coords, static_cast<const __half *>(grad_out), acc, n,
+                               w.gmax, headroom);
         SHACIRA_CHECK_LAUNCH();
     }
     if (whole.nbl == 0) return hipSuccess;
@@ -835,7 +971,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         hipLaunchKernelGGL((bin_consume_kernel<F>), dim3(max_units), dim3(kConsumeThreads), acc_bytes, s, lt, plan,
                            first_idx, w.base, w.unit_first, w.unit_bucket,
-                           reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0);
+                           reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, w.gmax,
+                           fx_headroom((uint64_t)plan.chunk + 1));   // a unit streams <= chunk items
         SHACIRA_CHECK_LAUNCH();
     }
     return hipSuccess;

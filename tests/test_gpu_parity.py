@@ -649,3 +649,40 @@ def test_saved_model_reproduces_the_validation_output(dev):
     assert torch.equal(got, want)
     est_bits = sum(grid.size(use_torchac=False)) + sum(p.numel() * 32 for n, p in nef.named_parameters() if "grid" not in n)
     assert 8 * len(data) < 1.2 * est_bits + 8 * 4096          # the file is what the size estimate promises (+ header)
+
+
+@pytest.mark.parametrize("name", ["D", "B"])
+def test_non_finite_and_extreme_gradients(dev, name):
+    """The backward accumulates in 64-bit fixed point scaled by max |grad| per level; a level that contains inf / NaN
+    must fall back to floating accumulation (non-finite values reach exactly the rows they touch), and huge / tiny
+    finite magnitudes must keep their relative accuracy."""
+    ops = _ops()
+    dim, res, bw = CONFIGS[name]
+    N = 30_000
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, N, seed=21, edge=False)
+    tc, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(first).to(dev)
+    L = len(res)
+    # per-level magnitudes spread over 60 decades-of-two: each level gets its own scale
+    mags = np.array([2.0 ** (-40 + 5 * l) for l in range(L)], dtype=np.float64)
+    go_s = (go.reshape(N, L, 2) * mags[None, :, None]).reshape(N, 2 * L).astype(np.float32)
+    got = ops.hashgrid_backward(dim, tc, torch.from_numpy(go_s).to(dev), T, torch.float32, tf, res, bw, 2).cpu().numpy()
+    ref = oc.backward(coords, go_s, (T, 2), first, res, bw)
+    for l in range(L):
+        lo, hi = int(first[l]), int(first[l]) + sizes[l]
+        scale = np.abs(ref[lo:hi]).max()
+        np.testing.assert_allclose(got[lo:hi], ref[lo:hi], rtol=RTOL, atol=RTOL * scale)
+    # inf in level 3 and NaN in level 5 of two samples: those levels' touched rows become non-finite, every other level
+    # stays exactly as accurate as before
+    bad = go.copy()
+    bad[100, 2 * 3] = np.inf
+    bad[200, 2 * 5 + 1] = np.nan
+    got_b = ops.hashgrid_backward(dim, tc, torch.from_numpy(bad).to(dev), T, torch.float32, tf, res, bw, 2).cpu().numpy()
+    ref_ok = oc.backward(coords, go, (T, 2), first, res, bw)
+    for l in range(L):
+        lo, hi = int(first[l]), int(first[l]) + sizes[l]
+        if l in (3, 5):
+            assert not np.isfinite(got_b[lo:hi]).all()
+            finite = np.isfinite(got_b[lo:hi])
+            assert finite.mean() > 0.5 or sizes[l] < 64          # only the touched rows are poisoned
+        else:
+            np.testing.assert_allclose(got_b[lo:hi], ref_ok[lo:hi], rtol=RTOL, atol=RTOL * np.abs(ref_ok[lo:hi]).max())
