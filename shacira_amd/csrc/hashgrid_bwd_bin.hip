@@ -141,7 +141,7 @@ __device__ __forceinline__ void enumerate_pairs(const double (&t)[DIM], int32_t 
 // ------------------------------------------------------------------------------------------------ fixed point
 // LDS integer atomics run 1.6x faster than ds_add_f64 (2.1-2.5 vs 1.3-1.4 T op/s, profiles/r01_microbench2), so the
 // accumulator images hold 64-bit fixed-point numbers. Scale per level: gmax[l] = max |grad_output| over the level's
-// columns (bit pattern of the float, gathered by pass T or by grad_absmax_kernel; integer max on the bits orders
+// columns (bit pattern of the float, gathered by pass T for free; integer max on the bits orders
 // finite < inf < NaN). Every contribution is |g * weight| <= gmax < 2^e, so with scale 2^(headroom - e) a contribution
 // stays below 2^headroom and n_max of them below 2^62: headroom = min(50, 62 - ceil(log2(n_max))). Conversion is one
 // fp64 fma with the 1.5 * 2^52 constant (the integer appears in the low mantissa bits) -- exact to the scale's LSB, i.e.
@@ -173,37 +173,14 @@ static inline int fx_headroom(uint64_t n_max) {
     return h > 50 ? 50 : (h < 24 ? 24 : h);
 }
 
-// max |grad_output| per level (bit patterns) for calls that do not transpose: thread-local running max, one LDS and
-// one global atomic per thread / level. The grid is a multiple of L blocks so a thread stays on one level.
-template <typename T, int F>
-__global__ __launch_bounds__(256) void grad_absmax_kernel(const T *__restrict__ go, int64_t N, int L,
-                                                          uint32_t *__restrict__ gmax) {
-    __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
-    if (threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t total = N * L, stride = (int64_t)gridDim.x * 256;
-    const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t m = 0;
-    for (int64_t e = e0; e < total; e += stride) {
-#pragma unroll
-        for (int j = 0; j < F; ++j) {
-            const uint32_t b = __float_as_uint(fabsf(Scalar<T>::load(go + e * F + j)));
-            m = b > m ? b : m;
-        }
-    }
-    if (e0 < total) atomicMax(&s_max[(int)(e0 % L)], m);
-    __syncthreads();
-    if ((int)threadIdx.x < L && s_max[threadIdx.x]) atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
-}
-
 // ------------------------------------------------------------------------------------------------- pass T
 // grad_output [N, L*F] (T) -> gT [L][N][F] fp32, through LDS, F scalars per lane per access. Block: 256 samples.
-template <typename T, int F>
+template <typename T, int F, bool GMAX>
 __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict__ go, float *__restrict__ gT,
                                                              int64_t N, int L, int lb, int le,
                                                              uint32_t *__restrict__ gmax) {
     __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
-    if (threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
+    if (GMAX && threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
     struct alignas(sizeof(T) * F) PieceIn { T v[F]; };
     struct alignas(sizeof(float) * F) PieceOut { float v[F]; };
     extern __shared__ __align__(16) unsigned char s_raw_g[];
@@ -227,10 +204,12 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
         uint32_t m = 0;
         if ((int)threadIdx.x < ns) {
             const PieceOut q = s_tile[threadIdx.x * pitch + l];
+            if constexpr (GMAX) {
 #pragma unroll
-            for (int j = 0; j < F; ++j) {
-                const uint32_t b = __float_as_uint(fabsf(q.v[j]));
-                m = b > m ? b : m;
+                for (int j = 0; j < F; ++j) {
+                    const uint32_t b = __float_as_uint(fabsf(q.v[j]));
+                    m = b > m ? b : m;
+                }
             }
             float *dst = reinterpret_cast<float *>(out + (int64_t)l * N + s0 + threadIdx.x);
             if constexpr (F == 2) {
@@ -242,16 +221,20 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
                 for (int j = 0; j < F; ++j) __builtin_nontemporal_store(q.v[j], dst + j);
             }
         }
-        // wave max -> one LDS atomic per wave and level
+        if constexpr (GMAX) {   // wave max -> one LDS atomic per wave and level
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t o = __shfl_xor(m, off, 64);
-            m = o > m ? o : m;
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = __shfl_xor(m, off, 64);
+                m = o > m ? o : m;
+            }
+            if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_max[l], m);
         }
-        if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_max[l], m);
     }
-    __syncthreads();
-    if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x]) atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
+    if constexpr (GMAX) {
+        __syncthreads();
+        if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x])
+            atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------- pass A
@@ -470,7 +453,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
 }
 
 // ------------------------------------------------------------------------------------------------- pass C
-template <int F>
+template <int F, bool FX>
 __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable lt, BinPlan plan,
                                                                       const int32_t *__restrict__ first_idx,
                                                                       const uint64_t *__restrict__ base,
@@ -497,7 +480,8 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
 
     for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) s_acc[e] = 0.0;   // all-zero bits either way
     __syncthreads();
-    const FxScale fx = fx_scale_of(gmax[lvl], headroom);
+    FxScale fx{1.0, 1.0, false};
+    if constexpr (FX) fx = fx_scale_of(gmax[lvl], headroom);
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
 
     const uint32_t chunk = unit - unit_first[gb];
@@ -517,7 +501,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         for (int u = 0; u < UN; ++u) {
             const uint32_t ra = it[u].key & 0x1FFFu, rb = (it[u].key >> 13) & 0x1FFFu;
             const float gx = 1.0f - it[u].fx;
-            if (fx.fixed) {
+            if (FX && fx.fixed) {
                 if (it[u].key & (1u << 26)) {
 #pragma unroll
                     for (int j = 0; j < F; ++j) atomicAdd(&s_fix[ra * F + j], fx_encode(it[u].a[j] * gx, fx.scale));
@@ -545,7 +529,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) {
         const int64_t grow = grow0 + e / F;
         if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
-        const float v = fx.fixed ? fx_decode(s_fix[e], fx.inv) : (float)s_acc[e];
+        const float v = (FX && fx.fixed) ? fx_decode(s_fix[e], fx.inv) : (float)s_acc[e];
         float *dst = grad_table + grow * F + (e % F);
         if (single) *dst = v;
         else if (v != 0.0f) unsafeAtomicAdd(dst, v);
@@ -558,7 +542,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
 // adds the image to the (zeroed) gradient table with coalesced float atomics at the end.
 // GT = float: gradients come from the transposed image gT [L][N][F]; otherwise (T = table scalar) straight from
 // grad_output [N, L*F] -- used when no level needs binning, which makes the transposing pass unnecessary.
-template <int DIM, int F, typename GT, bool TRANSPOSED>
+template <int DIM, int F, typename GT, bool TRANSPOSED, bool FX>
 __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(LevelTable lt, BinPlan plan,
                                                                             const int32_t *__restrict__ first_idx,
                                                                             const float *__restrict__ coords,
@@ -577,14 +561,16 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
     if (threadIdx.x == 0) s_all_fixed = 1;
     for (uint32_t e = threadIdx.x; e < rows * F; e += kConsumeThreads) s_acc[e] = 0.0;
     __syncthreads();
-    if ((int)threadIdx.x < lt.num_lods && ((mask >> threadIdx.x) & 1u)) {
-        const FxScale f = fx_scale_of(gmax[threadIdx.x], headroom);
-        s_scale[threadIdx.x] = f.scale;
-        s_inv[threadIdx.x] = f.inv;
-        if (!f.fixed) s_all_fixed = 0;     // one non-finite level: the whole group accumulates in fp64
+    if constexpr (FX) {
+        if ((int)threadIdx.x < lt.num_lods && ((mask >> threadIdx.x) & 1u)) {
+            const FxScale f = fx_scale_of(gmax[threadIdx.x], headroom);
+            s_scale[threadIdx.x] = f.scale;
+            s_inv[threadIdx.x] = f.inv;
+            if (!f.fixed) s_all_fixed = 0;     // one non-finite level: the whole group accumulates in fp64
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const bool fixed = s_all_fixed != 0;
+    const bool fixed = FX && s_all_fixed != 0;
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
     const int64_t stride = (int64_t)gridDim.x * kConsumeThreads;
     for (int64_t i = (int64_t)blockIdx.x * kConsumeThreads + threadIdx.x; i < N; i += stride) {
@@ -600,7 +586,7 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
             float g[F];
 #pragma unroll
             for (int j = 0; j < F; ++j) g[j] = Scalar<GT>::load(gp + j);
-            const double scale = s_scale[l];
+            const double scale = FX ? s_scale[l] : 1.0;
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 if (c.row[k] < bl.used) {
@@ -888,7 +874,10 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
     // only binned levels consume the transposed gradients (a later call on this workspace may, too: stage_all)
     const bool need_T = whole.nbl > 0 || stage_all || staged;
-    if (!staged) {   // per-level max |grad_output| for the fixed-point scales (kept in the workspace for REUSE_STAGED)
+    // fixed-point images pay off once the accumulation itself dominates; small batches are bound by fixed costs and
+    // keep the fp64 image (and skip the gmax bookkeeping): measured 100 vs 107 us at 65 536 samples
+    const bool use_fx = need_T && n >= (1 << 17);
+    if (!staged && use_fx) {   // per-level max |grad_output| for the scales (kept in the workspace for REUSE_STAGED)
         hipError_t e = hipMemsetAsync(w.gmax, 0, SHACIRA_MAX_LODS * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
     }
@@ -897,26 +886,23 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         // pass T over the whole batch (also gathers gmax)
         const uint32_t blocks = (uint32_t)((n + 255) / 256);
         const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
-        if (dtype == SHACIRA_F32)
-            hipLaunchKernelGGL((transpose_grad_kernel<float, F>), dim3(blocks), dim3(256), shmem, s,
+        if (dtype == SHACIRA_F32 && use_fx)
+            hipLaunchKernelGGL((transpose_grad_kernel<float, F, true>), dim3(blocks), dim3(256), shmem, s,
                                static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax);
-        else
-            hipLaunchKernelGGL((transpose_grad_kernel<__half, F>), dim3(blocks), dim3(256), shmem, s,
+        else if (dtype == SHACIRA_F32)
+            hipLaunchKernelGGL((transpose_grad_kernel<float, F, false>), dim3(blocks), dim3(256), shmem, s,
+                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr);
+        else if (use_fx)
+            hipLaunchKernelGGL((transpose_grad_kernel<__half, F, true>), dim3(blocks), dim3(256), shmem, s,
                                static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax);
-        SHACIRA_CHECK_LAUNCH();
-    } else if (!need_T) {
-        // nothing is transposed (every level is direct): one streaming read for gmax; grid = multiple of L blocks
-        int64_t blocks = (n * L + 256 * 16 - 1) / (256 * 16);
-        if (blocks > 2048) blocks = 2048;
-        blocks = (blocks + L - 1) / L * L;
-        if (dtype == SHACIRA_F32)
-            hipLaunchKernelGGL((grad_absmax_kernel<float, F>), dim3((uint32_t)blocks), dim3(256), 0, s,
-                               static_cast<const float *>(grad_out), n, L, w.gmax);
         else
-            hipLaunchKernelGGL((grad_absmax_kernel<__half, F>), dim3((uint32_t)blocks), dim3(256), 0, s,
-                               static_cast<const __half *>(grad_out), n, L, w.gmax);
+            hipLaunchKernelGGL((transpose_grad_kernel<__half, F, false>), dim3(blocks), dim3(256), shmem, s,
+                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr);
         SHACIRA_CHECK_LAUNCH();
     }
+    // When nothing is transposed (every level is direct: the image configs) gmax would cost an extra read of grad_output
+    // (tried: a streaming abs-max kernel); measured on config B it costs more than the faster atomics return (0.103 vs
+    // 0.082 ms for the whole backward), so those calls keep the fp64 image.
     // direct levels: one pass over the whole batch, no items
     if (whole.ngroups > 0) {
         const BinPlan &plan = whole;
@@ -927,18 +913,21 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         const dim3 grid(bpg, plan.ngroups);
         // a row receives at most (samples walked by one workgroup) x (corners) contributions
-        const int headroom = fx_headroom(((uint64_t)n / bpg + kConsumeThreads) * (1u << DIM));
-        if (need_T)
-            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true>), grid, dim3(kConsumeThreads), acc_bytes,
-                               s, lt, plan, first_idx, coords, w.gT, acc, n, w.gmax, headroom);
+        const int headroom = use_fx ? fx_headroom(((uint64_t)n / bpg + kConsumeThreads) * (1u << DIM)) : -1;
+        if (need_T && use_fx)
+            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, true>), grid, dim3(kConsumeThreads),
+                               acc_bytes, s, lt, plan, first_idx, coords, w.gT, acc, n, w.gmax, headroom);
+        else if (need_T)
+            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, false>), grid, dim3(kConsumeThreads),
+                               acc_bytes, s, lt, plan, first_idx, coords, w.gT, acc, n, nullptr, headroom);
         else if (dtype == SHACIRA_F32)
-            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, false>), grid, dim3(kConsumeThreads), acc_bytes,
-                               s, lt, plan, first_idx, coords, static_cast<const float *>(grad_out), acc, n, w.gmax,
-                               headroom);
+            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, false, false>), grid, dim3(kConsumeThreads),
+                               acc_bytes, s, lt, plan, first_idx, coords, static_cast<const float *>(grad_out), acc, n,
+                               nullptr, headroom);
         else
-            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, __half, false>), grid, dim3(kConsumeThreads),
+            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, __half, false, false>), grid, dim3(kConsumeThreads),
                                acc_bytes, s, lt, plan, first_idx, coords, static_cast<const __half *>(grad_out), acc, n,
-                               w.gmax, headroom);
+                               nullptr, headroom);
         SHACIRA_CHECK_LAUNCH();
     }
     if (whole.nbl == 0) return hipSuccess;
@@ -969,10 +958,15 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NP;
         const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + plan.total_buckets + 1;
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
-        hipLaunchKernelGGL((bin_consume_kernel<F>), dim3(max_units), dim3(kConsumeThreads), acc_bytes, s, lt, plan,
-                           first_idx, w.base, w.unit_first, w.unit_bucket,
-                           reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, w.gmax,
-                           fx_headroom((uint64_t)plan.chunk + 1));   // a unit streams <= chunk items
+        if (use_fx)   // a unit streams <= chunk items
+            hipLaunchKernelGGL((bin_consume_kernel<F, true>), dim3(max_units), dim3(kConsumeThreads), acc_bytes, s, lt,
+                               plan, first_idx, w.base, w.unit_first, w.unit_bucket,
+                               reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, w.gmax,
+                               fx_headroom((uint64_t)plan.chunk + 1));
+        else
+            hipLaunchKernelGGL((bin_consume_kernel<F, false>), dim3(max_units), dim3(kConsumeThreads), acc_bytes, s, lt,
+                               plan, first_idx, w.base, w.unit_first, w.unit_bucket,
+                               reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, nullptr, -1);
         SHACIRA_CHECK_LAUNCH();
     }
     return hipSuccess;
@@ -990,18 +984,22 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (e != hipSuccess) attr_err = e;
         };
-        set(reinterpret_cast<const void *>(&transpose_grad_kernel<float, 2>), 140 * 1024);
-        set(reinterpret_cast<const void *>(&transpose_grad_kernel<float, 4>), 140 * 1024);
-        set(reinterpret_cast<const void *>(&transpose_grad_kernel<__half, 2>), 140 * 1024);
-        set(reinterpret_cast<const void *>(&transpose_grad_kernel<__half, 4>), 140 * 1024);
+#define SHACIRA_T_ATTR(TT, FF)                                                                           \
+        set(reinterpret_cast<const void *>(&transpose_grad_kernel<TT, FF, true>), 140 * 1024);          \
+        set(reinterpret_cast<const void *>(&transpose_grad_kernel<TT, FF, false>), 140 * 1024);
+        SHACIRA_T_ATTR(float, 2) SHACIRA_T_ATTR(float, 4) SHACIRA_T_ATTR(__half, 2) SHACIRA_T_ATTR(__half, 4)
+#undef SHACIRA_T_ATTR
 #define SHACIRA_DIRECT_ATTR(D, FF)                                                                              \
-        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, float, true>), 16384 * sizeof(double));   \
-        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, float, false>), 16384 * sizeof(double));  \
-        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, __half, false>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, float, true, true>), 16384 * sizeof(double));   \
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, float, true, false>), 16384 * sizeof(double));  \
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, float, false, false>), 16384 * sizeof(double)); \
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, __half, false, false>), 16384 * sizeof(double));
         SHACIRA_DIRECT_ATTR(2, 2) SHACIRA_DIRECT_ATTR(2, 4) SHACIRA_DIRECT_ATTR(3, 2) SHACIRA_DIRECT_ATTR(3, 4)
 #undef SHACIRA_DIRECT_ATTR
-        set(reinterpret_cast<const void *>(&bin_consume_kernel<2>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&bin_consume_kernel<4>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<2, true>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<4, true>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<2, false>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<4, false>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4>), (size_t)kTile * 2 * (sizeof(Item<4>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
