@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     const uint64_t begin = base[gb] + (uint64_t)chunk * plan.chunk;
     const uint64_t bucket_end = base[gb + 1];
     const uint64_t end = (begin + plan.chunk < bucket_end) ? (begin + plan.chunk) : bucket_end;
-    constexpr int UN = 4;  // items in flight per thread (8 measured no faster: the pass is LDS-atomic bound)
+    constexpr int UN = 8;  // items in flight per thread (4: -1 %, 16: +3 % with the fixed-point atomics)
     for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
         Item<F> it[UN];
 #pragma unroll
