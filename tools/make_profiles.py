@@ -11,7 +11,7 @@ line = json.load(open(os.path.join(src, "bench_line.json")))
 json.dump(line, open(os.path.join(out, f"{tag}_bench_line.json"), "w"), indent=1)
 stats_line = json.load(open(os.path.join(src, "stats_line.json")))
 
-stats = glob.glob(os.path.join(src, "stats/*/*kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "stats/*/*kernel_stats.csv")), key=os.path.getmtime)   # newest run
 shutil.copy(stats, os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 fwd_k = ("hashgrid_fwd", "untranspose_feats")
@@ -41,7 +41,7 @@ with open(os.path.join(out, f"{tag}_bench_rocprof_summary.md"), "w") as f:
             f"direct_accumulate (DESIGN.md 4.3).\n")
 
 def counter(dirname):
-    f = glob.glob(os.path.join(src, dirname, "*/*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, dirname, "*/*counter_collection.csv")), key=os.path.getmtime)
     acc, calls = defaultdict(float), defaultdict(int)
     for r in csv.DictReader(open(f)):
         name = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]
