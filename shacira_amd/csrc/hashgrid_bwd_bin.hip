@@ -276,16 +276,24 @@ __global__ __launch_bounds__(64) void bin_scan_tiles_kernel(uint32_t *__restrict
     uint32_t *row = cnt + (size_t)blockIdx.x * num_tiles;
     const uint32_t lane = threadIdx.x;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < num_tiles; base += 64) {
-        const uint32_t idx = base + lane;
-        uint32_t v = (idx < num_tiles) ? row[idx] : 0u;
-        uint32_t incl = v;
+    for (uint32_t base = 0; base < num_tiles; base += 256) {   // 4 consecutive counters per lane and round
+        const uint32_t idx = base + lane * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (idx + k < num_tiles) ? row[idx + k] : 0u;
+        const uint32_t sum = (v[0] + v[1]) + (v[2] + v[3]);
+        uint32_t incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             uint32_t n = __shfl_up(incl, off, 64);
             if (lane >= (uint32_t)off) incl += n;
         }
-        if (idx < num_tiles) row[idx] = carry + incl - v;
+        uint32_t run = carry + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (idx + k < num_tiles) row[idx + k] = run;
+            run += v[k];
+        }
         carry += __shfl(incl, 63, 64);
     }
     if (lane == 0) totals[blockIdx.x] = carry;
