@@ -658,7 +658,7 @@ def test_non_finite_and_extreme_gradients(dev, name):
     finite magnitudes must keep their relative accuracy."""
     ops = _ops()
     dim, res, bw = CONFIGS[name]
-    N = 30_000
+    N = 140_000                                  # >= 2^17: the fixed-point kernels (3-D) / the fp64 direct kernels (B)
     sizes, first, T, coords, table, go = _problem(dim, res, bw, N, seed=21, edge=False)
     tc, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(first).to(dev)
     L = len(res)
@@ -686,3 +686,28 @@ def test_non_finite_and_extreme_gradients(dev, name):
             assert finite.mean() > 0.5 or sizes[l] < 64          # only the touched rows are poisoned
         else:
             np.testing.assert_allclose(got_b[lo:hi], ref_ok[lo:hi], rtol=RTOL, atol=RTOL * np.abs(ref_ok[lo:hi]).max())
+
+
+def test_level_ranges_share_the_fixed_point_scales(dev):
+    """N >= 2^17: the backward accumulates in fixed point scaled by max |grad| per level, recorded by the transpose of
+    the FIRST call of a level-range series (STAGE_ALL_LEVELS) and reused by the later calls (REUSE_STAGED)."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    N = 1 << 17
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, N, seed=31)
+    go = go * np.logspace(-3, 4, go.shape[1], dtype=np.float32)[None, :]        # a different scale in every level
+    tc, tg, tf = (torch.from_numpy(a).to(dev) for a in (coords, go, first))
+    full = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2)
+    ws = ops.backward_workspace(dim, N, T, torch.float32, res, bw, 2, dev)
+    out = torch.full((T, 2), 5.0, device=dev)
+    cuts = [0, 6, 11, 16]
+    for k in range(3):
+        ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, levels=(cuts[k], cuts[k + 1]), out=out,
+                              workspace=ws, flags=_lib.BWD_STAGE_ALL_LEVELS if k == 0 else _lib.BWD_REUSE_STAGED)
+    ref = oc.backward(coords, go, (T, 2), first, res, bw)
+    for l in range(len(res)):
+        lo, hi = int(first[l]), int(first[l]) + sizes[l]
+        scale = np.abs(ref[lo:hi]).max()
+        np.testing.assert_allclose(out[lo:hi].cpu().numpy(), ref[lo:hi], rtol=RTOL, atol=RTOL * scale)
+        np.testing.assert_allclose(full[lo:hi].cpu().numpy(), ref[lo:hi], rtol=RTOL, atol=RTOL * scale)
