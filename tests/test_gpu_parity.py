@@ -261,10 +261,12 @@ def test_out_of_table_corner_is_memory_safe(dev):
     assert float(grad.sum()) == pytest.approx(6.0, rel=1e-6)
 
 
-def test_half_precision_tables(dev):
-    """fp16 instantiation (what the reference's NeRF AMP path runs, grid.py:73 + .cu:198-211)."""
+@pytest.mark.parametrize("n", [20_000, 1 << 17])
+def test_half_precision_tables(dev, n):
+    """fp16 instantiation (what the reference's NeRF AMP path runs, grid.py:73 + .cu:198-211); the larger batch runs
+    the fixed-point accumulation kernels."""
     dim, res, bw = CONFIGS["D"]
-    sizes, first, T, coords, table, go = _problem(dim, res, bw, 20_000)
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n)
     table16 = table.astype(np.float16).astype(np.float32)
     go16 = go.astype(np.float16).astype(np.float32)
     feats, grad = _run(dev, dim, res, bw, coords, table, go, first, dtype=torch.float16)
