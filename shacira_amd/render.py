@@ -114,7 +114,9 @@ def _occupancy_u8(occupancy, level):
 
 def raymarch_ray(origins, dirs, dist_min, dist_max, occupancy, level, num_samples, jitter=None):
     """`OctreeAS._raymarch_ray` (reference octree_as.py:235-290) on a dense occupancy grid [G, G, G] (bool, [x][y][z]).
-    -> ridx int64 [S], samples [S, 3], depth_samples [S, 1], deltas [S, 1], boundary bool [S]."""
+    -> ridx int64 [S], samples [S, 3], depth_samples [S, 1], deltas [S, 1], boundary bool [S], and the per-ray pack
+    offsets int64 [num_rays + 1] (rays without samples have empty packs) for callers that want to integrate without
+    compacting the hit rays first."""
     _need_gpu(origins, dirs, occupancy)
     origins, dirs = origins.float().contiguous(), dirs.float().contiguous()
     N, dev = origins.shape[0], origins.device
@@ -140,7 +142,7 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, occupancy, level, num_sample
         _lib.check(L.shacira_raymarch_ray_emit(*args, _ptr(offsets), _ptr(ridx), _ptr(samples), _ptr(depth),
                                                _ptr(deltas), _ptr(boundary), _stream(origins)),
                    "shacira_raymarch_ray_emit")
-    return ridx, samples, depth, deltas, boundary.bool()
+    return ridx, samples, depth, deltas, boundary.bool(), offsets
 
 
 def raytrace_dense(origins, dirs, occupancy, level):

@@ -14,7 +14,8 @@ import torch
 
 ASQueryResults = namedtuple("ASQueryResults", ["pidx"])
 ASRaytraceResults = namedtuple("ASRaytraceResults", ["ridx", "pidx", "depth"])
-ASRaymarchResults = namedtuple("ASRaymarchResults", ["ridx", "samples", "depth_samples", "deltas", "boundary"])
+ASRaymarchResults = namedtuple("ASRaymarchResults", ["ridx", "samples", "depth_samples", "deltas", "boundary",
+                                                     "ray_offsets"], defaults=[None])
 
 
 def _morton_points(level: int) -> torch.Tensor:
@@ -133,10 +134,11 @@ class OctreeAS(BaseAS):
         octree_as.py:235-290): generation, occupancy filter and compaction in two HIP launches."""
         from ... import render
         level = self._level(level)
-        ridx, samples, depth, deltas, boundary = render.raymarch_ray(
+        ridx, samples, depth, deltas, boundary, offsets = render.raymarch_ray(
             rays.origins, rays.dirs, rays.dist_min, rays.dist_max, self._grid_on(rays.origins.device), level,
             num_samples)
-        return ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary)
+        return ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary,
+                                 ray_offsets=offsets)
 
     def raymarch(self, rays, raymarch_type, num_samples, level=None) -> ASRaymarchResults:
         if raymarch_type == "voxel":

@@ -41,12 +41,25 @@ class PackedRFTracer:
         num_samples = samples.shape[0]
         if num_samples == 0:
             return RenderBuffer(depth=depth, hit=hit, rgb=rgb, alpha=out_alpha)
-        ridx_hit = ridx[boundary]
         hit_ray_d = rays.dirs.index_select(0, ridx)
         field = nef(coords=samples, ray_d=hit_ray_d, lod_idx=lod_idx, channels=["rgb", "density"])
         color, density = field["rgb"], field["density"].reshape(num_samples, 1)
-
         tau = density * deltas                                   # optical thickness
+
+        offsets = getattr(marched, "ray_offsets", None)
+        if offsets is not None and not extra_channels:
+            # the marcher's per-ray pack offsets cover EVERY ray (empty packs integrate to zero), so the reductions
+            # come out per ray directly: no nonzero() read-back, no scatter of the hit rays (same values as below)
+            ray_colors, transmittance = spc_render.exponential_integration(color, tau, boundary, exclusive=True,
+                                                                           pack_start=offsets)
+            alpha = spc_render.sum_reduce(transmittance, boundary, pack_start=offsets)
+            if depth is not None:
+                depth = spc_render.sum_reduce(marched.depth_samples.reshape(num_samples, 1) * transmittance, boundary,
+                                              pack_start=offsets)
+            rgb = (1.0 - alpha) + ray_colors if bg_color == "white" else alpha * ray_colors
+            return RenderBuffer(depth=depth, hit=alpha[..., 0] > 0.0, rgb=rgb, alpha=alpha)
+
+        ridx_hit = ridx[boundary]
         pack_start = spc_render.pack_offsets(boundary)           # one scan of the boundary flags for all reductions
         ray_colors, transmittance = spc_render.exponential_integration(color, tau, boundary, exclusive=True,
                                                                        pack_start=pack_start)

@@ -84,8 +84,9 @@ def test_raymarch_ray_matches_reference_python(dev, level, ns):
     near, far = 1.5, 4.5
     full = torch.ones((G, G, G), dtype=torch.bool)
     # all cells occupied: every sample is emitted -> positions / depths / deltas of the whole lattice
-    r_all, s_all, dep_all, del_all, b_all = [t.cpu() for t in render.raymarch_ray(o.to(dev), d.to(dev), near, far,
-                                                                                 full.to(dev), level, ns, jit.to(dev))]
+    r_all, s_all, dep_all, del_all, b_all, off_all = [t.cpu() for t in render.raymarch_ray(
+        o.to(dev), d.to(dev), near, far, full.to(dev), level, ns, jit.to(dev))]
+    assert torch.equal(off_all, torch.arange(N + 1) * ns)
     assert r_all.shape[0] == N * ns and torch.equal(r_all, torch.arange(N).repeat_interleave(ns))
     ro, so, do, dlo, bo = orr.raymarch_ray(o, d, near, far, full, level, ns, jit)
     np.testing.assert_allclose(dep_all.numpy(), do.numpy(), rtol=1e-6, atol=1e-6)
@@ -93,8 +94,9 @@ def test_raymarch_ray_matches_reference_python(dev, level, ns):
     np.testing.assert_allclose(s_all.numpy(), so.numpy(), rtol=1e-5, atol=1e-6)
     assert torch.equal(b_all, bo)
     # real occupancy: exactly the reference's filter applied to the very same positions
-    r, s, dep, dl, b = [t.cpu() for t in render.raymarch_ray(o.to(dev), d.to(dev), near, far, occ.to(dev), level, ns,
-                                                             jit.to(dev))]
+    r, s, dep, dl, b, off = [t.cpu() for t in render.raymarch_ray(o.to(dev), d.to(dev), near, far, occ.to(dev), level,
+                                                                  ns, jit.to(dev))]
+    assert torch.equal(off[1:] - off[:-1], torch.bincount(r, minlength=N))        # per-ray pack sizes, empty ones too
     r2, s2, dep2, dl2, b2 = orr.filter_samples(s_all, dep_all, del_all, occ, level, N, ns)
     assert torch.equal(r, r2) and torch.equal(b, b2)
     assert torch.equal(s, s2) and torch.equal(dep, dep2) and torch.equal(dl, dl2)
