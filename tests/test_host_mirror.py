@@ -314,7 +314,45 @@ def test_install_as_wisp_aliases():
         import wisp.ops.grid as go
         from wisp.models.grids import LatentGrid as LG
         assert go is grid_ops and LG is LatentGrid
+        # the NeRF-side mirrors resolve under the reference's import paths too
+        from wisp.accelstructs import OctreeAS
+        from wisp.core import Rays
+        from wisp.models.embedders import get_positional_embedder
+        from wisp.models.nefs.nerf import NeuralRadianceField
+        from wisp.tracers.packed_rf_tracer import PackedRFTracer
+        assert OctreeAS.make_dense(2).points.shape == (64, 3) and get_positional_embedder(4)[1] == 27
+        assert PackedRFTracer().get_required_nef_channels() == {"rgb", "density"} and Rays and NeuralRadianceField
     finally:
         for k in [k for k in sys.modules if k == "wisp" or k.startswith("wisp.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_nerf_field_and_embedder_host_logic():
+    """NeuralRadianceField mirror: parameter names (optimiser groups key on them), decoder shapes of nerf.py:121-147,
+    embedder layout of positional_embedder.py:60-66 -- host-side checks, no kernels involved."""
+    from shacira_amd.wisp.models.embedders import PositionalEmbedder, get_positional_embedder
+    from shacira_amd.wisp.models.grids import HashGrid
+    from shacira_amd.wisp.models.nefs import NeuralRadianceField
+    emb, dim = get_positional_embedder(4)
+    assert dim == 3 + 4 * 3 * 2 and isinstance(emb, PositionalEmbedder)
+    x = torch.tensor([[0.1, -0.2, 0.3]])
+    y = emb(x)
+    assert y.shape == (1, 27) and torch.equal(y[:, :3], x)
+    bands = torch.tensor([1.0, 2.0, 4.0, 8.0])
+    np.testing.assert_allclose(y[0, 3:15].numpy(), torch.sin(x[0][None, :] * bands[:, None]).reshape(-1).numpy(), rtol=1e-6)
+    np.testing.assert_allclose(y[0, 15:27].numpy(), torch.cos(x[0][None, :] * bands[:, None]).reshape(-1).numpy(), rtol=1e-6)
+    grid = HashGrid.from_geometric(feature_dim=2, num_lods=16, multiscale_type="cat", resolution_dim=3, feature_std=0.01,
+                                   codebook_bitwidth=8, min_grid_res=4, max_grid_res=64, blas_level=2)
+    nef = NeuralRadianceField(grid, view_embedder="positional", view_multires=4, hidden_dim=64, num_layers=1,
+                              prune_density_decay=0.95, prune_min_density=1.0)
+    names = [n for n, _ in nef.named_parameters()]
+    assert names[0] == "grid.codebook" and any(n.startswith("decoder_density.") for n in names) \
+        and any(n.startswith("decoder_color.") for n in names)
+    assert nef.density_net_input_dim() == 32 and nef.color_net_input_dim() == 16 + 27
+    assert [l.in_features for l in nef.decoder_density.layers] == [32] and nef.decoder_density.lout.out_features == 16
+    assert [l.in_features for l in nef.decoder_color.layers] == [43, 64] and nef.decoder_color.lout.out_features == 3
+    assert float(nef.decoder_density.lout.bias[0]) == 1.0                       # nerf.py:138
+    assert nef.get_supported_channels() == {"density", "rgb"}
+    with pytest.raises(NotImplementedError):
+        NeuralRadianceField(grid, activation_type="sin")
