@@ -45,6 +45,8 @@ struct BinLevel {
     uint32_t shift;     // hashed: log2(BR)
     int32_t dgroup;     // >= 0: "direct" level (fits one LDS image): index of its group; -1: binned level
     uint32_t drow0;     // direct: first row of the level inside its group's LDS image
+    uint32_t compact;   // 1: dense 3-D level binned by z-slab with ONE 32-byte item per sample (all 8 corners)
+    uint32_t slab;      // compact: base-cell planes per bucket (its image holds slab + 1 planes)
 };
 
 struct BinPlan {
@@ -257,6 +259,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(LevelTable lt, B
         double t[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
+        if constexpr (DIM == 3) {
+            if (bl.compact) {   // one item of two slots per sample, bucket from the base cell's z alone
+                int32_t pz;
+                float fz, gz;
+                axis_transform(t[2], res, hi, pz, fz, gz);
+                atomicAdd(&s_hist[(uint32_t)pz / bl.slab], 2u);
+                continue;
+            }
+        }
         float fx;
         PairSlot ps[1 << (DIM - 1)];
         enumerate_pairs<DIM>(t, res, hi, dense, lt.mask, bl, plan.BR, fx, ps);
@@ -389,6 +400,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     uint32_t rank[SPT][NP];
     float fx[SPT];
     float g[SPT][F];
+    float fyz[SPT][2];   // compact levels: y / z fractions travel with the item
+    const bool compact = (DIM == 3) && bl.compact != 0;
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
         const int k = threadIdx.x + u * kBinThreads;
@@ -397,7 +410,29 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         double t[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live ? coords[i * DIM + a] : 0.0f);
-        enumerate_pairs<DIM>(t, res, hi, dense, lt.mask, bl, plan.BR, fx[u], ps[u]);
+        if (compact) {
+            if constexpr (DIM == 3) {
+                // slot key = local row of the base corner inside the bucket's image (slab + halo planes) | valid bit
+                int32_t pp[3];
+                float ff[3], gg[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) axis_transform(t[a], res, hi, pp[a], ff[a], gg[a]);
+                const uint32_t r = (uint32_t)res, b = (uint32_t)pp[2] / bl.slab;
+                const uint32_t local = ((uint32_t)pp[2] - b * bl.slab) * r * r + (uint32_t)pp[1] * r + (uint32_t)pp[0];
+                fx[u] = ff[0];
+                fyz[u][0] = ff[1];
+                fyz[u][1] = ff[2];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    ps[u][q].bucket = b;
+                    ps[u][q].key = 0;
+                    ps[u][q].wrest = 0.0f;
+                }
+                ps[u][0].key = local | (1u << 26);
+            }
+        } else {
+            enumerate_pairs<DIM>(t, res, hi, dense, lt.mask, bl, plan.BR, fx[u], ps[u]);
+        }
         if (live) {
             const float *gp = gT + ((int64_t)lvl * Ntotal + i) * F;
             if constexpr (F == 2) {
@@ -411,7 +446,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             if (!live) ps[u][q].key = 0;
-            rank[u][q] = (ps[u][q].key >> 26) ? atomicAdd(&s_hist[ps[u][q].bucket], 1u) : 0u;
+            rank[u][q] = (ps[u][q].key >> 26) ? atomicAdd(&s_hist[ps[u][q].bucket], compact ? 2u : 1u) : 0u;
         }
     }
     __syncthreads();
@@ -444,10 +479,26 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                 Item<F> it;
                 it.key = ps[u][q].key;
                 it.fx = fx[u];
+                if (compact) {
+                    if constexpr (F == 2) {   // two slots: {key, fx, fy, fz} {0, g0, g1, 0}
+                        it.a[0] = fyz[u][0];
+                        it.a[1] = fyz[u][1];
+                        s_items[pos] = it;
+                        Item<F> it2;
+                        it2.key = 0;
+                        it2.fx = g[u][0];
+                        it2.a[0] = g[u][1];
+                        it2.a[1] = 0.0f;
+                        s_items[pos + 1] = it2;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                        s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
+                    }
+                } else {
 #pragma unroll
-                for (int j = 0; j < F; ++j) it.a[j] = g[u][j] * ps[u][q].wrest;
-                s_items[pos] = it;
-                s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                    for (int j = 0; j < F; ++j) it.a[j] = g[u][j] * ps[u][q].wrest;
+                    s_items[pos] = it;
+                    s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                }
             }
         }
     }
@@ -483,7 +534,9 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         if (plan.lv[plan.blevel[q]].bucket0 <= gb) lvl = plan.blevel[q];
     const BinLevel bl = plan.lv[lvl];
     const uint32_t b = gb - bl.bucket0;
-    const uint32_t row0 = b * bl.rows_pb;
+    const uint32_t r1 = (uint32_t)lt.res[lvl];
+    // compact levels: the image starts at the bucket's first base plane and includes one halo plane
+    const uint32_t row0 = bl.compact ? b * bl.slab * r1 * r1 : b * bl.rows_pb;
     const uint32_t nrows = (bl.used - row0 < bl.rows_pb) ? (bl.used - row0) : bl.rows_pb;
 
     for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) s_acc[e] = 0.0;   // all-zero bits either way
@@ -496,6 +549,58 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     const uint64_t begin = base[gb] + (uint64_t)chunk * plan.chunk;
     const uint64_t bucket_end = base[gb + 1];
     const uint64_t end = (begin + plan.chunk < bucket_end) ? (begin + plan.chunk) : bucket_end;
+    if constexpr (F == 2) {
+        if (bl.compact) {
+            // one sample per two slots: {local base row | valid, fx, fy, fz} {-, g0, g1, -}; all 8 corners land here
+            constexpr int UC = 2;
+            const uint32_t r2 = r1 * r1;
+            for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
+                Item<F> ia[UC], ib[UC];
+#pragma unroll
+                for (int u = 0; u < UC; ++u) {
+                    const uint64_t p = p0 + 2ull * u * kConsumeThreads;
+                    if (p + 1 < end) {
+                        ia[u] = items[p];
+                        ib[u] = items[p + 1];
+                    } else {
+                        ia[u].key = 0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UC; ++u) {
+                    if (!(ia[u].key & (1u << 26))) continue;
+                    const uint32_t base_row = ia[u].key & 0x1FFFu;
+                    const float fxx = ia[u].fx, fyy = ia[u].a[0], fzz = ia[u].a[1];
+                    const float gxx = 1.0f - fxx, gyy = 1.0f - fyy, gzz = 1.0f - fzz;
+                    const float g0 = ib[u].fx, g1 = ib[u].a[0];
+                    const float wxy[4] = {gxx * gyy, gxx * fyy, fxx * gyy, fxx * fyy};   // reference order: (x * y) * z
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const uint32_t row = base_row + ((c >> 2) & 1) + ((c >> 1) & 1) * r1 + (c & 1) * r2;
+                        const float w = wxy[c >> 1] * ((c & 1) ? fzz : gzz);
+                        if (row >= nrows) continue;   // cannot happen for in-range cells; keeps the image safe
+                        if (FX && fx.fixed) {
+                            atomicAdd(&s_fix[row * 2 + 0], fx_encode(g0 * w, fx.scale));
+                            atomicAdd(&s_fix[row * 2 + 1], fx_encode(g1 * w, fx.scale));
+                        } else {
+                            atomicAdd(&s_acc[row * 2 + 0], (double)(g0 * w));
+                            atomicAdd(&s_acc[row * 2 + 1], (double)(g1 * w));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // neighbouring buckets share their boundary plane: everything is added atomically (the table is zeroed)
+            const int64_t grow0c = (int64_t)first_idx[lvl] + row0;
+            for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) {
+                const int64_t grow = grow0c + e / F;
+                if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
+                const float v = (FX && fx.fixed) ? fx_decode(s_fix[e], fx.inv) : (float)s_acc[e];
+                if (v != 0.0f) unsafeAtomicAdd(grad_table + grow * F + (e % F), v);
+            }
+            return;
+        }
+    }
     constexpr int UN = 8;  // items in flight per thread (4: -1 %, 16: +3 % with the fixed-point atomics)
     for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
         Item<F> it[UN];
@@ -689,6 +794,8 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
         bl.shift = shift;
         bl.dgroup = -1;
         bl.drow0 = 0;
+        bl.compact = 0;
+        bl.slab = 0;
         if (l < lt.level_begin || l >= lt.level_end) {  // not part of this call
             bl.nb = 0;
             bl.used = 0;
@@ -706,6 +813,20 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
             bl.rows_pb = (uint32_t)(bl.G * res);
             bl.nb = (uint32_t)((lines + bl.G - 1) / bl.G);
             bl.magicG = (((uint64_t)1 << 40) + bl.G - 1) / bl.G;
+            // Compact mode (3-D, F = 2): when an image holds at least two z-planes of the level, bucket = slab of base
+            // cells in z and the image = that slab plus one halo plane, so all 8 corners of a sample land in ONE
+            // bucket and the sample travels as one 32-byte item instead of four 16-byte pair items.
+            const uint64_t planes = (dim == 3 && F == 2 && g_bwd_compact.load() != 0) ? BR / (res * res) : 0;
+            if (planes >= 2 && res >= 3 && bl.used > BR) {
+                const uint32_t slab = (uint32_t)planes - 1;
+                const uint32_t nbz = ((uint32_t)res - 2u) / slab + 1u;      // base cells: z in [0, res - 2]
+                if (nbz <= (uint32_t)kMaxLevelBuckets) {
+                    bl.compact = 1;
+                    bl.slab = slab;
+                    bl.rows_pb = (slab + 1u) * (uint32_t)(res * res);
+                    bl.nb = nbz;
+                }
+            }
         } else {
             bl.used = lt.mask + 1u;
             bl.rows_pb = (bl.used < BR) ? bl.used : BR;
@@ -742,7 +863,7 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
     uint64_t chunk = (uint64_t)n_batch * plan.pairs / 48 + 1024;
     if (chunk < 8192) chunk = 8192;
     if (chunk > (1u << 22)) chunk = 1u << 22;
-    plan.chunk = (uint32_t)chunk;
+    plan.chunk = (uint32_t)chunk & ~1u;   // even: a compact item (two 16-byte slots) never straddles two work units
 }
 
 // sub-batch so that the item array stays below the cap (default 1.5 GiB, option "bin_batch_mib")

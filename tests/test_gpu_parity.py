@@ -713,3 +713,27 @@ def test_level_ranges_share_the_fixed_point_scales(dev):
         scale = np.abs(ref[lo:hi]).max()
         np.testing.assert_allclose(out[lo:hi].cpu().numpy(), ref[lo:hi], rtol=RTOL, atol=RTOL * scale)
         np.testing.assert_allclose(full[lo:hi].cpu().numpy(), ref[lo:hi], rtol=RTOL, atol=RTOL * scale)
+
+
+@pytest.mark.parametrize("n", [40_000, 1 << 17])
+def test_compact_dense_items_nerf_lego_table(dev, n):
+    """nerf_lego.yaml's table (3-D, 24 levels, res 16..512, bw 19): levels up to res 64 are dense and travel as ONE
+    32-byte item per sample in z-slab buckets with a halo plane (option bwd_compact); same gradient as the pair-item
+    path and as the oracle, small batch (64 KiB images) and large (128 KiB, fixed point)."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, bw = 3, 19
+    res = geo(16, 512, 24)
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, seed=41)
+    tc, tg, tf = (torch.from_numpy(a).to(dev) for a in (coords, go, first))
+    ref = oc.backward(coords, go, (T, 2), first, res, bw)
+    try:
+        for compact in (1, 0):
+            _lib.set_option("bwd_compact", compact)
+            got = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2).cpu().numpy()
+            for l in range(len(res)):
+                lo, hi = int(first[l]), int(first[l]) + sizes[l]
+                np.testing.assert_allclose(got[lo:hi], ref[lo:hi], rtol=RTOL, atol=RTOL * np.abs(ref[lo:hi]).max(),
+                                           err_msg=f"level {l} res {res[l]} compact={compact}")
+    finally:
+        _lib.set_option("bwd_compact", 1)
