@@ -1,0 +1,1 @@
+"""Module-level API of the mirror: grids, latent decoders, entropy models, decoder MLPs, embedders, neural fields."""

@@ -1,0 +1,1 @@
+"""Operator-level API of the mirror: `grid` (hash-grid autograd Functions) and `image.metrics`."""

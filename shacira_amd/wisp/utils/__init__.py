@@ -1,0 +1,1 @@
+"""Schedulers used by the fitting harnesses (mirror of the reference package layout)."""
