@@ -115,7 +115,7 @@ bool bin_supported(int dim, const LevelTable &lt);
 size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n);
 float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace);
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s);
+                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table);
 
 // variant 1 ("bin") whenever the shape allows it and the batch is big enough to amortise its fixed passes
 static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
@@ -146,7 +146,10 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
         acc = bin ? bin_acc32(dim, dtype, lt, n, workspace) : static_cast<float *>(workspace);
     }
     hipError_t e = hipSuccess;
-    if (lt.level_begin == 0 && lt.level_end == lt.num_lods) {
+    const bool full = lt.level_begin == 0 && lt.level_end == lt.num_lods;
+    if (full && bin) {
+        // zeroed inside bin_backward (on its side stream, next to the transpose, when it forks)
+    } else if (full) {
         e = hipMemsetAsync(acc, 0, (size_t)numel * sizeof(float), s);  // at::zeros_like, .cpp:81/:167
     } else {
         hipLaunchKernelGGL(zero_level_rows_kernel, dim3(2048), dim3(256), 0, s, acc, first_idx, lt.level_begin,
@@ -155,7 +158,7 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
     }
     if (e != hipSuccess) return e;
     if (bin) {
-        e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s);
+        e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s, full);
         if (e != hipSuccess) return e;
     } else if (n > 0) {
         if (dim == 3) {

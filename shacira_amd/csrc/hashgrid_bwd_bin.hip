@@ -946,7 +946,7 @@ float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *work
 // the objects exist -- they are created on the first eager call).
 struct SideStream {
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, zeroed = nullptr;
 };
 static hipError_t side_stream(SideStream **out) {
     static thread_local SideStream per_device[16];
@@ -957,12 +957,14 @@ static hipError_t side_stream(SideStream **out) {
     SideStream &ss = per_device[dev];
     if (!ss.stream) {
         hipStream_t st;
-        hipEvent_t a, b;
+        hipEvent_t a, b, c;
         if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&a, hipEventDisableTiming)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&b, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&c, hipEventDisableTiming)) != hipSuccess) return e;
         ss.fork = a;
         ss.join = b;
+        ss.zeroed = c;
         ss.stream = st;
     }
     *out = &ss;
@@ -971,7 +973,8 @@ static hipError_t side_stream(SideStream **out) {
 
 template <int DIM, int F>
 static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                          const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s) {
+                          const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s,
+                          bool zero_table) {
     const int L = lt.num_lods;
     BinPlan whole;
     const int acc_kib = choose_acc_kib(DIM, lt, n);
@@ -985,6 +988,11 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         if (e != hipSuccess) return e;
         if ((e = hipEventRecord(ss->fork, s)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(ss->stream, ss->fork, 0)) != hipSuccess) return e;
+        if (zero_table) {   // at::zeros_like of the reference: off the critical path, next to the transpose
+            e = hipMemsetAsync(acc, 0, (size_t)lt.table_rows * lt.feature_dim * sizeof(float), ss->stream);
+            if (e != hipSuccess) return e;
+            if ((e = hipEventRecord(ss->zeroed, ss->stream)) != hipSuccess) return e;
+        }
         BinPlan plan;
         make_plan(DIM, lt, n, plan, acc_kib);
         const dim3 grid(plan.num_tiles, plan.nbl);
@@ -998,6 +1006,10 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                            w.unit_first, w.unit_bucket, plan.total_buckets, plan.chunk);
         SHACIRA_CHECK_LAUNCH();
         if ((e = hipEventRecord(ss->join, ss->stream)) != hipSuccess) return e;
+    }
+    if (zero_table && !ss) {
+        hipError_t e = hipMemsetAsync(acc, 0, (size_t)lt.table_rows * lt.feature_dim * sizeof(float), s);
+        if (e != hipSuccess) return e;
     }
     const bool stage_all = (lt.stage_flags & SHACIRA_BWD_STAGE_ALL_LEVELS) != 0;
     const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
@@ -1032,8 +1044,12 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // When nothing is transposed (every level is direct: the image configs) gmax would cost an extra read of grad_output
     // (tried: a streaming abs-max kernel); measured on config B it costs more than the faster atomics return (0.103 vs
     // 0.082 ms for the whole backward), so those calls keep the fp64 image.
-    // direct levels: one pass over the whole batch, no items
+    // direct levels: one pass over the whole batch, no items (they add into the zeroed table)
     if (whole.ngroups > 0) {
+        if (zero_table && ss) {
+            hipError_t e = hipStreamWaitEvent(s, ss->zeroed, 0);
+            if (e != hipSuccess) return e;
+        }
         const BinPlan &plan = whole;
         uint32_t bpg = 512u / plan.ngroups;                       // ~512 workgroups in total (256 measured slower)
         const uint32_t need = (uint32_t)((n + 2047) / 2048);      // at least ~2 samples per thread each
@@ -1102,7 +1118,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
 }
 
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s) {
+                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table) {
     const BinWorkspace w = carve(dim, dtype, lt, n, workspace);
     static std::once_flag once;  // kernels that use more than 64 KiB of dynamic LDS must opt in once per process
     static hipError_t attr_err = hipSuccess;
@@ -1136,11 +1152,11 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
     });
     if (attr_err != hipSuccess) return attr_err;
     if (dim == 3) {
-        return lt.feature_dim == 2 ? run_bin<3, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s)
-                                   : run_bin<3, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s);
+        return lt.feature_dim == 2 ? run_bin<3, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table)
+                                   : run_bin<3, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table);
     }
-    return lt.feature_dim == 2 ? run_bin<2, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s)
-                               : run_bin<2, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s);
+    return lt.feature_dim == 2 ? run_bin<2, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table)
+                               : run_bin<2, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table);
 }
 
 }  // namespace shacira
