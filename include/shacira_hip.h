@@ -322,6 +322,8 @@ SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origi
  *   "fwd_variant", "bwd_variant": integer algorithm selectors, -1 = automatic.
  *   "bin_batch_mib": cap (MiB) of the backward's item array; larger batches are processed in sub-batches.
  *   "bin_acc_kib": LDS accumulator image per consumer workgroup: 64, 128, or 0 = chosen from the batch size (default).
+ *   "bwd_fuse": bucket counting fused into the transpose pass: 0 = never, 1 (default) = for batches where it measured
+ *               faster (up to 2^19 3-D / 2^20 2-D samples), 2 = always.
  *   "bwd_compact": 1 (default) = dense 3-D levels travel as one 32-byte item per sample (z-slab buckets), 0 = pair items.
  *   "mlp_variant": -1 (default) = decoder MLPs on the fp32 matrix cores wherever instantiated, 0 = VALU kernels.
  *   "bwd_fork": 1 (default) = the backward's count + scan passes are issued on a library-owned side stream, forked

@@ -12,6 +12,7 @@ std::atomic<int> g_fwd_variant{-1};
 std::atomic<int> g_bwd_variant{-1};
 std::atomic<int> g_mlp_variant{-1};       // -1: MFMA decoders wherever instantiated, 0: VALU kernels
 std::atomic<int> g_bwd_compact{1};        // dense 3-D levels: one 32-byte item per sample, z-slab buckets with a halo plane
+std::atomic<int> g_bwd_fuse{1};           // bucket counting fused into the transpose pass
 std::atomic<int> g_bwd_fork{1};           // 1: count + scans of the backward on a side stream next to the transpose
 std::atomic<int> g_bin_acc_kib{0};        // LDS accumulator image per consumer workgroup, KiB: 64, 128, 0 = by batch size
 std::atomic<int> g_bin_batch_mib{1536};   // cap of the backward's item array per sub-batch, MiB
@@ -75,6 +76,11 @@ int shacira_set_option(const char *name, int value) {
     }
     if (!std::strcmp(name, "bwd_fork")) { g_bwd_fork = value ? 1 : 0; return 0; }
     if (!std::strcmp(name, "mlp_variant")) { g_mlp_variant = value; return 0; }
+    if (!std::strcmp(name, "bwd_fuse")) {
+        if (value < 0 || value > 2) return SHACIRA_EINVAL;
+        g_bwd_fuse = value;
+        return 0;
+    }
     if (!std::strcmp(name, "bwd_compact")) { g_bwd_compact = value ? 1 : 0; return 0; }
     if (!std::strcmp(name, "bin_batch_mib")) {
         if (value < 1) return SHACIRA_EINVAL;
@@ -92,6 +98,7 @@ int shacira_get_option(const char *name) {
     if (!std::strcmp(name, "bin_acc_kib")) return g_bin_acc_kib;
     if (!std::strcmp(name, "bwd_fork")) return g_bwd_fork;
     if (!std::strcmp(name, "mlp_variant")) return g_mlp_variant;
+    if (!std::strcmp(name, "bwd_fuse")) return g_bwd_fuse;
     if (!std::strcmp(name, "bwd_compact")) return g_bwd_compact;
     return SHACIRA_EINVAL;
 }

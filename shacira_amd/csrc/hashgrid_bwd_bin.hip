@@ -280,6 +280,120 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(LevelTable lt, B
         cnt[(size_t)(bl.bucket0 + threadIdx.x) * plan.num_tiles + tile] = s_hist[threadIdx.x];
 }
 
+// ------------------------------------------------------------------------------------------------- passes T + A fused
+// One workgroup = one 1024-sample tile of passes A / B: four 256-sample rounds of the transpose (memory bound) with
+// the bucket counting of the same samples (ALU bound: corner hashing of every binned level) in between, so the two
+// overlap inside every CU -- issued as two kernels on two streams they mostly ran one after the other.
+constexpr int kFuseSlots = 4;                    // level slots per sample in the fused transpose + count kernel
+constexpr int kFuseThreads = 256 * kFuseSlots;
+template <int DIM, typename T, int F, bool GMAX>
+__global__ __launch_bounds__(kFuseThreads) void transpose_count_kernel(LevelTable lt, BinPlan plan, const T *__restrict__ go,
+                                                              float *__restrict__ gT, const float *__restrict__ coords,
+                                                              uint32_t *__restrict__ cnt, int64_t N, int lb, int le,
+                                                              uint32_t *__restrict__ gmax) {
+    __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
+    __shared__ uint32_t s_hist[SHACIRA_MAX_LODS][kMaxLevelBuckets];
+    struct alignas(sizeof(T) * F) PieceIn { T v[F]; };
+    struct alignas(sizeof(float) * F) PieceOut { float v[F]; };
+    extern __shared__ __align__(16) unsigned char s_raw_g[];
+    PieceOut *s_tile = reinterpret_cast<PieceOut *>(s_raw_g);  // [256][L + 1]
+    const int L = lt.num_lods, pitch = L + 1;
+    const uint32_t tile = blockIdx.x;
+    // thread = (sample sm of the round, level slot q): the transpose stores and the counting loop take every
+    // kFuseSlots-th level, so a round keeps 16 waves busy
+    const int sm_t = threadIdx.x & 255, q_t = threadIdx.x >> 8;
+    if (threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
+    for (uint32_t k = threadIdx.x; k < plan.nbl * (uint32_t)kMaxLevelBuckets; k += kFuseThreads) (&s_hist[0][0])[k] = 0;
+    __syncthreads();
+    PieceOut *out = reinterpret_cast<PieceOut *>(gT);
+    for (int sub = 0; sub < kTile / 256; ++sub) {
+        const int64_t s0 = (int64_t)tile * kTile + sub * 256;
+        if (s0 >= N) break;
+        const int ns = (int)((N - s0 < 256) ? (N - s0) : 256);
+        const PieceIn *in = reinterpret_cast<const PieceIn *>(go) + s0 * L;
+        const int total = ns * L;
+        for (int e = threadIdx.x; e < total; e += kFuseThreads) {
+            const int sm = e / L, l = e - sm * L;
+            const PieceIn p = in[e];
+            PieceOut q;
+#pragma unroll
+            for (int j = 0; j < F; ++j) q.v[j] = Scalar<T>::load(&p.v[j]);
+            s_tile[sm * pitch + l] = q;
+        }
+        // bucket counts of this round's sample while the rows above are in flight
+        if (sm_t < ns) {
+            const int64_t i = s0 + sm_t;
+            double t[DIM];
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
+            for (uint32_t li = (uint32_t)q_t; li < plan.nbl; li += kFuseSlots) {
+                const uint32_t lvl = plan.blevel[li];
+                const BinLevel bl = plan.lv[lvl];
+                bool done = false;
+                if constexpr (DIM == 3) {
+                    if (bl.compact) {
+                        int32_t pz;
+                        float fz, gz;
+                        axis_transform(t[2], lt.res[lvl], lt.hi[lvl], pz, fz, gz);
+                        atomicAdd(&s_hist[li][(uint32_t)pz / bl.slab], 2u);
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    float fx;
+                    PairSlot ps[1 << (DIM - 1)];
+                    enumerate_pairs<DIM>(t, lt.res[lvl], lt.hi[lvl], lt.dense[lvl] != 0, lt.mask, bl, plan.BR, fx, ps);
+#pragma unroll
+                    for (int q = 0; q < (1 << (DIM - 1)); ++q)
+                        if (ps[q].key >> 26) atomicAdd(&s_hist[li][ps[q].bucket], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        for (int l = lb + q_t; l < le; l += kFuseSlots) {
+            uint32_t m = 0;
+            if (sm_t < ns) {
+                const PieceOut q = s_tile[sm_t * pitch + l];
+                if constexpr (GMAX) {
+#pragma unroll
+                    for (int j = 0; j < F; ++j) {
+                        const uint32_t b = __float_as_uint(fabsf(q.v[j]));
+                        m = b > m ? b : m;
+                    }
+                }
+                float *dst = reinterpret_cast<float *>(out + (int64_t)l * N + s0 + sm_t);
+                if constexpr (F == 2) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 v = {q.v[0], q.v[1]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x2 *>(dst));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < F; ++j) __builtin_nontemporal_store(q.v[j], dst + j);
+                }
+            }
+            if constexpr (GMAX) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint32_t o = __shfl_xor(m, off, 64);
+                    m = o > m ? o : m;
+                }
+                if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_max[l], m);
+            }
+        }
+        __syncthreads();   // s_tile is refilled by the next round
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < plan.nbl * (uint32_t)kMaxLevelBuckets; k += kFuseThreads) {
+        const uint32_t li = k / kMaxLevelBuckets, b = k % kMaxLevelBuckets;
+        const BinLevel &bl = plan.lv[plan.blevel[li]];
+        if (b < bl.nb) cnt[(size_t)(bl.bucket0 + b) * plan.num_tiles + tile] = s_hist[li][b];
+    }
+    if constexpr (GMAX) {
+        if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x])
+            atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------- pass S
 // one wave per bucket: exclusive scan of cnt[bucket][0..num_tiles) in place; total -> totals[bucket]
 __global__ __launch_bounds__(64) void bin_scan_tiles_kernel(uint32_t *__restrict__ cnt, uint32_t *__restrict__ totals,
@@ -946,7 +1060,7 @@ float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *work
 // the objects exist -- they are created on the first eager call).
 struct SideStream {
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, zeroed = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, zeroed = nullptr, staged = nullptr;
 };
 static hipError_t side_stream(SideStream **out) {
     static thread_local SideStream per_device[16];
@@ -957,14 +1071,16 @@ static hipError_t side_stream(SideStream **out) {
     SideStream &ss = per_device[dev];
     if (!ss.stream) {
         hipStream_t st;
-        hipEvent_t a, b, c;
+        hipEvent_t a, b, c, d;
         if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&a, hipEventDisableTiming)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&b, hipEventDisableTiming)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&c, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&d, hipEventDisableTiming)) != hipSuccess) return e;
         ss.fork = a;
         ss.join = b;
         ss.zeroed = c;
+        ss.staged = d;
         ss.stream = st;
     }
     *out = &ss;
@@ -981,9 +1097,21 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     make_plan(DIM, lt, n, whole, acc_kib);
     const int64_t nb = bin_batch_samples(DIM, lt, n);
     const bool multi = nb < n;
-    // single sub-batch (the usual case): count + scans run on the side stream next to transpose + direct levels
+    const bool stage_all = (lt.stage_flags & SHACIRA_BWD_STAGE_ALL_LEVELS) != 0;
+    const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
+    // only binned levels consume the transposed gradients (a later call on this workspace may, too: stage_all)
+    const bool need_T = whole.nbl > 0 || stage_all || staged;
+    // single sub-batch (the usual case): a side stream takes what is off the critical path. With a transpose to do,
+    // counting is FUSED into it (transpose_count_kernel) and the side stream zeroes the table and runs the direct
+    // levels; a call that reuses staged gradients counts + scans on the side stream instead.
     SideStream *ss = nullptr;
-    if (whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 && n >= (1 << 18)) {   // measured: a loss at 64 K samples
+    const bool can_fork = whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 && n >= (1 << 18);   // a loss at 64 K
+    // measured (tools/fuse_check.py): fused wins by 4-9 % up to 2^19 3-D samples, loses 3-4 % at 2^20 ("bwd_fuse": 0 = never,
+    // 1 = by that rule, 2 = always)
+    const int fuse_opt = g_bwd_fuse.load();
+    const bool fuse = can_fork && need_T && !staged &&
+                      (fuse_opt == 2 || (fuse_opt == 1 && n * ((int64_t)1 << (DIM - 1)) <= ((int64_t)1 << 21)));
+    if (can_fork) {
         hipError_t e = side_stream(&ss);
         if (e != hipSuccess) return e;
         if ((e = hipEventRecord(ss->fork, s)) != hipSuccess) return e;
@@ -993,28 +1121,26 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             if (e != hipSuccess) return e;
             if ((e = hipEventRecord(ss->zeroed, ss->stream)) != hipSuccess) return e;
         }
-        BinPlan plan;
-        make_plan(DIM, lt, n, plan, acc_kib);
-        const dim3 grid(plan.num_tiles, plan.nbl);
-        hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, ss->stream, lt, plan, coords, w.cnt,
-                           (int64_t)0, n);
-        SHACIRA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, ss->stream, w.cnt, w.totals,
-                           plan.num_tiles);
-        SHACIRA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, ss->stream, w.totals, w.base,
-                           w.unit_first, w.unit_bucket, plan.total_buckets, plan.chunk);
-        SHACIRA_CHECK_LAUNCH();
-        if ((e = hipEventRecord(ss->join, ss->stream)) != hipSuccess) return e;
+        if (!fuse) {
+            BinPlan plan;
+            make_plan(DIM, lt, n, plan, acc_kib);
+            const dim3 grid(plan.num_tiles, plan.nbl);
+            hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, ss->stream, lt, plan, coords, w.cnt,
+                               (int64_t)0, n);
+            SHACIRA_CHECK_LAUNCH();
+            hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, ss->stream, w.cnt,
+                               w.totals, plan.num_tiles);
+            SHACIRA_CHECK_LAUNCH();
+            hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, ss->stream, w.totals, w.base,
+                               w.unit_first, w.unit_bucket, plan.total_buckets, plan.chunk);
+            SHACIRA_CHECK_LAUNCH();
+            if ((e = hipEventRecord(ss->join, ss->stream)) != hipSuccess) return e;
+        }
     }
     if (zero_table && !ss) {
         hipError_t e = hipMemsetAsync(acc, 0, (size_t)lt.table_rows * lt.feature_dim * sizeof(float), s);
         if (e != hipSuccess) return e;
     }
-    const bool stage_all = (lt.stage_flags & SHACIRA_BWD_STAGE_ALL_LEVELS) != 0;
-    const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
-    // only binned levels consume the transposed gradients (a later call on this workspace may, too: stage_all)
-    const bool need_T = whole.nbl > 0 || stage_all || staged;
     // fixed-point images pay off once the accumulation itself dominates; small batches are bound by fixed costs and
     // keep the fp64 image (and skip the gmax bookkeeping): measured 100 vs 107 us at 65 536 samples
     const bool use_fx = need_T && n >= (1 << 17);
@@ -1022,7 +1148,35 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         hipError_t e = hipMemsetAsync(w.gmax, 0, SHACIRA_MAX_LODS * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
     }
-    if (need_T && !staged) {
+    if (fuse) {
+        // passes T + A in one kernel, then the scans, all on the caller's stream
+        const int t_lb = stage_all ? 0 : lt.level_begin, t_le = stage_all ? L : lt.level_end;
+        const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
+        BinPlan plan;
+        make_plan(DIM, lt, n, plan, acc_kib);
+        const dim3 grid(plan.num_tiles);
+        if (dtype == SHACIRA_F32 && use_fx)
+            hipLaunchKernelGGL((transpose_count_kernel<DIM, float, F, true>), grid, dim3(kFuseThreads), shmem, s, lt, plan,
+                               static_cast<const float *>(grad_out), w.gT, coords, w.cnt, n, t_lb, t_le, w.gmax);
+        else if (dtype == SHACIRA_F32)
+            hipLaunchKernelGGL((transpose_count_kernel<DIM, float, F, false>), grid, dim3(kFuseThreads), shmem, s, lt, plan,
+                               static_cast<const float *>(grad_out), w.gT, coords, w.cnt, n, t_lb, t_le, nullptr);
+        else if (use_fx)
+            hipLaunchKernelGGL((transpose_count_kernel<DIM, __half, F, true>), grid, dim3(kFuseThreads), shmem, s, lt, plan,
+                               static_cast<const __half *>(grad_out), w.gT, coords, w.cnt, n, t_lb, t_le, w.gmax);
+        else
+            hipLaunchKernelGGL((transpose_count_kernel<DIM, __half, F, false>), grid, dim3(kFuseThreads), shmem, s, lt, plan,
+                               static_cast<const __half *>(grad_out), w.gT, coords, w.cnt, n, t_lb, t_le, nullptr);
+        SHACIRA_CHECK_LAUNCH();
+        hipError_t e;
+        if ((e = hipEventRecord(ss->staged, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, s, w.cnt, w.totals,
+                           plan.num_tiles);
+        SHACIRA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
+                           w.unit_bucket, plan.total_buckets, plan.chunk);
+        SHACIRA_CHECK_LAUNCH();
+    } else if (need_T && !staged) {
         const int t_lb = stage_all ? 0 : lt.level_begin, t_le = stage_all ? L : lt.level_end;
         // pass T over the whole batch (also gathers gmax)
         const uint32_t blocks = (uint32_t)((n + 255) / 256);
@@ -1045,8 +1199,14 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // (tried: a streaming abs-max kernel); measured on config B it costs more than the faster atomics return (0.103 vs
     // 0.082 ms for the whole backward), so those calls keep the fp64 image.
     // direct levels: one pass over the whole batch, no items (they add into the zeroed table)
+    hipStream_t ds = s;   // stream of the direct levels
+    if (fuse) {           // side stream: after its memset, once the staged gradients (and gmax) exist
+        hipError_t e = hipStreamWaitEvent(ss->stream, ss->staged, 0);
+        if (e != hipSuccess) return e;
+        ds = ss->stream;
+    }
     if (whole.ngroups > 0) {
-        if (zero_table && ss) {
+        if (zero_table && ss && !fuse) {
             hipError_t e = hipStreamWaitEvent(s, ss->zeroed, 0);
             if (e != hipSuccess) return e;
         }
@@ -1061,22 +1221,26 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const int headroom = use_fx ? fx_headroom(((uint64_t)n / bpg + kConsumeThreads) * (1u << DIM)) : -1;
         if (need_T && use_fx)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, true>), grid, dim3(kConsumeThreads),
-                               acc_bytes, s, lt, plan, first_idx, coords, w.gT, acc, n, w.gmax, headroom);
+                               acc_bytes, ds, lt, plan, first_idx, coords, w.gT, acc, n, w.gmax, headroom);
         else if (need_T)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, false>), grid, dim3(kConsumeThreads),
-                               acc_bytes, s, lt, plan, first_idx, coords, w.gT, acc, n, nullptr, headroom);
+                               acc_bytes, ds, lt, plan, first_idx, coords, w.gT, acc, n, nullptr, headroom);
         else if (dtype == SHACIRA_F32)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, false, false>), grid, dim3(kConsumeThreads),
-                               acc_bytes, s, lt, plan, first_idx, coords, static_cast<const float *>(grad_out), acc, n,
+                               acc_bytes, ds, lt, plan, first_idx, coords, static_cast<const float *>(grad_out), acc, n,
                                nullptr, headroom);
         else
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, __half, false, false>), grid, dim3(kConsumeThreads),
-                               acc_bytes, s, lt, plan, first_idx, coords, static_cast<const __half *>(grad_out), acc, n,
+                               acc_bytes, ds, lt, plan, first_idx, coords, static_cast<const __half *>(grad_out), acc, n,
                                nullptr, headroom);
         SHACIRA_CHECK_LAUNCH();
     }
+    if (fuse) {   // direct levels (and the table zeroing before them) join the caller's stream before the consume pass
+        hipError_t e = hipEventRecord(ss->join, ss->stream);
+        if (e != hipSuccess) return e;
+    }
     if (whole.nbl == 0) return hipSuccess;
-    if (ss) {
+    if (ss && !fuse) {
         hipError_t e = hipStreamWaitEvent(s, ss->join, 0);
         if (e != hipSuccess) return e;
     }
@@ -1103,6 +1267,10 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NP;
         const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + plan.total_buckets + 1;
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
+        if (fuse) {
+            hipError_t e = hipStreamWaitEvent(s, ss->join, 0);
+            if (e != hipSuccess) return e;
+        }
         if (use_fx)   // a unit streams <= chunk items
             hipLaunchKernelGGL((bin_consume_kernel<F, true>), dim3(max_units), dim3(kConsumeThreads), acc_bytes, s, lt,
                                plan, first_idx, w.base, w.unit_first, w.unit_bucket,
@@ -1131,7 +1299,11 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         };
 #define SHACIRA_T_ATTR(TT, FF)                                                                           \
         set(reinterpret_cast<const void *>(&transpose_grad_kernel<TT, FF, true>), 140 * 1024);          \
-        set(reinterpret_cast<const void *>(&transpose_grad_kernel<TT, FF, false>), 140 * 1024);
+        set(reinterpret_cast<const void *>(&transpose_grad_kernel<TT, FF, false>), 140 * 1024);         \
+        set(reinterpret_cast<const void *>(&transpose_count_kernel<2, TT, FF, true>), 120 * 1024);      \
+        set(reinterpret_cast<const void *>(&transpose_count_kernel<2, TT, FF, false>), 120 * 1024);     \
+        set(reinterpret_cast<const void *>(&transpose_count_kernel<3, TT, FF, true>), 120 * 1024);      \
+        set(reinterpret_cast<const void *>(&transpose_count_kernel<3, TT, FF, false>), 120 * 1024);
         SHACIRA_T_ATTR(float, 2) SHACIRA_T_ATTR(float, 4) SHACIRA_T_ATTR(__half, 2) SHACIRA_T_ATTR(__half, 4)
 #undef SHACIRA_T_ATTR
 #define SHACIRA_DIRECT_ATTR(D, FF)                                                                              \
