@@ -1105,7 +1105,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // counting is FUSED into it (transpose_count_kernel) and the side stream zeroes the table and runs the direct
     // levels; a call that reuses staged gradients counts + scans on the side stream instead.
     SideStream *ss = nullptr;
-    const bool can_fork = whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 && n >= (1 << 18);   // a loss at 64 K
+    const bool can_fork = whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 && n >= (1 << 18);   // a loss at 64 K and 128 K (also fused)
     // measured (tools/fuse_check.py): fused wins by 4-9 % up to 2^19 3-D samples, loses 3-4 % at 2^20 ("bwd_fuse": 0 = never,
     // 1 = by that rule, 2 = always)
     const int fuse_opt = g_bwd_fuse.load();
