@@ -737,3 +737,20 @@ def test_compact_dense_items_nerf_lego_table(dev, n):
                                            err_msg=f"level {l} res {res[l]} compact={compact}")
     finally:
         _lib.set_option("bwd_compact", 1)
+
+
+@pytest.mark.parametrize("n", [30_000, 200_000])
+def test_power_of_two_resolutions(dev, n):
+    """`from_octree` tables (res = 2^k): res 64 is the largest level whose two z-planes fill the 8192-row image exactly
+    (compact items, one base plane + halo per bucket); res 4 / 8 / 16 are direct, 128 is hashed."""
+    ops = _ops()
+    dim, bw = 3, 19
+    res = [4, 8, 16, 32, 64, 128]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, seed=51)
+    feats, grad = _run(dev, dim, res, bw, coords, table, go, first)
+    assert np.array_equal(feats.cpu().numpy(), oc.forward(coords, table, first, res, bw))
+    ref = oc.backward(coords, go, (T, 2), first, res, bw)
+    for l in range(len(res)):
+        lo, hi = int(first[l]), int(first[l]) + sizes[l]
+        np.testing.assert_allclose(grad[lo:hi].cpu().numpy(), ref[lo:hi], rtol=RTOL, atol=RTOL * np.abs(ref[lo:hi]).max(),
+                                   err_msg=f"level {l} res {res[l]}")
