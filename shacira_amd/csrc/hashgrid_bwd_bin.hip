@@ -968,6 +968,45 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
             nbk += bl.nb;
         }
     }
+    // Re-deal the direct levels over the same number of groups so that every group carries about the same NUMBER of
+    // levels: a group's workgroups walk all samples once per level they own, so the greedy fill (6 / 4 / 4 / 2 levels on
+    // the Kodak tables) left the slowest group with 1.5x the average work. Kept only if it fits the same group count.
+    if (plan.ngroups > 1) {
+        int dl[SHACIRA_MAX_LODS], ndl = 0;
+        for (int l = 0; l < lt.num_lods; ++l)
+            if (plan.lv[l].dgroup >= 0) dl[ndl++] = l;
+        uint32_t nmask[SHACIRA_MAX_LODS] = {0}, nrows[SHACIRA_MAX_LODS] = {0}, row0[SHACIRA_MAX_LODS] = {0};
+        int grp_of[SHACIRA_MAX_LODS];
+        uint32_t g = 0;
+        int in_group = 0, k = 0;
+        bool ok = true;
+        for (; k < ndl; ++k) {
+            const uint32_t used = plan.lv[dl[k]].used;
+            const int left_levels = ndl - k, left_groups = (int)plan.ngroups - (int)g;
+            const int quota = (left_levels + in_group + left_groups - 1) / left_groups;   // ceil of what is left per group
+            if (in_group > 0 && (nrows[g] + used > BR || in_group >= quota)) {
+                ++g;
+                in_group = 0;
+                if (g >= plan.ngroups) { ok = false; break; }
+            }
+            if (nrows[g] + used > BR) { ok = false; break; }
+            grp_of[k] = (int)g;
+            row0[k] = nrows[g];
+            nrows[g] += used;
+            nmask[g] |= 1u << dl[k];
+            ++in_group;
+        }
+        if (ok) {
+            for (uint32_t q = 0; q < plan.ngroups; ++q) {
+                plan.gmask[q] = nmask[q];
+                plan.grows[q] = nrows[q];
+            }
+            for (int q = 0; q < ndl; ++q) {
+                plan.lv[dl[q]].dgroup = grp_of[q];
+                plan.lv[dl[q]].drow0 = row0[q];
+            }
+        }
+    }
     plan.total_buckets = nbk;
     plan.BR = BR;
     plan.num_tiles = (uint32_t)((n_batch + kTile - 1) / kTile);
