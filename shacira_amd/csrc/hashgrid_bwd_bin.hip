@@ -1250,7 +1250,10 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             if (e != hipSuccess) return e;
         }
         const BinPlan &plan = whole;
-        uint32_t bpg = 512u / plan.ngroups;                       // ~512 workgroups in total (256 measured slower)
+        // one level group (S1's level 0): ~512 workgroups measured best; several groups (the all-direct image tables,
+        // 128 KiB images = one resident workgroup per CU): 256 in total = one wave of workgroups, no tail
+        // (config B backward 65 vs 77 us, tools/direct_blocks.py)
+        uint32_t bpg = (plan.ngroups > 1 ? 256u : 512u) / plan.ngroups;
         const uint32_t need = (uint32_t)((n + 2047) / 2048);      // at least ~2 samples per thread each
         if (bpg > need) bpg = need;
         if (bpg < 1) bpg = 1;
