@@ -1342,10 +1342,10 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
 #define SHACIRA_T_ATTR(TT, FF)                                                                           \
         set(reinterpret_cast<const void *>(&transpose_grad_kernel<TT, FF, true>), 140 * 1024);          \
         set(reinterpret_cast<const void *>(&transpose_grad_kernel<TT, FF, false>), 140 * 1024);         \
-        set(reinterpret_cast<const void *>(&transpose_count_kernel<2, TT, FF, true>), 120 * 1024);      \
-        set(reinterpret_cast<const void *>(&transpose_count_kernel<2, TT, FF, false>), 120 * 1024);     \
-        set(reinterpret_cast<const void *>(&transpose_count_kernel<3, TT, FF, true>), 120 * 1024);      \
-        set(reinterpret_cast<const void *>(&transpose_count_kernel<3, TT, FF, false>), 120 * 1024);
+        set(reinterpret_cast<const void *>(&transpose_count_kernel<2, TT, FF, true>), 140 * 1024);      \
+        set(reinterpret_cast<const void *>(&transpose_count_kernel<2, TT, FF, false>), 140 * 1024);     \
+        set(reinterpret_cast<const void *>(&transpose_count_kernel<3, TT, FF, true>), 140 * 1024);      \
+        set(reinterpret_cast<const void *>(&transpose_count_kernel<3, TT, FF, false>), 140 * 1024);
         SHACIRA_T_ATTR(float, 2) SHACIRA_T_ATTR(float, 4) SHACIRA_T_ATTR(__half, 2) SHACIRA_T_ATTR(__half, 4)
 #undef SHACIRA_T_ATTR
 #define SHACIRA_DIRECT_ATTR(D, FF)                                                                              \

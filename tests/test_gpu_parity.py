@@ -238,11 +238,13 @@ def test_backward_side_stream_fork(dev, name):
         _lib.set_option("bwd_fork", 1)
 
 
-def test_max_levels_and_wide_features(dev):
-    """SHACIRA_MAX_LODS = 32 levels with F = 4 (largest staging tiles of the transposing passes), 3-D and 2-D."""
+@pytest.mark.parametrize("n", [20_011, (1 << 18) + 5])
+def test_max_levels_and_wide_features(dev, n):
+    """SHACIRA_MAX_LODS = 32 levels with F = 4 (largest staging tiles of the transposing passes), 3-D and 2-D; the
+    larger batch runs the fused transpose + count kernel with its 135 KiB tile."""
     for dim, bw in ((3, 14), (2, 12)):
         res = geo(8, 300, 32)
-        sizes, first, T, coords, table, go = _problem(dim, res, bw, 20_011, F=4)
+        sizes, first, T, coords, table, go = _problem(dim, res, bw, n, F=4)
         feats, grad = _run(dev, dim, res, bw, coords, table, go, first)
         assert np.array_equal(feats.cpu().numpy(), oc.forward(coords, table, first, res, bw))
         ref_g = oc.backward(coords, go, (T, 4), first, res, bw)
