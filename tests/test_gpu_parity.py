@@ -263,10 +263,10 @@ def test_out_of_table_corner_is_memory_safe(dev):
     assert float(grad.sum()) == pytest.approx(6.0, rel=1e-6)
 
 
-@pytest.mark.parametrize("n", [20_000, 1 << 17])
+@pytest.mark.parametrize("n", [20_000, 1 << 17, 1 << 18])
 def test_half_precision_tables(dev, n):
-    """fp16 instantiation (what the reference's NeRF AMP path runs, grid.py:73 + .cu:198-211); the larger batch runs
-    the fixed-point accumulation kernels."""
+    """fp16 instantiation (what the reference's NeRF AMP path runs, grid.py:73 + .cu:198-211); the larger batches run
+    the fixed-point accumulation kernels and (2^18) the fused transpose + count kernel on fp16 gradients."""
     dim, res, bw = CONFIGS["D"]
     sizes, first, T, coords, table, go = _problem(dim, res, bw, n)
     table16 = table.astype(np.float16).astype(np.float32)
