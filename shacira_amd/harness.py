@@ -471,9 +471,13 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
     gen = torch.Generator().manual_seed(seed + 1)
     near, far = 1.2, 4.8
     samples_seen = 0
+    warm = min(20, steps // 10)          # first steps pay one-off costs (kernel attribute set-up, allocator growth)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(steps):
+        if it == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         o, d = camera_rays(rays, gen, device)
         batch = Rays(o, d, dist_min=near, dist_max=far)
         with torch.no_grad():
@@ -494,7 +498,7 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
         if prune_every and (it + 1) % prune_every == 0:
             nef.prune()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    ms = (time.perf_counter() - t0) / max(1, steps - warm) * 1e3
     with torch.no_grad():
         o, d = camera_rays(val_rays, torch.Generator().manual_seed(4242), device)
         batch = Rays(o, d, dist_min=near, dist_max=far)
