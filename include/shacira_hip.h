@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SHACIRA_ABI_VERSION 5
+#define SHACIRA_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define SHACIRA_API __attribute__((visibility("default")))
@@ -116,6 +116,42 @@ SHACIRA_API int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, in
                                      const int32_t *codebook_first_idx, int64_t table_rows, const float *coords,
                                      const void *grad_output, int dtype, void *grad_codebook, int level_begin,
                                      int level_end, int flags, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Forward / backward sharing one sample CONTEXT. A training step calls the forward and then the backward on the SAME
+ * coordinates (the reference's autograd Function saves them, wisp/ops/grid.py:85-87, :99-107). For large batches both
+ * directions first order the samples by the spatial block they fall in (hashgrid_tiled.hip: a counting sort giving a
+ * permutation, the coordinates in that order and a work list); with a caller-owned context buffer the forward builds
+ * that once and the backward of the same step reuses it instead of repeating the sort.
+ *
+ *   shacira_hashgrid_context_bytes   bytes of the context for this shape, or 0 when the shape does not use the
+ *                                    cell-sorted path in both directions (small batches, fp16 backward, options): then
+ *                                    pass context = NULL below, which makes the calls identical to the plain ones.
+ *   ctx_flags  SHACIRA_CTX_BUILD     the call builds the context from `coords` into `context` (forward; or a backward
+ *                                    that has no forward before it);
+ *              SHACIRA_CTX_REUSE     backward only: `context` was built by a call with the SAME coords pointer contents,
+ *                                    num_coords, dim and level arguments, earlier on the same stream (or ordered before
+ *                                    this call by the caller). Nothing in it is trusted beyond that contract.
+ * The context is plain device memory owned by the caller (keep it alive between the two calls: save it in the
+ * autograd ctx); it holds no pointers. The plain entry points above behave like these with context = NULL
+ * (the sort, when used, then lives in the workspace and is rebuilt by each call).
+ */
+#define SHACIRA_CTX_BUILD 1
+#define SHACIRA_CTX_REUSE 2
+SHACIRA_API size_t shacira_hashgrid_context_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                      int codebook_bitwidth, const int32_t *resolutions_host, int64_t table_rows,
+                                      int dtype);
+SHACIRA_API int shacira_hashgrid_forward_ctx(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                 int codebook_bitwidth, const int32_t *resolutions_host,
+                                 const int32_t *codebook_first_idx, int64_t table_rows, const float *coords,
+                                 const void *codebook, int dtype, void *feats, void *workspace, size_t workspace_bytes,
+                                 void *context, size_t context_bytes, int ctx_flags, void *stream);
+SHACIRA_API int shacira_hashgrid_backward_ctx(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                  int codebook_bitwidth, const int32_t *resolutions_host,
+                                  const int32_t *codebook_first_idx, int64_t table_rows, const float *coords,
+                                  const void *grad_output, int dtype, void *grad_codebook, void *workspace,
+                                  size_t workspace_bytes, void *context, size_t context_bytes, int ctx_flags,
+                                  void *stream);
 
 /*
  * Latent decode, deterministic (non-SGA) path of LatentDecoder.forward with num_layers_dec == 0
@@ -329,6 +365,9 @@ SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origi
  *               faster (up to 2^19 3-D / 2^20 2-D samples), 2 = always.
  *   "bwd_compact": 1 (default) = dense 3-D levels travel as one 32-byte item per sample (z-slab buckets), 0 = pair items.
  *   "mlp_variant": -1 (default) = decoder MLPs on the fp32 matrix cores wherever instantiated, 0 = VALU kernels.
+ *   "tiled": -1 (default) = the cell-sorted path (hashgrid_tiled.hip) for 3-D batches >= 2^18 samples, 0 = never,
+ *            1 = whenever the shape allows it. "fwd_variant" 8 / "bwd_variant" 2 also force it; other explicit variants exclude it.
+ *   "tiled_lc_fwd" / "tiled_lc_bwd": cap of its coarse (LDS sub-volume) level prefix, -1 (default) = planner's choice.
  *   "bwd_fork": 1 (default) = the backward's count + scan passes are issued on a library-owned side stream, forked
  *               from and joined back into the caller's stream with events (stream semantics unchanged); 0 = one stream.
  */

@@ -16,6 +16,11 @@ std::atomic<int> g_bwd_fuse{1};           // bucket counting fused into the tran
 std::atomic<int> g_bwd_fork{1};           // 1: count + scans of the backward on a side stream next to the transpose
 std::atomic<int> g_bin_acc_kib{0};        // LDS accumulator image per consumer workgroup, KiB: 64, 128, 0 = by batch size
 std::atomic<int> g_bin_batch_mib{1536};   // cap of the backward's item array per sub-batch, MiB
+std::atomic<int> g_tiled{-1};             // cell-sorted path (hashgrid_tiled.hip): -1 = by batch size, 0 = never, 1 = always
+std::atomic<int> g_tiled_lc_fwd{-1};      // cap of its coarse (LDS sub-volume) level prefix, forward; -1 = planner
+std::atomic<int> g_tiled_lc_bwd{-1};      // same, backward
+std::atomic<int> g_tiled_rows{1};         // tiled forward: coarse levels by the rows kernel (1) or the LDS sub-volume kernel (0)
+std::atomic<int> g_tiled_dbg{0};          // timing-only ablation mask (tools/): results are wrong when != 0
 
 static int build_level_table(int dim, int num_lods, int feature_dim, int bw, const int32_t *res_host,
                              int64_t table_rows, LevelTable &lt) {
@@ -82,6 +87,15 @@ int shacira_set_option(const char *name, int value) {
         return 0;
     }
     if (!std::strcmp(name, "bwd_compact")) { g_bwd_compact = value ? 1 : 0; return 0; }
+    if (!std::strcmp(name, "tiled")) {
+        if (value < -1 || value > 1) return SHACIRA_EINVAL;
+        g_tiled = value;
+        return 0;
+    }
+    if (!std::strcmp(name, "tiled_lc_fwd")) { g_tiled_lc_fwd = value < 0 ? -1 : value; return 0; }
+    if (!std::strcmp(name, "tiled_lc_bwd")) { g_tiled_lc_bwd = value < 0 ? -1 : value; return 0; }
+    if (!std::strcmp(name, "tiled_dbg")) { g_tiled_dbg = value; return 0; }
+    if (!std::strcmp(name, "tiled_rows")) { g_tiled_rows = value ? 1 : 0; return 0; }
     if (!std::strcmp(name, "bin_batch_mib")) {
         if (value < 1) return SHACIRA_EINVAL;
         g_bin_batch_mib = value;
@@ -89,6 +103,13 @@ int shacira_set_option(const char *name, int value) {
     }
     return SHACIRA_EINVAL;
 }
+
+#ifdef SHACIRA_TILED_STAMPS
+extern "C++" { namespace shacira { hipError_t tiled_read_stamps(unsigned long long *out32, int reset); } }
+extern "C" SHACIRA_API int shacira_debug_tiled_stamps(unsigned long long *out32_host, int reset) {
+    return (int)shacira::tiled_read_stamps(out32_host, reset);
+}
+#endif
 
 int shacira_get_option(const char *name) {
     if (!name) return SHACIRA_EINVAL;
@@ -100,6 +121,9 @@ int shacira_get_option(const char *name) {
     if (!std::strcmp(name, "mlp_variant")) return g_mlp_variant;
     if (!std::strcmp(name, "bwd_fuse")) return g_bwd_fuse;
     if (!std::strcmp(name, "bwd_compact")) return g_bwd_compact;
+    if (!std::strcmp(name, "tiled")) return g_tiled;
+    if (!std::strcmp(name, "tiled_lc_fwd")) return g_tiled_lc_fwd;
+    if (!std::strcmp(name, "tiled_lc_bwd")) return g_tiled_lc_bwd;
     return SHACIRA_EINVAL;
 }
 
@@ -115,6 +139,27 @@ int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feat
                              const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
                              const float *coords, const void *codebook, int dtype, void *feats, void *workspace,
                              size_t workspace_bytes, void *stream) {
+    return shacira_hashgrid_forward_ctx(dim, num_coords, num_lods, feature_dim, codebook_bitwidth, resolutions_host,
+                                        codebook_first_idx, table_rows, coords, codebook, dtype, feats, workspace,
+                                        workspace_bytes, nullptr, 0, 0, stream);
+}
+
+size_t shacira_hashgrid_context_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                                      const int32_t *resolutions_host, int64_t table_rows, int dtype) {
+    LevelTable lt;
+    if (build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt)) return 0;
+    if (num_coords < 1) return 0;
+    // a context is only worth keeping when BOTH directions of this shape take the cell-sorted path
+    if (!tiled_supported(dim, dtype, lt, num_coords, false) || !tiled_supported(dim, dtype, lt, num_coords, true))
+        return 0;
+    return tiled_context_bytes(dim, num_coords);
+}
+
+int shacira_hashgrid_forward_ctx(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                                 const int32_t *resolutions_host, const int32_t *codebook_first_idx,
+                                 int64_t table_rows, const float *coords, const void *codebook, int dtype, void *feats,
+                                 void *workspace, size_t workspace_bytes, void *context, size_t context_bytes,
+                                 int ctx_flags, void *stream) {
     LevelTable lt;
     int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
     if (rc) return rc;
@@ -124,8 +169,13 @@ int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feat
     if (!codebook_first_idx || !coords || !codebook || !feats) return SHACIRA_EINVAL;
     const size_t need = hashgrid_forward_workspace(dim, dtype, lt, num_coords);
     if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
+    if (context) {   // caller-owned context: only meaningful (and only accepted) where the cell-sorted path runs
+        if (ctx_flags != SHACIRA_CTX_BUILD) return SHACIRA_EINVAL;
+        if (!tiled_supported(dim, dtype, lt, num_coords, false)) return SHACIRA_EINVAL;
+        if (context_bytes < tiled_context_bytes(dim, num_coords)) return SHACIRA_EWORKSPACE;
+    }
     return (int)hashgrid_forward_dispatch(dim, dtype, lt, codebook_first_idx, coords, codebook, feats, workspace,
-                                          num_coords, (hipStream_t)stream);
+                                          num_coords, context, ctx_flags, (hipStream_t)stream);
 }
 
 size_t shacira_hashgrid_backward_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
@@ -143,6 +193,29 @@ int shacira_hashgrid_backward(int dim, int64_t num_coords, int num_lods, int fea
     return shacira_hashgrid_backward_levels(dim, num_coords, num_lods, feature_dim, codebook_bitwidth, resolutions_host,
                                             codebook_first_idx, table_rows, coords, grad_output, dtype, grad_codebook,
                                             0, num_lods, 0, workspace, workspace_bytes, stream);
+}
+
+int shacira_hashgrid_backward_ctx(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                                  const int32_t *resolutions_host, const int32_t *codebook_first_idx,
+                                  int64_t table_rows, const float *coords, const void *grad_output, int dtype,
+                                  void *grad_codebook, void *workspace, size_t workspace_bytes, void *context,
+                                  size_t context_bytes, int ctx_flags, void *stream) {
+    LevelTable lt;
+    int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
+    if (rc) return rc;
+    if (dtype != SHACIRA_F32 && dtype != SHACIRA_F16) return SHACIRA_EDTYPE;
+    if (num_coords < 0 || !grad_codebook) return SHACIRA_EINVAL;
+    if (num_coords > 0 && (!codebook_first_idx || !coords || !grad_output)) return SHACIRA_EINVAL;
+    if (context) {
+        if (ctx_flags != SHACIRA_CTX_BUILD && ctx_flags != SHACIRA_CTX_REUSE) return SHACIRA_EINVAL;
+        if (num_coords < 1 || !tiled_supported(dim, dtype, lt, num_coords, true)) return SHACIRA_EINVAL;
+        if (context_bytes < tiled_context_bytes(dim, num_coords)) return SHACIRA_EWORKSPACE;
+    }
+    const size_t need = hashgrid_backward_workspace(dim, dtype, lt, num_coords);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
+    return (int)hashgrid_backward_dispatch(dim, dtype, lt, codebook_first_idx, coords, grad_output, grad_codebook,
+                                           workspace, workspace_bytes, num_coords, context, ctx_flags,
+                                           (hipStream_t)stream);
 }
 
 int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
@@ -165,7 +238,7 @@ int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, int num_lods, 
     const size_t need = hashgrid_backward_workspace(dim, dtype, lt, num_coords);
     if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
     return (int)hashgrid_backward_dispatch(dim, dtype, lt, codebook_first_idx, coords, grad_output, grad_codebook,
-                                           workspace, workspace_bytes, num_coords, (hipStream_t)stream);
+                                           workspace, workspace_bytes, num_coords, nullptr, 0, (hipStream_t)stream);
 }
 
 int shacira_latent_decode_forward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,

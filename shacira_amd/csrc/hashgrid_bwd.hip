@@ -111,11 +111,7 @@ static hipError_t bwd_atomic_f(const LevelTable &lt, const int32_t *first_idx, c
 }
 
 // hashgrid_bwd_bin.hip
-bool bin_supported(int dim, const LevelTable &lt);
-size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n);
-float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace);
-hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table);
+
 
 // variant 1 ("bin") whenever the shape allows it and the batch is big enough to amortise its fixed passes
 static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
@@ -125,7 +121,17 @@ static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
     return n >= 8192;
 }
 
+static bool use_tiled_bwd(int dim, int dtype, const LevelTable &lt, int64_t n) {
+    const bool full = lt.level_begin == 0 && lt.level_end == lt.num_lods && lt.stage_flags == 0;
+    return full && tiled_supported(dim, dtype, lt, n, true);
+}
+
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
+    if (n > 0 && tiled_supported(dim, dtype, lt, n, true)) {
+        // level-range calls on the same shape use the bin pipeline: size for both
+        const size_t a = tiled_backward_workspace(dim, dtype, lt, n), b = bin_workspace_bytes(dim, dtype, lt, n);
+        return a > b ? a : b;
+    }
     size_t need = (dtype == SHACIRA_F16) ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0;
     if (bin_supported(dim, lt) && n > 0) {
         const size_t b = bin_workspace_bytes(dim, dtype, lt, n);
@@ -136,8 +142,12 @@ size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int
 
 hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                       const float *coords, const void *grad_out, void *grad_table, void *workspace,
-                                      size_t workspace_bytes, int64_t n, hipStream_t s) {
+                                      size_t workspace_bytes, int64_t n, void *context, int ctx_flags,
+                                      hipStream_t s) {
     (void)workspace_bytes;
+    if (n > 0 && use_tiled_bwd(dim, dtype, lt, n))   // fp32 tables, all levels: cell-sorted path (hashgrid_tiled.hip)
+        return tiled_backward(dim, dtype, lt, first_idx, coords, grad_out, static_cast<float *>(grad_table), workspace,
+                              n, context, ctx_flags, s);
     const int64_t numel = lt.table_rows * lt.feature_dim;
     const bool bin = n > 0 && use_bin(dim, lt, n);
     // fp16 tables accumulate in an fp32 image: the tail of the bin workspace, or the whole workspace (atomic variant)
@@ -158,7 +168,7 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
     }
     if (e != hipSuccess) return e;
     if (bin) {
-        e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s, full);
+        e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s, full, nullptr, nullptr);
         if (e != hipSuccess) return e;
     } else if (n > 0) {
         if (dim == 3) {

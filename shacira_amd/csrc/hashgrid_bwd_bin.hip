@@ -26,6 +26,7 @@
 #include <mutex>
 
 #include "internal.h"
+#include "fixed_point.h"
 
 namespace shacira {
 
@@ -140,47 +141,15 @@ __device__ __forceinline__ void enumerate_pairs(const double (&t)[DIM], int32_t 
     }
 }
 
-// ------------------------------------------------------------------------------------------------ fixed point
-// LDS integer atomics run 1.6x faster than ds_add_f64 (2.1-2.5 vs 1.3-1.4 T op/s, profiles/r01_microbench2), so the
-// accumulator images hold 64-bit fixed-point numbers. Scale per level: gmax[l] = max |grad_output| over the level's
-// columns (bit pattern of the float, gathered by pass T for free; integer max on the bits orders
-// finite < inf < NaN). Every contribution is |g * weight| <= gmax < 2^e, so with scale 2^(headroom - e) a contribution
-// stays below 2^headroom and n_max of them below 2^62: headroom = min(50, 62 - ceil(log2(n_max))). Conversion is one
-// fp64 fma with the 1.5 * 2^52 constant (the integer appears in the low mantissa bits) -- exact to the scale's LSB, i.e.
-// 2^-headroom relative to gmax (>= 41 bits here vs 24 of the reference's fp32 atomics) and order-independent.
-// A level whose gmax is inf / NaN falls back to the fp64 image so that non-finite gradients propagate as before.
-struct FxScale {
-    double scale, inv;   // 2^k, 2^-k
-    bool fixed;          // false: accumulate in fp64 (non-finite gradients)
-};
-__device__ __forceinline__ FxScale fx_scale_of(uint32_t gmax_bits, int headroom) {
-    FxScale f;
-    f.fixed = gmax_bits < 0x7F800000u;
-    int e = (int)((gmax_bits >> 23) & 0xFFu) - 126;   // |g| < 2^e for normal floats; denormals / zero: e = -126
-    if (e < -126) e = -126;
-    const int k = headroom - e;
-    f.scale = __longlong_as_double((long long)(1023 + k) << 52);
-    f.inv = __longlong_as_double((long long)(1023 - k) << 52);
-    return f;
-}
-__device__ __forceinline__ unsigned long long fx_encode(float c, double scale) {
-    const double magic = 6755399441055744.0;   // 1.5 * 2^52
-    return (unsigned long long)(__double_as_longlong(fma((double)c, scale, magic)) - __double_as_longlong(magic));
-}
-__device__ __forceinline__ float fx_decode(unsigned long long v, double inv) { return (float)((double)(long long)v * inv); }
-static inline int fx_headroom(uint64_t n_max) {
-    int bits = 0;
-    while (((uint64_t)1 << bits) < n_max) ++bits;
-    const int h = 62 - bits;
-    return h > 50 ? 50 : (h < 24 ? 24 : h);
-}
-
 // ------------------------------------------------------------------------------------------------- pass T
 // grad_output [N, L*F] (T) -> gT [L][N][F] fp32, through LDS, F scalars per lane per access. Block: 256 samples.
 template <typename T, int F, bool GMAX>
 __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict__ go, float *__restrict__ gT,
                                                              int64_t N, int L, int lb, int le,
-                                                             uint32_t *__restrict__ gmax) {
+                                                             uint32_t *__restrict__ gmax,
+                                                             const uint32_t *__restrict__ perm) {
+    // perm != NULL: staged row j is the gradient row of sample perm[j] (cell-sorted order of hashgrid_tiled.hip);
+    // a row is L*F contiguous scalars (128 B for L16 F2 fp32), so the gather still moves whole lines
     __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
     if (GMAX && threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
     struct alignas(sizeof(T) * F) PieceIn { T v[F]; };
@@ -191,10 +160,11 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
     const int64_t s0 = (int64_t)blockIdx.x * 256;
     const int ns = (int)((N - s0 < 256) ? (N - s0) : 256);
     const PieceIn *in = reinterpret_cast<const PieceIn *>(go) + s0 * L;
+    const PieceIn *in0 = reinterpret_cast<const PieceIn *>(go);
     const int total = ns * L;
     for (int e = threadIdx.x; e < total; e += 256) {
         const int sm = e / L, l = e - sm * L;
-        const PieceIn p = in[e];
+        const PieceIn p = perm ? in0[(int64_t)perm[s0 + sm] * L + l] : in[e];
         PieceOut q;
 #pragma unroll
         for (int j = 0; j < F; ++j) q.v[j] = Scalar<T>::load(&p.v[j]);
@@ -1087,6 +1057,14 @@ float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *work
     return carve(dim, dtype, lt, n, workspace).acc32;
 }
 
+// staged gradients gT [L][N][F] fp32 and the per-level max |grad| bit patterns inside a bin workspace
+void bin_staged_pointers(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace, float **gT,
+                         uint32_t **gmax) {
+    const BinWorkspace w = carve(dim, dtype, lt, n, workspace);
+    *gT = w.gT;
+    *gmax = w.gmax;
+}
+
 #define SHACIRA_CHECK_LAUNCH()                 \
     do {                                       \
         hipError_t e_ = hipGetLastError();     \
@@ -1129,7 +1107,8 @@ static hipError_t side_stream(SideStream **out) {
 template <int DIM, int F>
 static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                           const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s,
-                          bool zero_table) {
+                          bool zero_table, const uint32_t *perm,
+                          const std::function<hipError_t(hipStream_t)> *stage_hook) {
     const int L = lt.num_lods;
     BinPlan whole;
     const int acc_kib = choose_acc_kib(DIM, lt, n);
@@ -1148,7 +1127,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // measured (tools/fuse_check.py): fused wins by 4-9 % up to 2^19 3-D samples, loses 3-4 % at 2^20 ("bwd_fuse": 0 = never,
     // 1 = by that rule, 2 = always)
     const int fuse_opt = g_bwd_fuse.load();
-    const bool fuse = can_fork && need_T && !staged &&
+    const bool fuse = can_fork && need_T && !staged && !perm &&
                       (fuse_opt == 2 || (fuse_opt == 1 && n * ((int64_t)1 << (DIM - 1)) <= ((int64_t)1 << 21)));
     if (can_fork) {
         hipError_t e = side_stream(&ss);
@@ -1222,17 +1201,21 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
         if (dtype == SHACIRA_F32 && use_fx)
             hipLaunchKernelGGL((transpose_grad_kernel<float, F, true>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax);
+                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax, perm);
         else if (dtype == SHACIRA_F32)
             hipLaunchKernelGGL((transpose_grad_kernel<float, F, false>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr);
+                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr, perm);
         else if (use_fx)
             hipLaunchKernelGGL((transpose_grad_kernel<__half, F, true>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax);
+                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax, perm);
         else
             hipLaunchKernelGGL((transpose_grad_kernel<__half, F, false>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr);
+                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr, perm);
         SHACIRA_CHECK_LAUNCH();
+    }
+    if (stage_hook) {   // REUSE_STAGED caller that stages on this stream now (hashgrid_tiled.hip), next to the forked passes
+        hipError_t e = (*stage_hook)(s);
+        if (e != hipSuccess) return e;
     }
     // When nothing is transposed (every level is direct: the image configs) gmax would cost an extra read of grad_output
     // (tried: a streaming abs-max kernel); measured on config B it costs more than the faster atomics return (0.103 vs
@@ -1327,8 +1310,11 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     return hipSuccess;
 }
 
+// perm != NULL: `coords` are the cell-sorted coordinates of hashgrid_tiled.hip and staged row j belongs to sample perm[j]
+// (the transpose gathers through it); everything downstream then works in sorted order.
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table) {
+                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table,
+                        const uint32_t *perm, const std::function<hipError_t(hipStream_t)> *stage_hook) {
     const BinWorkspace w = carve(dim, dtype, lt, n, workspace);
     static std::once_flag once;  // kernels that use more than 64 KiB of dynamic LDS must opt in once per process
     static hipError_t attr_err = hipSuccess;
@@ -1366,11 +1352,11 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
     });
     if (attr_err != hipSuccess) return attr_err;
     if (dim == 3) {
-        return lt.feature_dim == 2 ? run_bin<3, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table)
-                                   : run_bin<3, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table);
+        return lt.feature_dim == 2 ? run_bin<3, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, perm, stage_hook)
+                                   : run_bin<3, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, perm, stage_hook);
     }
-    return lt.feature_dim == 2 ? run_bin<2, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table)
-                               : run_bin<2, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table);
+    return lt.feature_dim == 2 ? run_bin<2, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, perm, stage_hook)
+                               : run_bin<2, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, perm, stage_hook);
 }
 
 }  // namespace shacira

@@ -301,6 +301,127 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_pair_kernel(LevelTable lt, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Tiled forward, rows kernel (hashgrid_tiled.hip): variant 3's lane pairing over CELL-SORTED coordinates for the coarse
+// levels [0, lc) -- consecutive samples sit in the same spatial block, so their corner rows come out of L1 (measured:
+// a gather instruction whose lines hit L1 costs ~35 clk against ~84-148 from L2) -- then the fine levels' pieces are
+// read from the level-major staging buffer the level-per-XCD kernel wrote, and whole feature rows leave through the
+// permutation: feats[perm[i]] = row i (full contiguous rows, 16-byte chunks when the row size allows).
+template <int DIM, typename T, int F>
+__global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, const int32_t *__restrict__ first_idx,
+                                                                const float *__restrict__ coords,
+                                                                const uint32_t *__restrict__ perm,
+                                                                const T *__restrict__ table,
+                                                                const T *__restrict__ staged, T *__restrict__ feats,
+                                                                int64_t N, int lc) {
+    constexpr int NH = 1 << (DIM - 1);
+    struct alignas(sizeof(T) * F) Piece { T v[F]; };
+    extern __shared__ __align__(16) unsigned char s_rows_raw[];   // [4 waves][32 samples][pitch]
+    const int L = lt.num_lods;
+    const uint32_t row_bytes = (uint32_t)(L * F * sizeof(T));
+    const uint32_t pitch = (row_bytes + 15u) / 16u * 16u + 16u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dx = lane & 1, sl = lane >> 1;
+    unsigned char *my = s_rows_raw + (size_t)wave * 32 * pitch;
+    const int64_t wave_s0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t i = wave_s0 + sl;
+    const bool live = i < N;
+    double t[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live ? coords[i * DIM + a] : 0.0f);
+#pragma unroll 1
+    for (int l = 0; l < lc; ++l) {
+        const int32_t res = lt.res[l];
+        const float hi = lt.hi[l];
+        const bool dense = lt.dense[l] != 0;
+        int32_t p[DIM];
+        float f[DIM], g[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) axis_transform(t[a], res, hi, p[a], f[a], g[a]);
+        const uint32_t ux = (uint32_t)p[0] + (uint32_t)dx;
+        const uint32_t r = (uint32_t)res;
+        const int64_t base = (int64_t)first_idx[l];
+        float v[NH][F];
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+            const int dy = (DIM == 3) ? (q >> 1) : q;
+            const int dz = (DIM == 3) ? (q & 1) : 0;
+            const uint32_t uy = (uint32_t)p[1] + dy;
+            uint32_t row;
+            if (dense) {
+                row = ux + uy * r;
+                if constexpr (DIM == 3) row += ((uint32_t)p[2] + dz) * r * r;
+            } else {
+                row = ux ^ (uy * kPrimeY);
+                if constexpr (DIM == 3) row ^= ((uint32_t)p[2] + dz) * kPrimeZ;
+                row &= lt.mask;
+            }
+            const int64_t grow = base + (int64_t)row;
+            if (live && (uint64_t)grow < (uint64_t)lt.table_rows) {
+                load_row<T, F>(table + grow * F, v[q]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < F; ++j) v[q][j] = 0.0f;
+            }
+        }
+        float pv[NH][F];
+#pragma unroll
+        for (int q = 0; q < NH; ++q)
+#pragma unroll
+            for (int j = 0; j < F; ++j)
+                pv[q][j] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[q][j]), 0xB1, 0xF, 0xF, true));
+        if (dx == 0) {
+            float acc[F];
+#pragma unroll
+            for (int k = 0; k < 2 * NH; ++k) {
+                const int kx = k / NH, q = k % NH;
+                const int dy = (DIM == 3) ? (q >> 1) : q;
+                const int dz = (DIM == 3) ? (q & 1) : 0;
+                float w = (kx ? f[0] : g[0]) * (dy ? f[1] : g[1]);
+                if constexpr (DIM == 3) w = w * (dz ? f[2] : g[2]);
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    const float tv = kx ? pv[q][j] : v[q][j];
+                    acc[j] = (k == 0) ? tv * w : fmaf(tv, w, acc[j]);
+                }
+            }
+            store_row<T, F>(reinterpret_cast<T *>(my + (size_t)sl * pitch) + l * F, acc);
+        }
+    }
+    const int64_t rows = (N - wave_s0 < 32) ? (N - wave_s0) : 32;
+    if (rows <= 0) return;
+    // fine levels: pieces of the wave's 32 samples, lanes consecutive along the samples
+    const Piece *fine = reinterpret_cast<const Piece *>(staged);
+    const int nf = L - lc;
+    for (int e = lane; e < 32 * nf; e += 64) {
+        const int rr = e & 31, lf = e >> 5;
+        if (rr < rows)
+            reinterpret_cast<Piece *>(my + (size_t)rr * pitch)[lc + lf] = fine[(int64_t)(lc + lf) * N + wave_s0 + rr];
+    }
+    if (lane < rows) *reinterpret_cast<uint32_t *>(my + (size_t)lane * pitch + pitch - 16u) = perm[wave_s0 + lane];
+    // wave-private staging: no workgroup barrier (the wave's own LDS writes are visible to it after the wait below)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (row_bytes % 16u == 0) {
+        const uint32_t cpr = row_bytes / 16u;
+        for (uint32_t e = lane; e < (uint32_t)rows * cpr; e += 64) {
+            const uint32_t rr = e / cpr, q = e - rr * cpr;
+            const unsigned char *src = my + (size_t)rr * pitch;
+            const uint32_t pr = *reinterpret_cast<const uint32_t *>(src + pitch - 16u);
+            *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(feats) + (size_t)pr * row_bytes + q * 16u) =
+                *reinterpret_cast<const uint4 *>(src + q * 16u);
+        }
+    } else {
+        for (uint32_t e = lane; e < (uint32_t)rows * (uint32_t)L; e += 64) {
+            const uint32_t rr = e / (uint32_t)L, l = e - rr * (uint32_t)L;
+            const unsigned char *src = my + (size_t)rr * pitch;
+            const uint32_t pr = *reinterpret_cast<const uint32_t *>(src + pitch - 16u);
+            reinterpret_cast<Piece *>(feats)[(size_t)pr * L + l] = reinterpret_cast<const Piece *>(src)[l];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Variant 2 ("level per XCD"): block = (level, tile of 256 samples). Blocks are numbered so that the blocks an
 // XCD receives under round-robin dispatch (blockIdx % 8, a speed assumption only) all work on the same level:
 // XCD k walks levels k, k+8, k+16, ... one after the other, so its 4 MiB L2 holds exactly one level table and
@@ -356,9 +477,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
     constexpr int NH = 1 << (DIM - 1);
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t qb = blockIdx.x >> 3;
-    const uint32_t lvl = xcd + 8u * (qb / tiles);
+    const uint32_t lvl = (uint32_t)lt.level_begin + xcd + 8u * (qb / tiles);   // levels [level_begin, level_end)
     const uint32_t tile = qb % tiles;
-    if (lvl >= (uint32_t)lt.num_lods) return;
+    if (lvl >= (uint32_t)lt.level_end) return;
     const int dx = threadIdx.x & 1;
     const int32_t res = lt.res[lvl];
     const float hi = lt.hi[lvl];
@@ -604,7 +725,98 @@ static bool use_sorted(int dim, const LevelTable &lt, int64_t n) {
     return g_fwd_variant.load() == 7 && n > 0;
 }
 
+// levels [lt.level_begin, lt.level_end) of the level-per-XCD pair kernel into a level-major staging buffer [L][N][F]
+// (used by hashgrid_tiled.hip for the fine levels, over cell-sorted coordinates)
+template <int DIM, typename T, int F>
+static hipError_t launch_levels_staged(const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                                       const void *table, void *staged, int64_t n, hipStream_t s) {
+    const uint32_t nl = (uint32_t)(lt.level_end - lt.level_begin);
+    const uint32_t groups = (nl + 7) / 8;
+    const uint32_t tiles = (uint32_t)((n + 127) / 128);
+    hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true>), dim3(8u * tiles * groups), dim3(256), 0, s,
+                       lt, first_idx, coords, static_cast<const T *>(table), static_cast<T *>(staged), n, tiles);
+    return hipGetLastError();
+}
+
+hipError_t hashgrid_forward_levels_staged(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
+                                          const float *coords, const void *table, void *staged, int64_t n,
+                                          hipStream_t s) {
+    const int F = lt.feature_dim;
+    if (F != 2 && F != 4) return hipErrorInvalidValue;
+    if (dim == 3 && dtype == SHACIRA_F32)
+        return F == 2 ? launch_levels_staged<3, float, 2>(lt, first_idx, coords, table, staged, n, s)
+                      : launch_levels_staged<3, float, 4>(lt, first_idx, coords, table, staged, n, s);
+    if (dim == 3)
+        return F == 2 ? launch_levels_staged<3, __half, 2>(lt, first_idx, coords, table, staged, n, s)
+                      : launch_levels_staged<3, __half, 4>(lt, first_idx, coords, table, staged, n, s);
+    if (dtype == SHACIRA_F32)
+        return F == 2 ? launch_levels_staged<2, float, 2>(lt, first_idx, coords, table, staged, n, s)
+                      : launch_levels_staged<2, float, 4>(lt, first_idx, coords, table, staged, n, s);
+    return F == 2 ? launch_levels_staged<2, __half, 2>(lt, first_idx, coords, table, staged, n, s)
+                  : launch_levels_staged<2, __half, 4>(lt, first_idx, coords, table, staged, n, s);
+}
+
+template <int DIM, typename T, int F>
+static hipError_t launch_rows(const LevelTable &lt, const int32_t *first_idx, const float *sorted, const uint32_t *perm,
+                              const void *table, const void *staged, void *feats, int64_t n, int lc, hipStream_t s) {
+    const uint32_t row_bytes = (uint32_t)(lt.num_lods * F * sizeof(T));
+    const size_t shmem = (size_t)128 * ((row_bytes + 15u) / 16u * 16u + 16u);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hashgrid_fwd_rows_kernel<DIM, T, F>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    });
+    hipLaunchKernelGGL((hashgrid_fwd_rows_kernel<DIM, T, F>), dim3((uint32_t)((n + 127) / 128)), dim3(256), shmem, s, lt,
+                       first_idx, sorted, perm, static_cast<const T *>(table), static_cast<const T *>(staged),
+                       static_cast<T *>(feats), n, lc);
+    return hipGetLastError();
+}
+
+// coarse levels [0, lc) over cell-sorted coordinates + assembly of whole rows through perm (hashgrid_tiled.hip)
+hipError_t hashgrid_forward_rows(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *sorted,
+                                 const uint32_t *perm, const void *table, const void *staged, void *feats, int64_t n,
+                                 int lc, hipStream_t s) {
+    const int F = lt.feature_dim;
+    if (F != 2 && F != 4) return hipErrorInvalidValue;
+    if (dim == 3 && dtype == SHACIRA_F32)
+        return F == 2 ? launch_rows<3, float, 2>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s)
+                      : launch_rows<3, float, 4>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s);
+    if (dim == 3)
+        return F == 2 ? launch_rows<3, __half, 2>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s)
+                      : launch_rows<3, __half, 4>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s);
+    if (dtype == SHACIRA_F32)
+        return F == 2 ? launch_rows<2, float, 2>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s)
+                      : launch_rows<2, float, 4>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s);
+    return F == 2 ? launch_rows<2, __half, 2>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s)
+                  : launch_rows<2, __half, 4>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s);
+}
+
+template <typename T, int F>
+static hipError_t launch_untranspose(const void *staged, void *feats, int64_t n, int L, const uint32_t *perm,
+                                     hipStream_t s) {
+    const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(T);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&untranspose_feats_kernel<T, F>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    });
+    hipLaunchKernelGGL((untranspose_feats_kernel<T, F>), dim3((uint32_t)((n + 255) / 256)), dim3(256), shmem, s,
+                       static_cast<const T *>(staged), static_cast<T *>(feats), n, L, perm);
+    return hipGetLastError();
+}
+
+// staging [L][N][F] -> feats [N, L*F]; perm != NULL: staged row j belongs to sample perm[j]
+hipError_t hashgrid_untranspose(int dtype, int F, const void *staged, void *feats, int64_t n, int L,
+                                const uint32_t *perm, hipStream_t s) {
+    if (dtype == SHACIRA_F32)
+        return F == 2 ? launch_untranspose<float, 2>(staged, feats, n, L, perm, s)
+                      : launch_untranspose<float, 4>(staged, feats, n, L, perm, s);
+    return F == 2 ? launch_untranspose<__half, 2>(staged, feats, n, L, perm, s)
+                  : launch_untranspose<__half, 4>(staged, feats, n, L, perm, s);
+}
+
 size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
+    if (tiled_supported(dim, dtype, lt, n, false)) return tiled_forward_workspace(dim, dtype, lt, n);
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return 0;
     size_t b = ((size_t)n * lt.num_lods * lt.feature_dim * (dtype == SHACIRA_F32 ? 4 : 2) + 255) / 256 * 256;
     if (use_sorted(dim, lt, n)) b += cell_sort_workspace_bytes(dim, n);
@@ -613,7 +825,9 @@ size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int6
 
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                      const float *coords, const void *table, void *feats, void *ws, int64_t n,
-                                     hipStream_t s) {
+                                     void *context, int ctx_flags, hipStream_t s) {
+    if (tiled_supported(dim, dtype, lt, n, false))
+        return tiled_forward(dim, dtype, lt, first_idx, coords, table, feats, ws, n, context, ctx_flags, s);
     if (dim == 3) {
         return dtype == SHACIRA_F32 ? dispatch_f<3, float>(lt, first_idx, coords, table, feats, ws, n, s)
                                     : dispatch_f<3, __half>(lt, first_idx, coords, table, feats, ws, n, s);

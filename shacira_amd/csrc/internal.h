@@ -2,6 +2,7 @@
 #pragma once
 
 #include <atomic>
+#include <functional>
 #include <mutex>
 
 #include "hashgrid_device.h"
@@ -12,7 +13,7 @@ namespace shacira {
 size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                      const float *coords, const void *table, void *feats, void *workspace, int64_t n,
-                                     hipStream_t s);
+                                     void *context, int ctx_flags, hipStream_t s);
 // cell_sort.hip
 size_t cell_sort_workspace_bytes(int dim, int64_t n);
 hipError_t cell_sort(int dim, const float *coords, int64_t n, void *ws, uint32_t **perm_out, float **sorted_out,
@@ -21,7 +22,37 @@ hipError_t cell_sort(int dim, const float *coords, int64_t n, void *ws, uint32_t
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
 hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                       const float *coords, const void *grad_out, void *grad_table, void *workspace,
-                                      size_t workspace_bytes, int64_t n, hipStream_t s);
+                                      size_t workspace_bytes, int64_t n, void *context, int ctx_flags, hipStream_t s);
+
+// hashgrid_bwd_bin.hip
+bool bin_supported(int dim, const LevelTable &lt);
+size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n);
+float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace);
+void bin_staged_pointers(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace, float **gT,
+                         uint32_t **gmax);
+hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table,
+                        const uint32_t *perm, const std::function<hipError_t(hipStream_t)> *stage_hook);
+// hashgrid_fwd.hip: levels [lt.level_begin, lt.level_end) of the level-per-XCD pair kernel into staged [L][N][F]
+hipError_t hashgrid_forward_levels_staged(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
+                                          const float *coords, const void *table, void *staged, int64_t n,
+                                          hipStream_t s);
+hipError_t hashgrid_forward_rows(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *sorted,
+                                 const uint32_t *perm, const void *table, const void *staged, void *feats, int64_t n,
+                                 int lc, hipStream_t s);
+hipError_t hashgrid_untranspose(int dtype, int F, const void *staged, void *feats, int64_t n, int L,
+                                const uint32_t *perm, hipStream_t s);
+// hashgrid_tiled.hip: cell-sorted ("tiled") forward / backward for large batches
+bool tiled_supported(int dim, int dtype, const LevelTable &lt, int64_t n, bool backward);
+size_t tiled_context_bytes(int dim, int64_t n);
+size_t tiled_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
+size_t tiled_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
+hipError_t tiled_forward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                         const void *table, void *feats, void *workspace, int64_t n, void *context, int ctx_flags,
+                         hipStream_t s);
+hipError_t tiled_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                          const void *grad_out, float *acc, void *workspace, int64_t n, void *context, int ctx_flags,
+                          hipStream_t s);
 
 // latent.hip
 struct DecodeArgs {
@@ -98,5 +129,10 @@ extern std::atomic<int> g_bwd_fork;
 extern std::atomic<int> g_bwd_fuse;
 extern std::atomic<int> g_bwd_compact;
 extern std::atomic<int> g_mlp_variant;
+extern std::atomic<int> g_tiled;          // -1 auto, 0 off, 1 force the cell-sorted path
+extern std::atomic<int> g_tiled_lc_fwd;   // coarse (LDS-region) levels of the tiled forward, -1 = planner
+extern std::atomic<int> g_tiled_lc_bwd;
+extern std::atomic<int> g_tiled_rows;     // forward coarse levels: 1 = L1-resident gathers over sorted samples (rows kernel), 0 = LDS sub-volumes
+extern std::atomic<int> g_tiled_dbg;      // timing-only ablation mask of the unit kernels (results are wrong when != 0)
 
 }  // namespace shacira

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""S1 fwd + bwd (context shared) a few times -- run under rocprofv3 --kernel-trace --stats."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from shacira_amd import hip_ops, _lib
+
+def geo(mn, mx, L):
+    b = np.exp((np.log(mx) - np.log(mn)) / (L - 1)); return [int(1 + np.floor(mn * (b ** l))) for l in range(L)]
+
+dim = int(os.environ.get("DIM", 3)); bw = 19; N = int(os.environ.get("N", 1 << 20))
+res, F = geo(16, 2048, 16), 2
+sizes = [min(2 ** bw, r ** dim) for r in res]
+first = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)).cuda()
+T = sum(sizes)
+g = torch.Generator().manual_seed(0)
+table = (torch.randn(T, F, generator=g) * 0.01).cuda()
+coords = (torch.rand(N, dim, generator=g) * 2 - 1).cuda()
+go = torch.randn(N, 32, generator=g).cuda()
+for _ in range(int(os.environ.get("ITERS", 10))):
+    feats, ctx = hip_ops._hashgrid_forward(dim, coords, table, first, res, bw, want_context=True)
+    hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F, context=ctx)
+torch.cuda.synchronize()
