@@ -12,15 +12,13 @@ std::atomic<int> g_fwd_variant{-1};
 std::atomic<int> g_bwd_variant{-1};
 std::atomic<int> g_mlp_variant{-1};       // -1: MFMA decoders wherever instantiated, 0: VALU kernels
 std::atomic<int> g_bwd_compact{1};        // dense 3-D levels: one 32-byte item per sample, z-slab buckets with a halo plane
+std::atomic<int> g_bwd_rows{1};           // backward: pass T fused into pass B (bin_scatter_rows_kernel)
 std::atomic<int> g_bwd_fuse{1};           // bucket counting fused into the transpose pass
 std::atomic<int> g_bwd_fork{1};           // 1: count + scans of the backward on a side stream next to the transpose
 std::atomic<int> g_bin_acc_kib{0};        // LDS accumulator image per consumer workgroup, KiB: 64, 128, 0 = by batch size
 std::atomic<int> g_bin_batch_mib{1536};   // cap of the backward's item array per sub-batch, MiB
-std::atomic<int> g_tiled{-1};             // cell-sorted path (hashgrid_tiled.hip): -1 = by batch size, 0 = never, 1 = always
-std::atomic<int> g_tiled_lc_fwd{-1};      // cap of its coarse (LDS sub-volume) level prefix, forward; -1 = planner
-std::atomic<int> g_tiled_lc_bwd{-1};      // same, backward
-std::atomic<int> g_tiled_rows{1};         // tiled forward: coarse levels by the rows kernel (1) or the LDS sub-volume kernel (0)
-std::atomic<int> g_tiled_dbg{0};          // timing-only ablation mask (tools/): results are wrong when != 0
+std::atomic<int> g_tiled{-1};             // cell-sorted forward (hashgrid_tiled.hip): -1 = by batch size, 0 = never, 1 = always
+std::atomic<int> g_tiled_lc_fwd{-1};      // its number of coarse levels (rows kernel), -1 = planner
 
 static int build_level_table(int dim, int num_lods, int feature_dim, int bw, const int32_t *res_host,
                              int64_t table_rows, LevelTable &lt) {
@@ -87,15 +85,13 @@ int shacira_set_option(const char *name, int value) {
         return 0;
     }
     if (!std::strcmp(name, "bwd_compact")) { g_bwd_compact = value ? 1 : 0; return 0; }
+    if (!std::strcmp(name, "bwd_rows")) { g_bwd_rows = value ? 1 : 0; return 0; }
     if (!std::strcmp(name, "tiled")) {
         if (value < -1 || value > 1) return SHACIRA_EINVAL;
         g_tiled = value;
         return 0;
     }
     if (!std::strcmp(name, "tiled_lc_fwd")) { g_tiled_lc_fwd = value < 0 ? -1 : value; return 0; }
-    if (!std::strcmp(name, "tiled_lc_bwd")) { g_tiled_lc_bwd = value < 0 ? -1 : value; return 0; }
-    if (!std::strcmp(name, "tiled_dbg")) { g_tiled_dbg = value; return 0; }
-    if (!std::strcmp(name, "tiled_rows")) { g_tiled_rows = value ? 1 : 0; return 0; }
     if (!std::strcmp(name, "bin_batch_mib")) {
         if (value < 1) return SHACIRA_EINVAL;
         g_bin_batch_mib = value;
@@ -103,13 +99,6 @@ int shacira_set_option(const char *name, int value) {
     }
     return SHACIRA_EINVAL;
 }
-
-#ifdef SHACIRA_TILED_STAMPS
-extern "C++" { namespace shacira { hipError_t tiled_read_stamps(unsigned long long *out32, int reset); } }
-extern "C" SHACIRA_API int shacira_debug_tiled_stamps(unsigned long long *out32_host, int reset) {
-    return (int)shacira::tiled_read_stamps(out32_host, reset);
-}
-#endif
 
 int shacira_get_option(const char *name) {
     if (!name) return SHACIRA_EINVAL;
@@ -121,9 +110,9 @@ int shacira_get_option(const char *name) {
     if (!std::strcmp(name, "mlp_variant")) return g_mlp_variant;
     if (!std::strcmp(name, "bwd_fuse")) return g_bwd_fuse;
     if (!std::strcmp(name, "bwd_compact")) return g_bwd_compact;
+    if (!std::strcmp(name, "bwd_rows")) return g_bwd_rows;
     if (!std::strcmp(name, "tiled")) return g_tiled;
     if (!std::strcmp(name, "tiled_lc_fwd")) return g_tiled_lc_fwd;
-    if (!std::strcmp(name, "tiled_lc_bwd")) return g_tiled_lc_bwd;
     return SHACIRA_EINVAL;
 }
 
@@ -148,11 +137,8 @@ size_t shacira_hashgrid_context_bytes(int dim, int64_t num_coords, int num_lods,
                                       const int32_t *resolutions_host, int64_t table_rows, int dtype) {
     LevelTable lt;
     if (build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt)) return 0;
-    if (num_coords < 1) return 0;
-    // a context is only worth keeping when BOTH directions of this shape take the cell-sorted path
-    if (!tiled_supported(dim, dtype, lt, num_coords, false) || !tiled_supported(dim, dtype, lt, num_coords, true))
-        return 0;
-    return tiled_context_bytes(dim, num_coords);
+    if (num_coords < 1 || g_bwd_variant.load() == 0) return 0;
+    return bin_context_bytes(dim, dtype, lt, num_coords);
 }
 
 int shacira_hashgrid_forward_ctx(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
@@ -169,13 +155,26 @@ int shacira_hashgrid_forward_ctx(int dim, int64_t num_coords, int num_lods, int 
     if (!codebook_first_idx || !coords || !codebook || !feats) return SHACIRA_EINVAL;
     const size_t need = hashgrid_forward_workspace(dim, dtype, lt, num_coords);
     if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
-    if (context) {   // caller-owned context: only meaningful (and only accepted) where the cell-sorted path runs
-        if (ctx_flags != SHACIRA_CTX_BUILD) return SHACIRA_EINVAL;
-        if (!tiled_supported(dim, dtype, lt, num_coords, false)) return SHACIRA_EINVAL;
-        if (context_bytes < tiled_context_bytes(dim, num_coords)) return SHACIRA_EWORKSPACE;
-    }
-    return (int)hashgrid_forward_dispatch(dim, dtype, lt, codebook_first_idx, coords, codebook, feats, workspace,
-                                          num_coords, context, ctx_flags, (hipStream_t)stream);
+    const hipStream_t st = (hipStream_t)stream;
+    if (!context)
+        return (int)hashgrid_forward_dispatch(dim, dtype, lt, codebook_first_idx, coords, codebook, feats, workspace,
+                                              num_coords, st);
+    // caller-owned sample context: the bucket counts the backward of these coordinates needs are produced on the
+    // library's side stream while the lookup runs (the two are bound by different units: hashing vs gathers)
+    if (ctx_flags != SHACIRA_CTX_BUILD) return SHACIRA_EINVAL;
+    const size_t cneed = g_bwd_variant.load() == 0 ? 0 : bin_context_bytes(dim, dtype, lt, num_coords);
+    if (cneed == 0) return SHACIRA_EINVAL;
+    if (context_bytes < cneed) return SHACIRA_EWORKSPACE;
+    SideStream *ss = nullptr;
+    hipError_t e = side_stream(&ss);
+    if (e != hipSuccess) return (int)e;
+    if ((e = hipEventRecord(ss->fork, st)) != hipSuccess) return (int)e;
+    if ((e = hipStreamWaitEvent(ss->stream, ss->fork, 0)) != hipSuccess) return (int)e;
+    if ((e = bin_count_context(dim, dtype, lt, coords, num_coords, context, ss->stream)) != hipSuccess) return (int)e;
+    if ((e = hipEventRecord(ss->join, ss->stream)) != hipSuccess) return (int)e;
+    e = hashgrid_forward_dispatch(dim, dtype, lt, codebook_first_idx, coords, codebook, feats, workspace, num_coords, st);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamWaitEvent(st, ss->join, 0);
 }
 
 size_t shacira_hashgrid_backward_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
@@ -207,9 +206,10 @@ int shacira_hashgrid_backward_ctx(int dim, int64_t num_coords, int num_lods, int
     if (num_coords < 0 || !grad_codebook) return SHACIRA_EINVAL;
     if (num_coords > 0 && (!codebook_first_idx || !coords || !grad_output)) return SHACIRA_EINVAL;
     if (context) {
-        if (ctx_flags != SHACIRA_CTX_BUILD && ctx_flags != SHACIRA_CTX_REUSE) return SHACIRA_EINVAL;
-        if (num_coords < 1 || !tiled_supported(dim, dtype, lt, num_coords, true)) return SHACIRA_EINVAL;
-        if (context_bytes < tiled_context_bytes(dim, num_coords)) return SHACIRA_EWORKSPACE;
+        if (ctx_flags != SHACIRA_CTX_REUSE) return SHACIRA_EINVAL;
+        const size_t cneed = (num_coords < 1 || g_bwd_variant.load() == 0) ? 0 : bin_context_bytes(dim, dtype, lt, num_coords);
+        if (cneed == 0) return SHACIRA_EINVAL;
+        if (context_bytes < cneed) return SHACIRA_EWORKSPACE;
     }
     const size_t need = hashgrid_backward_workspace(dim, dtype, lt, num_coords);
     if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;

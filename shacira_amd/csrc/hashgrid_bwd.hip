@@ -121,17 +121,7 @@ static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
     return n >= 8192;
 }
 
-static bool use_tiled_bwd(int dim, int dtype, const LevelTable &lt, int64_t n) {
-    const bool full = lt.level_begin == 0 && lt.level_end == lt.num_lods && lt.stage_flags == 0;
-    return full && tiled_supported(dim, dtype, lt, n, true);
-}
-
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
-    if (n > 0 && tiled_supported(dim, dtype, lt, n, true)) {
-        // level-range calls on the same shape use the bin pipeline: size for both
-        const size_t a = tiled_backward_workspace(dim, dtype, lt, n), b = bin_workspace_bytes(dim, dtype, lt, n);
-        return a > b ? a : b;
-    }
     size_t need = (dtype == SHACIRA_F16) ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0;
     if (bin_supported(dim, lt) && n > 0) {
         const size_t b = bin_workspace_bytes(dim, dtype, lt, n);
@@ -145,9 +135,6 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
                                       size_t workspace_bytes, int64_t n, void *context, int ctx_flags,
                                       hipStream_t s) {
     (void)workspace_bytes;
-    if (n > 0 && use_tiled_bwd(dim, dtype, lt, n))   // fp32 tables, all levels: cell-sorted path (hashgrid_tiled.hip)
-        return tiled_backward(dim, dtype, lt, first_idx, coords, grad_out, static_cast<float *>(grad_table), workspace,
-                              n, context, ctx_flags, s);
     const int64_t numel = lt.table_rows * lt.feature_dim;
     const bool bin = n > 0 && use_bin(dim, lt, n);
     // fp16 tables accumulate in an fp32 image: the tail of the bin workspace, or the whole workspace (atomic variant)
@@ -168,7 +155,8 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
     }
     if (e != hipSuccess) return e;
     if (bin) {
-        e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s, full, nullptr, nullptr);
+        e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s, full, nullptr, nullptr,
+                         (ctx_flags & SHACIRA_CTX_REUSE) ? context : nullptr);
         if (e != hipSuccess) return e;
     } else if (n > 0) {
         if (dim == 3) {

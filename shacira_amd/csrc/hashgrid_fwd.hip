@@ -475,11 +475,17 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
                                                                       T *__restrict__ feats, int64_t N,
                                                                       uint32_t tiles) {
     constexpr int NH = 1 << (DIM - 1);
+    // work list = (level, tile) pairs, level-major, of levels [level_begin, level_end); XCD k (round-robin dispatch,
+    // blockIdx % 8 -- a speed assumption only) takes the k-th eighth of it and walks it in order, so that at any moment its
+    // L2 holds the table of one level (two at a slice boundary), whatever the number of levels
     const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t qb = blockIdx.x >> 3;
-    const uint32_t lvl = (uint32_t)lt.level_begin + xcd + 8u * (qb / tiles);   // levels [level_begin, level_end)
-    const uint32_t tile = qb % tiles;
-    if (lvl >= (uint32_t)lt.level_end) return;
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t per = gridDim.x >> 3;
+    const uint32_t work = (uint32_t)(lt.level_end - lt.level_begin) * tiles;
+    const uint32_t wi = xcd * per + slot;
+    if (wi >= work) return;
+    const uint32_t lvl = (uint32_t)lt.level_begin + wi / tiles;
+    const uint32_t tile = wi % tiles;
     const int dx = threadIdx.x & 1;
     const int32_t res = lt.res[lvl];
     const float hi = lt.hi[lvl];
@@ -610,8 +616,8 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
         if (use_staged(DIM, lt, num_coords) && workspace) {
             // variant 6: level-per-XCD schedule with lane pairing, features staged level-major (coalesced stores),
             // then one transposing copy into the caller's [N, L*F] layout
-            const uint32_t groups = (uint32_t)((lt.num_lods + 7) / 8);
             const uint32_t tiles = (uint32_t)((num_coords + 127) / 128);
+            const uint32_t grid_v6 = 8u * (uint32_t)(((uint64_t)lt.num_lods * tiles + 7) / 8);
             const uint32_t *perm = nullptr;
             hipError_t e;
             if (use_sorted(DIM, lt, num_coords)) {
@@ -624,7 +630,7 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
                 perm = perm_w;
                 coords = sorted;
             }
-            hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true>), dim3(8u * tiles * groups),
+            hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true>), dim3(grid_v6),
                                dim3(256), 0, stream, lt, first_idx, coords, static_cast<const T *>(table),
                                static_cast<T *>(workspace), num_coords, tiles);
             e = hipGetLastError();
@@ -663,15 +669,16 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
             }
         }
         if (variant == 4 || variant == 5) {
-            const uint32_t groups = (uint32_t)((lt.num_lods + 7) / 8);
             if (variant == 4) {
                 const uint32_t tiles = (uint32_t)((num_coords + 127) / 128);
-                hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1>), dim3(8u * tiles * groups), dim3(256),
+                hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1>),
+                                   dim3(8u * (uint32_t)(((uint64_t)lt.num_lods * tiles + 7) / 8)), dim3(256),
                                    0, stream, lt, first_idx, coords, static_cast<const T *>(table),
                                    static_cast<T *>(feats), num_coords, tiles);
             } else {
                 const uint32_t tiles = (uint32_t)((num_coords + 511) / 512);
-                hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 4>), dim3(8u * tiles * groups), dim3(256),
+                hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 4>),
+                                   dim3(8u * (uint32_t)(((uint64_t)lt.num_lods * tiles + 7) / 8)), dim3(256),
                                    0, stream, lt, first_idx, coords, static_cast<const T *>(table),
                                    static_cast<T *>(feats), num_coords, tiles);
             }
@@ -731,9 +738,9 @@ template <int DIM, typename T, int F>
 static hipError_t launch_levels_staged(const LevelTable &lt, const int32_t *first_idx, const float *coords,
                                        const void *table, void *staged, int64_t n, hipStream_t s) {
     const uint32_t nl = (uint32_t)(lt.level_end - lt.level_begin);
-    const uint32_t groups = (nl + 7) / 8;
     const uint32_t tiles = (uint32_t)((n + 127) / 128);
-    hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true>), dim3(8u * tiles * groups), dim3(256), 0, s,
+    hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true>),
+                       dim3(8u * (uint32_t)(((uint64_t)nl * tiles + 7) / 8)), dim3(256), 0, s,
                        lt, first_idx, coords, static_cast<const T *>(table), static_cast<T *>(staged), n, tiles);
     return hipGetLastError();
 }
@@ -816,7 +823,7 @@ hipError_t hashgrid_untranspose(int dtype, int F, const void *staged, void *feat
 }
 
 size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
-    if (tiled_supported(dim, dtype, lt, n, false)) return tiled_forward_workspace(dim, dtype, lt, n);
+    if (tiled_supported(dim, dtype, lt, n)) return tiled_forward_workspace(dim, dtype, lt, n);
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return 0;
     size_t b = ((size_t)n * lt.num_lods * lt.feature_dim * (dtype == SHACIRA_F32 ? 4 : 2) + 255) / 256 * 256;
     if (use_sorted(dim, lt, n)) b += cell_sort_workspace_bytes(dim, n);
@@ -825,9 +832,8 @@ size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int6
 
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                      const float *coords, const void *table, void *feats, void *ws, int64_t n,
-                                     void *context, int ctx_flags, hipStream_t s) {
-    if (tiled_supported(dim, dtype, lt, n, false))
-        return tiled_forward(dim, dtype, lt, first_idx, coords, table, feats, ws, n, context, ctx_flags, s);
+                                     hipStream_t s) {
+    if (tiled_supported(dim, dtype, lt, n)) return tiled_forward(dim, dtype, lt, first_idx, coords, table, feats, ws, n, s);
     if (dim == 3) {
         return dtype == SHACIRA_F32 ? dispatch_f<3, float>(lt, first_idx, coords, table, feats, ws, n, s)
                                     : dispatch_f<3, __half>(lt, first_idx, coords, table, feats, ws, n, s);

@@ -45,8 +45,9 @@ for dim, bw, N, mn, mx in cases:
     feats, ctx = f(True)
     if ctx is not None:
         gctx = b(ctx).clone()
+        tf2 = timed(lambda: f(True))
         tb = timed(lambda: b(ctx))
-        print(f"   backward with the forward's context: {tb:.3f} ms; equal-ish: {float((gctx - out[1][1]).abs().max()):.3e}")
+        print(f"   with a sample context: fwd {tf2:.3f} ms  bwd {tb:.3f} ms  sum {tf2+tb:.3f}; grad equal-ish: {float((gctx - out[1][1]).abs().max()):.3e}")
     _lib.set_option("tiled", -1)
     print("  forward bit-exact vs old path:", torch.equal(out[0][0], out[1][0]))
     d = (out[0][1] - out[1][1]).abs().max().item(); s = out[0][1].abs().max().item()
@@ -55,8 +56,8 @@ for dim, bw, N, mn, mx in cases:
     # oracle on a slice: run the tiled path on the slice itself (forced)
     _lib.set_option("tiled", 1)
     cs, gs = coords[:n_or].contiguous(), go[:n_or].contiguous()
-    fo = hip_ops._hashgrid_forward(dim, cs, table, first, res, bw)
-    gr = hip_ops.hashgrid_backward(dim, cs, gs, T, table.dtype, first, res, bw, F)
+    fo, c2 = hip_ops._hashgrid_forward(dim, cs, table, first, res, bw, want_context=True)
+    gr = hip_ops.hashgrid_backward(dim, cs, gs, T, table.dtype, first, res, bw, F, context=c2)
     _lib.set_option("tiled", -1)
     ref_f = oc.forward(cs.cpu().numpy(), table.cpu().numpy(), first_np, res, bw)
     print("  slice forward bit-exact vs oracle:", np.array_equal(fo.cpu().numpy(), ref_f))
