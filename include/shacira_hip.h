@@ -67,7 +67,7 @@ SHACIRA_API const char *shacira_strerror(int code);
  *   table_rows         total rows; used only to keep the reference's out-of-table corner (coord == +1 on a
  *                      dense level with res >= 258, weight 0) memory-safe
  *   workspace          scratch of at least shacira_hashgrid_forward_workspace_bytes(...) bytes (level-major staging
- *                      of the features; may be NULL when that returns 0)
+ *                      of the features, and the sample sort of large batches; may be NULL when that returns 0)
  */
 SHACIRA_API size_t shacira_hashgrid_forward_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
                                                 int codebook_bitwidth, const int32_t *resolutions_host,
@@ -77,6 +77,19 @@ SHACIRA_API int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lo
                              const int32_t *resolutions_host, const int32_t *codebook_first_idx,
                              int64_t table_rows, const float *coords, const void *codebook, int dtype,
                              void *feats, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Test hook (not used by any caller of the operators): the integers and weights behind one lookup, so that "hash
+ * indices bit-exact" can be checked directly instead of through the features. For every (sample, level):
+ *   corner_rows    int32 [num_coords, num_lods, 2^dim]  level-local row of corner k, i.e. hash_index / hash_index2d of
+ *                  the reference (hashgrid_interpolate_cuda.cu:17-39, hashgrid_interpolate2d_cuda.cu:17-36) applied to
+ *                  the corner positions of .cu:86-94 (k: bit2 -> x, bit1 -> y, bit0 -> z; 2-D: bit1 -> x, bit0 -> y)
+ *   corner_weights fp32  [num_coords, num_lods, 2^dim]  the weight products of .cu:77-84 / 2d.cu:72-75
+ * computed by the same device function every forward / backward kernel of this library uses. Either output may be NULL.
+ */
+SHACIRA_API int shacira_hashgrid_debug_corners(int dim, int64_t num_coords, int num_lods, int codebook_bitwidth,
+                                   const int32_t *resolutions_host, const float *coords, int32_t *corner_rows,
+                                   float *corner_weights, void *stream);
 
 /*
  * Backward: replaces hashgrid_interpolate_backward_cuda / hashgrid_interpolate2d_backward_cuda
@@ -116,42 +129,6 @@ SHACIRA_API int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, in
                                      const int32_t *codebook_first_idx, int64_t table_rows, const float *coords,
                                      const void *grad_output, int dtype, void *grad_codebook, int level_begin,
                                      int level_end, int flags, void *workspace, size_t workspace_bytes, void *stream);
-
-/*
- * Forward / backward sharing one sample CONTEXT. A training step calls the forward and then the backward on the SAME
- * coordinates (the reference's autograd Function saves them, wisp/ops/grid.py:85-87, :99-107). For large batches both
- * directions first order the samples by the spatial block they fall in (hashgrid_tiled.hip: a counting sort giving a
- * permutation, the coordinates in that order and a work list); with a caller-owned context buffer the forward builds
- * that once and the backward of the same step reuses it instead of repeating the sort.
- *
- *   shacira_hashgrid_context_bytes   bytes of the context for this shape, or 0 when the shape does not use the
- *                                    cell-sorted path in both directions (small batches, fp16 backward, options): then
- *                                    pass context = NULL below, which makes the calls identical to the plain ones.
- *   ctx_flags  SHACIRA_CTX_BUILD     the call builds the context from `coords` into `context` (forward; or a backward
- *                                    that has no forward before it);
- *              SHACIRA_CTX_REUSE     backward only: `context` was built by a call with the SAME coords pointer contents,
- *                                    num_coords, dim and level arguments, earlier on the same stream (or ordered before
- *                                    this call by the caller). Nothing in it is trusted beyond that contract.
- * The context is plain device memory owned by the caller (keep it alive between the two calls: save it in the
- * autograd ctx); it holds no pointers. The plain entry points above behave like these with context = NULL
- * (the sort, when used, then lives in the workspace and is rebuilt by each call).
- */
-#define SHACIRA_CTX_BUILD 1
-#define SHACIRA_CTX_REUSE 2
-SHACIRA_API size_t shacira_hashgrid_context_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
-                                      int codebook_bitwidth, const int32_t *resolutions_host, int64_t table_rows,
-                                      int dtype);
-SHACIRA_API int shacira_hashgrid_forward_ctx(int dim, int64_t num_coords, int num_lods, int feature_dim,
-                                 int codebook_bitwidth, const int32_t *resolutions_host,
-                                 const int32_t *codebook_first_idx, int64_t table_rows, const float *coords,
-                                 const void *codebook, int dtype, void *feats, void *workspace, size_t workspace_bytes,
-                                 void *context, size_t context_bytes, int ctx_flags, void *stream);
-SHACIRA_API int shacira_hashgrid_backward_ctx(int dim, int64_t num_coords, int num_lods, int feature_dim,
-                                  int codebook_bitwidth, const int32_t *resolutions_host,
-                                  const int32_t *codebook_first_idx, int64_t table_rows, const float *coords,
-                                  const void *grad_output, int dtype, void *grad_codebook, void *workspace,
-                                  size_t workspace_bytes, void *context, size_t context_bytes, int ctx_flags,
-                                  void *stream);
 
 /*
  * Latent decode, deterministic (non-SGA) path of LatentDecoder.forward with num_layers_dec == 0
@@ -365,9 +342,10 @@ SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origi
  *               faster (up to 2^19 3-D / 2^20 2-D samples), 2 = always.
  *   "bwd_compact": 1 (default) = dense 3-D levels travel as one 32-byte item per sample (z-slab buckets), 0 = pair items.
  *   "mlp_variant": -1 (default) = decoder MLPs on the fp32 matrix cores wherever instantiated, 0 = VALU kernels.
- *   "tiled": -1 (default) = the cell-sorted path (hashgrid_tiled.hip) for 3-D batches >= 2^18 samples, 0 = never,
- *            1 = whenever the shape allows it. "fwd_variant" 8 / "bwd_variant" 2 also force it; other explicit variants exclude it.
- *   "tiled_lc_fwd" / "tiled_lc_bwd": cap of its coarse (LDS sub-volume) level prefix, -1 (default) = planner's choice.
+ *   "tiled": -1 (default) = the cell-sorted forward (hashgrid_tiled.hip: counting sort of the samples by spatial block,
+ *            coarse levels gathered out of L1 in that order) for batches where it measured faster (>= 2^19 samples),
+ *            0 = never, 1 = whenever the shape allows it. "fwd_variant" 8 also forces it; other explicit variants exclude it.
+ *   "tiled_lc_fwd": its number of coarse levels, -1 (default) = planner's choice.
  *   "bwd_fork": 1 (default) = the backward's count + scan passes are issued on a library-owned side stream, forked
  *               from and joined back into the caller's stream with events (stream semantics unchanged); 0 = one stream.
  */

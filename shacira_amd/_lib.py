@@ -14,7 +14,6 @@ LIB_PATH = os.path.join(_HERE, "lib", "libshacira_hip.so")
 F32, F16 = 0, 1
 EINVAL, EDTYPE, EODD, EWORKSPACE = -1, -2, -3, -4
 BWD_STAGE_ALL_LEVELS, BWD_REUSE_STAGED = 1, 2
-CTX_BUILD, CTX_REUSE = 1, 2
 
 _lock = threading.Lock()
 _lib = None
@@ -29,10 +28,7 @@ SIGNATURES = {
     "shacira_get_option": (_i, [ctypes.c_char_p]),
     "shacira_hashgrid_forward_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i, _p, _i64, _i]),
     "shacira_hashgrid_forward": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p]),
-    "shacira_hashgrid_context_bytes": (_sz, [_i, _i64, _i, _i, _i, _p, _i64, _i]),
-    "shacira_hashgrid_forward_ctx": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p, _sz, _i, _p]),
-    "shacira_hashgrid_backward_ctx": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p, _sz, _i,
-                                           _p]),
+    "shacira_hashgrid_debug_corners": (_i, [_i, _i64, _i, _i, _p, _p, _p, _p, _p]),
     "shacira_hashgrid_backward_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i, _p, _i64, _i]),
     "shacira_hashgrid_backward": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p]),
     "shacira_hashgrid_backward_levels": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _i, _i, _i, _p, _sz,

@@ -12,7 +12,6 @@ std::atomic<int> g_fwd_variant{-1};
 std::atomic<int> g_bwd_variant{-1};
 std::atomic<int> g_mlp_variant{-1};       // -1: MFMA decoders wherever instantiated, 0: VALU kernels
 std::atomic<int> g_bwd_compact{1};        // dense 3-D levels: one 32-byte item per sample, z-slab buckets with a halo plane
-std::atomic<int> g_bwd_rows{1};           // backward: pass T fused into pass B (bin_scatter_rows_kernel)
 std::atomic<int> g_bwd_fuse{1};           // bucket counting fused into the transpose pass
 std::atomic<int> g_bwd_fork{1};           // 1: count + scans of the backward on a side stream next to the transpose
 std::atomic<int> g_bin_acc_kib{0};        // LDS accumulator image per consumer workgroup, KiB: 64, 128, 0 = by batch size
@@ -85,7 +84,6 @@ int shacira_set_option(const char *name, int value) {
         return 0;
     }
     if (!std::strcmp(name, "bwd_compact")) { g_bwd_compact = value ? 1 : 0; return 0; }
-    if (!std::strcmp(name, "bwd_rows")) { g_bwd_rows = value ? 1 : 0; return 0; }
     if (!std::strcmp(name, "tiled")) {
         if (value < -1 || value > 1) return SHACIRA_EINVAL;
         g_tiled = value;
@@ -110,7 +108,6 @@ int shacira_get_option(const char *name) {
     if (!std::strcmp(name, "mlp_variant")) return g_mlp_variant;
     if (!std::strcmp(name, "bwd_fuse")) return g_bwd_fuse;
     if (!std::strcmp(name, "bwd_compact")) return g_bwd_compact;
-    if (!std::strcmp(name, "bwd_rows")) return g_bwd_rows;
     if (!std::strcmp(name, "tiled")) return g_tiled;
     if (!std::strcmp(name, "tiled_lc_fwd")) return g_tiled_lc_fwd;
     return SHACIRA_EINVAL;
@@ -128,24 +125,6 @@ int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feat
                              const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
                              const float *coords, const void *codebook, int dtype, void *feats, void *workspace,
                              size_t workspace_bytes, void *stream) {
-    return shacira_hashgrid_forward_ctx(dim, num_coords, num_lods, feature_dim, codebook_bitwidth, resolutions_host,
-                                        codebook_first_idx, table_rows, coords, codebook, dtype, feats, workspace,
-                                        workspace_bytes, nullptr, 0, 0, stream);
-}
-
-size_t shacira_hashgrid_context_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
-                                      const int32_t *resolutions_host, int64_t table_rows, int dtype) {
-    LevelTable lt;
-    if (build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt)) return 0;
-    if (num_coords < 1 || g_bwd_variant.load() == 0) return 0;
-    return bin_context_bytes(dim, dtype, lt, num_coords);
-}
-
-int shacira_hashgrid_forward_ctx(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
-                                 const int32_t *resolutions_host, const int32_t *codebook_first_idx,
-                                 int64_t table_rows, const float *coords, const void *codebook, int dtype, void *feats,
-                                 void *workspace, size_t workspace_bytes, void *context, size_t context_bytes,
-                                 int ctx_flags, void *stream) {
     LevelTable lt;
     int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
     if (rc) return rc;
@@ -155,26 +134,19 @@ int shacira_hashgrid_forward_ctx(int dim, int64_t num_coords, int num_lods, int 
     if (!codebook_first_idx || !coords || !codebook || !feats) return SHACIRA_EINVAL;
     const size_t need = hashgrid_forward_workspace(dim, dtype, lt, num_coords);
     if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
-    const hipStream_t st = (hipStream_t)stream;
-    if (!context)
-        return (int)hashgrid_forward_dispatch(dim, dtype, lt, codebook_first_idx, coords, codebook, feats, workspace,
-                                              num_coords, st);
-    // caller-owned sample context: the bucket counts the backward of these coordinates needs are produced on the
-    // library's side stream while the lookup runs (the two are bound by different units: hashing vs gathers)
-    if (ctx_flags != SHACIRA_CTX_BUILD) return SHACIRA_EINVAL;
-    const size_t cneed = g_bwd_variant.load() == 0 ? 0 : bin_context_bytes(dim, dtype, lt, num_coords);
-    if (cneed == 0) return SHACIRA_EINVAL;
-    if (context_bytes < cneed) return SHACIRA_EWORKSPACE;
-    SideStream *ss = nullptr;
-    hipError_t e = side_stream(&ss);
-    if (e != hipSuccess) return (int)e;
-    if ((e = hipEventRecord(ss->fork, st)) != hipSuccess) return (int)e;
-    if ((e = hipStreamWaitEvent(ss->stream, ss->fork, 0)) != hipSuccess) return (int)e;
-    if ((e = bin_count_context(dim, dtype, lt, coords, num_coords, context, ss->stream)) != hipSuccess) return (int)e;
-    if ((e = hipEventRecord(ss->join, ss->stream)) != hipSuccess) return (int)e;
-    e = hashgrid_forward_dispatch(dim, dtype, lt, codebook_first_idx, coords, codebook, feats, workspace, num_coords, st);
-    if (e != hipSuccess) return (int)e;
-    return (int)hipStreamWaitEvent(st, ss->join, 0);
+    return (int)hashgrid_forward_dispatch(dim, dtype, lt, codebook_first_idx, coords, codebook, feats, workspace,
+                                          num_coords, (hipStream_t)stream);
+}
+
+int shacira_hashgrid_debug_corners(int dim, int64_t num_coords, int num_lods, int codebook_bitwidth,
+                                   const int32_t *resolutions_host, const float *coords, int32_t *corner_rows,
+                                   float *corner_weights, void *stream) {
+    LevelTable lt;
+    int rc = build_level_table(dim, num_lods, 2, codebook_bitwidth, resolutions_host, 0, lt);
+    if (rc) return rc;
+    if (num_coords < 0 || num_coords * (int64_t)num_lods >= ((int64_t)1 << 31) * 256) return SHACIRA_EINVAL;
+    if (num_coords > 0 && (!coords || (!corner_rows && !corner_weights))) return SHACIRA_EINVAL;
+    return (int)hashgrid_debug_corners(dim, lt, coords, num_coords, corner_rows, corner_weights, (hipStream_t)stream);
 }
 
 size_t shacira_hashgrid_backward_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
@@ -192,30 +164,6 @@ int shacira_hashgrid_backward(int dim, int64_t num_coords, int num_lods, int fea
     return shacira_hashgrid_backward_levels(dim, num_coords, num_lods, feature_dim, codebook_bitwidth, resolutions_host,
                                             codebook_first_idx, table_rows, coords, grad_output, dtype, grad_codebook,
                                             0, num_lods, 0, workspace, workspace_bytes, stream);
-}
-
-int shacira_hashgrid_backward_ctx(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
-                                  const int32_t *resolutions_host, const int32_t *codebook_first_idx,
-                                  int64_t table_rows, const float *coords, const void *grad_output, int dtype,
-                                  void *grad_codebook, void *workspace, size_t workspace_bytes, void *context,
-                                  size_t context_bytes, int ctx_flags, void *stream) {
-    LevelTable lt;
-    int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
-    if (rc) return rc;
-    if (dtype != SHACIRA_F32 && dtype != SHACIRA_F16) return SHACIRA_EDTYPE;
-    if (num_coords < 0 || !grad_codebook) return SHACIRA_EINVAL;
-    if (num_coords > 0 && (!codebook_first_idx || !coords || !grad_output)) return SHACIRA_EINVAL;
-    if (context) {
-        if (ctx_flags != SHACIRA_CTX_REUSE) return SHACIRA_EINVAL;
-        const size_t cneed = (num_coords < 1 || g_bwd_variant.load() == 0) ? 0 : bin_context_bytes(dim, dtype, lt, num_coords);
-        if (cneed == 0) return SHACIRA_EINVAL;
-        if (context_bytes < cneed) return SHACIRA_EWORKSPACE;
-    }
-    const size_t need = hashgrid_backward_workspace(dim, dtype, lt, num_coords);
-    if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
-    return (int)hashgrid_backward_dispatch(dim, dtype, lt, codebook_first_idx, coords, grad_output, grad_codebook,
-                                           workspace, workspace_bytes, num_coords, context, ctx_flags,
-                                           (hipStream_t)stream);
 }
 
 int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
@@ -238,7 +186,7 @@ int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, int num_lods, 
     const size_t need = hashgrid_backward_workspace(dim, dtype, lt, num_coords);
     if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
     return (int)hashgrid_backward_dispatch(dim, dtype, lt, codebook_first_idx, coords, grad_output, grad_codebook,
-                                           workspace, workspace_bytes, num_coords, nullptr, 0, (hipStream_t)stream);
+                                           workspace, workspace_bytes, num_coords, (hipStream_t)stream);
 }
 
 int shacira_latent_decode_forward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,

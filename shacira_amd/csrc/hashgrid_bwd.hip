@@ -111,7 +111,11 @@ static hipError_t bwd_atomic_f(const LevelTable &lt, const int32_t *first_idx, c
 }
 
 // hashgrid_bwd_bin.hip
-
+bool bin_supported(int dim, const LevelTable &lt);
+size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n);
+float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace);
+hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table);
 
 // variant 1 ("bin") whenever the shape allows it and the batch is big enough to amortise its fixed passes
 static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
@@ -132,8 +136,7 @@ size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int
 
 hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                       const float *coords, const void *grad_out, void *grad_table, void *workspace,
-                                      size_t workspace_bytes, int64_t n, void *context, int ctx_flags,
-                                      hipStream_t s) {
+                                      size_t workspace_bytes, int64_t n, hipStream_t s) {
     (void)workspace_bytes;
     const int64_t numel = lt.table_rows * lt.feature_dim;
     const bool bin = n > 0 && use_bin(dim, lt, n);
@@ -155,8 +158,7 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
     }
     if (e != hipSuccess) return e;
     if (bin) {
-        e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s, full, nullptr, nullptr,
-                         (ctx_flags & SHACIRA_CTX_REUSE) ? context : nullptr);
+        e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s, full);
         if (e != hipSuccess) return e;
     } else if (n > 0) {
         if (dim == 3) {

@@ -24,10 +24,8 @@
 // Results differ from the reference only by summation order / two fp32 roundings per term (the reference's own
 // atomicAdd order is unspecified); tests hold them to 1e-5 relative against the fp64-accumulating oracle.
 #include <mutex>
-#include <utility>
 
 #include "internal.h"
-#include "fixed_point.h"
 
 namespace shacira {
 
@@ -142,15 +140,47 @@ __device__ __forceinline__ void enumerate_pairs(const double (&t)[DIM], int32_t 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fixed point
+// LDS integer atomics run 1.6x faster than ds_add_f64 (2.1-2.5 vs 1.3-1.4 T op/s, profiles/r01_microbench2), so the
+// accumulator images hold 64-bit fixed-point numbers. Scale per level: gmax[l] = max |grad_output| over the level's
+// columns (bit pattern of the float, gathered by pass T for free; integer max on the bits orders
+// finite < inf < NaN). Every contribution is |g * weight| <= gmax < 2^e, so with scale 2^(headroom - e) a contribution
+// stays below 2^headroom and n_max of them below 2^62: headroom = min(50, 62 - ceil(log2(n_max))). Conversion is one
+// fp64 fma with the 1.5 * 2^52 constant (the integer appears in the low mantissa bits) -- exact to the scale's LSB, i.e.
+// 2^-headroom relative to gmax (>= 41 bits here vs 24 of the reference's fp32 atomics) and order-independent.
+// A level whose gmax is inf / NaN falls back to the fp64 image so that non-finite gradients propagate as before.
+struct FxScale {
+    double scale, inv;   // 2^k, 2^-k
+    bool fixed;          // false: accumulate in fp64 (non-finite gradients)
+};
+__device__ __forceinline__ FxScale fx_scale_of(uint32_t gmax_bits, int headroom) {
+    FxScale f;
+    f.fixed = gmax_bits < 0x7F800000u;
+    int e = (int)((gmax_bits >> 23) & 0xFFu) - 126;   // |g| < 2^e for normal floats; denormals / zero: e = -126
+    if (e < -126) e = -126;
+    const int k = headroom - e;
+    f.scale = __longlong_as_double((long long)(1023 + k) << 52);
+    f.inv = __longlong_as_double((long long)(1023 - k) << 52);
+    return f;
+}
+__device__ __forceinline__ unsigned long long fx_encode(float c, double scale) {
+    const double magic = 6755399441055744.0;   // 1.5 * 2^52
+    return (unsigned long long)(__double_as_longlong(fma((double)c, scale, magic)) - __double_as_longlong(magic));
+}
+__device__ __forceinline__ float fx_decode(unsigned long long v, double inv) { return (float)((double)(long long)v * inv); }
+static inline int fx_headroom(uint64_t n_max) {
+    int bits = 0;
+    while (((uint64_t)1 << bits) < n_max) ++bits;
+    const int h = 62 - bits;
+    return h > 50 ? 50 : (h < 24 ? 24 : h);
+}
+
 // ------------------------------------------------------------------------------------------------- pass T
 // grad_output [N, L*F] (T) -> gT [L][N][F] fp32, through LDS, F scalars per lane per access. Block: 256 samples.
 template <typename T, int F, bool GMAX>
 __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict__ go, float *__restrict__ gT,
                                                              int64_t N, int L, int lb, int le,
-                                                             uint32_t *__restrict__ gmax,
-                                                             const uint32_t *__restrict__ perm) {
-    // perm != NULL: staged row j is the gradient row of sample perm[j] (cell-sorted order of hashgrid_tiled.hip);
-    // a row is L*F contiguous scalars (128 B for L16 F2 fp32), so the gather still moves whole lines
+                                                             uint32_t *__restrict__ gmax) {
     __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
     if (GMAX && threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
     struct alignas(sizeof(T) * F) PieceIn { T v[F]; };
@@ -161,11 +191,10 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
     const int64_t s0 = (int64_t)blockIdx.x * 256;
     const int ns = (int)((N - s0 < 256) ? (N - s0) : 256);
     const PieceIn *in = reinterpret_cast<const PieceIn *>(go) + s0 * L;
-    const PieceIn *in0 = reinterpret_cast<const PieceIn *>(go);
     const int total = ns * L;
     for (int e = threadIdx.x; e < total; e += 256) {
         const int sm = e / L, l = e - sm * L;
-        const PieceIn p = perm ? in0[(int64_t)perm[s0 + sm] * L + l] : in[e];
+        const PieceIn p = in[e];
         PieceOut q;
 #pragma unroll
         for (int j = 0; j < F; ++j) q.v[j] = Scalar<T>::load(&p.v[j]);
@@ -594,231 +623,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         // write-once / read-once stream: non-temporal stores (measured -7 % on the whole backward)
         store_item_nt<F>(items + s_gbase[b] + (pos - s_start[b]), s_items[pos]);
     }
-}
-
-// ------------------------------------------------------------------------------------------------- passes T + B fused
-// One workgroup = one 1024-sample tile, ALL binned levels: the tile's gradient rows grad_output[i] (whole rows, read once,
-// 16-byte chunks through LDS) end up in registers -- every thread keeps the L*F gradients of its two samples -- and the
-// level loop of pass B runs inside the kernel. No transposed copy gT exists: saves pass T (read + write of the whole
-// gradient, 0.27 GB on S1) and its place on the critical path. The per-level max |g| (fixed-point scale of pass C) is
-// gathered in the prologue. Needs L*F <= 32 (register budget) and rows that are a multiple of 16 bytes.
-template <int... Is, typename Fn>
-__device__ __forceinline__ void static_for_levels(std::integer_sequence<int, Is...>, Fn &&fn) {
-    (fn(std::integral_constant<int, Is>{}), ...);
-}
-
-constexpr int kRowRegs = 32;   // gradient scalars per sample kept in registers
-
-template <int DIM, typename T, int F, bool GMAX>
-__global__ __launch_bounds__(kBinThreads) void bin_scatter_rows_kernel(LevelTable lt, BinPlan plan,
-                                                                       const float *__restrict__ coords,
-                                                                       const T *__restrict__ go,
-                                                                       const uint32_t *__restrict__ tile_off,
-                                                                       const uint64_t *__restrict__ base,
-                                                                       Item<F> *__restrict__ items, int64_t N,
-                                                                       uint32_t *__restrict__ gmax) {
-    constexpr int NP = 1 << (DIM - 1);
-    constexpr int SPT = kTile / kBinThreads;   // samples per thread
-    constexpr int kStage = kTile * NP;         // staged items per level
-    constexpr int MAXL = kRowRegs / F;
-    extern __shared__ __align__(16) unsigned char s_raw[];
-    Item<F> *s_items = reinterpret_cast<Item<F> *>(s_raw);
-    uint8_t *s_bucket = reinterpret_cast<uint8_t *>(s_items + kStage);
-    __shared__ uint32_t s_hist[kMaxLevelBuckets];
-    __shared__ uint32_t s_start[kMaxLevelBuckets + 1];
-    __shared__ uint64_t s_gbase[kMaxLevelBuckets];
-    __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
-
-    const uint32_t tile = blockIdx.x;
-    const int L = lt.num_lods;
-    const int64_t s0 = (int64_t)tile * kTile;
-    const uint32_t count = (uint32_t)((N - s0 < kTile) ? (N - s0) : kTile);
-    if (GMAX && threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
-
-    // ---- prologue: the tile's rows -> registers, rounds of kRound rows through LDS (the item staging's memory)
-    float g[SPT][kRowRegs];
-#pragma unroll
-    for (int u = 0; u < SPT; ++u)
-#pragma unroll
-        for (int e = 0; e < kRowRegs; ++e) g[u][e] = 0.0f;
-    const uint32_t row_bytes = (uint32_t)(L * F * sizeof(T));
-    const uint32_t pitch = row_bytes + 16u;
-    const uint32_t cpr = row_bytes / 16u;
-    constexpr uint32_t kRound = 256;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    for (uint32_t r0 = 0; r0 < count; r0 += kRound) {
-        const uint32_t nr = (count - r0 < kRound) ? (count - r0) : kRound;
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(go) + (size_t)(s0 + r0) * row_bytes;
-        __syncthreads();
-        constexpr int UB = 4;   // chunks in flight per thread; the rows of a round are one contiguous piece of memory
-        for (uint32_t e0 = 0; e0 < nr * cpr; e0 += kBinThreads * UB) {
-            u32x4 v[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const uint32_t e = e0 + u * kBinThreads + threadIdx.x;
-                v[u] = u32x4{0u, 0u, 0u, 0u};
-                if (e < nr * cpr) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + e);
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const uint32_t e = e0 + u * kBinThreads + threadIdx.x;
-                const uint32_t rr = e / cpr, q = e - rr * cpr;
-                if (e < nr * cpr) *reinterpret_cast<u32x4 *>(s_raw + (size_t)rr * pitch + q * 16u) = v[u];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-            const uint32_t k = threadIdx.x + u * kBinThreads;
-            if (k >= r0 && k < r0 + nr) {
-                const T *row = reinterpret_cast<const T *>(s_raw + (size_t)(k - r0) * pitch);
-#pragma unroll
-                for (int e = 0; e < kRowRegs; ++e)
-                    if (e < L * F) g[u][e] = Scalar<T>::load(row + e);
-            }
-        }
-    }
-    if constexpr (GMAX) {   // per-level max |g| of the tile: wave max, LDS max, one global max per level and workgroup
-        static_for_levels(std::make_integer_sequence<int, MAXL>{}, [&](auto lc_) __attribute__((always_inline)) {
-            constexpr int l = decltype(lc_)::value;
-            if (l >= L) return;
-            uint32_t m = 0;
-#pragma unroll
-            for (int u = 0; u < SPT; ++u)
-#pragma unroll
-                for (int j = 0; j < F; ++j) {
-                    const uint32_t b = __float_as_uint(fabsf(g[u][l * F + j]));
-                    m = b > m ? b : m;
-                }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t o = __shfl_xor(m, off, 64);
-                m = o > m ? o : m;
-            }
-            if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_max[l], m);
-        });
-    }
-    __syncthreads();
-    if constexpr (GMAX) {
-        if ((int)threadIdx.x < L && s_max[threadIdx.x]) atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
-    }
-    double t[SPT][DIM];
-#pragma unroll
-    for (int u = 0; u < SPT; ++u) {
-        const uint32_t k = threadIdx.x + u * kBinThreads;
-#pragma unroll
-        for (int a = 0; a < DIM; ++a) t[u][a] = axis_unit(k < count ? coords[(s0 + k) * DIM + a] : 0.0f);
-    }
-
-    // ---- pass B for every binned level of the tile
-    static_for_levels(std::make_integer_sequence<int, MAXL>{}, [&](auto lc_) __attribute__((always_inline)) {
-        constexpr int lvl = decltype(lc_)::value;
-        if (lvl >= L) return;
-        const BinLevel bl = plan.lv[lvl];
-        if (bl.dgroup >= 0 || bl.nb == 0) return;   // direct level, or not part of this call (uniform)
-        if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
-        __syncthreads();
-        const int32_t res = lt.res[lvl];
-        const float hi = lt.hi[lvl];
-        const bool dense = lt.dense[lvl] != 0;
-        PairSlot ps[SPT][NP];
-        uint32_t rank[SPT][NP];
-        float fx[SPT];
-        float fyz[SPT][2];   // compact levels: y / z fractions travel with the item
-        const bool compact = (DIM == 3) && bl.compact != 0;
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-            const uint32_t k = threadIdx.x + u * kBinThreads;
-            const bool live = k < count;
-            if (compact) {
-                if constexpr (DIM == 3) {
-                    int32_t pp[3];
-                    float ff[3], gg[3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) axis_transform(t[u][a], res, hi, pp[a], ff[a], gg[a]);
-                    const uint32_t r = (uint32_t)res, b = (uint32_t)pp[2] / bl.slab;
-                    const uint32_t local = ((uint32_t)pp[2] - b * bl.slab) * r * r + (uint32_t)pp[1] * r + (uint32_t)pp[0];
-                    fx[u] = ff[0];
-                    fyz[u][0] = ff[1];
-                    fyz[u][1] = ff[2];
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) {
-                        ps[u][q].bucket = b;
-                        ps[u][q].key = 0;
-                        ps[u][q].wrest = 0.0f;
-                    }
-                    ps[u][0].key = local | (1u << 26);
-                }
-            } else {
-                enumerate_pairs<DIM>(t[u], res, hi, dense, lt.mask, bl, plan.BR, fx[u], ps[u]);
-            }
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                if (!live) ps[u][q].key = 0;
-                rank[u][q] = (ps[u][q].key >> 26) ? atomicAdd(&s_hist[ps[u][q].bucket], compact ? 2u : 1u) : 0u;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {  // wave 0: exclusive scan of the <= 128 bucket counts, two per lane
-            const uint32_t lane = threadIdx.x;
-            const uint32_t c0 = (2 * lane < bl.nb) ? s_hist[2 * lane] : 0u;
-            const uint32_t c1 = (2 * lane + 1 < bl.nb) ? s_hist[2 * lane + 1] : 0u;
-            uint32_t incl = c0 + c1;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t nbr = __shfl_up(incl, off, 64);
-                if (lane >= (uint32_t)off) incl += nbr;
-            }
-            const uint32_t excl = incl - (c0 + c1);
-            if (2 * lane < bl.nb) s_start[2 * lane] = excl;
-            if (2 * lane + 1 < bl.nb) s_start[2 * lane + 1] = excl + c0;
-            if (lane == 63) s_start[bl.nb] = incl;
-        }
-        if (threadIdx.x < bl.nb) {
-            const size_t gb = bl.bucket0 + threadIdx.x;
-            s_gbase[threadIdx.x] = base[gb] + tile_off[gb * plan.num_tiles + tile];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                if (ps[u][q].key >> 26) {
-                    const uint32_t pos = s_start[ps[u][q].bucket] + rank[u][q];
-                    Item<F> it;
-                    it.key = ps[u][q].key;
-                    it.fx = fx[u];
-                    if (compact) {
-                        if constexpr (F == 2) {   // two slots: {key, fx, fy, fz} {0, g0, g1, 0}
-                            it.a[0] = fyz[u][0];
-                            it.a[1] = fyz[u][1];
-                            s_items[pos] = it;
-                            Item<F> it2;
-                            it2.key = 0;
-                            it2.fx = g[u][lvl * F + 0];
-                            it2.a[0] = g[u][lvl * F + 1];
-                            it2.a[1] = 0.0f;
-                            s_items[pos + 1] = it2;
-                            s_bucket[pos] = (uint8_t)ps[u][q].bucket;
-                            s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < F; ++j) it.a[j] = g[u][lvl * F + j] * ps[u][q].wrest;
-                        s_items[pos] = it;
-                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        const uint32_t staged = s_start[bl.nb];
-        for (uint32_t pos = threadIdx.x; pos < staged; pos += kBinThreads) {
-            const uint32_t b = s_bucket[pos];
-            store_item_nt<F>(items + s_gbase[b] + (pos - s_start[b]), s_items[pos]);
-        }
-        __syncthreads();   // s_items / s_hist / s_start are reused by the next level
-    });
 }
 
 // ------------------------------------------------------------------------------------------------- pass C
@@ -1283,14 +1087,6 @@ float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *work
     return carve(dim, dtype, lt, n, workspace).acc32;
 }
 
-// staged gradients gT [L][N][F] fp32 and the per-level max |grad| bit patterns inside a bin workspace
-void bin_staged_pointers(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace, float **gT,
-                         uint32_t **gmax) {
-    const BinWorkspace w = carve(dim, dtype, lt, n, workspace);
-    *gT = w.gT;
-    *gmax = w.gmax;
-}
-
 #define SHACIRA_CHECK_LAUNCH()                 \
     do {                                       \
         hipError_t e_ = hipGetLastError();     \
@@ -1301,7 +1097,11 @@ void bin_staged_pointers(int dim, int dtype, const LevelTable &lt, int64_t n, vo
 // bound while the transpose and the direct levels are memory/LDS bound, so they share the chip well. One per host
 // thread and device; fork/join with events keeps the caller's stream semantics (and is capturable in a HIP graph once
 // the objects exist -- they are created on the first eager call).
-hipError_t side_stream(SideStream **out) {
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, zeroed = nullptr, staged = nullptr;
+};
+static hipError_t side_stream(SideStream **out) {
     static thread_local SideStream per_device[16];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1329,8 +1129,7 @@ hipError_t side_stream(SideStream **out) {
 template <int DIM, int F>
 static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                           const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s,
-                          bool zero_table, const uint32_t *perm,
-                          const std::function<hipError_t(hipStream_t)> *stage_hook, bool precounted) {
+                          bool zero_table) {
     const int L = lt.num_lods;
     BinPlan whole;
     const int acc_kib = choose_acc_kib(DIM, lt, n);
@@ -1349,14 +1148,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // measured (tools/fuse_check.py): fused wins by 4-9 % up to 2^19 3-D samples, loses 3-4 % at 2^20 ("bwd_fuse": 0 = never,
     // 1 = by that rule, 2 = always)
     const int fuse_opt = g_bwd_fuse.load();
-    // precounted: w.cnt / w.base / w.unit_* point into a sample context that already holds this batch's bucket counts
-    // and scans (bin_count_context, run next to the forward of the same coordinates): passes A and S are skipped
-    // rows: passes T + B fused (bin_scatter_rows_kernel): no transposed copy of the gradients at all. Full single
-    // sub-batch calls whose rows fit the register budget; level-range / staged calls keep the staged form.
-    const size_t row_bytes = (size_t)L * F * (dtype == SHACIRA_F32 ? 4 : 2);
-    const bool rows = g_bwd_rows.load() != 0 && whole.nbl > 0 && !multi && !staged && !stage_all && !perm && !stage_hook &&
-                      L * F <= kRowRegs && row_bytes % 16 == 0 && lt.level_begin == 0 && lt.level_end == L;
-    const bool fuse = can_fork && need_T && !staged && !perm && !precounted && !rows &&
+    const bool fuse = can_fork && need_T && !staged &&
                       (fuse_opt == 2 || (fuse_opt == 1 && n * ((int64_t)1 << (DIM - 1)) <= ((int64_t)1 << 21)));
     if (can_fork) {
         hipError_t e = side_stream(&ss);
@@ -1369,20 +1161,18 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             if ((e = hipEventRecord(ss->zeroed, ss->stream)) != hipSuccess) return e;
         }
         if (!fuse) {
-            if (!precounted) {
-                BinPlan plan;
-                make_plan(DIM, lt, n, plan, acc_kib);
-                const dim3 grid(plan.num_tiles, plan.nbl);
-                hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, ss->stream, lt, plan, coords,
-                                   w.cnt, (int64_t)0, n);
-                SHACIRA_CHECK_LAUNCH();
-                hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, ss->stream, w.cnt,
-                                   w.totals, plan.num_tiles);
-                SHACIRA_CHECK_LAUNCH();
-                hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, ss->stream, w.totals, w.base,
-                                   w.unit_first, w.unit_bucket, plan.total_buckets, plan.chunk);
-                SHACIRA_CHECK_LAUNCH();
-            }
+            BinPlan plan;
+            make_plan(DIM, lt, n, plan, acc_kib);
+            const dim3 grid(plan.num_tiles, plan.nbl);
+            hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, ss->stream, lt, plan, coords, w.cnt,
+                               (int64_t)0, n);
+            SHACIRA_CHECK_LAUNCH();
+            hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, ss->stream, w.cnt,
+                               w.totals, plan.num_tiles);
+            SHACIRA_CHECK_LAUNCH();
+            hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, ss->stream, w.totals, w.base,
+                               w.unit_first, w.unit_bucket, plan.total_buckets, plan.chunk);
+            SHACIRA_CHECK_LAUNCH();
             if ((e = hipEventRecord(ss->join, ss->stream)) != hipSuccess) return e;
         }
     }
@@ -1392,7 +1182,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     }
     // fixed-point images pay off once the accumulation itself dominates; small batches are bound by fixed costs and
     // keep the fp64 image (and skip the gmax bookkeeping): measured 100 vs 107 us at 65 536 samples
-    const bool use_fx = need_T && n >= (1 << 17);   // (rows: the scales come from the fused kernel's prologue)
+    const bool use_fx = need_T && n >= (1 << 17);
     if (!staged && use_fx) {   // per-level max |grad_output| for the scales (kept in the workspace for REUSE_STAGED)
         hipError_t e = hipMemsetAsync(w.gmax, 0, SHACIRA_MAX_LODS * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
@@ -1425,28 +1215,24 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
                            w.unit_bucket, plan.total_buckets, plan.chunk);
         SHACIRA_CHECK_LAUNCH();
-    } else if (need_T && !staged && !rows) {
+    } else if (need_T && !staged) {
         const int t_lb = stage_all ? 0 : lt.level_begin, t_le = stage_all ? L : lt.level_end;
         // pass T over the whole batch (also gathers gmax)
         const uint32_t blocks = (uint32_t)((n + 255) / 256);
         const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
         if (dtype == SHACIRA_F32 && use_fx)
             hipLaunchKernelGGL((transpose_grad_kernel<float, F, true>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax, perm);
+                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax);
         else if (dtype == SHACIRA_F32)
             hipLaunchKernelGGL((transpose_grad_kernel<float, F, false>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr, perm);
+                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr);
         else if (use_fx)
             hipLaunchKernelGGL((transpose_grad_kernel<__half, F, true>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax, perm);
+                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax);
         else
             hipLaunchKernelGGL((transpose_grad_kernel<__half, F, false>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr, perm);
+                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr);
         SHACIRA_CHECK_LAUNCH();
-    }
-    if (stage_hook) {   // REUSE_STAGED caller that stages on this stream now (hashgrid_tiled.hip), next to the forked passes
-        hipError_t e = (*stage_hook)(s);
-        if (e != hipSuccess) return e;
     }
     // When nothing is transposed (every level is direct: the image configs) gmax would cost an extra read of grad_output
     // (tried: a streaming abs-max kernel); measured on config B it costs more than the faster atomics return (0.103 vs
@@ -1458,9 +1244,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         if (e != hipSuccess) return e;
         ds = ss->stream;
     }
-    if (rows && ss) ds = ss->stream;   // rows: the direct levels read grad_output in place, next to the fused scatter
     if (whole.ngroups > 0) {
-        if (zero_table && ss && !fuse && !rows) {
+        if (zero_table && ss && !fuse) {
             hipError_t e = hipStreamWaitEvent(s, ss->zeroed, 0);
             if (e != hipSuccess) return e;
         }
@@ -1476,10 +1261,10 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const dim3 grid(bpg, plan.ngroups);
         // a row receives at most (samples walked by one workgroup) x (corners) contributions
         const int headroom = use_fx ? fx_headroom(((uint64_t)n / bpg + kConsumeThreads) * (1u << DIM)) : -1;
-        if (need_T && use_fx && !rows)
+        if (need_T && use_fx)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, true>), grid, dim3(kConsumeThreads),
                                acc_bytes, ds, lt, plan, first_idx, coords, w.gT, acc, n, w.gmax, headroom);
-        else if (need_T && !rows)
+        else if (need_T)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, false>), grid, dim3(kConsumeThreads),
                                acc_bytes, ds, lt, plan, first_idx, coords, w.gT, acc, n, nullptr, headroom);
         else if (dtype == SHACIRA_F32)
@@ -1496,10 +1281,6 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         hipError_t e = hipEventRecord(ss->join, ss->stream);
         if (e != hipSuccess) return e;
     }
-    if (rows && ss && whole.ngroups > 0) {
-        hipError_t e = hipEventRecord(ss->staged, ss->stream);
-        if (e != hipSuccess) return e;
-    }
     if (whole.nbl == 0) return hipSuccess;
     if (ss && !fuse) {
         hipError_t e = hipStreamWaitEvent(s, ss->join, 0);
@@ -1510,7 +1291,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         BinPlan plan;
         make_plan(DIM, lt, hi - s0, plan, acc_kib);
         const dim3 grid(plan.num_tiles, plan.nbl);
-        if (!ss && !precounted) {
+        if (!ss) {
             hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, s, lt, plan, coords, w.cnt, s0, hi);
             SHACIRA_CHECK_LAUNCH();
             hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, s, w.cnt, w.totals,
@@ -1522,34 +1303,9 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         }
         constexpr int NP = 1 << (DIM - 1);
         const size_t stage = (size_t)kTile * NP * (sizeof(Item<F>) + 1);
-        if (rows) {
-            const dim3 rgrid(plan.num_tiles);
-            if (dtype == SHACIRA_F32 && use_fx)
-                hipLaunchKernelGGL((bin_scatter_rows_kernel<DIM, float, F, true>), rgrid, dim3(kBinThreads), stage, s, lt,
-                                   plan, coords, static_cast<const float *>(grad_out), w.cnt, w.base,
-                                   reinterpret_cast<Item<F> *>(w.items), n, w.gmax);
-            else if (dtype == SHACIRA_F32)
-                hipLaunchKernelGGL((bin_scatter_rows_kernel<DIM, float, F, false>), rgrid, dim3(kBinThreads), stage, s, lt,
-                                   plan, coords, static_cast<const float *>(grad_out), w.cnt, w.base,
-                                   reinterpret_cast<Item<F> *>(w.items), n, nullptr);
-            else if (use_fx)
-                hipLaunchKernelGGL((bin_scatter_rows_kernel<DIM, __half, F, true>), rgrid, dim3(kBinThreads), stage, s, lt,
-                                   plan, coords, static_cast<const __half *>(grad_out), w.cnt, w.base,
-                                   reinterpret_cast<Item<F> *>(w.items), n, w.gmax);
-            else
-                hipLaunchKernelGGL((bin_scatter_rows_kernel<DIM, __half, F, false>), rgrid, dim3(kBinThreads), stage, s, lt,
-                                   plan, coords, static_cast<const __half *>(grad_out), w.cnt, w.base,
-                                   reinterpret_cast<Item<F> *>(w.items), n, nullptr);
-            SHACIRA_CHECK_LAUNCH();
-            if (ss && whole.ngroups > 0) {   // the direct levels ran next to it on the side stream
-                hipError_t e = hipStreamWaitEvent(s, ss->staged, 0);
-                if (e != hipSuccess) return e;
-            }
-        } else {
-            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,
-                               w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n);
-            SHACIRA_CHECK_LAUNCH();
-        }
+        hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,
+                           w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n);
+        SHACIRA_CHECK_LAUNCH();
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NP;
         const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + plan.total_buckets + 1;
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
@@ -1571,86 +1327,9 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     return hipSuccess;
 }
 
-// perm != NULL: `coords` are the cell-sorted coordinates of hashgrid_tiled.hip and staged row j belongs to sample perm[j]
-// (the transpose gathers through it); everything downstream then works in sorted order.
-// ---- sample context: this batch's bucket counts + scans, in caller-owned memory
-struct BinContext {
-    uint32_t *cnt, *totals;
-    uint64_t *base;
-    uint32_t *unit_first, *unit_bucket;
-    size_t bytes;
-};
-static BinContext carve_context(int dim, const LevelTable &lt, int64_t n, void *buf) {
-    BinPlan plan;
-    make_plan(dim, lt, n, plan, choose_acc_kib(dim, lt, n));
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_cnt = take((size_t)plan.total_buckets * plan.num_tiles * sizeof(uint32_t));
-    const size_t o_tot = take((size_t)(plan.total_buckets + 1) * sizeof(uint32_t));
-    const size_t o_base = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
-    const size_t o_unit = take((size_t)(kMaxBuckets + 2) * sizeof(uint32_t));
-    const uint64_t max_items = (uint64_t)n * plan.nbl * plan.pairs;
-    const size_t o_ub = take((size_t)(max_items / plan.chunk + plan.total_buckets + 2) * sizeof(uint32_t));
-    BinContext c{};
-    unsigned char *p = static_cast<unsigned char *>(buf);
-    if (p) {
-        c.cnt = reinterpret_cast<uint32_t *>(p + o_cnt);
-        c.totals = reinterpret_cast<uint32_t *>(p + o_tot);
-        c.base = reinterpret_cast<uint64_t *>(p + o_base);
-        c.unit_first = reinterpret_cast<uint32_t *>(p + o_unit);
-        c.unit_bucket = reinterpret_cast<uint32_t *>(p + o_ub);
-    }
-    c.bytes = off;
-    return c;
-}
-
-// 0: this shape's backward would not use pre-counted buckets (not binned, nothing to bin, or several sub-batches)
-size_t bin_context_bytes(int dim, int dtype, const LevelTable &lt, int64_t n) {
-    (void)dtype;
-    if (n < 8192 || !bin_supported(dim, lt)) return 0;   // hashgrid_bwd.hip: use_bin
-    if (bin_batch_samples(dim, lt, n) < n) return 0;
-    BinPlan plan;
-    make_plan(dim, lt, n, plan, choose_acc_kib(dim, lt, n));
-    if (plan.nbl == 0) return 0;
-    return carve_context(dim, lt, n, nullptr).bytes;
-}
-
-// passes A + S of the backward for `coords`, into `context` (enqueued on s; the forward runs it on its side stream)
-hipError_t bin_count_context(int dim, int dtype, const LevelTable &lt, const float *coords, int64_t n, void *context,
-                             hipStream_t s) {
-    (void)dtype;
-    const BinContext c = carve_context(dim, lt, n, context);
-    BinPlan plan;
-    make_plan(dim, lt, n, plan, choose_acc_kib(dim, lt, n));
-    const dim3 grid(plan.num_tiles, plan.nbl);
-    if (dim == 3)
-        hipLaunchKernelGGL((bin_count_kernel<3>), grid, dim3(kBinThreads), 0, s, lt, plan, coords, c.cnt, (int64_t)0, n);
-    else
-        hipLaunchKernelGGL((bin_count_kernel<2>), grid, dim3(kBinThreads), 0, s, lt, plan, coords, c.cnt, (int64_t)0, n);
-    SHACIRA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, s, c.cnt, c.totals, plan.num_tiles);
-    SHACIRA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, c.totals, c.base, c.unit_first,
-                       c.unit_bucket, plan.total_buckets, plan.chunk);
-    SHACIRA_CHECK_LAUNCH();
-    return hipSuccess;
-}
-
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table,
-                        const uint32_t *perm, const std::function<hipError_t(hipStream_t)> *stage_hook,
-                        void *context) {
-    BinWorkspace w = carve(dim, dtype, lt, n, workspace);
-    const bool full = lt.level_begin == 0 && lt.level_end == lt.num_lods && lt.stage_flags == 0;
-    const bool precounted = context != nullptr && full && bin_context_bytes(dim, dtype, lt, n) > 0;
-    if (precounted) {
-        const BinContext c = carve_context(dim, lt, n, context);
-        w.cnt = c.cnt;
-        w.totals = c.totals;
-        w.base = c.base;
-        w.unit_first = c.unit_first;
-        w.unit_bucket = c.unit_bucket;
-    }
+                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table) {
+    const BinWorkspace w = carve(dim, dtype, lt, n, workspace);
     static std::once_flag once;  // kernels that use more than 64 KiB of dynamic LDS must opt in once per process
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
@@ -1680,13 +1359,6 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, true>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2, false>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, false>), 16384 * sizeof(double));
-#define SHACIRA_ROWS_ATTR(D, FF)                                                                                              \
-        set(reinterpret_cast<const void *>(&bin_scatter_rows_kernel<D, float, FF, true>), (size_t)kTile * (1 << (D - 1)) * (sizeof(Item<FF>) + 1));   \
-        set(reinterpret_cast<const void *>(&bin_scatter_rows_kernel<D, float, FF, false>), (size_t)kTile * (1 << (D - 1)) * (sizeof(Item<FF>) + 1));  \
-        set(reinterpret_cast<const void *>(&bin_scatter_rows_kernel<D, __half, FF, true>), (size_t)kTile * (1 << (D - 1)) * (sizeof(Item<FF>) + 1));  \
-        set(reinterpret_cast<const void *>(&bin_scatter_rows_kernel<D, __half, FF, false>), (size_t)kTile * (1 << (D - 1)) * (sizeof(Item<FF>) + 1));
-        SHACIRA_ROWS_ATTR(2, 2) SHACIRA_ROWS_ATTR(2, 4) SHACIRA_ROWS_ATTR(3, 2) SHACIRA_ROWS_ATTR(3, 4)
-#undef SHACIRA_ROWS_ATTR
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4>), (size_t)kTile * 2 * (sizeof(Item<4>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
@@ -1694,15 +1366,11 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
     });
     if (attr_err != hipSuccess) return attr_err;
     if (dim == 3) {
-        return lt.feature_dim == 2 ? run_bin<3, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, perm, stage_hook,
-                                                     precounted)
-                                   : run_bin<3, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, perm, stage_hook,
-                                                     precounted);
+        return lt.feature_dim == 2 ? run_bin<3, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table)
+                                   : run_bin<3, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table);
     }
-    return lt.feature_dim == 2 ? run_bin<2, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, perm, stage_hook,
-                                                     precounted)
-                               : run_bin<2, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, perm, stage_hook,
-                                                     precounted);
+    return lt.feature_dim == 2 ? run_bin<2, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table)
+                               : run_bin<2, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table);
 }
 
 }  // namespace shacira

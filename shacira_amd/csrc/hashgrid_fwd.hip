@@ -822,6 +822,42 @@ hipError_t hashgrid_untranspose(int dtype, int F, const void *staged, void *feat
                   : launch_untranspose<__half, 4>(staged, feats, n, L, perm, s);
 }
 
+// Test hook: the level-local corner rows and interpolation weights exactly as the kernels compute them
+// (compute_corners of hashgrid_device.h = hash_index / hash_index2d and the weight products of the reference,
+// hashgrid_interpolate_cuda.cu:17-39, :68-94), one (sample, level) per thread.
+template <int DIM>
+__global__ __launch_bounds__(256) void debug_corners_kernel(LevelTable lt, const float *__restrict__ coords, int64_t N,
+                                                            int32_t *__restrict__ idx, float *__restrict__ w) {
+    constexpr int NC = 1 << DIM;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int L = lt.num_lods;
+    if (e >= N * L) return;
+    const int64_t i = e / L;
+    const int l = (int)(e - i * L);
+    double t[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
+    Corners<DIM> c;
+    compute_corners<DIM>(t, lt.res[l], lt.hi[l], lt.dense[l] != 0, lt.mask, c);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        if (idx) idx[e * NC + k] = (int32_t)c.row[k];
+        if (w) w[e * NC + k] = c.w[k];
+    }
+}
+
+hipError_t hashgrid_debug_corners(int dim, const LevelTable &lt, const float *coords, int64_t n, int32_t *idx, float *w,
+                                  hipStream_t s) {
+    const int64_t items = n * lt.num_lods;
+    if (items <= 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)((items + 255) / 256);
+    if (dim == 3)
+        hipLaunchKernelGGL(debug_corners_kernel<3>, dim3(blocks), dim3(256), 0, s, lt, coords, n, idx, w);
+    else
+        hipLaunchKernelGGL(debug_corners_kernel<2>, dim3(blocks), dim3(256), 0, s, lt, coords, n, idx, w);
+    return hipGetLastError();
+}
+
 size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
     if (tiled_supported(dim, dtype, lt, n)) return tiled_forward_workspace(dim, dtype, lt, n);
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return 0;

@@ -94,13 +94,15 @@ static void make_tile_plan(int dim, const LevelTable &lt, int64_t n, TilePlan &t
     }
     tp.num_blocks = (uint32_t)(tp.nb[0] * tp.nb[1] * tp.nb[2]);
     tp.num_tiles = (uint32_t)((n + kSortTileS - 1) / kSortTileS);
-    // coarse levels: those whose cell count does not exceed ~4x the batch keep enough reuse inside a block for the rows
-    // kernel to beat the level-per-XCD kernel (tools/tiled_sweep.py)
+    // coarse levels (rows kernel) vs fine levels (level-per-XCD kernel), measured (tools/tiled_sweep.py): 3-D -- the levels
+    // whose cell count does not exceed ~4x the batch keep enough reuse inside a block (S1: 8 or 9 of 16 are equally good,
+    // 12 costs +30 %); 2-D -- every level (lines are shared along x at any resolution: 0.140 ms against 0.157 ms with one
+    // fine level and 0.235 ms for the unsorted kernels on 2^20 samples)
     int lc = 0;
     while (lc < lt.num_lods) {
         double cells = 1.0;
         for (int a = 0; a < dim; ++a) cells *= (double)lt.res[lc];
-        if (cells > 4.0 * (double)n) break;
+        if (dim == 3 && cells > 4.0 * (double)n) break;
         ++lc;
     }
     const int opt = g_tiled_lc_fwd.load();
@@ -293,7 +295,6 @@ static hipError_t sort_samples(int dim, const TilePlan &tp, const float *coords,
 
 // ----------------------------------------------------------------------------------------------- host side
 bool tiled_supported(int dim, int dtype, const LevelTable &lt, int64_t n) {
-    (void)dtype;
     const int opt = g_tiled.load();
     if (opt == 0) return false;
     // explicit algorithm selectors win: forward variant 8 forces this path, any other explicit variant excludes it
@@ -302,9 +303,11 @@ bool tiled_supported(int dim, int dtype, const LevelTable &lt, int64_t n) {
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return false;
     if (n < 1 || n >= ((int64_t)1 << 31)) return false;
     if (opt == 1 || v == 8) return true;
-    // measured rule (tools/tiled_check.py): 3-D batches from 2^19 samples on; smaller batches and 2-D tables (whose
-    // levels are mostly dense and L2-resident anyway) are faster through variants 3 / 6
-    return dim == 3 && n >= ((int64_t)1 << 19);
+    // measured rule (tools/tiled_check.py): tables that do not fit an XCD's L2 (the Kodak tables of configs B / C are
+    // L1 / LDS resident: sorting only costs there), 3-D batches from 2^19 samples, 2-D from 2^18
+    const size_t table_bytes = (size_t)lt.table_rows * lt.feature_dim * (dtype == SHACIRA_F32 ? 4 : 2);
+    if (table_bytes < ((size_t)8 << 20)) return false;
+    return n >= ((int64_t)1 << (dim == 3 ? 19 : 18));
 }
 
 static size_t staged_bytes(int dtype, const LevelTable &lt, int64_t n) {

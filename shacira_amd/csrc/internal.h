@@ -2,7 +2,6 @@
 #pragma once
 
 #include <atomic>
-#include <functional>
 #include <mutex>
 
 #include "hashgrid_device.h"
@@ -14,6 +13,21 @@ size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int6
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                      const float *coords, const void *table, void *feats, void *workspace, int64_t n,
                                      hipStream_t s);
+// levels [lt.level_begin, lt.level_end) of the level-per-XCD pair kernel into a level-major staging buffer [L][N][F]
+hipError_t hashgrid_forward_levels_staged(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
+                                          const float *coords, const void *table, void *staged, int64_t n,
+                                          hipStream_t s);
+// coarse levels [0, lc) over cell-sorted coordinates + assembly of whole feature rows through perm
+hipError_t hashgrid_forward_rows(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *sorted,
+                                 const uint32_t *perm, const void *table, const void *staged, void *feats, int64_t n,
+                                 int lc, hipStream_t s);
+// hashgrid_tiled.hip: cell-sorted ("tiled") forward for large batches
+bool tiled_supported(int dim, int dtype, const LevelTable &lt, int64_t n);
+size_t tiled_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
+hipError_t tiled_forward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                         const void *table, void *feats, void *workspace, int64_t n, hipStream_t s);
+hipError_t hashgrid_debug_corners(int dim, const LevelTable &lt, const float *coords, int64_t n, int32_t *idx, float *w,
+                                  hipStream_t s);
 // cell_sort.hip
 size_t cell_sort_workspace_bytes(int dim, int64_t n);
 hipError_t cell_sort(int dim, const float *coords, int64_t n, void *ws, uint32_t **perm_out, float **sorted_out,
@@ -22,41 +36,7 @@ hipError_t cell_sort(int dim, const float *coords, int64_t n, void *ws, uint32_t
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
 hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                       const float *coords, const void *grad_out, void *grad_table, void *workspace,
-                                      size_t workspace_bytes, int64_t n, void *context, int ctx_flags, hipStream_t s);
-
-// hashgrid_bwd_bin.hip
-bool bin_supported(int dim, const LevelTable &lt);
-size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n);
-float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace);
-void bin_staged_pointers(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace, float **gT,
-                         uint32_t **gmax);
-hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table,
-                        const uint32_t *perm, const std::function<hipError_t(hipStream_t)> *stage_hook,
-                        void *context);
-// hashgrid_fwd.hip: levels [lt.level_begin, lt.level_end) of the level-per-XCD pair kernel into staged [L][N][F]
-hipError_t hashgrid_forward_levels_staged(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
-                                          const float *coords, const void *table, void *staged, int64_t n,
-                                          hipStream_t s);
-hipError_t hashgrid_forward_rows(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *sorted,
-                                 const uint32_t *perm, const void *table, const void *staged, void *feats, int64_t n,
-                                 int lc, hipStream_t s);
-hipError_t hashgrid_untranspose(int dtype, int F, const void *staged, void *feats, int64_t n, int L,
-                                const uint32_t *perm, hipStream_t s);
-// hashgrid_tiled.hip: cell-sorted ("tiled") forward for large batches
-bool tiled_supported(int dim, int dtype, const LevelTable &lt, int64_t n);
-size_t tiled_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
-hipError_t tiled_forward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                         const void *table, void *feats, void *workspace, int64_t n, hipStream_t s);
-// hashgrid_bwd_bin.hip: sample context = the backward's bucket counts of a batch (counted while the forward runs)
-size_t bin_context_bytes(int dim, int dtype, const LevelTable &lt, int64_t n);
-hipError_t bin_count_context(int dim, int dtype, const LevelTable &lt, const float *coords, int64_t n, void *context,
-                             hipStream_t s);
-struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, zeroed = nullptr, staged = nullptr;
-};
-hipError_t side_stream(SideStream **out);
+                                      size_t workspace_bytes, int64_t n, hipStream_t s);
 
 // latent.hip
 struct DecodeArgs {
@@ -132,9 +112,8 @@ extern std::atomic<int> g_bin_acc_kib;
 extern std::atomic<int> g_bwd_fork;
 extern std::atomic<int> g_bwd_fuse;
 extern std::atomic<int> g_bwd_compact;
-extern std::atomic<int> g_bwd_rows;       // 1: transpose fused into the scatter (gradient rows in registers), 0: staged gT
 extern std::atomic<int> g_mlp_variant;
-extern std::atomic<int> g_tiled;          // -1 auto, 0 off, 1 force the cell-sorted path
-extern std::atomic<int> g_tiled_lc_fwd;   // coarse (LDS-region) levels of the tiled forward, -1 = planner
+extern std::atomic<int> g_tiled;          // cell-sorted forward: -1 by batch size, 0 never, 1 whenever the shape allows
+extern std::atomic<int> g_tiled_lc_fwd;   // its number of coarse levels (rows kernel), -1 = planner
 
 }  // namespace shacira

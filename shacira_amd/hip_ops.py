@@ -41,13 +41,7 @@ def _dtype_code(t):
         raise RuntimeError(f"shacira_amd: unsupported table dtype {t.dtype} (fp32 and fp16 are implemented)")
 
 
-def _context_bytes(L, dim, N, res, F, bw, T, dt):
-    return L.shacira_hashgrid_context_bytes(dim, N, len(res), F, int(bw), _res_array(res), T, dt)
-
-
-def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth, want_context=False):
-    """``want_context``: also return the sample context (a uint8 tensor, or None when this shape does not use one) that
-    ``hashgrid_backward(..., context=...)`` of the SAME coords can reuse instead of re-sorting the batch."""
+def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth):
     _need_gpu(coords, codebook, codebook_first_idx)
     if coords.dtype != torch.float32:
         raise RuntimeError("expected scalar type Float for coords")  # data_ptr<float>() in the reference
@@ -60,31 +54,21 @@ def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, cod
         nbytes = L.shacira_hashgrid_forward_workspace_bytes(dim, N, len(res), F, int(codebook_bitwidth),
                                                             _res_array(res), T, dt)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=codebook.device) if nbytes else None
-        context = None
-        if want_context:
-            cbytes = _context_bytes(L, dim, N, res, F, codebook_bitwidth, T, dt)
-            if cbytes:
-                context = torch.empty((cbytes,), dtype=torch.uint8, device=codebook.device)
-        rc = L.shacira_hashgrid_forward_ctx(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
-                                            _ptr(codebook_first_idx), T, _ptr(coords), _ptr(codebook), dt, _ptr(feats),
-                                            _ptr(ws), nbytes, _ptr(context),
-                                            context.numel() if context is not None else 0,
-                                            _lib.CTX_BUILD if context is not None else 0, _stream(codebook))
+        rc = L.shacira_hashgrid_forward(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
+                                        _ptr(codebook_first_idx), T, _ptr(coords), _ptr(codebook), dt, _ptr(feats),
+                                        _ptr(ws), nbytes, _stream(codebook))
     _lib.check(rc, "hashgrid_interpolate")
-    return (feats, context) if want_context else feats
+    return feats
 
 
 def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codebook_first_idx, resolution,
-                      codebook_bitwidth, feature_dim, levels=None, out=None, workspace=None, flags=0, context=None):
+                      codebook_bitwidth, feature_dim, levels=None, out=None, workspace=None, flags=0):
     """grad_codebook [table_rows, feature_dim] of ``table_dtype`` (the codebook's values are not needed).
 
     ``levels=(begin, end)`` computes (and overwrites) only the rows of those levels inside ``out`` (an existing
     gradient buffer) -- used to overlap the all-reduce of finished rows with the remaining levels. A series of such
     calls can share ``workspace`` (see ``backward_workspace``) with ``flags`` BWD_STAGE_ALL_LEVELS on the first and
-    BWD_REUSE_STAGED on the following ones, so the gradients are transposed once.
-
-    ``context``: the tensor returned by ``_hashgrid_forward(..., want_context=True)`` for the SAME coords (all levels
-    only); the backward then skips its own sort of the batch."""
+    BWD_REUSE_STAGED on the following ones, so the gradients are transposed once."""
     _need_gpu(coords, grad_output, codebook_first_idx)
     res = tuple(int(r) for r in resolution)
     N, T, F = coords.shape[0], int(table_rows), int(feature_dim)
@@ -113,19 +97,26 @@ def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codeboo
             ws = workspace
         else:
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
-        if context is not None and (lb, le) == (0, len(res)) and not flags and \
-                _context_bytes(L, dim, N, res, F, codebook_bitwidth, T, dt) == context.numel():
-            rc = L.shacira_hashgrid_backward_ctx(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
-                                                 _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
-                                                 _ptr(grad_codebook), _ptr(ws), nbytes, _ptr(context), context.numel(),
-                                                 _lib.CTX_REUSE, _stream(grad_output))
-        else:
-            rc = L.shacira_hashgrid_backward_levels(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
-                                                    _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
-                                                    _ptr(grad_codebook), lb, le, int(flags), _ptr(ws), nbytes,
-                                                    _stream(grad_output))
+        rc = L.shacira_hashgrid_backward_levels(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
+                                                _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
+                                                _ptr(grad_codebook), lb, le, int(flags), _ptr(ws), nbytes,
+                                                _stream(grad_output))
     _lib.check(rc, "hashgrid_interpolate_backward")
     return grad_codebook
+
+
+def hashgrid_debug_corners(dim, coords, resolution, codebook_bitwidth):
+    """Test hook: (rows int32 [N, L, 2^dim], weights fp32 [N, L, 2^dim]) exactly as the kernels compute them."""
+    _need_gpu(coords)
+    res = tuple(int(r) for r in resolution)
+    N = coords.shape[0]
+    rows = torch.empty((N, len(res), 1 << dim), dtype=torch.int32, device=coords.device)
+    w = torch.empty((N, len(res), 1 << dim), dtype=torch.float32, device=coords.device)
+    with torch.cuda.device(coords.device):
+        rc = _lib.lib().shacira_hashgrid_debug_corners(dim, N, len(res), int(codebook_bitwidth), _res_array(res),
+                                                       _ptr(coords), _ptr(rows), _ptr(w), _stream(coords))
+    _lib.check(rc, "hashgrid_debug_corners")
+    return rows, w
 
 
 def backward_workspace(dim, num_coords, table_rows, table_dtype, resolution, codebook_bitwidth, feature_dim, device):

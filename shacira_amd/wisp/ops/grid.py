@@ -24,13 +24,9 @@ def _check_feature_dim(codebook):
 
 def _forward(ctx, dim, coords, resolutions, codebook_bitwidth, codebook, codebook_first_idx):
     _check_feature_dim(codebook)
-    # the forward orders large batches by spatial block; the backward of the same coordinates reuses that order
-    # (sample context, include/shacira_hip.h) -- only kept when a gradient can be asked for
-    want = codebook.requires_grad and torch.is_grad_enabled()
-    out = hip_ops._hashgrid_forward(dim, coords.float().contiguous(), codebook.contiguous(), codebook_first_idx,
-                                    resolutions, codebook_bitwidth, want_context=want)
-    feats_out, ctx.sample_context = out if want else (out, None)
-    feats_out = feats_out.contiguous()
+    op = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
+    feats_out = op(coords.float().contiguous(), codebook.contiguous(), codebook_first_idx, resolutions,
+                   codebook_bitwidth).contiguous()
     ctx.save_for_backward(coords, codebook_first_idx)
     ctx.resolutions = resolutions
     ctx.num_lods = len(resolutions)
@@ -46,7 +42,7 @@ def _backward(ctx, dim, grad_output):
     coords, codebook_first_idx = ctx.saved_tensors
     grad_codebook = hip_ops.hashgrid_backward(dim, coords.float().contiguous(), grad_output.contiguous(),
                                               ctx.table_rows, ctx.table_dtype, codebook_first_idx, ctx.resolutions,
-                                              ctx.codebook_bitwidth, ctx.feature_dim, context=ctx.sample_context)
+                                              ctx.codebook_bitwidth, ctx.feature_dim)
     return (None, None, None, None, grad_codebook, None, None)
 
 

@@ -62,8 +62,19 @@ def _run(dev, dim, res, bw, coords, table, go, first, dtype=torch.float32):
     return feats, grad
 
 
+def _assert_grad_close(got, ref, first, sizes, rtol=RTOL):
+    """Gradients against the fp64 oracle, LEVEL BY LEVEL: atol = rtol * max|ref| of that level (fine-level rows are
+    10-20x smaller than level-0 rows, so one table-wide atol would hold them to 1e-4 only)."""
+    got = np.asarray(got, dtype=np.float64)
+    for l in range(len(sizes)):
+        lo, hi = int(first[l]), int(first[l]) + int(sizes[l])
+        scale = np.abs(ref[lo:hi]).max()
+        np.testing.assert_allclose(got[lo:hi], ref[lo:hi], rtol=rtol, atol=rtol * max(scale, 1e-30),
+                                   err_msg=f"level {l}")
+
+
 @pytest.mark.parametrize("name", ["A", "B", "Bp", "D"])
-@pytest.mark.parametrize("variant", [(-1, -1), (0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1)])
+@pytest.mark.parametrize("variant", [(-1, -1), (0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1)])
 def test_forward_bit_exact_backward_within_tolerance(dev, name, variant):
     from shacira_amd import _lib
     dim, res, bw = CONFIGS[name]
@@ -81,8 +92,7 @@ def test_forward_bit_exact_backward_within_tolerance(dev, name, variant):
     assert np.array_equal(got_f, ref_f), f"forward not bit-identical: {np.abs(got_f - ref_f).max()}"
     ref_g = oc.backward(coords, go, (T, 2), first, res, bw)
     got_g = grad.cpu().numpy().astype(np.float64)
-    scale = np.abs(ref_g).max()
-    np.testing.assert_allclose(got_g, ref_g, rtol=RTOL, atol=RTOL * scale)
+    _assert_grad_close(got_g, ref_g, first, sizes)
     # per-level conservation: sum of the gradient rows of level l == sum of grad_output columns of level l
     for l in range(len(res)):
         lo, hi = first[l], first[l] + sizes[l]
@@ -546,6 +556,122 @@ def test_config_c_full_size_properties(dev):
     g5k = ops.hashgrid_backward(2, coords[:5000].contiguous(), go[:5000].contiguous(), T, torch.float32, tf, res, bw, 2)
     np.testing.assert_allclose(g5k.cpu().numpy(), ref, rtol=RTOL, atol=RTOL * np.abs(ref).max())
     assert torch.isfinite(g1).all()
+
+
+@pytest.mark.parametrize("name", ["A", "B", "Bp", "D"])
+def test_corner_rows_and_weights_bit_exact(dev, name):
+    """north_star: "hash indices bit-exact". The integers themselves (level-local row of every corner = hash_index /
+    hash_index2d of the reference, hashgrid_interpolate_cuda.cu:17-39) and the interpolation weights, straight from the
+    device function all kernels share (shacira_hashgrid_debug_corners), against the oracle's idx_out / w_out -- edge
+    coordinates (+-1, NaN, out of range, 1 - 2^-24) included."""
+    ops = _ops()
+    dim, res, bw = CONFIGS[name]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, 20_011)
+    rows, w = ops.hashgrid_debug_corners(dim, torch.from_numpy(coords).to(dev), res, bw)
+    _, ref_idx, ref_w = oc.forward(coords, table, first, res, bw, want_corners=True)
+    got_idx = rows.cpu().numpy()
+    assert got_idx.dtype == np.int32 and got_idx.shape == ref_idx.shape
+    assert np.array_equal(got_idx, ref_idx), f"{int((got_idx != ref_idx).sum())} corner rows differ"
+    got_w = w.cpu().numpy()
+    assert np.array_equal(got_w.view(np.uint32), ref_w.view(np.uint32)), "interpolation weights differ in some bit"
+    # the rows are inside their level wherever the reference is defined (a +1 corner of a res >= 258 dense level at
+    # coord == +1 is the reference's own out-of-level read, weight 0)
+    for l in range(len(res)):
+        inside = ref_w[:, l, :] != 0
+        assert (got_idx[:, l, :][inside] >= 0).all() and (got_idx[:, l, :][inside] < sizes[l]).all()
+
+
+@pytest.mark.parametrize("dim,n", [(3, (1 << 19) + 13), (2, (1 << 18) + 5)])
+def test_tiled_forward_at_size(dev, dim, n):
+    """The cell-sorted forward (default for large batches of big tables): bit-identical to the unsorted kernels on the
+    whole batch and to the oracle on a slice, ragged size, edge coordinates, a cluster that overfills one block."""
+    from shacira_amd import _lib
+    ops = _ops()
+    _, res, bw = CONFIGS["D" if dim == 3 else "Bp"]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n)
+    coords[1000:60_000] = (np.float32(0.31) + np.random.default_rng(3).normal(0, 0.003, (59_000, dim))).astype(np.float32)
+    tc, tt, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(table).to(dev), torch.from_numpy(first).to(dev)
+    fwd = ops.hashgrid_interpolate_cuda if dim == 3 else ops.hashgrid_interpolate2d_cuda
+    assert _lib.get_option("tiled") == -1
+    auto = fwd(tc, tt, tf, res, bw)                       # the automatic choice IS the tiled path at this size
+    _lib.set_option("tiled", 0)
+    try:
+        plain = fwd(tc, tt, tf, res, bw)
+    finally:
+        _lib.set_option("tiled", -1)
+    assert torch.equal(auto, plain)
+    sl = np.r_[0:64, 900:1100, n - 300:n]
+    assert np.array_equal(auto.cpu().numpy()[sl], oc.forward(coords[sl], table, first, res, bw))
+    for lc in (0, 3, len(res)):                            # every split between the rows kernel and the level kernel
+        _lib.set_option("tiled_lc_fwd", lc)
+        try:
+            assert torch.equal(fwd(tc, tt, tf, res, bw), plain)
+        finally:
+            _lib.set_option("tiled_lc_fwd", -1)
+
+
+def test_config_c_on_the_kodak_table(dev):
+    """BASELINE config C as benchmarked: 24 Kodak-sized lattices (N = 9 437 184) on the bw-11 Kodak table of configs
+    B / C (26 704 rows: every level is 'direct', ~1 400 adds per row and image). Full-size properties + oracle slices of
+    both directions."""
+    ops = _ops()
+    dim, res, bw = CONFIGS["B"]
+    sizes, first, T = table_layout(res, bw, dim)
+    H, W, IM = 512, 768, 24
+    rows = (torch.arange(H, dtype=torch.float32) / H - 0.5) * 2
+    cols = (torch.arange(W, dtype=torch.float32) / W - 0.5) * 2
+    rr, cc = torch.meshgrid(rows, cols, indexing="ij")
+    lattice = torch.stack([rr, cc], -1).reshape(-1, 2)
+    g = torch.Generator().manual_seed(0)
+    coords = torch.cat([lattice[torch.randperm(H * W, generator=g)] for _ in range(IM)]).to(dev)
+    N = coords.shape[0]
+    assert N == 9_437_184
+    tf = torch.from_numpy(first).to(dev)
+    table = (torch.randn(T, 2, generator=g) * 0.01).to(dev)
+    go = torch.randn(N, 32, generator=g).to(dev)
+    feats = ops.hashgrid_interpolate2d_cuda(coords, table, tf, res, bw)
+    grad = ops.hashgrid_backward(2, coords, go, T, torch.float32, tf, res, bw, 2)
+    sl = slice(5_000_000, 5_002_048)
+    assert np.array_equal(feats[sl].cpu().numpy(), oc.forward(coords[sl].cpu().numpy(), table.cpu().numpy(), first, res, bw))
+    lhs = float((feats.double() * go.double()).sum())
+    rhs = float((table.double() * grad.double()).sum())
+    assert lhs == pytest.approx(rhs, rel=1e-4)                      # adjointness <F t, go> == <t, F^T go>
+    for l in range(16):                                             # conservation, every level
+        lo, hi = int(first[l]), int(first[l]) + sizes[l]
+        np.testing.assert_allclose(grad[lo:hi].double().sum(0).cpu().numpy(),
+                                   go[:, 2 * l:2 * l + 2].double().sum(0).cpu().numpy(), rtol=1e-3, atol=1.0)
+    # linearity in the batch: the gradient of the whole batch is the sum of the gradients of its 24 images' halves
+    half = N // 2
+    ga = ops.hashgrid_backward(2, coords[:half].contiguous(), go[:half].contiguous(), T, torch.float32, tf, res, bw, 2)
+    gb = ops.hashgrid_backward(2, coords[half:].contiguous(), go[half:].contiguous(), T, torch.float32, tf, res, bw, 2)
+    tot = (ga.double() + gb.double()).cpu().numpy()
+    _assert_grad_close(grad.cpu().numpy(), tot, first, sizes)
+    # oracle slice of the backward: one image's first 30 000 pixels through the same all-direct kernel
+    n_or = 30_000
+    ref = oc.backward(coords[:n_or].cpu().numpy(), go[:n_or].cpu().numpy(), (T, 2), first, res, bw)
+    g_or = ops.hashgrid_backward(2, coords[:n_or].contiguous(), go[:n_or].contiguous(), T, torch.float32, tf, res, bw, 2)
+    _assert_grad_close(g_or.cpu().numpy(), ref, first, sizes)
+
+
+def test_s3_ray_points_against_the_oracle(dev):
+    """SURVEY S3 / BASELINE config 4: the real NeRF batch -- 4096 rays x 16 stratified samples = 65 536 ray points
+    (strongly non-uniform: points cluster along rays through the cube centre) on the nerf_hash table. Both directions
+    against the oracle at full size."""
+    from shacira_amd import harness
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T = table_layout(res, bw, dim)
+    g = torch.Generator().manual_seed(7)
+    coords = harness.ray_points(4096, 16, g).contiguous()
+    assert coords.shape == (65536, 3)
+    table = (torch.randn(T, 2, generator=g) * 0.01)
+    go = torch.randn(65536, 32, generator=g)
+    tf = torch.from_numpy(first).to(dev)
+    feats = ops.hashgrid_interpolate_cuda(coords.to(dev), table.to(dev), tf, res, bw)
+    grad = ops.hashgrid_backward(3, coords.to(dev), go.to(dev), T, torch.float32, tf, res, bw, 2)
+    assert np.array_equal(feats.cpu().numpy(), oc.forward(coords.numpy(), table.numpy(), first, res, bw))
+    ref = oc.backward(coords.numpy(), go.numpy(), (T, 2), first, res, bw)
+    _assert_grad_close(grad.cpu().numpy(), ref, first, sizes)
 
 
 def test_concurrent_calls_from_two_threads(dev):

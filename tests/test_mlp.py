@@ -87,71 +87,3 @@ def _check_fused_mlp(dims, n, dev):
         y, y64, got, want = both(x0[~bad_rows], gy[~bad_rows])
     for a, b in zip(got, want):
         torch.testing.assert_close(a.double(), b, rtol=1e-5, atol=1e-5 * float(b.abs().max()) + 1e-9)
-
-
-@pytest.mark.gpu
-def test_fused_mlp_speed_on_image_batch():
-    dev = torch.device("cuda:0")
-    dec = BasicDecoder(32, 3, torch.relu, True, nn.Linear, 2, 16, []).to(dev)
-    x = torch.randn(393216, 32, device=dev, requires_grad=True)
-    gy = torch.randn(393216, 3, device=dev)
-
-    def run(fn, iters=20):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(iters):
-            fn()
-        b.record()
-        torch.cuda.synchronize()
-        return a.elapsed_time(b) / iters
-
-    def fused():
-        y = dec(x); y.backward(gy)
-
-    def layers():
-        y = _torch_mlp(dec, x); y.backward(gy)
-    from shacira_amd import _lib
-    tf, tl = run(fused), run(layers)
-    _lib.set_option("mlp_variant", 0)
-    try:
-        tv = run(fused)
-    finally:
-        _lib.set_option("mlp_variant", -1)
-    print(f"decoder MLP fwd+bwd on 393216 px: MFMA 16x16x4 {tf:.3f} ms, VALU kernels {tv:.3f} ms, torch Linear layers "
-          f"{tl:.3f} ms")
-    assert tf < tl
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("dims", [(32, 64, 1, 16), (43, 64, 2, 3)])
-def test_mfma_mlp_speed_on_nerf_batch(dims):
-    dev = torch.device("cuda:0")
-    IN, H, NH, OUT = dims
-    dec = BasicDecoder(IN, OUT, torch.relu, True, nn.Linear, NH, H, []).to(dev)
-    n = 1 << 19
-    x = torch.randn(n, IN, device=dev, requires_grad=True)
-    gy = torch.randn(n, OUT, device=dev)
-
-    def run(fn, iters=10):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(iters):
-            fn()
-        b.record()
-        torch.cuda.synchronize()
-        return a.elapsed_time(b) / iters
-
-    def fused():
-        y = dec(x); y.backward(gy)
-
-    def layers():
-        y = _torch_mlp(dec, x); y.backward(gy)
-    tf, tl = run(fused), run(layers)
-    print(f"NeRF decoder {dims} fwd+bwd on {n} samples: MFMA kernels {tf:.3f} ms vs torch Linear layers {tl:.3f} ms")
-    assert tf < tl

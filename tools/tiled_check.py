@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Cell-sorted ("tiled") path vs the previous kernels and the oracle: bit-exact forward, backward tolerance, timing."""
+"""Cell-sorted ("tiled") forward vs the other variants and the oracle: bit-exactness + timing over batch sizes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,9 +18,11 @@ def timed(fn, it=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / it
 
-cases = [(3, 19, 1 << 20, 16, 2048), (3, 19, (1 << 18) + 77, 16, 2048), (2, 19, 1 << 20, 16, 2048), (2, 11, 393216, 16, 512)]
-if len(sys.argv) > 1:
-    cases = cases[:int(sys.argv[1])]
+cases = []
+for dim in (3, 2):
+    for e in (16, 17, 18, 19, 20, 21):
+        cases.append((dim, 19, (1 << e) + (77 if e == 18 else 0), 16, 2048))
+cases += [(2, 11, 393216, 16, 512), (2, 11, 24 * 393216, 16, 512)]
 for dim, bw, N, mn, mx in cases:
     res, F = geo(mn, mx, 16), 2
     sizes = [min(2 ** bw, r ** dim) for r in res]
@@ -32,39 +34,19 @@ for dim, bw, N, mn, mx in cases:
     coords = (torch.rand(N, dim, generator=g) * 2 - 1)
     coords[0] = 1.0; coords[1] = -1.0; coords[2] = float("nan"); coords[3] = 2.5; coords[4] = -9.0
     coords = coords.cuda()
-    go = torch.randn(N, 32, generator=g).cuda()
-    f = lambda ctx=False: hip_ops._hashgrid_forward(dim, coords, table, first, res, bw, want_context=ctx)
-    b = lambda ctx=None: hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F, context=ctx)
-    out = {}
+    f = lambda: hip_ops._hashgrid_forward(dim, coords, table, first, res, bw)
+    out, tm = {}, {}
     for tiled in (0, 1):
         _lib.set_option("tiled", tiled)
-        feats = f().clone(); grad = b().clone()
-        tf, tb = timed(f), timed(b)
-        out[tiled] = (feats, grad)
-        print(f"dim{dim} bw{bw} N={N} tiled={tiled}: fwd {tf:.3f} ms  bwd {tb:.3f} ms  sum {tf+tb:.3f}")
-    feats, ctx = f(True)
-    if ctx is not None:
-        gctx = b(ctx).clone()
-        tf2 = timed(lambda: f(True))
-        tb = timed(lambda: b(ctx))
-        print(f"   with a sample context: fwd {tf2:.3f} ms  bwd {tb:.3f} ms  sum {tf2+tb:.3f}; grad equal-ish: {float((gctx - out[1][1]).abs().max()):.3e}")
+        out[tiled] = f().clone()
+        tm[tiled] = timed(f)
     _lib.set_option("tiled", -1)
-    print("  forward bit-exact vs old path:", torch.equal(out[0][0], out[1][0]))
-    d = (out[0][1] - out[1][1]).abs().max().item(); s = out[0][1].abs().max().item()
-    print(f"  backward max|diff| vs old path {d:.3e} (scale {s:.3e})")
-    n_or = min(N, 1 << 16)
-    # oracle on a slice: run the tiled path on the slice itself (forced)
+    ta = timed(f)
+    n_or = min(N, 1 << 15)
     _lib.set_option("tiled", 1)
-    cs, gs = coords[:n_or].contiguous(), go[:n_or].contiguous()
-    fo, c2 = hip_ops._hashgrid_forward(dim, cs, table, first, res, bw, want_context=True)
-    gr = hip_ops.hashgrid_backward(dim, cs, gs, T, table.dtype, first, res, bw, F, context=c2)
+    cs = coords[:n_or].contiguous()
+    fo = hip_ops._hashgrid_forward(dim, cs, table, first, res, bw)
     _lib.set_option("tiled", -1)
-    ref_f = oc.forward(cs.cpu().numpy(), table.cpu().numpy(), first_np, res, bw)
-    print("  slice forward bit-exact vs oracle:", np.array_equal(fo.cpu().numpy(), ref_f))
-    ref_g = oc.backward(cs.cpu().numpy(), gs.cpu().numpy(), (T, F), first_np, res, bw)
-    err = 0.0
-    for l in range(16):
-        lo = first_np[l]; hi = lo + sizes[l]
-        sc = np.abs(ref_g[lo:hi]).max()
-        err = max(err, float(np.abs(gr[lo:hi].cpu().numpy() - ref_g[lo:hi]).max() / max(sc, 1e-30)))
-    print(f"  slice backward max per-level relative error vs oracle: {err:.3e}")
+    ok_or = np.array_equal(fo.cpu().numpy(), oc.forward(cs.cpu().numpy(), table.cpu().numpy(), first_np, res, bw))
+    print(f"dim{dim} bw{bw} N={N:9d}: other variants {tm[0]:.3f} ms  tiled {tm[1]:.3f} ms  auto {ta:.3f} ms | "
+          f"tiled == others bit-exact: {torch.equal(out[0], out[1])}, tiled slice == oracle: {ok_or}")

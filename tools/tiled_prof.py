@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""S1 fwd + bwd (context shared) a few times -- run under rocprofv3 --kernel-trace --stats."""
+"""S1 (or DIM / N from the environment) fwd + bwd a few times -- run under rocprofv3 --kernel-trace --stats."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,6 +18,7 @@ table = (torch.randn(T, F, generator=g) * 0.01).cuda()
 coords = (torch.rand(N, dim, generator=g) * 2 - 1).cuda()
 go = torch.randn(N, 32, generator=g).cuda()
 for _ in range(int(os.environ.get("ITERS", 10))):
-    feats, ctx = hip_ops._hashgrid_forward(dim, coords, table, first, res, bw, want_context=True)
-    hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F, context=ctx)
+    hip_ops._hashgrid_forward(dim, coords, table, first, res, bw)
+    if not os.environ.get("FWD_ONLY"):
+        hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F)
 torch.cuda.synchronize()

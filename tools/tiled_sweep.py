@@ -31,10 +31,8 @@ _lib.set_option("tiled", 0)
 ref = f().clone()
 print(f"old path fwd {timed(f):.3f} ms")
 _lib.set_option("tiled", 1)
-for rows in (1, 0):
-    _lib.set_option("tiled_rows", rows)
-    for lc in (-1, 7, 6, 5, 4):
-        _lib.set_option("tiled_lc_fwd", lc)
-        ok = torch.equal(f(), ref)
-        print(f"tiled fwd rows={rows} lc={lc}: {timed(f):.3f} ms  bit-exact={ok}")
-_lib.set_option("tiled_lc_fwd", -1); _lib.set_option("tiled_rows", 1)
+for lc in (-1, 16, 12, 10, 9, 8, 7, 6, 5, 4, 0):
+    _lib.set_option("tiled_lc_fwd", lc)
+    ok = torch.equal(f(), ref)
+    print(f"tiled fwd lc={lc}: {timed(f):.3f} ms  bit-exact={ok}")
+_lib.set_option("tiled_lc_fwd", -1)
