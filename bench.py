@@ -142,7 +142,54 @@ def main():
                     help="steps of the NeRF-style render-and-fit on the analytic scene for the second PSNR figure (0 = skip)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 17)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="only exercise the multi-rank launch (spawn, rendezvous, one all-reduce, JSON line with n_gpus); "
+                         "needs no GPU: ranks use the gloo backend. The metric value is null.")
     args = ap.parse_args()
+
+    # --gpus N launched plainly (no torchrun environment): start the N rank processes ourselves, BEFORE anything in this
+    # process touches the GPU (a process that has initialised HIP must never be replaced or forked into ranks); this
+    # parent only waits and relays the children's output (rank 0 prints the JSON line) and exit code.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        visible = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        if not args.selftest_launch and visible == 1:
+            # one visible GPU: all ranks share it over gloo -- exercises the control flow only, not a scaling figure
+            print(f"bench.py: --gpus {args.gpus} with 1 visible GPU: ranks share cuda:0 over gloo "
+                  "(SHACIRA_TEST_SINGLE_GPU=1); control-flow check only", file=sys.stderr)
+            env["SHACIRA_TEST_SINGLE_GPU"] = "1"
+        elif not args.selftest_launch and visible < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {visible} GPUs are visible")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+    if args.selftest_launch:
+        rank = int(os.environ.get("RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "hash-grid samples/sec fwd+bwd (16 lvl, F=2)", "value": None, "unit": "samples/s",
+                              "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
+                              "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "none",
+                              "config": {"workload": "launch self-test (gloo, no kernels)", "scaling": args.scaling,
+                                         "allreduce_check": float(t.item()) == world * (world + 1) / 2}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from shacira_amd import _lib
     from shacira_amd import dist as sdist
@@ -150,8 +197,7 @@ def main():
     rank, world, device = sdist.init_from_env()
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: using the launcher's world size", file=sys.stderr)
         args.gpus = world
     if device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
@@ -314,7 +360,7 @@ def main():
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "dim": dim, "levels": L, "feature_dim": F, "bitwidth": bw,
-                       "table_rows": T, "samples_per_gpu": n_local,
+                       "table_rows": T, "samples_per_gpu": n_local, "scaling": args.scaling,
                        "parallelism": f"dp{world}" + ("" if world == 1 else
                                                       "+one allreduce(grad_codebook) after the backward"
                                                       if len(groups) == 1 else

@@ -4,8 +4,9 @@
 Where the algorithm comes from:
   * `raymarch_ray`        reference wisp/accelstructs/octree_as.py:235-290 (`OctreeAS._raymarch_ray`, the reference's own
                           Python) with `fast_filter_method` :20-32; the occupancy query it calls is kaolin's
-                          `spc_ops.unbatched_query` on points quantised by `quantize_points` (floor(clamp(res*(x+1)/2, 0,
-                          res-1))).
+                          `spc_ops.unbatched_query` on FLOAT points: cell = floor(res*(x*0.5+0.5)) per axis, and kaolin's
+                          `identify` (spc_math.h, "Check if in bounds") answers -1 for a cell outside [0, res) -- a point
+                          outside the cube (or exactly on its +1 face) belongs to no cell.
   * `raymarch_voxel`      reference octree_as.py:171-233 (`_raymarch_voxel`) + wisp/ops/spc/sampling.py:35-71
                           (`sample_from_depth_intervals`, `expand_pack_boundary`); the ray / cell intersections it starts
                           from come from kaolin's `spc_render.unbatched_raytrace(..., with_exit=True)`.
@@ -71,9 +72,13 @@ def quantize_points(x, level):
 
 
 def query_dense(occupancy, coords, level):
-    """occupancy: bool [G, G, G] indexed [x, y, z]. -> bool [N] (the reference's `pidx > -1`)."""
-    q = quantize_points(coords, level)
-    return occupancy[q[:, 0], q[:, 1], q[:, 2]]
+    """occupancy: bool [G, G, G] indexed [x, y, z]. -> bool [N] (the reference's `pidx > -1`): the point's cell is
+    occupied; points outside the cube have no cell (kaolin's identify returns -1 out of bounds)."""
+    res = 2 ** level
+    cell = torch.floor(res * (coords + 1.0) / 2.0)
+    inside = ((cell >= 0) & (cell < res)).all(dim=-1)
+    q = torch.nan_to_num(cell, nan=0.0).clamp(0, res - 1).long()
+    return inside & occupancy[q[:, 0], q[:, 1], q[:, 2]]
 
 
 def raymarch_ray(origins, dirs, dist_min, dist_max, occupancy, level, num_samples, jitter):

@@ -146,18 +146,19 @@ hipError_t cell_sort(int dim, const float *coords, int64_t n, void *ws, uint32_t
     uint32_t *base = reinterpret_cast<uint32_t *>(p);
     *perm_out = perm;
     *sorted_out = sorted;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
+    static PerDeviceOnce once;
+    const hipError_t attr_err = once.run([]() -> hipError_t {
         const int bytes = kSortKeys * (int)sizeof(uint32_t);
         const void *fns[] = {reinterpret_cast<const void *>(&sort_count_kernel<2>),
                              reinterpret_cast<const void *>(&sort_count_kernel<3>),
                              reinterpret_cast<const void *>(&sort_scatter_kernel<2>),
                              reinterpret_cast<const void *>(&sort_scatter_kernel<3>)};
+        hipError_t err = hipSuccess;
         for (const void *fn : fns) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            if (e != hipSuccess) attr_err = e;
+            if (e != hipSuccess) err = e;
         }
+        return err;
     });
     if (attr_err != hipSuccess) return attr_err;
     const size_t shmem = kSortKeys * sizeof(uint32_t);

@@ -1330,11 +1330,11 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                         const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table) {
     const BinWorkspace w = carve(dim, dtype, lt, n, workspace);
-    static std::once_flag once;  // kernels that use more than 64 KiB of dynamic LDS must opt in once per process
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
+    static PerDeviceOnce once;  // kernels that use more than 64 KiB of dynamic LDS must opt in once per device
+    const hipError_t attr_err = once.run([]() -> hipError_t {
+        hipError_t attr_err = hipSuccess;
         // dynamic LDS actually requested (static LDS of the kernels comes on top and must fit in 160 KiB too)
-        auto set = [](const void *fn, size_t bytes) {
+        auto set = [&attr_err](const void *fn, size_t bytes) {
             if (bytes <= 64 * 1024) return;
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (e != hipSuccess) attr_err = e;
@@ -1363,6 +1363,7 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4>), (size_t)kTile * 2 * (sizeof(Item<4>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
+        return attr_err;
     });
     if (attr_err != hipSuccess) return attr_err;
     if (dim == 3) {

@@ -636,11 +636,12 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             const size_t shmem = (size_t)256 * (lt.num_lods + 1) * F * sizeof(T);
-            static std::once_flag once;  // per instantiation: allow > 64 KiB of dynamic LDS (L = 32, F = 4, fp32)
-            std::call_once(once, [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&untranspose_feats_kernel<T, F>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+            static PerDeviceOnce once;  // per instantiation and device: allow > 64 KiB of dynamic LDS (L = 32, F = 4, fp32)
+            e = once.run([]() -> hipError_t {
+                return hipFuncSetAttribute(reinterpret_cast<const void *>(&untranspose_feats_kernel<T, F>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
             });
+            if (e != hipSuccess) return e;
             hipLaunchKernelGGL((untranspose_feats_kernel<T, F>), dim3((uint32_t)((num_coords + 255) / 256)), dim3(256),
                                shmem, stream, static_cast<const T *>(workspace), static_cast<T *>(feats), num_coords,
                                lt.num_lods, perm);
@@ -768,11 +769,12 @@ static hipError_t launch_rows(const LevelTable &lt, const int32_t *first_idx, co
                               const void *table, const void *staged, void *feats, int64_t n, int lc, hipStream_t s) {
     const uint32_t row_bytes = (uint32_t)(lt.num_lods * F * sizeof(T));
     const size_t shmem = (size_t)128 * ((row_bytes + 15u) / 16u * 16u + 16u);
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hashgrid_fwd_rows_kernel<DIM, T, F>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    static PerDeviceOnce once;
+    const hipError_t oe = once.run([]() -> hipError_t {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&hashgrid_fwd_rows_kernel<DIM, T, F>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     });
+    if (oe != hipSuccess) return oe;
     hipLaunchKernelGGL((hashgrid_fwd_rows_kernel<DIM, T, F>), dim3((uint32_t)((n + 127) / 128)), dim3(256), shmem, s, lt,
                        first_idx, sorted, perm, static_cast<const T *>(table), static_cast<const T *>(staged),
                        static_cast<T *>(feats), n, lc);
@@ -802,11 +804,12 @@ template <typename T, int F>
 static hipError_t launch_untranspose(const void *staged, void *feats, int64_t n, int L, const uint32_t *perm,
                                      hipStream_t s) {
     const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(T);
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&untranspose_feats_kernel<T, F>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    static PerDeviceOnce once;
+    const hipError_t oe = once.run([]() -> hipError_t {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&untranspose_feats_kernel<T, F>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     });
+    if (oe != hipSuccess) return oe;
     hipLaunchKernelGGL((untranspose_feats_kernel<T, F>), dim3((uint32_t)((n + 255) / 256)), dim3(256), shmem, s,
                        static_cast<const T *>(staged), static_cast<T *>(feats), n, L, perm);
     return hipGetLastError();

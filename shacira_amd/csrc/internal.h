@@ -8,6 +8,22 @@
 
 namespace shacira {
 
+// hipFuncSetAttribute (the opt-in for > 64 KiB of dynamic LDS) is a per-DEVICE setting: the opt-ins run once for every
+// device this process launches on (the current device must be the one the caller's stream belongs to; the PyTorch
+// wrappers enter `torch.cuda.device(tensor.device)` around every call).
+struct PerDeviceOnce {
+    std::once_flag flag[16];
+    hipError_t err[16] = {};
+    template <typename Fn> hipError_t run(Fn &&fn) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+        std::call_once(flag[dev], [&] { err[dev] = fn(); });
+        return err[dev];
+    }
+};
+
 // hashgrid_fwd.hip
 size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,

@@ -287,13 +287,15 @@ static hipError_t mlp_run(bool bwd, int64_t N, const float *x, const float *para
     const int tpb = (int)((tiles + blocks - 1) / blocks);
     constexpr int P = kMlpTile + 4;
     const size_t shmem = ((size_t)(S::n_params + 3) / 4 * 4 + (size_t)(IN + NH * H + NH * H + OUT) * P) * sizeof(float);
-    static std::once_flag once;
-    std::call_once(once, [] {
+    static PerDeviceOnce once;
+    const hipError_t oe = once.run([]() -> hipError_t {
         constexpr size_t need = ((size_t)(S::n_params + 3) / 4 * 4 + (size_t)(IN + NH * H + NH * H + OUT) * P) * sizeof(float);
         if (need > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_backward_kernel<IN, H, NH, OUT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_backward_kernel<IN, H, NH, OUT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+        return hipSuccess;
     });
+    if (oe != hipSuccess) return oe;
     hipLaunchKernelGGL((mlp_backward_kernel<IN, H, NH, OUT>), dim3((uint32_t)blocks), dim3(kMlpTile), shmem, s, x,
                        params, gy, gx, partials, N, tpb);
     hipError_t e = hipGetLastError();

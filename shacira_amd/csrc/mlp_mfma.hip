@@ -402,9 +402,8 @@ hipError_t wide_mlp_run(bool bwd, int64_t N, const float *x, const float *params
     constexpr size_t bwd_lds =
         ((size_t)S::lds_weights + (S::n_params + 3) / 4 * 4 + (size_t)kMfmaWaves * S::stage_floats) * sizeof(float);
     static_assert(bwd_lds <= 160 * 1024, "backward LDS plan exceeds the CU's 160 KiB");
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
+    static PerDeviceOnce once;
+    const hipError_t attr_err = once.run([]() -> hipError_t {
         hipError_t e = hipSuccess;
         if (fwd_lds > 64 * 1024)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_mlp_forward_kernel<MB, IN, H, NH, OUT>),
@@ -412,7 +411,7 @@ hipError_t wide_mlp_run(bool bwd, int64_t N, const float *x, const float *params
         if (e == hipSuccess && bwd_lds > 64 * 1024)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_mlp_backward_kernel<MB, IN, H, NH, OUT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
-        attr_err = e;
+        return e;
     });
     if (attr_err != hipSuccess) return attr_err;
     if (!bwd) {

@@ -161,10 +161,10 @@ __global__ __launch_bounds__(64 * kPackWaves) void pack_broadcast_kernel(const f
 
 // ---------------------------------------------------------------------------------------------- sample generation
 __device__ __forceinline__ int quantize_axis(float x, int G) {
-    // kaolin quantize_points: floor(clamp(res * (x + 1) / 2, 0, res - 1))
-    float v = (float)G * (x + 1.0f) / 2.0f;
-    v = fminf(fmaxf(v, 0.0f), (float)(G - 1));
-    return (int)floorf(v);
+    // kaolin's float query: cell = floor(res * (x + 1) / 2); a cell outside [0, res) does not exist (spc identify returns
+    // -1 out of bounds), so a point outside the cube -- or a NaN -- belongs to no cell: -1
+    const float v = floorf((float)G * (x + 1.0f) / 2.0f);
+    return (v >= 0.0f && v < (float)G) ? (int)v : -1;
 }
 
 __device__ __forceinline__ bool occupied(const uint8_t *__restrict__ occ, int G, int x, int y, int z) {
@@ -201,7 +201,8 @@ __global__ __launch_bounds__(64 * kPackWaves) void raymarch_ray_kernel(
             px = fmaf(dx, depth, ox);
             py = fmaf(dy, depth, oy);
             pz = fmaf(dz, depth, oz);
-            keep = occupied(occ, G, quantize_axis(px, G), quantize_axis(py, G), quantize_axis(pz, G));
+            const int qx = quantize_axis(px, G), qy = quantize_axis(py, G), qz = quantize_axis(pz, G);
+            keep = qx >= 0 && qy >= 0 && qz >= 0 && occupied(occ, G, qx, qy, qz);
         }
         const unsigned long long m = __ballot(keep);
         if constexpr (EMIT) {

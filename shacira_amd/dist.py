@@ -75,11 +75,30 @@ class FlatGradients:
             self.offsets.append(off)
             off += (n + 31) // 32 * 32
         self.flat = torch.zeros(off, dtype=dt, device=dev)
+        self._touched = set()
         for p, o in zip(self.params, self.offsets):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
+            # which parameters took part in this step's loss: the views are never None, so without this Adam would
+            # apply weight decay / moment decay to parameters that received no gradient (torch skips grad=None ones,
+            # and so does the 1-GPU path that zeroes with set_to_none) and 1-GPU / N-GPU runs would diverge
+            p.register_post_accumulate_grad_hook(lambda q, s=self: s._touched.add(id(q)))
 
     def zero_(self):
         self.flat.zero_()
+        self._touched.clear()
+
+    def hide_untouched(self):
+        """Before optimizer.step(): parameters that received no gradient this step get ``.grad = None`` (the optimiser
+        skips them, as with one GPU). Returns the list to hand to ``restore`` afterwards. The loss graph is the same on
+        every rank, so every rank hides the same parameters."""
+        hidden = [p for p in self.params if id(p) not in self._touched]
+        for p in hidden:
+            p.grad = None
+        return hidden
+
+    def restore(self, hidden):
+        for p in hidden:
+            p.grad = self.view_of(p)
 
     def view_of(self, param):
         for p, o in zip(self.params, self.offsets):
@@ -97,6 +116,7 @@ class FlatGradients:
         return self.flat.numel() * self.flat.element_size()
 
 
-def global_mean_loss(local_sum, local_count, world):
-    """Loss whose gradient, summed over ranks, equals the gradient of the mean over the GLOBAL batch."""
-    return local_sum / (local_count * world)
+def global_mean_loss(local_sum, global_count):
+    """Loss whose gradient, summed over ranks, equals the gradient of the mean over the GLOBAL batch: the local sum
+    over the GLOBAL element count (shards need not be equal: ``shard_bounds`` hands out near-equal ones)."""
+    return local_sum / global_count

@@ -177,11 +177,15 @@ class ImageFitter:
         with torch.no_grad():
             q = lambda t: (torch.clamp(t, 0, 1) * 255).to(torch.uint8).float()
             stats = torch.stack([sq_sum.detach(), ((q(pred) - q(self.rgb)) ** 2).sum()]).double()
+        hidden = []
         if self.bucket is not None:
             self.bucket.allreduce()
             if dist.is_initialized():
                 dist.all_reduce(stats)
+            hidden = self.bucket.hide_untouched()      # e.g. the entropy model while lambda == 0
         self.optimizer.step()
+        if self.bucket is not None:
+            self.bucket.restore(hidden)
         n = self.global_pixels * 3
         rgb_loss = float(stats[0]) / n
         psnr = 20 * math.log10(255.0) - 10 * math.log10(max(float(stats[1]) / n, 1e-12))   # clamped_psnr, globally
@@ -374,9 +378,13 @@ def fit_field_3d(device, steps=500, rays=4096, samples_per_ray=16, seed=0, codeb
             opt.zero_grad(set_to_none=True)
         loss = (nef.rgb(local) - target).abs().sum() / (n_global * 3)     # global-mean L1 (multiview_trainer.py:105-108)
         loss.backward()
+        hidden = []
         if bucket is not None:
             bucket.allreduce()
+            hidden = bucket.hide_untouched()
         opt.step()
+        if bucket is not None:
+            bucket.restore(hidden)
     if device.type == "cuda":
         torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3

@@ -158,18 +158,12 @@ def latent_decode_supported(latent_dim, feature_dim):
     return latent_dim in (1, 2, 3, 4, 8) and feature_dim in (1, 2, 4, 8) and not (latent_dim == 8 and feature_dim == 1)
 
 
-_ws_cache = {}
-
-
 def _latent_workspace(device):
-    """One reusable scratch buffer per (device, stream): fp64 block partials of the table reductions."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _ws_cache.get(key)
-    if ws is None:
-        n = _lib.lib().shacira_entropy_bits_workspace_bytes(0, 1)
-        ws = torch.empty((n,), dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
-    return ws
+    """fp64 block partials of the table reductions: a fresh buffer per call (the caching allocator makes that cheap).
+    A buffer cached per stream would be shared by two host threads working on that stream -- A.kernel, B.kernel,
+    A.finish reduces B's partials -- and could be captured into a graph pool and then reused eagerly."""
+    n = _lib.lib().shacira_entropy_bits_workspace_bytes(0, 1)
+    return torch.empty((n,), dtype=torch.uint8, device=device)
 
 
 def latent_decode_forward(latent, div, matrix, colscale, shift, clamp_weights):

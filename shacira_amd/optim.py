@@ -27,10 +27,12 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.zero_grad_in_step = zero_grad_in_step
         self.capturable = capturable
-        self._step_dev = None
-        self._step_host = 0
 
-    def _launch(self, batch, b1, b2, eps, device):
+    # Bias correction follows every parameter's OWN ``state['step']`` (as torch.optim.Adam does): a parameter that gets its
+    # first gradient late starts at t = 1, and a restored checkpoint continues at the saved count. Parameters that share a
+    # count are stepped by one launch. capturable: the count is an int32 DEVICE tensor shared by the parameters that were
+    # born in the same step (the kernel reads it, so the launch can be replayed from a HIP graph while it advances).
+    def _launch(self, batch, b1, b2, eps, device, step, step_dev):
         k = len(batch)
         PtrArr, I64Arr, FArr = ctypes.c_void_p * k, ctypes.c_int64 * k, ctypes.c_float * k
         ps = PtrArr(*[p.data_ptr() for p, _, _, _, _, _ in batch])
@@ -40,12 +42,25 @@ class FusedAdam(torch.optim.Optimizer):
         ns = I64Arr(*[p.numel() for p, _, _, _, _, _ in batch])
         lrs = FArr(*[float(lr) for _, _, _, _, lr, _ in batch])
         wds = FArr(*[float(wd) for _, _, _, _, _, wd in batch])
-        step_dev = ctypes.c_void_p(self._step_dev.data_ptr()) if self.capturable else None
+        sd = ctypes.c_void_p(step_dev.data_ptr()) if step_dev is not None else None
         with torch.cuda.device(device):
             rc = _lib.lib().shacira_adam_step_multi(k, ns, ps, gs, ms, vs, lrs, wds, float(b1), float(b2), float(eps),
-                                                    int(self._step_host), step_dev, int(self.zero_grad_in_step),
+                                                    int(step), sd, int(self.zero_grad_in_step),
                                                     ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
         _lib.check(rc, "adam_step_multi")
+
+    def _new_state(self, p, born):
+        st = self.state[p]
+        if self.capturable:
+            key = p.device
+            if key not in born:                      # one shared device counter for everything born in this step
+                born[key] = torch.zeros((1,), dtype=torch.int32, device=p.device)
+            st["step"] = born[key]
+        else:
+            st["step"] = torch.tensor(0.0)
+        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -53,13 +68,9 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        self._step_host += 1
-        if self.capturable:
-            if self._step_dev is None:
-                dev = next(p for g in self.param_groups for p in g["params"]).device
-                self._step_dev = torch.full((1,), self._step_host - 1, dtype=torch.int32, device=dev)
-            self._step_dev += 1          # on the stream: part of the captured graph
-        pending = {}                      # (device, b1, b2, eps) -> list of tensors for the fused launch
+        pending = {}      # (device, b1, b2, eps, step key) -> (host step, device step tensor, [tensors])
+        bumped = set()    # device counters already advanced in this call
+        born = {}
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -67,21 +78,26 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 st = self.state[p]
                 if not st:
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st = self._new_state(p, born)
                 g, m, v = p.grad, st["exp_avg"], st["exp_avg_sq"]
-                if not self.capturable:
-                    st["step"] += 1
                 fused = (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous()
                          and g.dtype == torch.float32 and not g.is_sparse)
-                if fused:
-                    key = (p.device, b1, b2, group["eps"])
-                    pending.setdefault(key, []).append((p, g, m, v, group["lr"], group["weight_decay"]))
-                    continue
                 if self.capturable:
-                    raise RuntimeError("FusedAdam(capturable=True) handles fp32 contiguous GPU parameters only")
+                    if not fused:
+                        raise RuntimeError("FusedAdam(capturable=True) handles fp32 contiguous GPU parameters only")
+                    sd = st["step"]
+                    if sd.data_ptr() not in bumped:
+                        sd += 1                      # on the stream: part of the captured graph
+                        bumped.add(sd.data_ptr())
+                    key = (p.device, b1, b2, group["eps"], sd.data_ptr())
+                    pending.setdefault(key, (1, sd, []))[2].append((p, g, m, v, group["lr"], group["weight_decay"]))
+                    continue
+                st["step"] += 1
                 t = int(st["step"])
+                if fused:
+                    key = (p.device, b1, b2, group["eps"], t)
+                    pending.setdefault(key, (t, None, []))[2].append((p, g, m, v, group["lr"], group["weight_decay"]))
+                    continue
                 gr = g.add(p, alpha=group["weight_decay"]) if group["weight_decay"] else g
                 m.mul_(b1).add_(gr, alpha=1 - b1)
                 v.mul_(b2).addcmul_(gr, gr, value=1 - b2)
@@ -89,7 +105,26 @@ class FusedAdam(torch.optim.Optimizer):
                 p.addcdiv_(m, denom, value=-group["lr"] / (1 - b1 ** t))
                 if self.zero_grad_in_step:
                     g.zero_()
-        for (device, b1, b2, eps), items in pending.items():
+        for (device, b1, b2, eps, _), (t, sd, items) in pending.items():
             for i in range(0, len(items), _MAX):
-                self._launch(items[i:i + _MAX], b1, b2, eps, device)
+                self._launch(items[i:i + _MAX], b1, b2, eps, device, t, sd)
         return loss
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam-compatible: restores the moments AND the per-parameter step counts (a checkpoint written by
+        torch.optim.Adam or by this class). capturable: equal counts on one device are re-shared as one device counter."""
+        super().load_state_dict(state_dict)
+        shared = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if not st or "step" not in st:
+                    continue
+                t = int(torch.as_tensor(st["step"]).item())
+                if self.capturable:
+                    key = (p.device, t)
+                    if key not in shared:
+                        shared[key] = torch.full((1,), t, dtype=torch.int32, device=p.device)
+                    st["step"] = shared[key]
+                else:
+                    st["step"] = torch.tensor(float(t))

@@ -93,13 +93,16 @@ class OctreeAS(BaseAS):
         return self.max_level
 
     def query(self, coords, level=None, with_parents=False) -> ASQueryResults:
-        """pidx [N]: Morton index of the cell holding each point (kaolin quantize_points rule), -1 if unoccupied."""
+        """pidx [N]: Morton index of the cell holding each point, -1 if that cell is unoccupied or the point lies outside
+        the cube (kaolin's float query: cell = floor(G * (x + 1) / 2), out of bounds -> -1)."""
         if with_parents:
             raise NotImplementedError("with_parents needs the point hierarchy")
         level = self._level(level)
         G = 1 << level
-        q = torch.floor(torch.clamp(G * (coords + 1.0) / 2.0, 0, G - 1.0)).long()
-        occ = self._grid_on(coords.device)[q[:, 0], q[:, 1], q[:, 2]]
+        cell = torch.floor(G * (coords + 1.0) / 2.0)
+        inside = ((cell >= 0) & (cell < G)).all(dim=-1)
+        q = torch.nan_to_num(cell, nan=0.0).clamp(0, G - 1).long()
+        occ = inside & self._grid_on(coords.device)[q[:, 0], q[:, 1], q[:, 2]]
         pidx = torch.where(occ, _morton_index(q, level), torch.full_like(q[:, 0], -1))
         return ASQueryResults(pidx=pidx)
 

@@ -78,7 +78,7 @@ def test_shard_bounds_cover_batch_exactly():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
-    assert sdist.global_mean_loss(torch.tensor(8.0), 4, 2).item() == 1.0
+    assert sdist.global_mean_loss(torch.tensor(8.0), 8).item() == 1.0      # local sum over the GLOBAL count
 
 
 # ------------------------------------------------------------------------------------------------ DP image fit
@@ -160,3 +160,22 @@ def test_field_fit_3d_two_ranks_matches_one_rank(tmp_path):
     finally:
         hip_ops.hashgrid_interpolate2d_cuda, hip_ops.hashgrid_interpolate_cuda, hip_ops.hashgrid_backward = saved
     assert abs(two["psnr"] - one["psnr"]) < 0.05, (two["psnr"], one["psnr"])
+
+
+def test_flat_gradients_hide_parameters_outside_the_loss():
+    """A parameter that takes no part in a step's loss keeps grad=None for the optimiser (as with one GPU, where
+    zero_grad(set_to_none=True) leaves it None): no weight decay / moment decay is applied to it."""
+    a = torch.nn.Parameter(torch.ones(4))
+    b = torch.nn.Parameter(torch.ones(3))
+    bucket = sdist.FlatGradients([a, b])
+    opt = torch.optim.Adam([a, b], lr=0.1, weight_decay=0.5)
+    for _ in range(2):
+        bucket.zero_()
+        (a * 2.0).sum().backward()                 # b is not in the graph
+        hidden = bucket.hide_untouched()
+        assert [id(p) for p in hidden] == [id(b)] and b.grad is None and a.grad is not None
+        opt.step()
+        bucket.restore(hidden)
+        assert b.grad is not None and b.grad.data_ptr() == bucket.view_of(b).data_ptr()
+    assert torch.equal(b.detach(), torch.ones(3)) and not torch.equal(a.detach(), torch.ones(4))
+    assert b not in opt.state or not opt.state[b]

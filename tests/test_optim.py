@@ -36,3 +36,51 @@ def test_fused_adam_kernel_matches_torch():
         torch.testing.assert_close(x, y, rtol=2e-6, atol=1e-7)   # updates are ~1e-2: 1e-7 abs = 1e-5 of a step
     c, _ = _run(FusedAdam, "cuda:0", 3, zero_grad_in_step=True)
     assert all(float(p.grad.abs().sum()) == 0.0 for p in c)
+
+
+def _resume_and_late_grad(device, **kw):
+    """save -> load into a fresh optimiser -> continue, and a parameter that gets its first gradient late: FusedAdam
+    must track torch.optim.Adam step for step (bias correction follows each parameter's own state['step'])."""
+    def make(cls, **k):
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.randn(300, 2, device=device) * 0.1),
+              torch.nn.Parameter(torch.randn(7, device=device) * 0.1)]
+        return ps, cls([{"params": ps[:1], "lr": 0.02}, {"params": ps[1:], "lr": 1e-3, "weight_decay": 0.01}], **k)
+
+    def feed(ps, gen, late_ok):
+        ps[0].grad = torch.randn(ps[0].shape, generator=gen).to(device)
+        late = torch.randn(ps[1].shape, generator=gen).to(device)
+        ps[1].grad = late if late_ok else None          # second parameter: no gradient in the first steps
+
+    (pa, oa), (pb, ob) = make(torch.optim.Adam), make(FusedAdam, **kw)
+    ga, gb = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    for k in range(6):
+        feed(pa, ga, k >= 3); feed(pb, gb, k >= 3)
+        oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        torch.testing.assert_close(x, y, rtol=2e-6, atol=1e-7)
+    assert int(torch.as_tensor(ob.state[pb[0]]["step"]).item()) == 6
+    assert int(torch.as_tensor(ob.state[pb[1]]["step"]).item()) == 3     # born late: its own count
+    # checkpoint: a TORCH optimiser's state dict restores into FusedAdam and the other way round
+    (pa2, oa2), (pb2, ob2) = make(torch.optim.Adam), make(FusedAdam, **kw)
+    with torch.no_grad():
+        for dst, src in zip(pa2 + pb2, pa + pb):
+            dst.copy_(src)
+    oa2.load_state_dict(ob.state_dict() if not kw.get("capturable") else oa.state_dict())
+    ob2.load_state_dict(oa.state_dict())
+    for k in range(4):
+        feed(pa2, ga, True); feed(pb2, gb, True)
+        oa2.step(); ob2.step()
+    for x, y in zip(pa2, pb2):
+        torch.testing.assert_close(x, y, rtol=2e-6, atol=1e-7)
+    assert int(torch.as_tensor(ob2.state[pb2[0]]["step"]).item()) == 10
+
+
+def test_fused_adam_resume_and_late_gradient_cpu():
+    _resume_and_late_grad("cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("capturable", [False, True])
+def test_fused_adam_resume_and_late_gradient_gpu(capturable):
+    _resume_and_late_grad("cuda:0", capturable=capturable)

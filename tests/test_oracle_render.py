@@ -89,7 +89,7 @@ def test_occupancy_mirror_query_and_pruned_set():
     assert dense.points.shape == (512, 3) and torch.equal(dense.points, _morton_points(level))
     pts = torch.tensor([[-1.0, -1.0, -1.0], [0.99, 0.99, 0.99], [0.0, 0.0, 0.0], [5.0, -5.0, 0.1]])
     pidx = dense.query(pts).pidx
-    assert pidx[0] == 0 and pidx[1] == 511 and (pidx >= 0).all()       # out-of-range points clamp to border cells
+    assert pidx[0] == 0 and pidx[1] == 511 and pidx[2] >= 0 and pidx[3] == -1   # a point outside the cube has no cell
     assert torch.equal(dense.points[pidx[2]].long(), torch.tensor([4, 4, 4]))
     kept = torch.tensor([[4, 4, 4], [0, 0, 0], [7, 0, 3]])
     pruned = OctreeAS.from_quantized_points(kept, level)
@@ -99,3 +99,14 @@ def test_occupancy_mirror_query_and_pruned_set():
     # points come back in Morton order
     codes = [int(c) for c in (pruned.points.long() * torch.tensor([1, 1, 1])).sum(1)]
     assert torch.equal(pruned.points[0].long(), torch.tensor([0, 0, 0])) and len(codes) == 3
+
+
+def test_points_outside_the_cube_have_no_cell():
+    """kaolin's float query (spc `identify`: "check if in bounds" -> -1): a point outside [-1, 1)^3 belongs to no cell,
+    whatever the border cells hold. Known answers at level 2 (4 cells per axis, all occupied)."""
+    level = 2
+    occ = torch.ones(4, 4, 4, dtype=torch.bool)
+    pts = torch.tensor([[0.0, 0.0, 0.0], [-1.0, -1.0, -1.0], [0.999, 0.999, 0.999],     # inside (incl. the -1 faces)
+                        [1.0, 0.0, 0.0], [0.0, 1.0001, 0.0], [0.0, 0.0, -1.0001],       # on the +1 face / outside
+                        [2.5, 0.0, 0.0], [float("nan"), 0.0, 0.0]])
+    assert orr.query_dense(occ, pts, level).tolist() == [True, True, True, False, False, False, False, False]
