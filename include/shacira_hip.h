@@ -255,6 +255,31 @@ SHACIRA_API int shacira_latent_decode_sga_backward(int64_t num_rows, int latent_
                                        size_t workspace_bytes, void *stream);
 
 /*
+ * Per-level latent decoders -- HierarchicalLatentDecoder (wisp/models/latent_decoders/hierarchical_latent_decoder.py:3-36,
+ * built by LatentGrid.setup_decoders, wisp/models/grids/latent_grid.py:176-190): level l decodes the rows
+ * [row_offsets[l], row_offsets[l+1]) of the table with ITS OWN div / matrix / colscale / shift; rounding or SGA
+ * (uniforms != NULL) as in the single-decoder operators above. One launch for all levels.
+ *   row_offsets_host  HOST int64 [num_levels + 1]; level starts ascend. The reference builds the last entry as the LAST
+ *                     LEVEL'S SIZE, not the table's end (latent_grid.py:182): a boundary that falls before a level's
+ *                     start makes that level empty. Rows no level owns decode to 0 (the reference leaves them
+ *                     uninitialised) and receive a zero latent gradient.
+ *   div [num_levels, latent_dim], matrix [num_levels, latent_dim, feature_dim], colscale / shift [num_levels,
+ *   feature_dim] (NULL as above); the gradients of the backward have the same stacked shapes, written per level.
+ */
+SHACIRA_API int shacira_latent_decode_levels_forward(int num_levels, const int64_t *row_offsets_host, int64_t num_rows,
+                                         int latent_dim, int feature_dim, const float *latent, const float *uniforms,
+                                         float temperature, int diff_sampling, const float *div, const float *matrix,
+                                         const float *colscale, const float *shift, float clamp_weights,
+                                         float *decoded, void *stream);
+SHACIRA_API int shacira_latent_decode_levels_backward(int num_levels, const int64_t *row_offsets_host, int64_t num_rows,
+                                          int latent_dim, int feature_dim, const float *latent, const float *uniforms,
+                                          float temperature, int diff_sampling, const float *div, const float *matrix,
+                                          const float *colscale, const float *shift, float clamp_weights,
+                                          const float *grad_decoded, float *grad_latent, float *grad_matrix,
+                                          float *grad_colscale, float *grad_shift, void *workspace,
+                                          size_t workspace_bytes, void *stream);
+
+/*
  * Symbol statistics and entropy coding of the rounded latents -- replaces the per-channel
  * `torch.round(...).long()` + `torch.unique(return_counts=True)` of LatentGrid.size
  * (wisp/models/grids/latent_grid.py:141-143) and the torchac.encode_float_cdf call (:155-172).

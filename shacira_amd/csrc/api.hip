@@ -255,6 +255,66 @@ int shacira_latent_decode_sga_backward(int64_t num_rows, int latent_dim, int fea
     return (int)latent_decode_dispatch(true, latent_dim, feature_dim, a, (hipStream_t)stream);
 }
 
+static int levels_args_ok(int num_levels, const int64_t *row_offsets_host, int64_t num_rows, int latent_dim,
+                          int feature_dim) {
+    if (num_levels < 1 || num_levels > SHACIRA_MAX_LODS || !row_offsets_host) return SHACIRA_EINVAL;
+    if (num_rows < 0 || latent_dim < 1 || feature_dim < 1) return SHACIRA_EINVAL;
+    if (!latent_decode_supported(latent_dim, feature_dim)) return SHACIRA_EDTYPE;
+    int64_t prev = 0;
+    for (int l = 0; l <= num_levels; ++l) {
+        const int64_t o = row_offsets_host[l];
+        if (o < 0 || o > num_rows) return SHACIRA_EINVAL;
+        if (l < num_levels && o < prev) return SHACIRA_EINVAL;   // level starts ascend; the LAST boundary may fall short
+        prev = o;
+    }
+    return 0;
+}
+
+int shacira_latent_decode_levels_forward(int num_levels, const int64_t *row_offsets_host, int64_t num_rows,
+                                         int latent_dim, int feature_dim, const float *latent, const float *uniforms,
+                                         float temperature, int diff_sampling, const float *div, const float *matrix,
+                                         const float *colscale, const float *shift, float clamp_weights, float *decoded,
+                                         void *stream) {
+    if (int rc = levels_args_ok(num_levels, row_offsets_host, num_rows, latent_dim, feature_dim)) return rc;
+    if (uniforms && !(temperature > 0.0f)) return SHACIRA_EINVAL;
+    if (num_rows == 0) return 0;
+    if (!latent || !div || !matrix || !decoded) return SHACIRA_EINVAL;
+    // rows no level owns (before the first level, after the last boundary) decode to 0
+    hipError_t e = hipMemsetAsync(decoded, 0, (size_t)num_rows * feature_dim * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    DecodeArgs a{};
+    a.latent = latent; a.div = div; a.matrix = matrix; a.colscale = colscale; a.shift = shift;
+    a.clampw = clamp_weights; a.decoded = decoded; a.rows = num_rows;
+    a.uniforms = uniforms; a.temperature = temperature; a.diff_sampling = diff_sampling;
+    return (int)latent_decode_levels_dispatch(false, latent_dim, feature_dim, num_levels, row_offsets_host, a,
+                                              (hipStream_t)stream);
+}
+
+int shacira_latent_decode_levels_backward(int num_levels, const int64_t *row_offsets_host, int64_t num_rows,
+                                          int latent_dim, int feature_dim, const float *latent, const float *uniforms,
+                                          float temperature, int diff_sampling, const float *div, const float *matrix,
+                                          const float *colscale, const float *shift, float clamp_weights,
+                                          const float *grad_decoded, float *grad_latent, float *grad_matrix,
+                                          float *grad_colscale, float *grad_shift, void *workspace,
+                                          size_t workspace_bytes, void *stream) {
+    if (int rc = levels_args_ok(num_levels, row_offsets_host, num_rows, latent_dim, feature_dim)) return rc;
+    if (uniforms && !(temperature > 0.0f)) return SHACIRA_EINVAL;
+    if (!workspace || workspace_bytes < latent_workspace_bytes()) return SHACIRA_EWORKSPACE;
+    if (num_rows > 0 && (!latent || !div || !matrix || !grad_decoded)) return SHACIRA_EINVAL;
+    if (grad_latent && num_rows > 0) {
+        hipError_t e = hipMemsetAsync(grad_latent, 0, (size_t)num_rows * latent_dim * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    DecodeArgs a{};
+    a.latent = latent; a.div = div; a.matrix = matrix; a.colscale = colscale; a.shift = shift;
+    a.clampw = clamp_weights; a.grad_decoded = grad_decoded; a.grad_latent = grad_latent;
+    a.grad_matrix = grad_matrix; a.grad_colscale = grad_colscale; a.grad_shift = grad_shift;
+    a.partials = static_cast<double *>(workspace); a.rows = num_rows;
+    a.uniforms = uniforms; a.temperature = temperature; a.diff_sampling = diff_sampling;
+    return (int)latent_decode_levels_dispatch(true, latent_dim, feature_dim, num_levels, row_offsets_host, a,
+                                              (hipStream_t)stream);
+}
+
 int shacira_latent_symbol_range(int64_t num_rows, int latent_dim, const float *latent, int32_t *minmax, void *stream) {
     if (num_rows < 0 || latent_dim < 1 || !minmax || (num_rows > 0 && !latent)) return SHACIRA_EINVAL;
     if (!symbols_supported(latent_dim)) return SHACIRA_EDTYPE;

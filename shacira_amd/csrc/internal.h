@@ -77,6 +77,8 @@ struct EntropyArgs {
 size_t latent_workspace_bytes();
 bool latent_decode_supported(int ld, int f);
 hipError_t latent_decode_dispatch(bool bwd, int ld, int f, const DecodeArgs &a, hipStream_t s);
+hipError_t latent_decode_levels_dispatch(bool bwd, int ld, int f, int levels, const int64_t *offsets,
+                                         const DecodeArgs &a, hipStream_t s);
 bool entropy_supported(int ld);
 hipError_t entropy_dispatch(bool bwd, int ld, const EntropyArgs &a, hipStream_t s);
 

@@ -245,6 +245,144 @@ template <int LD, int F> static hipError_t decode_launch(bool bwd, const DecodeA
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Per-level decoders (HierarchicalLatentDecoder, reference hierarchical_latent_decoder.py:3-36 with the offsets of
+// latent_grid.py:176-190): level l owns rows [lo[l], lo[l+1]) and has its own div / matrix / colscale / shift. ONE launch:
+// grid.y = level, the level's parameters are rows of stacked arrays. The reference runs num_lods decoders (each the
+// ~10-kernel ATen chain) and a torch.cat.
+struct LevelRows {
+    int64_t lo[SHACIRA_MAX_LODS + 1];
+};
+
+template <int LD, int F, bool SGA>
+__global__ __launch_bounds__(kThreads) void latent_decode_levels_fwd_kernel(
+    LevelRows lr, const float *__restrict__ latent, const float *__restrict__ div, const float *__restrict__ matrix,
+    const float *__restrict__ colscale, const float *__restrict__ shift, float clampw, float *__restrict__ decoded,
+    SgaArgs sga) {
+    const int l = blockIdx.y;
+    const int64_t lo = lr.lo[l], hi = lr.lo[l + 1];
+    DecodeConsts<LD, F> p;
+    p.load(div + l * LD, matrix + l * LD * F, colscale ? colscale + l * F : nullptr, shift ? shift + l * F : nullptr,
+           clampw);
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t r = lo + (int64_t)blockIdx.x * kThreads + threadIdx.x; r < hi; r += stride) {
+        float z[LD], dq[LD], zm[F], y[F];
+        decode_row<LD, F, SGA>(p, latent, r, sga, z, dq, zm, y);
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            float v = y[j];
+            if (clampw > 0.0f) v = fminf(fmaxf(v, -clampw), clampw);
+            decoded[r * F + j] = v;
+        }
+    }
+}
+
+template <int LD, int F, bool SGA>
+__global__ __launch_bounds__(kThreads) void latent_decode_levels_bwd_kernel(
+    LevelRows lr, const float *__restrict__ latent, const float *__restrict__ div, const float *__restrict__ matrix,
+    const float *__restrict__ colscale, const float *__restrict__ shift, float clampw,
+    const float *__restrict__ grad_decoded, float *__restrict__ grad_latent, double *__restrict__ partials,
+    SgaArgs sga) {
+    constexpr int NRED = LD * F + 2 * F;
+    const int l = blockIdx.y;
+    const int64_t lo = lr.lo[l], hi = lr.lo[l + 1];
+    DecodeConsts<LD, F> p;
+    p.load(div + l * LD, matrix + l * LD * F, colscale ? colscale + l * F : nullptr, shift ? shift + l * F : nullptr,
+           clampw);
+    float acc[NRED];
+#pragma unroll
+    for (int q = 0; q < NRED; ++q) acc[q] = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t r = lo + (int64_t)blockIdx.x * kThreads + threadIdx.x; r < hi; r += stride) {
+        float z[LD], dq[LD], zm[F], y[F], gy[F];
+        decode_row<LD, F, SGA>(p, latent, r, sga, z, dq, zm, y);
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            float g = grad_decoded[r * F + j];
+            if (clampw > 0.0f && !(y[j] >= -clampw && y[j] <= clampw)) g = 0.0f;
+            gy[j] = g;
+            acc[LD * F + j] += g * zm[j];
+            acc[LD * F + F + j] += g;
+        }
+#pragma unroll
+        for (int c = 0; c < LD; ++c) {
+            float gl = 0.0f;
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                const float gs = gy[j] * p.cs[j];
+                acc[c * F + j] += z[c] * gs;
+                gl = fmaf(gs, p.mat[c * F + j], gl);
+            }
+            if (grad_latent) grad_latent[r * LD + c] = gl / p.div[c] * dq[c];
+        }
+    }
+    // partials[level][block][NRED]
+    block_reduce_store<NRED>(acc, partials + (size_t)l * gridDim.x * NRED);
+}
+
+// per level: out[l][q] = sum_b partials[l][b][q]; grid = (nred, levels)
+__global__ __launch_bounds__(256) void finish_level_partials_kernel(const double *__restrict__ partials, int nblocks,
+                                                                    int nred, float *__restrict__ out0, int n0,
+                                                                    float *__restrict__ out1, int n1,
+                                                                    float *__restrict__ out2, int n2) {
+    __shared__ double s_w[4];
+    const int q = blockIdx.x, l = blockIdx.y;
+    const double *pl = partials + (size_t)l * nblocks * nred;
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) v += pl[(size_t)b * nred + q];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        if (q < n0) {
+            if (out0) out0[(size_t)l * n0 + q] = (float)v;
+        } else if (q < n0 + n1) {
+            if (out1) out1[(size_t)l * n1 + (q - n0)] = (float)v;
+        } else if (q < n0 + n1 + n2) {
+            if (out2) out2[(size_t)l * n2 + (q - n0 - n1)] = (float)v;
+        }
+    }
+}
+
+template <int LD, int F>
+static hipError_t decode_levels_launch(bool bwd, int levels, const int64_t *offsets, const DecodeArgs &a, hipStream_t s) {
+    LevelRows lr{};
+    int64_t longest = 0;
+    for (int l = 0; l <= levels; ++l) lr.lo[l] = offsets[l];
+    for (int l = 0; l < levels; ++l) {
+        if (lr.lo[l + 1] < lr.lo[l]) lr.lo[l + 1] = lr.lo[l];   // empty level (the reference's last-offset quirk)
+        if (lr.lo[l + 1] - lr.lo[l] > longest) longest = lr.lo[l + 1] - lr.lo[l];
+    }
+    int blocks = grid_for(longest);
+    const int cap = kMaxPartialBlocks / levels;   // the fp64 partials of all levels share the one workspace
+    if (blocks > cap) blocks = cap < 1 ? 1 : cap;
+    const SgaArgs sga{a.uniforms, a.temperature, a.diff_sampling};
+    const dim3 grid(blocks, levels);
+    if (!bwd) {
+        if (a.uniforms)
+            hipLaunchKernelGGL((latent_decode_levels_fwd_kernel<LD, F, true>), grid, dim3(kThreads), 0, s, lr, a.latent,
+                               a.div, a.matrix, a.colscale, a.shift, a.clampw, a.decoded, sga);
+        else
+            hipLaunchKernelGGL((latent_decode_levels_fwd_kernel<LD, F, false>), grid, dim3(kThreads), 0, s, lr, a.latent,
+                               a.div, a.matrix, a.colscale, a.shift, a.clampw, a.decoded, sga);
+        return hipGetLastError();
+    }
+    if (a.uniforms)
+        hipLaunchKernelGGL((latent_decode_levels_bwd_kernel<LD, F, true>), grid, dim3(kThreads), 0, s, lr, a.latent,
+                           a.div, a.matrix, a.colscale, a.shift, a.clampw, a.grad_decoded, a.grad_latent, a.partials, sga);
+    else
+        hipLaunchKernelGGL((latent_decode_levels_bwd_kernel<LD, F, false>), grid, dim3(kThreads), 0, s, lr, a.latent,
+                           a.div, a.matrix, a.colscale, a.shift, a.clampw, a.grad_decoded, a.grad_latent, a.partials, sga);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(finish_level_partials_kernel, dim3(LD * F + 2 * F, levels), dim3(256), 0, s, a.partials, blocks,
+                       LD * F + 2 * F, a.grad_matrix, LD * F, a.grad_colscale, F, a.grad_shift, F);
+    return hipGetLastError();
+}
+
+typedef hipError_t (*decode_levels_fn)(bool, int, const int64_t *, const DecodeArgs &, hipStream_t);
+
 typedef hipError_t (*decode_fn)(bool, const DecodeArgs &, hipStream_t);
 
 static decode_fn decode_lookup(int ld, int f) {
@@ -257,6 +395,23 @@ static decode_fn decode_lookup(int ld, int f) {
     SHACIRA_DEC(8, 2) SHACIRA_DEC(8, 4) SHACIRA_DEC(8, 8)
 #undef SHACIRA_DEC
     return nullptr;
+}
+
+static decode_levels_fn decode_levels_lookup(int ld, int f) {
+#define SHACIRA_DECL(LD, F) \
+    if (ld == LD && f == F) return &decode_levels_launch<LD, F>;
+    SHACIRA_DECL(1, 1) SHACIRA_DECL(1, 2) SHACIRA_DECL(1, 4) SHACIRA_DECL(1, 8)
+    SHACIRA_DECL(2, 1) SHACIRA_DECL(2, 2) SHACIRA_DECL(2, 4) SHACIRA_DECL(2, 8)
+    SHACIRA_DECL(3, 1) SHACIRA_DECL(3, 2) SHACIRA_DECL(3, 4) SHACIRA_DECL(3, 8)
+    SHACIRA_DECL(4, 1) SHACIRA_DECL(4, 2) SHACIRA_DECL(4, 4) SHACIRA_DECL(4, 8)
+    SHACIRA_DECL(8, 2) SHACIRA_DECL(8, 4) SHACIRA_DECL(8, 8)
+#undef SHACIRA_DECL
+    return nullptr;
+}
+
+hipError_t latent_decode_levels_dispatch(bool bwd, int ld, int f, int levels, const int64_t *offsets,
+                                         const DecodeArgs &a, hipStream_t s) {
+    return decode_levels_lookup(ld, f)(bwd, levels, offsets, a, s);
 }
 
 bool latent_decode_supported(int ld, int f) { return decode_lookup(ld, f) != nullptr; }

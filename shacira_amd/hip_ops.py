@@ -234,6 +234,47 @@ def latent_decode_sga_backward(latent, uniforms, temperature, diff_sampling, div
     return g_lat, g_mat, g_cs, g_sh
 
 
+def _offsets_array(offsets):
+    return (ctypes.c_int64 * len(offsets))(*[int(o) for o in offsets])
+
+
+def latent_decode_levels_forward(latent, offsets, uniforms, temperature, diff_sampling, div, matrix, colscale, shift,
+                                 clamp_weights):
+    """Per-level decoders in one launch: ``offsets`` (host ints, [L+1]) bound the levels' rows; ``div`` [L, ld],
+    ``matrix`` [L, ld, F], ``colscale`` / ``shift`` [L, F] or None; ``uniforms`` [T, ld, 2] selects the SGA path."""
+    _need_gpu(latent, uniforms, div, matrix, colscale, shift)
+    T, ld = latent.shape
+    F = matrix.shape[-1]
+    out = torch.empty((T, F), dtype=torch.float32, device=latent.device)
+    with torch.cuda.device(latent.device):
+        rc = _lib.lib().shacira_latent_decode_levels_forward(
+            len(offsets) - 1, _offsets_array(offsets), T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature),
+            int(bool(diff_sampling)), _ptr(div), _ptr(matrix), _ptr(colscale), _ptr(shift), float(clamp_weights),
+            _ptr(out), _stream(latent))
+    _lib.check(rc, "latent_decode_levels_forward")
+    return out
+
+
+def latent_decode_levels_backward(latent, offsets, uniforms, temperature, diff_sampling, div, matrix, colscale, shift,
+                                  clamp_weights, grad_decoded):
+    _need_gpu(latent, grad_decoded)
+    T, ld = latent.shape
+    L, F = len(offsets) - 1, matrix.shape[-1]
+    dev = latent.device
+    g_lat = torch.empty_like(latent)
+    g_mat = torch.empty((L, ld, F), dtype=torch.float32, device=dev)
+    g_cs = torch.empty((L, F), dtype=torch.float32, device=dev) if colscale is not None else None
+    g_sh = torch.empty((L, F), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _latent_workspace(dev)
+        rc = _lib.lib().shacira_latent_decode_levels_backward(
+            L, _offsets_array(offsets), T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature),
+            int(bool(diff_sampling)), _ptr(div), _ptr(matrix), _ptr(colscale), _ptr(shift), float(clamp_weights),
+            _ptr(grad_decoded), _ptr(g_lat), _ptr(g_mat), _ptr(g_cs), _ptr(g_sh), _ptr(ws), ws.numel(), _stream(latent))
+    _lib.check(rc, "latent_decode_levels_backward")
+    return g_lat, g_mat, g_cs, g_sh
+
+
 def entropy_supported(latent_dim):
     return latent_dim in (1, 2, 3, 4, 8)
 

@@ -9,6 +9,8 @@ What is pinned by the real reference code (executed, not restated):
   latent_decoder_sga.npz  LatentDecoder.forward/backward on the SGA path (use_sga, diff_sampling on/off), with the
                       uniforms the reference's RelaxedOneHotCategorical drew                            basic_latent_decoder.py:183-191
                       (written by `python tests/golden/make_golden.py sga`, leaves the other files untouched)
+  hierarchical_decoder.npz  HierarchicalLatentDecoder.forward/backward over row ranges, incl. an empty level and the
+                      (sic) last offset of latent_grid.py:182 (`python tests/golden/make_golden.py hier`)   hierarchical_latent_decoder.py:3-36
   bit_estimator.npz   BitEstimator CDF + gradients for num_layers 1..4                               bit_estimator.py:9-65
   latent_grid.npz     LatentGrid.from_geometric tables/buffers/param names, ent_loss (train + val),
                       size(), interpolate() glue ('cat'/'sum', rep trick, [B,S,d] flattening)         latent_grid.py:32-382
@@ -408,10 +410,70 @@ def make_sga():
     print("SGA golden vectors written")
 
 
+def make_hier():
+    """HierarchicalLatentDecoder of the reference, executed (rounding path): per-level decoders over row ranges, with
+    well-formed offsets and with the (sic) offsets LatentGrid.setup_decoders builds (last boundary = last level's size)."""
+    _install_shims()
+    import importlib
+    core_mod = importlib.import_module("wisp.core.wisp_module")
+    sys.modules["wisp.core"].WispModule = core_mod.WispModule
+    importlib.import_module("wisp.models.latent_decoders")
+    hmod = importlib.import_module("wisp.models.latent_decoders.hierarchical_latent_decoder")
+    out, cases = {}, []
+    g = torch.Generator().manual_seed(777)
+    for ci, (ld, fd, mat, shift, offsets, clampw) in enumerate([
+            (1, 2, "sq", True, [0, 40, 100, 257], 0.0),
+            (2, 2, "sq", False, [0, 17, 17, 90, 301], 0.0),          # an empty level
+            (2, 4, "dft", True, [0, 64, 200, 300], 0.05),
+            (1, 2, "sq", True, [0, 50, 150, 120], 0.0)]):            # (sic): last boundary before the last start
+        torch.manual_seed(300 + ci)
+        L = len(offsets) - 1
+        conf = dict(latent_dim=ld, feature_dim=fd, norm="none", ldecode_matrix=mat, use_shift=shift, ldec_std=0.1,
+                    clamp_weights=clampw)
+        dec = hmod.HierarchicalLatentDecoder(L, torch.tensor(offsets, dtype=torch.int32), conf)
+        with torch.no_grad():
+            for l, d in enumerate(dec.decoders):
+                d.div.copy_(torch.rand(ld, generator=g) * 2.0 + 0.5)
+                if shift:
+                    d.layers[0].shift.copy_(torch.randn(1, fd, generator=g) * 0.01)
+        T = max(offsets) + 9
+        lat = ((torch.rand(T, ld, generator=g) - 0.5) * 9.0)
+        lat[0] = 0.5; lat[1] = 1.5; lat[2] = -2.5                      # ties round to even
+        lat.requires_grad_(True)
+        y = dec(lat)
+        gy = torch.randn(y.shape, generator=g)
+        owned = torch.zeros(T, dtype=torch.bool)
+        for l in range(L):
+            owned[offsets[l]:offsets[l + 1]] = True
+        (y[owned] * gy[owned]).sum().backward()                         # rows no level owns are torch.empty garbage
+        pre = f"c{ci}_"
+        out[pre + "latent"] = lat.detach().numpy()
+        out[pre + "owned"] = owned.numpy()
+        out[pre + "out"] = torch.where(owned[:, None], y.detach(), torch.zeros_like(y)).numpy()
+        out[pre + "grad_out"] = gy.numpy()
+        out[pre + "grad_latent"] = lat.grad.numpy()
+        for l, d in enumerate(dec.decoders):
+            out[pre + f"div{l}"] = d.div.detach().numpy()
+            out[pre + f"scale{l}"] = d.layers[0].scale.detach().numpy()
+            gs = d.layers[0].scale.grad
+            out[pre + f"grad_scale{l}"] = (gs if gs is not None else torch.zeros_like(d.layers[0].scale)).numpy()
+            if shift:
+                out[pre + f"shift{l}"] = d.layers[0].shift.detach().numpy()
+                gh = d.layers[0].shift.grad
+                out[pre + f"grad_shift{l}"] = (gh if gh is not None else torch.zeros_like(d.layers[0].shift)).numpy()
+        cases.append(dict(latent_dim=ld, feature_dim=fd, ldecode_matrix=mat, use_shift=shift, offsets=offsets,
+                          clamp_weights=clampw, rows=T))
+    out["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "hierarchical_decoder.npz"), **out)
+    print("hierarchical decoder golden vectors written")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; goldens can only be regenerated in the dev container")
     if len(sys.argv) > 1 and sys.argv[1] == "sga":
         make_sga()
+    elif len(sys.argv) > 1 and sys.argv[1] == "hier":
+        make_hier()
     else:
         main()

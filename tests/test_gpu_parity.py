@@ -882,3 +882,49 @@ def test_power_of_two_resolutions(dev, n):
         lo, hi = int(first[l]), int(first[l]) + sizes[l]
         np.testing.assert_allclose(grad[lo:hi].cpu().numpy(), ref[lo:hi], rtol=RTOL, atol=RTOL * np.abs(ref[lo:hi]).max(),
                                    err_msg=f"level {l} res {res[l]}")
+
+
+def test_fused_hierarchical_decoder_against_reference_vectors(dev, golden):
+    """Row f4: the per-level decoders as ONE fused kernel each way (shacira_latent_decode_levels_*), against the vectors
+    of the reference's executed HierarchicalLatentDecoder; the module must actually take the fused path."""
+    from test_host_mirror import _hier_case
+    from shacira_amd.wisp.models.latent_decoders import hierarchical_latent_decoder as hmod
+    g = golden("hierarchical_decoder.npz")
+    calls = []
+    orig = hmod._FusedLevelsDecode.apply
+    hmod._FusedLevelsDecode.apply = staticmethod(lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    try:
+        for ci, case in enumerate(npz_json(g["cases_json"])):
+            _hier_case(g, ci, case, dev)
+    finally:
+        hmod._FusedLevelsDecode.apply = orig
+    assert len(calls) == len(npz_json(g["cases_json"]))
+
+
+def test_fused_hierarchical_decoder_sga_matches_per_level_kernels(dev):
+    """SGA path: with the same uniforms, the one-launch form equals the per-level fused decoders run on their slices."""
+    ops = _ops()
+    torch.manual_seed(0)
+    T, ld, F, offs = 5000, 2, 2, (0, 700, 700, 3100, 4800)
+    L = len(offs) - 1
+    lat = ((torch.rand(T, ld) - 0.5) * 8).to(dev)
+    uni = torch.rand(T, ld, 2).to(dev)
+    div = (torch.rand(L, ld) + 0.5).to(dev)
+    mat = (torch.randn(L, ld, F) * 0.1).to(dev)
+    sh = (torch.randn(L, F) * 0.01).to(dev)
+    gy = torch.randn(T, F).to(dev)
+    out = ops.latent_decode_levels_forward(lat, offs, uni, 0.4, True, div, mat, None, sh, 0.0)
+    g_lat, g_mat, g_cs, g_sh = ops.latent_decode_levels_backward(lat, offs, uni, 0.4, True, div, mat, None, sh, 0.0, gy)
+    assert g_cs is None and float(out[4800:].abs().sum()) == 0.0 and float(g_lat[4800:].abs().sum()) == 0.0
+    for l in range(L):
+        lo, hi = offs[l], offs[l + 1]
+        if hi == lo:
+            assert float(g_mat[l].abs().sum()) == 0.0
+            continue
+        o1 = ops.latent_decode_sga_forward(lat[lo:hi].contiguous(), uni[lo:hi].contiguous(), 0.4, True, div[l], mat[l],
+                                           None, sh[l], 0.0)
+        gl1, gm1, _, gs1 = ops.latent_decode_sga_backward(lat[lo:hi].contiguous(), uni[lo:hi].contiguous(), 0.4, True,
+                                                          div[l], mat[l], None, sh[l], 0.0, gy[lo:hi].contiguous(), False)
+        assert torch.equal(out[lo:hi], o1) and torch.equal(g_lat[lo:hi], gl1)
+        torch.testing.assert_close(g_mat[l], gm1, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(g_sh[l], gs1.reshape(-1), rtol=1e-5, atol=1e-6)

@@ -83,23 +83,25 @@ def test_raymarch_ray_matches_reference_python(dev, level, ns):
     jit = torch.from_numpy(rng.random((N, ns)).astype(np.float32))
     near, far = 1.5, 4.5
     full = torch.ones((G, G, G), dtype=torch.bool)
-    # all cells occupied: every sample is emitted -> positions / depths / deltas of the whole lattice
+    # all cells occupied: every sample INSIDE the cube is emitted (a point outside has no cell, as in kaolin's query)
     r_all, s_all, dep_all, del_all, b_all, off_all = [t.cpu() for t in render.raymarch_ray(
         o.to(dev), d.to(dev), near, far, full.to(dev), level, ns, jit.to(dev))]
-    assert torch.equal(off_all, torch.arange(N + 1) * ns)
-    assert r_all.shape[0] == N * ns and torch.equal(r_all, torch.arange(N).repeat_interleave(ns))
     ro, so, do, dlo, bo = orr.raymarch_ray(o, d, near, far, full, level, ns, jit)
+    assert 0 < r_all.shape[0] < N * ns and torch.equal(r_all, ro)
+    assert torch.equal(off_all[1:] - off_all[:-1], torch.bincount(r_all, minlength=N)) and off_all[0] == 0
+    assert bool((s_all.abs() <= 1.0).all())
     np.testing.assert_allclose(dep_all.numpy(), do.numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(del_all.numpy(), dlo.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(s_all.numpy(), so.numpy(), rtol=1e-5, atol=1e-6)
     assert torch.equal(b_all, bo)
-    # real occupancy: exactly the reference's filter applied to the very same positions
+    # real occupancy: exactly the reference's filter applied to the very same positions (deltas are differences of the
+    # sample LATTICE, so they do not change when neighbours are dropped)
     r, s, dep, dl, b, off = [t.cpu() for t in render.raymarch_ray(o.to(dev), d.to(dev), near, far, occ.to(dev), level,
                                                                   ns, jit.to(dev))]
     assert torch.equal(off[1:] - off[:-1], torch.bincount(r, minlength=N))        # per-ray pack sizes, empty ones too
-    r2, s2, dep2, dl2, b2 = orr.filter_samples(s_all, dep_all, del_all, occ, level, N, ns)
-    assert torch.equal(r, r2) and torch.equal(b, b2)
-    assert torch.equal(s, s2) and torch.equal(dep, dep2) and torch.equal(dl, dl2)
+    keep = orr.query_dense(occ, s_all, level)
+    assert torch.equal(r, r_all[keep]) and torch.equal(b, orr.mark_pack_boundaries(r))
+    assert torch.equal(s, s_all[keep]) and torch.equal(dep, dep_all[keep]) and torch.equal(dl, del_all[keep])
     # nothing occupied -> nothing emitted
     none = render.raymarch_ray(o.to(dev), d.to(dev), near, far, torch.zeros_like(full).to(dev), level, ns, jit.to(dev))
     assert none[0].numel() == 0 and none[4].numel() == 0

@@ -227,6 +227,45 @@ def test_multi_latent_decoder_module(golden):
         assert dec.size() == pytest.approx(float(g[p + "size"]), rel=1e-6)
 
 
+def _hier_case(g, ci, case, device):
+    p = f"c{ci}_"
+    L = len(case["offsets"]) - 1
+    conf_d = dict(latent_dim=case["latent_dim"], feature_dim=case["feature_dim"], norm="none",
+                  ldecode_matrix=case["ldecode_matrix"], use_shift=case["use_shift"], ldec_std=0.1,
+                  clamp_weights=case["clamp_weights"])
+    dec = HierarchicalLatentDecoder(L, torch.tensor(case["offsets"], dtype=torch.int32), conf_d)
+    with torch.no_grad():
+        for l, d in enumerate(dec.decoders):
+            d.div.copy_(torch.from_numpy(g[p + f"div{l}"]))
+            d.layers[0].scale.copy_(torch.from_numpy(g[p + f"scale{l}"]))
+            if case["use_shift"]:
+                d.layers[0].shift.copy_(torch.from_numpy(g[p + f"shift{l}"]))
+    dec = dec.to(device)
+    lat = torch.from_numpy(g[p + "latent"]).to(device).requires_grad_(True)
+    owned = torch.from_numpy(g[p + "owned"]).to(device)
+    y = dec(lat)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[p + "out"], rtol=1e-5, atol=1e-7)   # unowned rows: zeros
+    gy = torch.from_numpy(g[p + "grad_out"]).to(device)
+    (y[owned] * gy[owned]).sum().backward()
+    np.testing.assert_allclose(lat.grad.cpu().numpy(), g[p + "grad_latent"], rtol=1e-5, atol=1e-7)
+    for l, d in enumerate(dec.decoders):
+        gs = d.layers[0].scale.grad
+        got = gs.cpu().numpy() if gs is not None else np.zeros_like(g[p + f"grad_scale{l}"])
+        np.testing.assert_allclose(got, g[p + f"grad_scale{l}"], rtol=1e-4, atol=1e-6, err_msg=f"scale {l}")
+        if case["use_shift"]:
+            gh = d.layers[0].shift.grad
+            got = gh.cpu().numpy() if gh is not None else np.zeros_like(g[p + f"grad_shift{l}"])
+            np.testing.assert_allclose(got, g[p + f"grad_shift{l}"], rtol=1e-4, atol=1e-6, err_msg=f"shift {l}")
+
+
+def test_hierarchical_latent_decoder_module(golden):
+    """Row f4: HierarchicalLatentDecoder (host path: per-level decoders) against vectors produced by the reference's own
+    module -- row ranges, an empty level, the (sic) last offset of latent_grid.py:182."""
+    g = golden("hierarchical_decoder.npz")
+    for ci, case in enumerate(npz_json(g["cases_json"])):
+        _hier_case(g, ci, case, torch.device("cpu"))
+
+
 # ------------------------------------------------------------------------------------------------ decoder / CDF
 def test_latent_decoder_module(golden):
     g = golden("latent_decoder.npz")
