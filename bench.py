@@ -84,6 +84,21 @@ def quick_measure(name, device, iters=10):
             "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS}
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the HIP sources and headers of the library: identifies WHICH kernels a committed
+    counter file was measured on (a git hash cannot: committing the file changes it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "shacira_amd", "csrc", "*.hip")) +
+                       glob.glob(os.path.join(ROOT, "shacira_amd", "csrc", "*.h")) +
+                       glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes_per_sample(dim, L, F, s=4):
     """fwd = 4d + L*2^d*F*s + L*F*s ; bwd = 4d + L*F*s + L*2^d*F*s."""
     one = 4 * dim + L * (2 ** dim) * F * s + L * F * s
@@ -95,7 +110,7 @@ def cpu_baseline(dim, res, bw, F, first, T, n_samples, budget_s, seed=0):
     about `budget_s` seconds of CPU work (the first pass sizes the number of timed passes)."""
     from oracle import hashgrid_c as oc
     from oracle import hashgrid_torch as ot
-    cores = min(os.cpu_count() or 1, 32)   # more threads only add contention to index_add_ on this workload
+    cores = os.cpu_count() or 1            # BASELINE.md section 3 protocol: every host core
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(seed)
     coords = torch.rand(n_samples, dim, generator=g) * 2 - 1
@@ -121,6 +136,39 @@ def cpu_baseline(dim, res, bw, F, first, T, n_samples, budget_s, seed=0):
             "s_per_pass": dt, "c_oracle_1thread_samples_per_s": n_c / dt_c}
 
 
+def psnr_parity(device, steps=300, height=96, width=128, seed=2):
+    """PSNR at a fixed step, HIP path vs the CPU restatement of the reference kernels (the C
+    oracle behind the same host code), same init / batches / entropy noise. A reduced image so that the scalar CPU leg
+    stays within seconds; both values are REPORTED (level = mean over the last 20 steps; rounding makes single steps
+    chaotic in their last bits). Part of the cpu_baseline leg: the only place the product code runs on the oracle."""
+    import numpy as _np
+    from oracle import hashgrid_c as oc
+    from shacira_amd import harness, hip_ops
+    gpu = harness.fit_image(device, steps=steps, height=height, width=width, seed=seed, log_every=1)
+    saved = (hip_ops.hashgrid_interpolate_cuda, hip_ops.hashgrid_interpolate2d_cuda, hip_ops.hashgrid_backward)
+
+    def fwd(coords, codebook, first_idx, resolution, bw):
+        return torch.from_numpy(oc.forward(coords.detach().numpy(), codebook.detach().numpy(), first_idx.numpy(),
+                                           list(resolution), bw))
+
+    def bwd(dim, coords, grad_output, table_rows, table_dtype, first_idx, resolution, bw, feature_dim, **kw):
+        g = oc.backward(coords.detach().numpy(), grad_output.detach().numpy(), (table_rows, feature_dim),
+                        first_idx.numpy(), list(resolution), bw)
+        return torch.from_numpy(g.astype(_np.float32))
+    t0 = time.perf_counter()
+    try:
+        hip_ops.hashgrid_interpolate_cuda = hip_ops.hashgrid_interpolate2d_cuda = fwd
+        hip_ops.hashgrid_backward = bwd
+        cpu = harness.fit_image(torch.device("cpu"), steps=steps, height=height, width=width, seed=seed, log_every=1)
+    finally:
+        hip_ops.hashgrid_interpolate_cuda, hip_ops.hashgrid_interpolate2d_cuda, hip_ops.hashgrid_backward = saved
+    tail = lambda r: float(_np.mean([h[2] for h in r["history"][-20:]]))
+    return {"config": f"config-B LatentGrid image fit, {height}x{width} procedural image, {steps} steps, seed {seed}",
+            "gpu_db": tail(gpu), "cpu_restatement_db": tail(cpu), "delta_db": tail(gpu) - tail(cpu),
+            "gpu_at_step_db": gpu["psnr"], "cpu_restatement_at_step_db": cpu["psnr"],
+            "bpp_gpu": gpu["bpp"], "bpp_cpu_restatement": cpu["bpp"], "cpu_seconds": time.perf_counter() - t0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,8 +188,9 @@ def main():
     ap.add_argument("--psnr-steps", type=int, default=1000, help="image-fit steps for the PSNR figure (0 = skip)")
     ap.add_argument("--nerf-steps", type=int, default=500,
                     help="steps of the NeRF-style render-and-fit on the analytic scene for the second PSNR figure (0 = skip)")
-    ap.add_argument("--cpu-samples", type=int, default=1 << 17)
-    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--cpu-samples", type=int, default=1 << 20,
+                    help="samples of the CPU baseline leg (BASELINE.md protocol: the headline N = 2^20)")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--selftest-launch", action="store_true",
                     help="only exercise the multi-rank launch (spawn, rendezvous, one all-reduce, JSON line with n_gpus); "
                          "needs no GPU: ranks use the gloo backend. The metric value is null.")
@@ -347,11 +396,17 @@ def main():
         dom = ("backward", ms_bwd, b_bwd) if ms_bwd >= ms_fwd else ("forward", ms_fwd, b_fwd)
         # HBM bytes per launch from the PMC counters (collected offline with rocprofv3 --pmc in separate passes on
         # the same operators and workload; see the note inside the file). Only valid for the workload it was taken on.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        # Attached ONLY when the file was measured on exactly these kernel sources (kernel_source_hash); else null.
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if args.workload.startswith("S1_") and os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh)["operators"].get(dom[0], {}).get("hbm_bytes_per_launch")
+                rec = json.load(fh)
+            if rec.get("kernel_source_hash") == kernel_source_hash():
+                traffic = rec["operators"].get(dom[0], {}).get("hbm_bytes_per_launch")
+            else:
+                traffic_note = ("profiles/r02_pmc_traffic.json was measured on other kernel sources "
+                                f"({rec.get('kernel_source_hash')} != {kernel_source_hash()}): not attached")
         achieved = dom[2] * n_local / (dom[1] * 1e-3) / 1e9
         path_gbs = (b_fwd + b_bwd) * n_local / ((ms_fwd + ms_bwd) * 1e-3) / 1e9
         out = {
@@ -370,9 +425,10 @@ def main():
                          "kernel": (f"hashgrid_{dom[0]} operator = one C-ABI call, HIP events on its stream; kernels: "
                                     + ("transpose_grad + bin_count + 2 scans + bin_scatter + bin_consume + "
                                        "direct_accumulate" if dom[0] == "backward" else
-                                       "hashgrid_fwd_level_pair + untranspose_feats")),
+                                       "sample sort + hashgrid_fwd_level_pair (fine levels) + hashgrid_fwd_rows")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": dom[2] * n_local,
+                         "traffic": traffic, "traffic_note": traffic_note,
+                         "algorithmic_bytes_per_launch": dom[2] * n_local,
                          "ms_per_launch": dom[1],
                          "fwd_bwd_path": {"achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS,
                                           "bytes_per_sample": b_fwd + b_bwd}},
@@ -388,6 +444,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, res, bw, F, first_np, T, min(args.cpu_samples, n_local),
                                                args.cpu_budget_s)
+            if args.psnr_steps > 0:
+                out["psnr_parity"] = psnr_parity(device)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
