@@ -301,15 +301,14 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_pair_kernel(LevelTable lt, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Tiled forward, rows kernel (hashgrid_tiled.hip): variant 3's lane pairing over CELL-SORTED coordinates for the coarse
+// Tiled forward, rows kernel (hashgrid_tiled.hip): variant 3's lane pairing over CELL-SORTED sample records for the coarse
 // levels [0, lc) -- consecutive samples sit in the same spatial block, so their corner rows come out of L1 (measured:
 // a gather instruction whose lines hit L1 costs ~35 clk against ~84-148 from L2) -- then the fine levels' pieces are
 // read from the level-major staging buffer the level-per-XCD kernel wrote, and whole feature rows leave through the
 // permutation: feats[perm[i]] = row i (full contiguous rows, 16-byte chunks when the row size allows).
 template <int DIM, typename T, int F>
 __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, const int32_t *__restrict__ first_idx,
-                                                                const float *__restrict__ coords,
-                                                                const uint32_t *__restrict__ perm,
+                                                                const float4 *__restrict__ sorted4,
                                                                 const T *__restrict__ table,
                                                                 const T *__restrict__ staged, T *__restrict__ feats,
                                                                 int64_t N, int lc) {
@@ -325,9 +324,13 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
     const int64_t wave_s0 = (int64_t)blockIdx.x * 128 + wave * 32;
     const int64_t i = wave_s0 + sl;
     const bool live = i < N;
+    // one 16-byte record per sample: {x, y, z (0 in 2-D), bit pattern of the sample's original index}
+    float4 c4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (live) c4 = sorted4[i];
     double t[DIM];
-#pragma unroll
-    for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live ? coords[i * DIM + a] : 0.0f);
+    t[0] = axis_unit(c4.x);
+    t[1] = axis_unit(c4.y);
+    if constexpr (DIM == 3) t[2] = axis_unit(c4.z);
 #pragma unroll 1
     for (int l = 0; l < lc; ++l) {
         const int32_t res = lt.res[l];
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
         if (rr < rows)
             reinterpret_cast<Piece *>(my + (size_t)rr * pitch)[lc + lf] = fine[(int64_t)(lc + lf) * N + wave_s0 + rr];
     }
-    if (lane < rows) *reinterpret_cast<uint32_t *>(my + (size_t)lane * pitch + pitch - 16u) = perm[wave_s0 + lane];
+    if (dx == 0 && sl < rows) *reinterpret_cast<uint32_t *>(my + (size_t)sl * pitch + pitch - 16u) = __float_as_uint(c4.w);
     // wave-private staging: no workgroup barrier (the wave's own LDS writes are visible to it after the wait below)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -467,7 +470,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_kernel(LevelTable lt, 
 // table) + variant 3's lane pairing (corners x / x+1 in one instruction -> one L2 request). The per-level feature
 // piece of a sample (F scalars) is written with a non-temporal store and coords are read non-temporally so that
 // the streams do not evict the table from L2 (a plain 8-byte store allocates a whole 128-byte line).
-template <int DIM, typename T, int F, int U, bool TRANSPOSED = false>
+// PACKED: `coords` is an array of 16-byte records {x, y, z (0 in 2-D), bits} (the cell-sorted copy of hashgrid_tiled.hip):
+// one dwordx4 load per sample instead of DIM dword loads -- the kernel is bound by vector-memory instructions.
+template <int DIM, typename T, int F, int U, bool TRANSPOSED = false, bool PACKED = false>
 __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable lt,
                                                                       const int32_t *__restrict__ first_idx,
                                                                       const float *__restrict__ coords,
@@ -503,8 +508,16 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
         idx[u] = i;
         live[u] = i < N;
         double t[DIM];
+        if constexpr (PACKED) {
+            float4 c4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (live[u]) c4 = reinterpret_cast<const float4 *>(coords)[i];
+            t[0] = axis_unit(c4.x);
+            t[1] = axis_unit(c4.y);
+            if constexpr (DIM == 3) t[2] = axis_unit(c4.z);
+        } else {
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live[u] ? coords[i * DIM + a] : 0.0f);
+            for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live[u] ? coords[i * DIM + a] : 0.0f);
+        }
         int32_t p[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; ++a) axis_transform(t[a], res, hi, p[a], f[u][a], g[u][a]);
@@ -734,13 +747,13 @@ static bool use_sorted(int dim, const LevelTable &lt, int64_t n) {
 }
 
 // levels [lt.level_begin, lt.level_end) of the level-per-XCD pair kernel into a level-major staging buffer [L][N][F]
-// (used by hashgrid_tiled.hip for the fine levels, over cell-sorted coordinates)
+// (used by hashgrid_tiled.hip for the fine levels; `coords` = its cell-sorted 16-byte sample records)
 template <int DIM, typename T, int F>
 static hipError_t launch_levels_staged(const LevelTable &lt, const int32_t *first_idx, const float *coords,
                                        const void *table, void *staged, int64_t n, hipStream_t s) {
     const uint32_t nl = (uint32_t)(lt.level_end - lt.level_begin);
     const uint32_t tiles = (uint32_t)((n + 127) / 128);
-    hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true>),
+    hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true, true>),
                        dim3(8u * (uint32_t)(((uint64_t)nl * tiles + 7) / 8)), dim3(256), 0, s,
                        lt, first_idx, coords, static_cast<const T *>(table), static_cast<T *>(staged), n, tiles);
     return hipGetLastError();
@@ -765,7 +778,7 @@ hipError_t hashgrid_forward_levels_staged(int dim, int dtype, const LevelTable &
 }
 
 template <int DIM, typename T, int F>
-static hipError_t launch_rows(const LevelTable &lt, const int32_t *first_idx, const float *sorted, const uint32_t *perm,
+static hipError_t launch_rows(const LevelTable &lt, const int32_t *first_idx, const float *sorted4,
                               const void *table, const void *staged, void *feats, int64_t n, int lc, hipStream_t s) {
     const uint32_t row_bytes = (uint32_t)(lt.num_lods * F * sizeof(T));
     const size_t shmem = (size_t)128 * ((row_bytes + 15u) / 16u * 16u + 16u);
@@ -776,28 +789,27 @@ static hipError_t launch_rows(const LevelTable &lt, const int32_t *first_idx, co
     });
     if (oe != hipSuccess) return oe;
     hipLaunchKernelGGL((hashgrid_fwd_rows_kernel<DIM, T, F>), dim3((uint32_t)((n + 127) / 128)), dim3(256), shmem, s, lt,
-                       first_idx, sorted, perm, static_cast<const T *>(table), static_cast<const T *>(staged),
-                       static_cast<T *>(feats), n, lc);
+                       first_idx, reinterpret_cast<const float4 *>(sorted4), static_cast<const T *>(table),
+                       static_cast<const T *>(staged), static_cast<T *>(feats), n, lc);
     return hipGetLastError();
 }
 
 // coarse levels [0, lc) over cell-sorted coordinates + assembly of whole rows through perm (hashgrid_tiled.hip)
-hipError_t hashgrid_forward_rows(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *sorted,
-                                 const uint32_t *perm, const void *table, const void *staged, void *feats, int64_t n,
-                                 int lc, hipStream_t s) {
+hipError_t hashgrid_forward_rows(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *sorted4,
+                                 const void *table, const void *staged, void *feats, int64_t n, int lc, hipStream_t s) {
     const int F = lt.feature_dim;
     if (F != 2 && F != 4) return hipErrorInvalidValue;
     if (dim == 3 && dtype == SHACIRA_F32)
-        return F == 2 ? launch_rows<3, float, 2>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s)
-                      : launch_rows<3, float, 4>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s);
+        return F == 2 ? launch_rows<3, float, 2>(lt, first_idx, sorted4, table, staged, feats, n, lc, s)
+                      : launch_rows<3, float, 4>(lt, first_idx, sorted4, table, staged, feats, n, lc, s);
     if (dim == 3)
-        return F == 2 ? launch_rows<3, __half, 2>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s)
-                      : launch_rows<3, __half, 4>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s);
+        return F == 2 ? launch_rows<3, __half, 2>(lt, first_idx, sorted4, table, staged, feats, n, lc, s)
+                      : launch_rows<3, __half, 4>(lt, first_idx, sorted4, table, staged, feats, n, lc, s);
     if (dtype == SHACIRA_F32)
-        return F == 2 ? launch_rows<2, float, 2>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s)
-                      : launch_rows<2, float, 4>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s);
-    return F == 2 ? launch_rows<2, __half, 2>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s)
-                  : launch_rows<2, __half, 4>(lt, first_idx, sorted, perm, table, staged, feats, n, lc, s);
+        return F == 2 ? launch_rows<2, float, 2>(lt, first_idx, sorted4, table, staged, feats, n, lc, s)
+                      : launch_rows<2, float, 4>(lt, first_idx, sorted4, table, staged, feats, n, lc, s);
+    return F == 2 ? launch_rows<2, __half, 2>(lt, first_idx, sorted4, table, staged, feats, n, lc, s)
+                  : launch_rows<2, __half, 4>(lt, first_idx, sorted4, table, staged, feats, n, lc, s);
 }
 
 template <typename T, int F>

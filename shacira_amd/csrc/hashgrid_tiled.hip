@@ -11,7 +11,7 @@
 // block ("coarse" levels: 0-7 of S1), so walking the samples block by block turns those levels' gathers into L1 hits.
 // Levels finer than that (one sample per cell: no reuse possible in any order) keep the level-per-XCD pair kernel.
 //
-//   sort      counting sort of the samples by block id -> perm, coordinates in sorted order (exact copies)
+//   sort      counting sort of the samples by block id -> 16-byte records {coordinates (exact copies), sample index}
 //   fine      hashgrid_fwd_level_pair_kernel over the sorted coordinates, levels [lc, L) -> staging [L][N][F]
 //   rows      hashgrid_fwd_rows_kernel: coarse levels [0, lc) over the sorted coordinates (lane pairs, L1-resident
 //             lines), then whole feature rows (coarse from the wave's LDS + fine from the staging) are scattered back
@@ -47,8 +47,7 @@ struct TilePlan {
 
 struct TileCtx {            // device pointers into the sort's scratch / outputs
     uint32_t *header;       // [0] magic, [1] num_blocks, [2] n
-    uint32_t *perm;         // [n]     sorted position -> sample
-    float *sorted;          // [n*dim] coordinates in sorted order (exact copies)
+    float4 *sorted4;        // [n] sample records in sorted order: {x, y, z (0 in 2-D) -- exact copies --, bits of the sample index}
     uint32_t *block_start;  // [num_blocks + 1]
     uint32_t *cnt;          // [num_blocks][num_tiles] sort scratch
     uint32_t *totals;       // [num_blocks]
@@ -119,8 +118,7 @@ static TileCtx carve_ctx(int dim, int64_t n, void *buf, size_t *bytes) {
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off = up256(off + b); return o; };
     const size_t o_hdr = take(256);
-    const size_t o_perm = take((size_t)n * 4);
-    const size_t o_sorted = take((size_t)n * dim * 4);
+    const size_t o_sorted = take((size_t)n * sizeof(float4));
     const size_t o_bs = take((size_t)(kMaxBlocksS + 1) * 4);
     const size_t o_cnt = take((size_t)tp.num_blocks * tp.num_tiles * 4);
     const size_t o_tot = take((size_t)kMaxBlocksS * 4);
@@ -128,8 +126,7 @@ static TileCtx carve_ctx(int dim, int64_t n, void *buf, size_t *bytes) {
     unsigned char *p = static_cast<unsigned char *>(buf);
     if (p) {
         c.header = reinterpret_cast<uint32_t *>(p + o_hdr);
-        c.perm = reinterpret_cast<uint32_t *>(p + o_perm);
-        c.sorted = reinterpret_cast<float *>(p + o_sorted);
+        c.sorted4 = reinterpret_cast<float4 *>(p + o_sorted);
         c.block_start = reinterpret_cast<uint32_t *>(p + o_bs);
         c.cnt = reinterpret_cast<uint32_t *>(p + o_cnt);
         c.totals = reinterpret_cast<uint32_t *>(p + o_tot);
@@ -241,8 +238,7 @@ template <int DIM>
 __global__ __launch_bounds__(kSortThreadsS) void ctx_scatter_kernel(TilePlan tp, const float *__restrict__ coords,
                                                                     int64_t N, const uint32_t *__restrict__ tile_off,
                                                                     const uint32_t *__restrict__ block_start,
-                                                                    uint32_t *__restrict__ perm,
-                                                                    float *__restrict__ sorted) {
+                                                                    float4 *__restrict__ sorted4) {
     __shared__ uint32_t s_hist[kMaxBlocksS];
     for (uint32_t k = threadIdx.x; k < tp.num_blocks; k += kSortThreadsS) s_hist[k] = 0;
     __syncthreads();
@@ -257,9 +253,7 @@ __global__ __launch_bounds__(kSortThreadsS) void ctx_scatter_kernel(TilePlan tp,
             const uint32_t key = block_key<DIM>(c, tp);
             const uint32_t rank = atomicAdd(&s_hist[key], 1u);
             const uint32_t pos = block_start[key] + tile_off[(size_t)key * tp.num_tiles + blockIdx.x] + rank;
-            perm[pos] = (uint32_t)i;
-#pragma unroll
-            for (int a = 0; a < DIM; ++a) sorted[(size_t)pos * DIM + a] = c[a];
+            sorted4[pos] = make_float4(c[0], c[1], DIM == 3 ? c[DIM - 1] : 0.0f, __uint_as_float((uint32_t)i));
         }
     }
 }
@@ -285,10 +279,10 @@ static hipError_t sort_samples(int dim, const TilePlan &tp, const float *coords,
     SHACIRA_CHECK_LAUNCH();
     if (dim == 3)
         hipLaunchKernelGGL(ctx_scatter_kernel<3>, dim3(tp.num_tiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt,
-                           c.block_start, c.perm, c.sorted);
+                           c.block_start, c.sorted4);
     else
         hipLaunchKernelGGL(ctx_scatter_kernel<2>, dim3(tp.num_tiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt,
-                           c.block_start, c.perm, c.sorted);
+                           c.block_start, c.sorted4);
     SHACIRA_CHECK_LAUNCH();
     return hipSuccess;
 }
@@ -332,10 +326,12 @@ hipError_t tiled_forward(int dim, int dtype, const LevelTable &lt, const int32_t
         LevelTable fine = lt;
         fine.level_begin = tp.lc;
         fine.level_end = L;
-        e = hashgrid_forward_levels_staged(dim, dtype, fine, first_idx, ctx.sorted, table, staged, n, s);
+        e = hashgrid_forward_levels_staged(dim, dtype, fine, first_idx, reinterpret_cast<const float *>(ctx.sorted4), table,
+                                           staged, n, s);
         if (e != hipSuccess) return e;
     }
-    return hashgrid_forward_rows(dim, dtype, lt, first_idx, ctx.sorted, ctx.perm, table, staged, feats, n, tp.lc, s);
+    return hashgrid_forward_rows(dim, dtype, lt, first_idx, reinterpret_cast<const float *>(ctx.sorted4), table, staged,
+                                 feats, n, tp.lc, s);
 }
 
 }  // namespace shacira

@@ -34,9 +34,8 @@ hipError_t hashgrid_forward_levels_staged(int dim, int dtype, const LevelTable &
                                           const float *coords, const void *table, void *staged, int64_t n,
                                           hipStream_t s);
 // coarse levels [0, lc) over cell-sorted coordinates + assembly of whole feature rows through perm
-hipError_t hashgrid_forward_rows(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *sorted,
-                                 const uint32_t *perm, const void *table, const void *staged, void *feats, int64_t n,
-                                 int lc, hipStream_t s);
+hipError_t hashgrid_forward_rows(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *sorted4,
+                                 const void *table, const void *staged, void *feats, int64_t n, int lc, hipStream_t s);
 // hashgrid_tiled.hip: cell-sorted ("tiled") forward for large batches
 bool tiled_supported(int dim, int dtype, const LevelTable &lt, int64_t n);
 size_t tiled_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);

@@ -5,23 +5,36 @@ TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}f
 mkdir -p $OUT
-python bench.py > $OUT/bench_line.json 2> $OUT/bench_err.txt
-tail -c 600 $OUT/bench_line.json
+STAGES=${STAGES:-"bench checks stats pmc ctr"}    # subset to re-run, e.g. STAGES="bench ctr"
+has() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
+if has bench; then
+( time python bench.py > $OUT/bench_line.json 2> $OUT/bench_err.txt ) 2> $OUT/bench_wall.txt
+tail -c 600 $OUT/bench_line.json; cat $OUT/bench_wall.txt
+fi
+if has checks; then
 python tools/gpu_check.py > $OUT/parity_and_timing.txt 2>&1
 python tools/config_c.py > $OUT/config_c.txt 2>&1
 python tools/tiled_check.py > $OUT/tiled_check.txt 2>&1
+fi
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --psnr-steps 0 --nerf-steps 0 --no-secondary > $OUT/stats_line.json 2>/dev/null
+if has stats; then
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --psnr-steps 0 --nerf-steps 0 --no-secondary > $OUT/stats_line.json 2>/dev/null
+fi
+if has pmc; then
 for op in fwd bwd; do for c in FETCH_SIZE WRITE_SIZE; do
-rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${op}_${c} -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py $op -1 3 3 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${op}_${c} -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py $op -1 3 3 > /dev/null 2>&1
 done; done
-# forward kernels, unit counters (separate passes; SQ: 8 slots, TCC: 4 slots): cell-sorted path and the unsorted kernels
+fi
+if has ctr; then
+# forward kernels, unit counters (separate passes; SQ: 8 slots, TCC: 4 slots). Keep the TA / TCP groups at two counters:
+# the five-counter TA group (with the *_STALLED_BY_* pair) hung the profiler twice on this pool: cell-sorted path and the unsorted kernels
 for mode in tiled plain; do
 if [ $mode = plain ]; then export SHACIRA_OPTIONS="tiled=0"; else unset SHACIRA_OPTIONS; fi
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/ctr_${mode}_sq -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py fwd -1 3 3 > /dev/null 2>&1
-rocprofv3 --pmc TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/ctr_${mode}_ta -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py fwd -1 3 3 > /dev/null 2>&1
-rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum --kernel-trace --output-format csv -d $OUT/ctr_${mode}_tcp -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py fwd -1 3 3 > /dev/null 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $OUT/ctr_${mode}_tcc -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py fwd -1 3 3 > /dev/null 2>&1
+timeout 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/ctr_${mode}_sq -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py fwd -1 3 3 > /dev/null 2>&1
+timeout 120 rocprofv3 --pmc TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum --kernel-trace --output-format csv -d $OUT/ctr_${mode}_ta -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py fwd -1 3 3 > /dev/null 2>&1
+timeout 120 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum --kernel-trace --output-format csv -d $OUT/ctr_${mode}_tcp -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py fwd -1 3 3 > /dev/null 2>&1
+timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $OUT/ctr_${mode}_tcc -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py fwd -1 3 3 > /dev/null 2>&1
 done
 unset SHACIRA_OPTIONS
+fi
 ls $OUT
