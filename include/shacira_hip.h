@@ -280,6 +280,34 @@ SHACIRA_API int shacira_latent_decode_levels_backward(int num_levels, const int6
                                           size_t workspace_bytes, void *stream);
 
 /*
+ * MultiLatentDecoder (wisp/models/latent_decoders/multi_latent_decoder.py:27-210, built by LatentGrid.setup_decoders for
+ * `ldecode_type: multi`), no hidden layers: num_decoders affine decoders mixed per table entry by the selector alpha:
+ *     a_soft = softmax_k(alpha[k, r] / temperature) ;  a = one-hot(arg-max) if straight_through (gradient: identity) else a_soft
+ *     x      = rint(latent[r]) / div            (uniforms == NULL)   or the SGA sample with the same temperature
+ *     'dft' (dft != NULL): per_k = (x @ dft) * scale[k, 0, :] + shift[k, :] ;  decoded = sum_k per_k * a_k
+ *     'sq'  (dft == NULL): mixed = sum_k (x @ scale[k]) * a_k ;  decoded = sum_k (mixed + shift[k, :]) * a_k
+ *       (the reference's forward mixes twice, multi_latent_decoder.py:74-81; kept)
+ *   alpha [num_decoders, num_rows]; scale [num_decoders, S, feature_dim] with S = latent_dim ('sq') or 1 ('dft');
+ *   dft [latent_dim, feature_dim]; shift [num_decoders, feature_dim] or NULL; clamp as above.
+ * Backward writes grad_latent [num_rows, latent_dim] (straight-through rounding / SGA), grad_alpha [num_decoders, num_rows]
+ * (through the softmax), grad_scale, grad_shift (NULL = skip, except grad_scale). num_decoders <= 8 and the
+ * (latent_dim, feature_dim) pairs of shacira_latent_multi_supported; else SHACIRA_EDTYPE.
+ */
+SHACIRA_API int shacira_latent_multi_supported(int latent_dim, int feature_dim, int num_decoders);
+SHACIRA_API int shacira_latent_multi_decode_forward(int64_t num_rows, int latent_dim, int feature_dim, int num_decoders,
+                                        const float *latent, const float *alpha, const float *uniforms,
+                                        float temperature, int straight_through, int diff_sampling, const float *div,
+                                        const float *scale, const float *dft, const float *shift, float clamp_weights,
+                                        float *decoded, void *stream);
+SHACIRA_API int shacira_latent_multi_decode_backward(int64_t num_rows, int latent_dim, int feature_dim, int num_decoders,
+                                         const float *latent, const float *alpha, const float *uniforms,
+                                         float temperature, int straight_through, int diff_sampling, const float *div,
+                                         const float *scale, const float *dft, const float *shift, float clamp_weights,
+                                         const float *grad_decoded, float *grad_latent, float *grad_alpha,
+                                         float *grad_scale, float *grad_shift, void *workspace, size_t workspace_bytes,
+                                         void *stream);
+
+/*
  * Symbol statistics and entropy coding of the rounded latents -- replaces the per-channel
  * `torch.round(...).long()` + `torch.unique(return_counts=True)` of LatentGrid.size
  * (wisp/models/grids/latent_grid.py:141-143) and the torchac.encode_float_cdf call (:155-172).

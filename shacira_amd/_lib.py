@@ -45,6 +45,10 @@ SIGNATURES = {
     "shacira_latent_decode_levels_forward": (_i, [_i, _p, _i64, _i, _i, _p, _p, _f, _i, _p, _p, _p, _p, _f, _p, _p]),
     "shacira_latent_decode_levels_backward": (_i, [_i, _p, _i64, _i, _i, _p, _p, _f, _i, _p, _p, _p, _p, _f, _p, _p, _p,
                                                    _p, _p, _p, _sz, _p]),
+    "shacira_latent_multi_supported": (_i, [_i, _i, _i]),
+    "shacira_latent_multi_decode_forward": (_i, [_i64, _i, _i, _i, _p, _p, _p, _f, _i, _i, _p, _p, _p, _p, _f, _p, _p]),
+    "shacira_latent_multi_decode_backward": (_i, [_i64, _i, _i, _i, _p, _p, _p, _f, _i, _i, _p, _p, _p, _p, _f, _p, _p,
+                                                  _p, _p, _p, _p, _sz, _p]),
     "shacira_latent_symbol_range": (_i, [_i64, _i, _p, _p, _p]),
     "shacira_latent_symbol_histogram": (_i, [_i64, _i, _p, _p, _i, _p, _p]),
     "shacira_rc_encode_bound": (_sz, [_i64]),

@@ -315,6 +315,46 @@ int shacira_latent_decode_levels_backward(int num_levels, const int64_t *row_off
                                               (hipStream_t)stream);
 }
 
+int shacira_latent_multi_supported(int latent_dim, int feature_dim, int num_decoders) {
+    return latent_multi_supported(latent_dim, feature_dim, num_decoders) ? 1 : 0;
+}
+
+static int multi_args_ok(int64_t num_rows, int latent_dim, int feature_dim, int num_decoders, float temperature) {
+    if (num_rows < 0 || latent_dim < 1 || feature_dim < 1 || num_decoders < 1 || !(temperature > 0.0f)) return SHACIRA_EINVAL;
+    if (!latent_multi_supported(latent_dim, feature_dim, num_decoders)) return SHACIRA_EDTYPE;
+    return 0;
+}
+
+int shacira_latent_multi_decode_forward(int64_t num_rows, int latent_dim, int feature_dim, int num_decoders,
+                                        const float *latent, const float *alpha, const float *uniforms,
+                                        float temperature, int straight_through, int diff_sampling, const float *div,
+                                        const float *scale, const float *dft, const float *shift, float clamp_weights,
+                                        float *decoded, void *stream) {
+    if (int rc = multi_args_ok(num_rows, latent_dim, feature_dim, num_decoders, temperature)) return rc;
+    if (num_rows == 0) return 0;
+    if (!latent || !alpha || !div || !scale || !decoded) return SHACIRA_EINVAL;
+    return (int)latent_multi_dispatch(false, latent_dim, feature_dim, dft != nullptr, latent, alpha, num_decoders, uniforms,
+                                      temperature, straight_through, diff_sampling, div, scale, dft, shift, clamp_weights,
+                                      num_rows, decoded, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                      (hipStream_t)stream);
+}
+
+int shacira_latent_multi_decode_backward(int64_t num_rows, int latent_dim, int feature_dim, int num_decoders,
+                                         const float *latent, const float *alpha, const float *uniforms,
+                                         float temperature, int straight_through, int diff_sampling, const float *div,
+                                         const float *scale, const float *dft, const float *shift, float clamp_weights,
+                                         const float *grad_decoded, float *grad_latent, float *grad_alpha,
+                                         float *grad_scale, float *grad_shift, void *workspace, size_t workspace_bytes,
+                                         void *stream) {
+    if (int rc = multi_args_ok(num_rows, latent_dim, feature_dim, num_decoders, temperature)) return rc;
+    if (!workspace || workspace_bytes < latent_workspace_bytes()) return SHACIRA_EWORKSPACE;
+    if (!grad_scale || (num_rows > 0 && (!latent || !alpha || !div || !scale || !grad_decoded))) return SHACIRA_EINVAL;
+    return (int)latent_multi_dispatch(true, latent_dim, feature_dim, dft != nullptr, latent, alpha, num_decoders, uniforms,
+                                      temperature, straight_through, diff_sampling, div, scale, dft, shift, clamp_weights,
+                                      num_rows, nullptr, grad_decoded, grad_latent, grad_alpha, grad_scale, grad_shift,
+                                      static_cast<double *>(workspace), (hipStream_t)stream);
+}
+
 int shacira_latent_symbol_range(int64_t num_rows, int latent_dim, const float *latent, int32_t *minmax, void *stream) {
     if (num_rows < 0 || latent_dim < 1 || !minmax || (num_rows > 0 && !latent)) return SHACIRA_EINVAL;
     if (!symbols_supported(latent_dim)) return SHACIRA_EDTYPE;

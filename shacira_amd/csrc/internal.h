@@ -78,6 +78,13 @@ bool latent_decode_supported(int ld, int f);
 hipError_t latent_decode_dispatch(bool bwd, int ld, int f, const DecodeArgs &a, hipStream_t s);
 hipError_t latent_decode_levels_dispatch(bool bwd, int ld, int f, int levels, const int64_t *offsets,
                                          const DecodeArgs &a, hipStream_t s);
+bool latent_multi_supported(int ld, int f, int K);
+hipError_t latent_multi_dispatch(bool bwd, int ld, int f, bool dft, const float *latent, const float *alpha, int K,
+                                 const float *uniforms, float temperature, int straight_through, int diff_sampling,
+                                 const float *div, const float *scale, const float *dftm, const float *shift,
+                                 float clampw, int64_t rows, float *decoded, const float *grad_decoded,
+                                 float *grad_latent, float *grad_alpha, float *grad_scale, float *grad_shift,
+                                 double *partials, hipStream_t s);
 bool entropy_supported(int ld);
 hipError_t entropy_dispatch(bool bwd, int ld, const EntropyArgs &a, hipStream_t s);
 

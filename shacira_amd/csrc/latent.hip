@@ -383,6 +383,244 @@ static hipError_t decode_levels_launch(bool bwd, int levels, const int64_t *offs
 
 typedef hipError_t (*decode_levels_fn)(bool, int, const int64_t *, const DecodeArgs &, hipStream_t);
 
+// ---------------------------------------------------------------------------------------------------------
+// MultiLatentDecoder (reference wisp/models/latent_decoders/multi_latent_decoder.py:27-210, no hidden layers): K affine
+// decoders mixed per table entry by a learned selector alpha [K, T]:
+//     a_soft = softmax_k(alpha[:, r] / T);  a = straight_through ? onehot(argmax a_soft) : a_soft   (gradient: identity)
+//     x = quantise(latent[r]) / div                                  (rounding, or SGA with the same temperature T)
+//     'dft': per_k = (x @ dft) * scale_k + shift_k ;  y = sum_k per_k a_k
+//     'sq' : mixed = sum_k (x @ scale_k) a_k ; per_k = mixed + shift_k ; y = sum_k per_k a_k    (the reference mixes TWICE)
+// One pass each way; the reference evaluates ~20 ATen kernels over [K, T, F] temporaries. Backward: grad_latent, grad_alpha
+// [K, T] (through the softmax), grad_scale [K, S, F], grad_shift [K, F] (fp64 block partials, S = LD for 'sq', 1 for 'dft').
+constexpr int kMultiMaxK = 8;
+
+struct MultiArgs {
+    const float *latent, *alpha, *div, *scale, *dft, *shift, *uniforms, *grad_decoded;
+    float *decoded, *grad_latent, *grad_alpha, *grad_scale, *grad_shift;
+    double *partials;
+    int64_t rows;
+    int K, straight_through, diff_sampling;
+    float temperature, clampw;
+};
+
+template <int LD, int F, bool DFT, bool SGA, bool BWD>
+__global__ __launch_bounds__(kThreads) void multi_decode_kernel(MultiArgs a) {
+    constexpr int S = DFT ? 1 : LD, SF = S * F, KM = kMultiMaxK;
+    constexpr int NRED = KM * (SF + F);
+    __shared__ float s_scale[KM * SF], s_shift[KM * F], s_dft[LD * F], s_div[LD];
+    const int K = a.K;
+    for (int e = threadIdx.x; e < K * SF; e += kThreads) s_scale[e] = a.scale[e];
+    for (int e = threadIdx.x; e < K * F; e += kThreads) s_shift[e] = a.shift ? a.shift[e] : 0.0f;
+    if (DFT)
+        for (int e = threadIdx.x; e < LD * F; e += kThreads) s_dft[e] = a.dft[e];
+    if (threadIdx.x < LD) s_div[threadIdx.x] = a.div[threadIdx.x];
+    __syncthreads();
+    float acc[BWD ? NRED : 1];
+    if constexpr (BWD) {
+#pragma unroll
+        for (int q = 0; q < NRED; ++q) acc[q] = 0.0f;
+    }
+    const float T = a.temperature;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < a.rows; r += stride) {
+        // selector
+        float al[KM], mx = -INFINITY;
+        int win = 0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            al[k] = (k < K) ? a.alpha[(int64_t)k * a.rows + r] / T : -INFINITY;
+            if (al[k] > mx) { mx = al[k]; win = k; }          // first maximum, as torch.argmax
+        }
+        float asoft[KM], den = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            asoft[k] = (k < K) ? expf(al[k] - mx) : 0.0f;
+            den += asoft[k];
+        }
+        float am[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            asoft[k] /= den;
+            am[k] = a.straight_through ? ((k == win) ? 1.0f : 0.0f) : asoft[k];
+        }
+        // quantised, normalised latent
+        float x[LD], dq[LD];
+#pragma unroll
+        for (int c = 0; c < LD; ++c) {
+            if constexpr (SGA) {
+                float q;
+                const float2 u = *reinterpret_cast<const float2 *>(a.uniforms + (r * LD + c) * 2);
+                sga_quantise(a.latent[r * LD + c], u.x, u.y, T, a.diff_sampling != 0, q, dq[c]);
+                x[c] = q / s_div[c];
+            } else {
+                x[c] = rintf(a.latent[r * LD + c]) / s_div[c];
+                dq[c] = 1.0f;
+            }
+        }
+        float y[F], zm[F], mixed[F];
+        float u[DFT ? 1 : KM][F];
+        if constexpr (DFT) {
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                float sacc = x[0] * s_dft[j];
+#pragma unroll
+                for (int c = 1; c < LD; ++c) sacc = fmaf(x[c], s_dft[c * F + j], sacc);
+                zm[j] = sacc;
+                float yy = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) yy += (zm[j] * s_scale[k * F + j] + s_shift[k * F + j]) * am[k];
+                y[j] = yy;
+                mixed[j] = 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                float mj = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KM; ++k) {
+                    float sacc = 0.0f;
+                    if (k < K) {
+                        sacc = x[0] * s_scale[k * SF + j];
+#pragma unroll
+                        for (int c = 1; c < LD; ++c) sacc = fmaf(x[c], s_scale[k * SF + c * F + j], sacc);
+                        mj += sacc * am[k];
+                    }
+                    u[k][j] = sacc;
+                }
+                mixed[j] = mj;
+                float yy = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) yy += (mj + s_shift[k * F + j]) * am[k];
+                y[j] = yy;
+                zm[j] = 0.0f;
+            }
+        }
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                float v = y[j];
+                if (a.clampw > 0.0f) v = fminf(fmaxf(v, -a.clampw), a.clampw);
+                a.decoded[r * F + j] = v;
+            }
+        } else {
+            float gy[F], da[KM], dx[LD];
+#pragma unroll
+            for (int k = 0; k < KM; ++k) da[k] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < LD; ++c) dx[c] = 0.0f;
+            float asum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) asum += am[k];
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                float g = a.grad_decoded[r * F + j];
+                if (a.clampw > 0.0f && !(y[j] >= -a.clampw && y[j] <= a.clampw)) g = 0.0f;
+                gy[j] = g;
+                if constexpr (DFT) {
+                    float dzm = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) {
+                        if (k < K) {
+                            const float sc = s_scale[k * F + j];
+                            da[k] += g * (zm[j] * sc + s_shift[k * F + j]);
+                            acc[k * SF + j] += g * am[k] * zm[j];            // grad_scale[k, 0, j]
+                            acc[KM * SF + k * F + j] += g * am[k];           // grad_shift[k, j]
+                            dzm += g * am[k] * sc;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < LD; ++c) dx[c] = fmaf(dzm, s_dft[c * F + j], dx[c]);
+                } else {
+                    const float dmixed = g * asum;
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) {
+                        if (k < K) {
+                            da[k] += g * (mixed[j] + s_shift[k * F + j]) + dmixed * u[k][j];
+                            acc[KM * SF + k * F + j] += g * am[k];           // grad_shift[k, j]
+                            const float du = dmixed * am[k];
+#pragma unroll
+                            for (int c = 0; c < LD; ++c) {
+                                acc[k * SF + c * F + j] += x[c] * du;        // grad_scale[k, c, j]
+                                dx[c] = fmaf(du, s_scale[k * SF + c * F + j], dx[c]);
+                            }
+                        }
+                    }
+                }
+            }
+            // selector gradient through the softmax (straight-through passes d(one-hot) to the soft weights unchanged)
+            float dot = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) dot += asoft[k] * da[k];
+            if (a.grad_alpha) {
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) a.grad_alpha[(int64_t)k * a.rows + r] = asoft[k] * (da[k] - dot) / T;
+            }
+            if (a.grad_latent) {
+#pragma unroll
+                for (int c = 0; c < LD; ++c) a.grad_latent[r * LD + c] = dx[c] / s_div[c] * dq[c];
+            }
+        }
+    }
+    if constexpr (BWD) block_reduce_store<NRED>(acc, a.partials);
+}
+
+template <int LD, int F, bool DFT>
+static hipError_t multi_launch(bool bwd, const MultiArgs &a, hipStream_t s) {
+    constexpr int S = DFT ? 1 : LD, SF = S * F, NRED = kMultiMaxK * (SF + F);
+    static_assert(NRED <= kMaxRed, "reduction width exceeds the partials workspace");
+    const int blocks = grid_for(a.rows);
+    const bool sga = a.uniforms != nullptr;
+    if (!bwd) {
+        if (sga) hipLaunchKernelGGL((multi_decode_kernel<LD, F, DFT, true, false>), dim3(blocks), dim3(kThreads), 0, s, a);
+        else hipLaunchKernelGGL((multi_decode_kernel<LD, F, DFT, false, false>), dim3(blocks), dim3(kThreads), 0, s, a);
+        return hipGetLastError();
+    }
+    if (sga) hipLaunchKernelGGL((multi_decode_kernel<LD, F, DFT, true, true>), dim3(blocks), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((multi_decode_kernel<LD, F, DFT, false, true>), dim3(blocks), dim3(kThreads), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // block partials: [KM][SF] scale part, then [KM][F] shift part; the first K entries of each are the outputs
+    hipLaunchKernelGGL(finish_partials_kernel, dim3(a.K * SF), dim3(256), 0, s, a.partials, blocks, NRED,
+                       (const float *)nullptr, a.grad_scale, a.K * SF, (float *)nullptr, 0, (float *)nullptr, 0);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.grad_shift) {
+        hipLaunchKernelGGL(finish_partials_kernel, dim3(a.K * F), dim3(256), 0, s, a.partials + kMultiMaxK * SF, blocks,
+                           NRED, (const float *)nullptr, a.grad_shift, a.K * F, (float *)nullptr, 0, (float *)nullptr, 0);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+typedef hipError_t (*multi_fn)(bool, const MultiArgs &, hipStream_t);
+static multi_fn multi_lookup(int ld, int f, bool dft) {
+#define SHACIRA_MULTI(LD, F)                                    \
+    if (ld == LD && f == F) return dft ? &multi_launch<LD, F, true> : &multi_launch<LD, F, false>;
+    SHACIRA_MULTI(1, 2) SHACIRA_MULTI(2, 2) SHACIRA_MULTI(1, 4) SHACIRA_MULTI(2, 4) SHACIRA_MULTI(4, 2)
+#undef SHACIRA_MULTI
+    return nullptr;
+}
+
+bool latent_multi_supported(int ld, int f, int K) { return K >= 1 && K <= kMultiMaxK && multi_lookup(ld, f, false) != nullptr; }
+
+hipError_t latent_multi_dispatch(bool bwd, int ld, int f, bool dft, const float *latent, const float *alpha, int K,
+                                 const float *uniforms, float temperature, int straight_through, int diff_sampling,
+                                 const float *div, const float *scale, const float *dftm, const float *shift,
+                                 float clampw, int64_t rows, float *decoded, const float *grad_decoded,
+                                 float *grad_latent, float *grad_alpha, float *grad_scale, float *grad_shift,
+                                 double *partials, hipStream_t s) {
+    MultiArgs a{};
+    a.latent = latent; a.alpha = alpha; a.div = div; a.scale = scale; a.dft = dftm; a.shift = shift;
+    a.uniforms = uniforms; a.grad_decoded = grad_decoded; a.decoded = decoded; a.grad_latent = grad_latent;
+    a.grad_alpha = grad_alpha; a.grad_scale = grad_scale; a.grad_shift = grad_shift; a.partials = partials;
+    a.rows = rows; a.K = K; a.straight_through = straight_through; a.diff_sampling = diff_sampling;
+    a.temperature = temperature; a.clampw = clampw;
+    return multi_lookup(ld, f, dft)(bwd, a, s);
+}
+
 typedef hipError_t (*decode_fn)(bool, const DecodeArgs &, hipStream_t);
 
 static decode_fn decode_lookup(int ld, int f) {

@@ -275,6 +275,47 @@ def latent_decode_levels_backward(latent, offsets, uniforms, temperature, diff_s
     return g_lat, g_mat, g_cs, g_sh
 
 
+def latent_multi_supported(latent_dim, feature_dim, num_decoders):
+    return bool(_lib.lib().shacira_latent_multi_supported(int(latent_dim), int(feature_dim), int(num_decoders)))
+
+
+def latent_multi_decode_forward(latent, alpha, uniforms, temperature, straight_through, diff_sampling, div, scale, dft,
+                                shift, clamp_weights):
+    """MultiLatentDecoder in one kernel: alpha [K, T], scale [K, S, F], dft [ld, F] or None, shift [K, F] or None."""
+    _need_gpu(latent, alpha, uniforms, div, scale, dft, shift)
+    T, ld = latent.shape
+    K, F = scale.shape[0], scale.shape[-1]
+    out = torch.empty((T, F), dtype=torch.float32, device=latent.device)
+    with torch.cuda.device(latent.device):
+        rc = _lib.lib().shacira_latent_multi_decode_forward(
+            T, ld, F, K, _ptr(latent), _ptr(alpha), _ptr(uniforms), float(temperature), int(bool(straight_through)),
+            int(bool(diff_sampling)), _ptr(div), _ptr(scale), _ptr(dft), _ptr(shift), float(clamp_weights), _ptr(out),
+            _stream(latent))
+    _lib.check(rc, "latent_multi_decode_forward")
+    return out
+
+
+def latent_multi_decode_backward(latent, alpha, uniforms, temperature, straight_through, diff_sampling, div, scale, dft,
+                                 shift, clamp_weights, grad_decoded):
+    _need_gpu(latent, alpha, grad_decoded)
+    T, ld = latent.shape
+    K, F = scale.shape[0], scale.shape[-1]
+    dev = latent.device
+    g_lat = torch.empty_like(latent)
+    g_alpha = torch.empty_like(alpha)
+    g_scale = torch.empty_like(scale)
+    g_shift = torch.empty((K, F), dtype=torch.float32, device=dev) if shift is not None else None
+    with torch.cuda.device(dev):
+        ws = _latent_workspace(dev)
+        rc = _lib.lib().shacira_latent_multi_decode_backward(
+            T, ld, F, K, _ptr(latent), _ptr(alpha), _ptr(uniforms), float(temperature), int(bool(straight_through)),
+            int(bool(diff_sampling)), _ptr(div), _ptr(scale), _ptr(dft), _ptr(shift), float(clamp_weights),
+            _ptr(grad_decoded), _ptr(g_lat), _ptr(g_alpha), _ptr(g_scale), _ptr(g_shift), _ptr(ws), ws.numel(),
+            _stream(latent))
+    _lib.check(rc, "latent_multi_decode_backward")
+    return g_lat, g_alpha, g_scale, g_shift
+
+
 def entropy_supported(latent_dim):
     return latent_dim in (1, 2, 3, 4, 8)
 

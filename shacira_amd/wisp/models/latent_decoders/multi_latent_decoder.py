@@ -3,8 +3,9 @@
 
 Same constructor arguments, parameter names (``div``, ``alpha``, ``layers.N.scale``, ``layers.N.use_shift``,
 ``layers.N.dft``), runtime switches (``temperature``, ``straight_through``, ``use_sga``, ``diff_sampling``) and
-``size()`` accounting as reference wisp/models/latent_decoders/multi_latent_decoder.py:27-210. Evaluated with torch
-ops on whatever device the table lives on (the per-entry mixing has no fused kernel yet).
+``size()`` accounting as reference wisp/models/latent_decoders/multi_latent_decoder.py:27-210. Without hidden layers, on the
+GPU, the whole forward (softmax / arg-max selector, rounding or SGA, the K decoders, the mixing) is ONE fused HIP kernel
+each way (``shacira_latent_multi_decode_*``); otherwise torch ops, as in the reference.
 
 Reference quirks kept on purpose (they change the numbers):
   * the 'sq' branch mixes twice: ``sum_k alpha_k (x @ scale_k)`` is formed, the shift is added, and the result is
@@ -19,6 +20,7 @@ from torch import Tensor
 from torch.nn import Module, Parameter, init
 from torch.nn.modules.utils import _ntuple
 
+from .... import hip_ops
 from .basic_latent_decoder import _ACTIVATIONS
 from .decode_layer import get_dft_matrix
 from .quantizers import StraightThrough, sga_sample
@@ -35,6 +37,33 @@ class StraightThroughOneHot(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         return grad_output
+
+
+class _FusedMultiDecode(torch.autograd.Function):
+    """selector softmax / arg-max + round or SGA + K affine decoders + mixing (+ clamp), one HIP kernel each way."""
+
+    @staticmethod
+    def forward(ctx, latent, alpha, uniforms, div, scale, dft, shift, temperature, straight_through, diff_sampling,
+                clamp_weights):
+        latent, alpha, scale = latent.contiguous(), alpha.contiguous(), scale.contiguous()
+        shift2 = shift.reshape(shift.shape[0], -1).contiguous() if shift is not None else None
+        ctx.save_for_backward(latent, alpha, uniforms, div, scale, dft, shift2)
+        ctx.opts = (float(temperature), bool(straight_through), bool(diff_sampling), float(clamp_weights))
+        ctx.shift_shape = shift.shape if shift is not None else None
+        return hip_ops.latent_multi_decode_forward(latent, alpha, uniforms, temperature, straight_through, diff_sampling,
+                                                   div, scale, dft, shift2, clamp_weights)
+
+    @staticmethod
+    def backward(ctx, grad_decoded):
+        latent, alpha, uniforms, div, scale, dft, shift2 = ctx.saved_tensors
+        temperature, straight_through, diff_sampling, clamp_weights = ctx.opts
+        g_lat, g_alpha, g_scale, g_shift = hip_ops.latent_multi_decode_backward(
+            latent, alpha, uniforms, temperature, straight_through, diff_sampling, div, scale, dft, shift2,
+            clamp_weights, grad_decoded.contiguous())
+        return (g_lat if ctx.needs_input_grad[0] else None, g_alpha if ctx.needs_input_grad[1] else None, None, None,
+                g_scale if ctx.needs_input_grad[4] else None, None,
+                g_shift.reshape(ctx.shift_shape) if (g_shift is not None and ctx.needs_input_grad[6]) else None,
+                None, None, None, None)
 
 
 class MultiLatentDecoderLayer(Module):
@@ -150,7 +179,22 @@ class MultiLatentDecoder(Module):
         bits = torch.clamp(-1.0 * torch.log(probs + 1e-10) / math.log(2.0), 0, 1000)
         return torch.sum(bits * counts).item() + fp_size
 
+    def _fusable(self, weight: Tensor) -> bool:
+        return (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2 and self.num_layers_dec == 0
+                and isinstance(self.act, nn.Identity) and isinstance(self.final_activation, nn.Identity)
+                and self.alpha.shape[1] == weight.shape[0]
+                and hip_ops.latent_multi_supported(self.latent_dim, self.channels, self.num_decoders))
+
     def forward(self, weight: Tensor) -> Tensor:
+        if self._fusable(weight):
+            layer = self._decoder_layers()[0]
+            dft = layer.dft if "dft" in self.ldecode_matrix else None
+            uniforms = None
+            if self.use_sga:
+                uniforms = torch.rand(weight.shape + (2,), dtype=weight.dtype, device=weight.device)
+            return _FusedMultiDecode.apply(weight, self.alpha, uniforms, self.div, layer.scale, dft, layer.use_shift,
+                                           float(self.temperature), bool(self.straight_through),
+                                           bool(self.diff_sampling), float(self.clamp_weights))
         alpha = nn.functional.softmax(self.alpha / self.temperature, dim=0)
         if self.straight_through:
             alpha = StraightThroughOneHot.apply(alpha)

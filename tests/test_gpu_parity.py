@@ -928,3 +928,36 @@ def test_fused_hierarchical_decoder_sga_matches_per_level_kernels(dev):
         assert torch.equal(out[lo:hi], o1) and torch.equal(g_lat[lo:hi], gl1)
         torch.testing.assert_close(g_mat[l], gm1, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(g_sh[l], gs1.reshape(-1), rtol=1e-5, atol=1e-6)
+
+
+def test_fused_multi_decoder_against_reference_vectors(dev, golden):
+    """Row f4: MultiLatentDecoder (softmax / straight-through selector over K decoders, 'sq' with the reference's double
+    mixing and 'dft') as ONE fused kernel each way, against the vectors of the reference's executed module."""
+    from shacira_amd.wisp.models.latent_decoders import MultiLatentDecoder
+    from shacira_amd.wisp.models.latent_decoders import multi_latent_decoder as mmod
+    g = golden("multi_decoder.npz")
+    calls = []
+    orig = mmod._FusedMultiDecode.apply
+    mmod._FusedMultiDecode.apply = staticmethod(lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    try:
+        for ci, case in enumerate(npz_json(g["cases_json"])):
+            p = f"m{ci}_"
+            dec = MultiLatentDecoder(latent_dim=case["latent_dim"], feature_dim=case["feature_dim"], norm="none",
+                                     ldecode_matrix=case["ldecode_matrix"], use_shift=case["use_shift"], num_entries=97,
+                                     ldec_std=0.1, num_decoders=case["num_decoders"], alpha_std=1.0)
+            dec.load_state_dict({k[len(p) + 2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(p + "p_")})
+            dec = dec.to(dev)
+            dec.straight_through = case["straight_through"]
+            dec.temperature = 0.7
+            lat = torch.from_numpy(g[p + "latent"]).to(dev).requires_grad_(True)
+            y = dec(lat)
+            np.testing.assert_allclose(y.detach().cpu().numpy(), g[p + "out"], rtol=1e-5, atol=1e-7)
+            y.backward(torch.from_numpy(g[p + "grad_out"]).to(dev))
+            np.testing.assert_allclose(lat.grad.cpu().numpy(), g[p + "grad_latent"], rtol=1e-5, atol=1e-7)
+            for n, prm in dec.named_parameters():
+                want = g[p + "g_" + n]
+                got = prm.grad.cpu().numpy() if prm.grad is not None else np.zeros_like(want)
+                np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6, err_msg=f"case {ci} {n}")
+    finally:
+        mmod._FusedMultiDecode.apply = orig
+    assert len(calls) == len(npz_json(g["cases_json"]))
