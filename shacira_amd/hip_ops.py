@@ -28,6 +28,19 @@ def _res_array(resolutions):
     return (ctypes.c_int32 * len(resolutions))(*resolutions)
 
 
+_warned = set()
+
+
+def warn_unfused(what, why):
+    """One warning per (what, why): a GPU tensor is about to take the torch-op chain instead of a fused HIP kernel."""
+    key = (what, why)
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn(f"shacira_amd: {what} runs as torch ops, not as the fused HIP kernel ({why})", RuntimeWarning,
+                      stacklevel=3)
+
+
 def _need_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

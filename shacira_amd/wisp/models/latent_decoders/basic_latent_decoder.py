@@ -110,6 +110,9 @@ class LatentDecoder(nn.Module):
                 return _FusedLatentDecodeSGA.apply(weight, uniforms, float(self.temperature), bool(self.diff_sampling),
                                                    self.div, matrix, colscale, shift, float(self.clamp_weights))
             return _FusedLatentDecode.apply(weight, self.div, matrix, colscale, shift, float(self.clamp_weights))
+        if weight.is_cuda:
+            hip_ops.warn_unfused("LatentDecoder.forward", "hidden decoder layers / activations, or an unsupported "
+                                 f"(latent_dim, feature_dim) = ({self.latent_dim}, {self.channels})")
         if self.use_sga:
             weight = sga_sample(weight, self.temperature, self.diff_sampling)
         else:

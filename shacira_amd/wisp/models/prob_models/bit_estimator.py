@@ -91,6 +91,8 @@ class BitEstimator(nn.Module):
         if (latent.is_cuda and latent.dtype == torch.float32 and latent.dim() == 2 and self._plain
                 and hip_ops.entropy_supported(latent.shape[1])):
             return _FusedEntropyBits.apply(latent, noise, self.packed_params(), self.num_layers)
+        if latent.is_cuda:
+            hip_ops.warn_unfused("BitEstimator.total_bits", "unsupported latent_dim / dtype, or is_symmetric / is_unimodal")
         weight = (latent + noise) if noise is not None else torch.round(latent)
         prob = self(weight + 0.5) - self(weight - 0.5)
         return torch.sum(torch.clamp(-1.0 * torch.log(prob + 1e-10) / math.log(2.0), 0, 50))

@@ -961,3 +961,32 @@ def test_fused_multi_decoder_against_reference_vectors(dev, golden):
     finally:
         mmod._FusedMultiDecode.apply = orig
     assert len(calls) == len(npz_json(g["cases_json"]))
+
+
+@pytest.mark.parametrize("dim,F,dtype", [(3, 2, torch.float16), (3, 4, torch.float32), (2, 4, torch.float16),
+                                         (3, 2, torch.float32)])
+def test_tiled_forward_other_shapes(dev, dim, F, dtype):
+    """The cell-sorted forward (forced: fwd_variant 8) for fp16 tables (the reference's AMP mode) and F = 4, odd level
+    counts (row size not a multiple of 16 bytes -> piece-wise row stores) and a level split in the middle: bit-identical to
+    the oracle evaluated on the table as stored (fp16 tables: values rounded to fp16 first, result rounded once)."""
+    from shacira_amd import _lib
+    ops = _ops()
+    res = geo(16, 512, 7) if dim == 3 else geo(16, 1024, 9)       # odd L
+    bw = 14
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, 70_001, F=F)
+    stored = table.astype(np.float16).astype(np.float32) if dtype == torch.float16 else table
+    tc, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(first).to(dev)
+    tt = torch.from_numpy(table).to(dev).to(dtype)
+    fwd = ops.hashgrid_interpolate_cuda if dim == 3 else ops.hashgrid_interpolate2d_cuda
+    ref = oc.forward(coords, stored, first, res, bw)
+    want = ref.astype(np.float16) if dtype == torch.float16 else ref
+    _lib.set_option("fwd_variant", 8)
+    try:
+        for lc in (-1, 3, 0):
+            _lib.set_option("tiled_lc_fwd", lc)
+            got = fwd(tc, tt, tf, res, bw)
+            assert got.dtype == dtype
+            assert np.array_equal(got.cpu().numpy(), want), f"lc={lc}"
+    finally:
+        _lib.set_option("fwd_variant", -1)
+        _lib.set_option("tiled_lc_fwd", -1)
