@@ -401,6 +401,9 @@ SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origi
  *   "tiled_lc_fwd": its number of coarse levels, -1 (default) = planner's choice.
  *   "bwd_fork": 1 (default) = the backward's count + scan passes are issued on a library-owned side stream, forked
  *               from and joined back into the caller's stream with events (stream semantics unchanged); 0 = one stream.
+ *   "bwd_groups": 1 (default) = one scatter and one consume launch over all binned levels; g > 1 = the levels in g groups,
+ *               the scatter of group k + 1 on the caller's stream beside the consume of group k on the side stream
+ *               (an experiment hook: every g measured slower, both passes share the same memory queues).
  */
 SHACIRA_API int shacira_set_option(const char *name, int value);
 SHACIRA_API int shacira_get_option(const char *name);

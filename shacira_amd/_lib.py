@@ -9,7 +9,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libshacira_hip.so")
+LIB_PATH = os.environ.get("SHACIRA_HIP_LIB") or os.path.join(_HERE, "lib", "libshacira_hip.so")   # env: A/B builds (tools/)
 
 F32, F16 = 0, 1
 EINVAL, EDTYPE, EODD, EWORKSPACE = -1, -2, -3, -4

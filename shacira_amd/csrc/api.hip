@@ -13,6 +13,7 @@ std::atomic<int> g_bwd_variant{-1};
 std::atomic<int> g_mlp_variant{-1};       // -1: MFMA decoders wherever instantiated, 0: VALU kernels
 std::atomic<int> g_bwd_compact{1};        // dense 3-D levels: one 32-byte item per sample, z-slab buckets with a halo plane
 std::atomic<int> g_bwd_fuse{1};           // bucket counting fused into the transpose pass
+std::atomic<int> g_bwd_groups{1};         // > 1: binned levels in that many groups, scatter of group g + 1 beside consume of group g (measured slower)
 std::atomic<int> g_bwd_fork{1};           // 1: count + scans of the backward on a side stream next to the transpose
 std::atomic<int> g_bin_acc_kib{0};        // LDS accumulator image per consumer workgroup, KiB: 64, 128, 0 = by batch size
 std::atomic<int> g_bin_batch_mib{1536};   // cap of the backward's item array per sub-batch, MiB
@@ -77,6 +78,7 @@ int shacira_set_option(const char *name, int value) {
         return 0;
     }
     if (!std::strcmp(name, "bwd_fork")) { g_bwd_fork = value ? 1 : 0; return 0; }
+    if (!std::strcmp(name, "bwd_groups")) { g_bwd_groups = value < 0 ? 0 : (value > 16 ? 16 : value); return 0; }
     if (!std::strcmp(name, "mlp_variant")) { g_mlp_variant = value; return 0; }
     if (!std::strcmp(name, "bwd_fuse")) {
         if (value < 0 || value > 2) return SHACIRA_EINVAL;
@@ -105,6 +107,7 @@ int shacira_get_option(const char *name) {
     if (!std::strcmp(name, "bin_batch_mib")) return g_bin_batch_mib;
     if (!std::strcmp(name, "bin_acc_kib")) return g_bin_acc_kib;
     if (!std::strcmp(name, "bwd_fork")) return g_bwd_fork;
+    if (!std::strcmp(name, "bwd_groups")) return g_bwd_groups;
     if (!std::strcmp(name, "mlp_variant")) return g_mlp_variant;
     if (!std::strcmp(name, "bwd_fuse")) return g_bwd_fuse;
     if (!std::strcmp(name, "bwd_compact")) return g_bwd_compact;

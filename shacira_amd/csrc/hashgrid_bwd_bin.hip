@@ -29,8 +29,14 @@
 
 namespace shacira {
 
-constexpr int kTile = 1024;           // samples per (level, tile) block in passes A and B
-constexpr int kBinThreads = 512;      // threads of passes A and B
+#ifndef SHACIRA_KTILE
+#define SHACIRA_KTILE 1024
+#endif
+#ifndef SHACIRA_KBIN
+#define SHACIRA_KBIN 512
+#endif
+constexpr int kTile = SHACIRA_KTILE;       // samples per (level, tile) block in passes A and B
+constexpr int kBinThreads = SHACIRA_KBIN;  // threads of passes A and B
 constexpr int kConsumeThreads = 1024;
 constexpr int kMaxBuckets = 2048;     // over all levels
 constexpr int kMaxLevelBuckets = 128; // per level (LDS histogram size)
@@ -57,7 +63,7 @@ struct BinPlan {
     uint32_t pairs;     // items per (sample, level) = 2^(dim-1)
     uint32_t chunk;     // items per consumer work unit
     uint32_t nbl;       // number of binned levels
-    uint8_t blevel[SHACIRA_MAX_LODS];   // their level indices (grid.y of passes A/B)
+    uint32_t blevel[SHACIRA_MAX_LODS];  // their level indices (grid.y of passes A/B); 32-bit = scalar loads
     uint32_t ngroups;   // groups of direct levels
     uint32_t gmask[SHACIRA_MAX_LODS];   // levels of each group (bit l)
     uint32_t grows[SHACIRA_MAX_LODS];   // rows of each group's LDS image
@@ -68,6 +74,10 @@ template <int F> struct alignas(F == 2 ? 16 : 8) Item {
     float fx;
     float a[F];
 };
+
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also drains the wave's global loads AND stores
+// (s_waitcnt vmcnt(0)), which serialises a block's write-out with its next phase.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Items are written once and read once: stream them past the caches (non-temporal).
 template <int F> __device__ __forceinline__ void store_item_nt(Item<F> *p, const Item<F> &it) {
@@ -237,47 +247,6 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
         if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x])
             atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
     }
-}
-
-// ------------------------------------------------------------------------------------------------- pass A
-template <int DIM>
-__global__ __launch_bounds__(kBinThreads) void bin_count_kernel(LevelTable lt, BinPlan plan,
-                                                                const float *__restrict__ coords,
-                                                                uint32_t *__restrict__ cnt, int64_t sample0,
-                                                                int64_t N) {
-    __shared__ uint32_t s_hist[kMaxLevelBuckets];
-    const uint32_t tile = blockIdx.x, lvl = plan.blevel[blockIdx.y];
-    const BinLevel bl = plan.lv[lvl];
-    if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    const int32_t res = lt.res[lvl];
-    const float hi = lt.hi[lvl];
-    const bool dense = lt.dense[lvl] != 0;
-    for (int k = threadIdx.x; k < kTile; k += kBinThreads) {
-        const int64_t i = sample0 + (int64_t)tile * kTile + k;
-        if (i >= N) break;
-        double t[DIM];
-#pragma unroll
-        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
-        if constexpr (DIM == 3) {
-            if (bl.compact) {   // one item of two slots per sample, bucket from the base cell's z alone
-                int32_t pz;
-                float fz, gz;
-                axis_transform(t[2], res, hi, pz, fz, gz);
-                atomicAdd(&s_hist[(uint32_t)pz / bl.slab], 2u);
-                continue;
-            }
-        }
-        float fx;
-        PairSlot ps[1 << (DIM - 1)];
-        enumerate_pairs<DIM>(t, res, hi, dense, lt.mask, bl, plan.BR, fx, ps);
-#pragma unroll
-        for (int q = 0; q < (1 << (DIM - 1)); ++q)
-            if (ps[q].key >> 26) atomicAdd(&s_hist[ps[q].bucket], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < bl.nb)
-        cnt[(size_t)(bl.bucket0 + threadIdx.x) * plan.num_tiles + tile] = s_hist[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------- passes T + A fused
@@ -491,7 +460,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                                                                   const uint32_t *__restrict__ tile_off,
                                                                   const uint64_t *__restrict__ base,
                                                                   Item<F> *__restrict__ items, int64_t sample0,
-                                                                  int64_t N, int64_t Ntotal) {
+                                                                  int64_t N, int64_t Ntotal, uint32_t lvl_off) {
     constexpr int NP = 1 << (DIM - 1);
     constexpr int SPT = kTile / kBinThreads;   // samples per thread
     constexpr int kStage = kTile * NP;         // staged items per block
@@ -502,7 +471,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     __shared__ uint32_t s_start[kMaxLevelBuckets + 1];
     __shared__ uint64_t s_gbase[kMaxLevelBuckets];
 
-    const uint32_t tile = blockIdx.x, lvl = plan.blevel[blockIdx.y];
+    const uint32_t tile = blockIdx.x, lvl = plan.blevel[blockIdx.y + lvl_off];
     const BinLevel bl = plan.lv[lvl];
     if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -625,6 +594,63 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     }
 }
 
+// ------------------------------------------------------------------------------------------------- pass A
+// One workgroup per TILE counting every binned level: the coordinates are loaded once (all loads of the block in flight
+// together) and there are 10-15x fewer workgroups than one per (tile, level): 55 vs 88 us on S1. The same restructuring of
+// pass B measured slower (283 vs 247 us): profiles/r02_bwd_ablation.md.
+template <int DIM>
+__global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTable lt, BinPlan plan,
+                                                                       const float *__restrict__ coords,
+                                                                       uint32_t *__restrict__ cnt, int64_t sample0,
+                                                                       int64_t N) {
+    __shared__ uint32_t s_hist[SHACIRA_MAX_LODS][kMaxLevelBuckets];
+    constexpr int SPT = kTile / kBinThreads;
+    const uint32_t tile = blockIdx.x;
+    for (uint32_t e = threadIdx.x; e < plan.nbl * kMaxLevelBuckets; e += kBinThreads) (&s_hist[0][0])[e] = 0;
+    double t[SPT][DIM];
+    bool live[SPT];
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+        const int64_t i = sample0 + (int64_t)tile * kTile + threadIdx.x + u * kBinThreads;
+        live[u] = i < N;
+        load_unit_coords<DIM>(coords, i, N, t[u]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t bi = 0; bi < plan.nbl; ++bi) {
+        const uint32_t lvl = plan.blevel[bi];
+        const BinLevel bl = plan.lv[lvl];
+        const int32_t res = lt.res[lvl];
+        const float hi = lt.hi[lvl];
+        const bool dense = lt.dense[lvl] != 0;
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            if (!live[u]) continue;
+            if constexpr (DIM == 3) {
+                if (bl.compact) {
+                    int32_t pz;
+                    float fz, gz;
+                    axis_transform(t[u][2], res, hi, pz, fz, gz);
+                    atomicAdd(&s_hist[bi][(uint32_t)pz / bl.slab], 2u);
+                    continue;
+                }
+            }
+            float fx;
+            PairSlot ps[1 << (DIM - 1)];
+            enumerate_pairs<DIM>(t[u], res, hi, dense, lt.mask, bl, plan.BR, fx, ps);
+#pragma unroll
+            for (int q = 0; q < (1 << (DIM - 1)); ++q)
+                if (ps[q].key >> 26) atomicAdd(&s_hist[bi][ps[q].bucket], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t bi = 0; bi < plan.nbl; ++bi) {
+        const BinLevel bl = plan.lv[plan.blevel[bi]];
+        for (uint32_t b = threadIdx.x; b < bl.nb; b += kBinThreads)
+            cnt[(size_t)(bl.bucket0 + b) * plan.num_tiles + tile] = s_hist[bi][b];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------- pass C
 template <int F, bool FX>
 __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable lt, BinPlan plan,
@@ -636,11 +662,12 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
                                                                       float *__restrict__ grad_table,
                                                                       int force_atomic,
                                                                       const uint32_t *__restrict__ gmax,
-                                                                      int headroom) {
+                                                                      int headroom, uint32_t bucket_lo,
+                                                                      uint32_t bucket_hi) {
     extern __shared__ double s_acc[];  // [rows_pb][F]: fp64, or 64-bit fixed point (same size)
-    const uint32_t nbk = plan.total_buckets;
-    const uint32_t unit = blockIdx.x;
-    if (unit >= unit_first[nbk]) return;
+    // this launch consumes the work units of buckets [bucket_lo, bucket_hi) (one group of levels, or all of them)
+    const uint32_t unit = blockIdx.x + unit_first[bucket_lo];
+    if (unit >= unit_first[bucket_hi]) return;
     const uint32_t gb = unit_bucket[unit];
     // level of the bucket
     uint32_t lvl = plan.blevel[0];
@@ -964,7 +991,7 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
             bl.bucket0 = 0xFFFFFFFFu;
             bl.nb = 0;
         } else {
-            plan.blevel[plan.nbl++] = (uint8_t)l;
+            plan.blevel[plan.nbl++] = (uint32_t)l;
             nbk += bl.nb;
         }
     }
@@ -1099,7 +1126,7 @@ float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *work
 // the objects exist -- they are created on the first eager call).
 struct SideStream {
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, zeroed = nullptr, staged = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, zeroed = nullptr, staged = nullptr, group = nullptr, done = nullptr;
 };
 static hipError_t side_stream(SideStream **out) {
     static thread_local SideStream per_device[16];
@@ -1110,16 +1137,20 @@ static hipError_t side_stream(SideStream **out) {
     SideStream &ss = per_device[dev];
     if (!ss.stream) {
         hipStream_t st;
-        hipEvent_t a, b, c, d;
+        hipEvent_t a, b, c, d, g2, d2;
         if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&a, hipEventDisableTiming)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&b, hipEventDisableTiming)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&c, hipEventDisableTiming)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&d, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&g2, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&d2, hipEventDisableTiming)) != hipSuccess) return e;
         ss.fork = a;
         ss.join = b;
         ss.zeroed = c;
         ss.staged = d;
+        ss.group = g2;
+        ss.done = d2;
         ss.stream = st;
     }
     *out = &ss;
@@ -1164,8 +1195,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             BinPlan plan;
             make_plan(DIM, lt, n, plan, acc_kib);
             const dim3 grid(plan.num_tiles, plan.nbl);
-            hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, ss->stream, lt, plan, coords, w.cnt,
-                               (int64_t)0, n);
+            hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), dim3(plan.num_tiles), dim3(kBinThreads), 0, ss->stream, lt,
+                               plan, coords, w.cnt, (int64_t)0, n);
             SHACIRA_CHECK_LAUNCH();
             hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, ss->stream, w.cnt,
                                w.totals, plan.num_tiles);
@@ -1286,13 +1317,64 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         hipError_t e = hipStreamWaitEvent(s, ss->join, 0);
         if (e != hipSuccess) return e;
     }
+    constexpr int NP = 1 << (DIM - 1);
+    const size_t stage = (size_t)kTile * NP * (sizeof(Item<F>) + 1);
+    auto consume = [&](const BinPlan &plan, uint32_t grid_units, uint32_t b_lo, uint32_t b_hi, int force_atomic,
+                       hipStream_t cs) -> hipError_t {
+        const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
+        if (use_fx)   // a unit streams <= chunk items
+            hipLaunchKernelGGL((bin_consume_kernel<F, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, cs, lt,
+                               plan, first_idx, w.base, w.unit_first, w.unit_bucket,
+                               reinterpret_cast<const Item<F> *>(w.items), acc, force_atomic, w.gmax,
+                               fx_headroom((uint64_t)plan.chunk + 1), b_lo, b_hi);
+        else
+            hipLaunchKernelGGL((bin_consume_kernel<F, false>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, cs, lt,
+                               plan, first_idx, w.base, w.unit_first, w.unit_bucket,
+                               reinterpret_cast<const Item<F> *>(w.items), acc, force_atomic, nullptr, -1, b_lo, b_hi);
+        return hipGetLastError();
+    };
+    // Level groups: the scatter pass is bound by the chip's WRITE rate (3.4 TB/s: a kernel that only stores the items
+    // takes 195 of its 254 us), the consume pass by reads and LDS atomics -- opposite directions of the fabric. With the
+    // binned levels cut into groups, the caller's stream scatters group g + 1 while the side stream consumes group g.
+    const int groups_opt = g_bwd_groups.load();
+    if (ss && !multi && groups_opt > 1 && whole.nbl >= 2) {
+        const BinPlan &plan = whole;
+        const uint32_t G = (uint32_t)groups_opt < plan.nbl ? (uint32_t)groups_opt : plan.nbl;
+        // equal item bytes per group (a compact level moves half of what a pair level does)
+        uint32_t weight[SHACIRA_MAX_LODS], total = 0;
+        for (uint32_t q = 0; q < plan.nbl; ++q) total += (weight[q] = plan.lv[plan.blevel[q]].compact ? 1u : 2u);
+        uint32_t q0 = 0, spent = 0;
+        for (uint32_t g = 0; g < G && q0 < plan.nbl; ++g) {
+            uint32_t q1 = q0, acc_w = 0;
+            const uint32_t target = (total - spent + (G - g) - 1) / (G - g);
+            while (q1 < plan.nbl && (acc_w < target || g + 1 == G)) acc_w += weight[q1++];
+            spent += acc_w;
+            const dim3 grid(plan.num_tiles, q1 - q0);
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,
+                               w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), (int64_t)0, n, n, q0);
+            SHACIRA_CHECK_LAUNCH();
+            hipError_t e = hipEventRecord(ss->group, s);
+            if (e != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(ss->stream, ss->group, 0)) != hipSuccess) return e;
+            const BinLevel &first = plan.lv[plan.blevel[q0]], &last = plan.lv[plan.blevel[q1 - 1]];
+            const uint32_t b_lo = first.bucket0, b_hi = last.bucket0 + last.nb;
+            const uint64_t max_items = (uint64_t)n * NP * (q1 - q0);
+            const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + (b_hi - b_lo) + 1;
+            if ((e = consume(plan, max_units, b_lo, b_hi, 0, ss->stream)) != hipSuccess) return e;
+            q0 = q1;
+        }
+        hipError_t e = hipEventRecord(ss->done, ss->stream);   // the side stream carries everything the table waits for:
+        if (e != hipSuccess) return e;                         // its zeroing, (fused mode) the direct levels, the consumes
+        return hipStreamWaitEvent(s, ss->done, 0);
+    }
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
         BinPlan plan;
         make_plan(DIM, lt, hi - s0, plan, acc_kib);
         const dim3 grid(plan.num_tiles, plan.nbl);
         if (!ss) {
-            hipLaunchKernelGGL((bin_count_kernel<DIM>), grid, dim3(kBinThreads), 0, s, lt, plan, coords, w.cnt, s0, hi);
+            hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), dim3(plan.num_tiles), dim3(kBinThreads), 0, s, lt, plan,
+                               coords, w.cnt, s0, hi);
             SHACIRA_CHECK_LAUNCH();
             hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, s, w.cnt, w.totals,
                                plan.num_tiles);
@@ -1301,28 +1383,17 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                                w.unit_bucket, plan.total_buckets, plan.chunk);
             SHACIRA_CHECK_LAUNCH();
         }
-        constexpr int NP = 1 << (DIM - 1);
-        const size_t stage = (size_t)kTile * NP * (sizeof(Item<F>) + 1);
         hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,
-                           w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n);
+                           w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n, 0u);
         SHACIRA_CHECK_LAUNCH();
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NP;
         const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + plan.total_buckets + 1;
-        const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         if (fuse) {
             hipError_t e = hipStreamWaitEvent(s, ss->join, 0);
             if (e != hipSuccess) return e;
         }
-        if (use_fx)   // a unit streams <= chunk items
-            hipLaunchKernelGGL((bin_consume_kernel<F, true>), dim3(max_units), dim3(kConsumeThreads), acc_bytes, s, lt,
-                               plan, first_idx, w.base, w.unit_first, w.unit_bucket,
-                               reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, w.gmax,
-                               fx_headroom((uint64_t)plan.chunk + 1));
-        else
-            hipLaunchKernelGGL((bin_consume_kernel<F, false>), dim3(max_units), dim3(kConsumeThreads), acc_bytes, s, lt,
-                               plan, first_idx, w.base, w.unit_first, w.unit_bucket,
-                               reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, nullptr, -1);
-        SHACIRA_CHECK_LAUNCH();
+        hipError_t e = consume(plan, max_units, 0u, plan.total_buckets, multi ? 1 : 0, s);
+        if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }

@@ -21,7 +21,8 @@ constexpr uint32_t kPrimeZ = 805459861u;   // .cu:25
 struct LevelTable {
     int32_t res[SHACIRA_MAX_LODS];    // resolution per level
     float hi[SHACIRA_MAX_LODS];       // (float)(res - 1 - 1e-5), the fp64->fp32 narrowed upper clamp
-    uint8_t dense[SHACIRA_MAX_LODS];  // 1 = dense index rule, 0 = spatial hash
+    uint32_t dense[SHACIRA_MAX_LODS]; // 1 = dense index rule, 0 = spatial hash (32-bit: a dynamically indexed byte of the
+                                      // kernel arguments costs a vector load + s_waitcnt vmcnt(0), a dword is a scalar load)
     uint32_t mask;                    // codebook_size - 1   (uint32 % 2^bw == & mask)
     int32_t num_lods;
     int32_t feature_dim;
@@ -51,6 +52,19 @@ __device__ __forceinline__ void axis_transform(double t, int32_t res, float hi, 
 }
 
 __device__ __forceinline__ double axis_unit(float c) { return (double)c * 0.5 + 0.5; }
+
+// Coordinates of sample i of [0, n): the loads are unconditional (index clamped into the batch) so that all of them are
+// in flight together -- `live ? coords[..] : 0` compiles to one branch + load + s_waitcnt vmcnt(0) PER AXIS, i.e. DIM
+// serialised memory latencies per sample. Callers ignore the result of samples >= n.
+template <int DIM>
+__device__ __forceinline__ void load_unit_coords(const float *__restrict__ coords, int64_t i, int64_t n, double (&t)[DIM]) {
+    const float *p = coords + (i < n ? i : n - 1) * DIM;
+    float c[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) c[a] = p[a];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) t[a] = axis_unit(c[a]);
+}
 
 // Scalar <-> storage conversions (fp32 math everywhere, like static_cast<float>(codebook[..]) in .cu:98)
 template <typename T> struct Scalar;

@@ -144,8 +144,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_sample_kernel(LevelTable lt,
     const int64_t i = wave_s0 + lane;
     const bool live = i < N;
     double t[DIM];
-#pragma unroll
-    for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live ? coords[i * DIM + a] : 0.0f);
+    load_unit_coords<DIM>(coords, i, N, t);
 #pragma unroll 1
     for (int l = 0; l < L; ++l) {
         Corners<DIM> c;
@@ -215,8 +214,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_pair_kernel(LevelTable lt, c
     const int64_t i = wave_s0 + sl;
     const bool live = i < N;
     double t[DIM];
-#pragma unroll
-    for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live ? coords[i * DIM + a] : 0.0f);
+    load_unit_coords<DIM>(coords, i, N, t);
 #pragma unroll 1
     for (int l = 0; l < L; ++l) {
         const int32_t res = lt.res[l];
@@ -515,8 +513,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
             t[1] = axis_unit(c4.y);
             if constexpr (DIM == 3) t[2] = axis_unit(c4.z);
         } else {
-#pragma unroll
-            for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live[u] ? coords[i * DIM + a] : 0.0f);
+            load_unit_coords<DIM>(coords, i, N, t);
         }
         int32_t p[DIM];
 #pragma unroll
