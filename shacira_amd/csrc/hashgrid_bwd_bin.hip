@@ -94,6 +94,22 @@ template <int F> __device__ __forceinline__ void store_item_nt(Item<F> *p, const
     }
 }
 
+template <int F> __device__ __forceinline__ Item<F> load_item_nt(const Item<F> *p) {
+    Item<F> it;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (sizeof(Item<F>) == 16) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        __builtin_memcpy(&it, &v, 16);
+    } else {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+        uint32_t d[sizeof(Item<F>) / 4];
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(Item<F>) / 4); ++k) d[k] = __builtin_nontemporal_load(q + k);
+        __builtin_memcpy(&it, d, sizeof(Item<F>));
+    }
+    return it;
+}
+
 // One x-pair of corners of a (sample, level), in bucket coordinates.
 struct PairSlot {
     uint32_t bucket;  // level-local bucket index
@@ -701,8 +717,8 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
                 for (int u = 0; u < UC; ++u) {
                     const uint64_t p = p0 + 2ull * u * kConsumeThreads;
                     if (p + 1 < end) {
-                        ia[u] = items[p];
-                        ib[u] = items[p + 1];
+                        ia[u] = load_item_nt<F>(items + p);
+                        ib[u] = load_item_nt<F>(items + p + 1);
                     } else {
                         ia[u].key = 0;
                     }
@@ -748,7 +764,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const uint64_t p = p0 + (uint64_t)u * kConsumeThreads;
-            if (p < end) it[u] = items[p];
+            if (p < end) it[u] = load_item_nt<F>(items + p);
             else it[u].key = 0;
         }
 #pragma unroll
