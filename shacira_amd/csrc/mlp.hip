@@ -316,6 +316,8 @@ static mlp_fn mlp_lookup(int in, int h, int nh, int out) {
     SHACIRA_WIDE(32, 32, 64, 2, 3)   // image / 3-D field decoders with hidden_dim 64
     SHACIRA_WIDE(32, 16, 64, 2, 3)
     SHACIRA_WIDE(32, 32, 64, 1, 3)
+    SHACIRA_WIDE(32, 96, 128, 1, 16) // nerf_lego.yaml (hidden_dim 128): 24 levels x F=4 -> 128 -> 16
+    SHACIRA_WIDE(32, 43, 128, 2, 3)  // nerf_lego.yaml colour decoder: 16 + 27 -> 128 -> 128 -> rgb
     SHACIRA_WIDE(16, 32, 16, 2, 3)   // config B image decoder on 16x16x4 MFMA
     SHACIRA_WIDE(16, 24, 16, 2, 3)
     SHACIRA_WIDE(16, 16, 16, 2, 3)

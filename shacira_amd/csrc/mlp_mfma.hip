@@ -52,7 +52,8 @@ template <int MB> __device__ __forceinline__ constexpr int crow(int v, int q) {
 }
 
 template <int MB, int IN, int H, int NH, int OUT> struct WideShape {
-    static_assert(H % MB == 0 && OUT <= MB && IN <= 64 && NH >= 1 && NH <= 2, "shape not covered by the MFMA kernels");
+    static_assert(H % MB == 0 && OUT <= MB && IN <= 128 && NH >= 1 && NH <= 2, "shape not covered by the MFMA kernels");
+    static constexpr bool kSplit = H > 64;   // width 128: the weight gradients are split over the workgroup's waves
     static constexpr int KB0 = (IN + MB - 1) / MB;   // MB-wide k blocks of the first layer
     static constexpr int HB = H / MB;
     static constexpr int fan_in(int l) { return l == 0 ? IN : H; }
@@ -76,6 +77,10 @@ template <int MB, int IN, int H, int NH, int OUT> struct WideShape {
     static constexpr int max_kb = KB0 > HB ? KB0 : HB;
     static constexpr int stage_in_pitch = MB * max_kb + 1;
     static constexpr int stage_floats = MB * stage_in_pitch + MB * HB * (MB + 1);   // In [sample][k] + dZ [o][sample]
+    // backward LDS plan (floats): per-wave stages + the block's gradient image, or (split) ONE shared stage
+    static constexpr size_t bwd_lds_floats =
+        kSplit ? (size_t)lds_weights + stage_floats
+               : (size_t)lds_weights + (n_params + 3) / 4 * 4 + (size_t)kMfmaWaves * stage_floats;
 };
 
 // zero-padded copy of the parameters into LDS
@@ -121,6 +126,8 @@ __device__ __forceinline__ void layer_forward(const float *__restrict__ sW, int 
             for (int v = 0; v < M::NA; ++v) acc[v] = fmaxf(acc[v], 0.0f);
         }
         out[ob] = acc;
+        // width 128: keep the scheduler from hoisting every block's LDS operand loads to the top (spills at 512 registers)
+        if constexpr (KB * OB > 4) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -145,6 +152,7 @@ __device__ __forceinline__ void layer_backward(const float *__restrict__ sW, int
             }
         }
         din[kb] = acc;
+        if constexpr (KB * OB > 4) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -243,6 +251,7 @@ __device__ __forceinline__ void accumulate_dw(const float *__restrict__ s_in, in
                 const float b = s_in[(M::NQ * st + q) * in_pitch + MB * kb + i];
                 dw[ob][kb] = M::mma(a[st], b, dw[ob][kb]);
             }
+            if constexpr (KB > 2) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -382,6 +391,153 @@ __global__ __launch_bounds__(64 * kMfmaWaves) void wide_mlp_backward_kernel(
         partials[(size_t)blockIdx.x * S::n_params + e] = (double)s_gp[e];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Width-128 decoders (nerf_lego.yaml: hidden_dim 128 -> density 96 -> 128 -> 16, colour 43 -> 128 -> 128 -> 3).
+// One layer's weight gradient is 4 x 4 MFMA blocks = 256 accumulator registers, so a wave cannot keep all of dW like the
+// width-64 kernel does. Here every wave still chains ITS OWN 32-sample tile through the network in registers, but the
+// weight gradients are split by OUTPUT-ROW block: wave w owns rows [32w, 32w + 32) of dW_0 and dW_1 and k-block w of
+// dW_out. The four tiles of an iteration take turns in ONE shared LDS stage (In [32][129] + dZ [128][33] = 33 KiB next to
+// 118 KiB of padded weights): the owner wave writes its tile's operands, all four waves accumulate their rows from it.
+// No block-level gradient image: every element of dW has exactly one owner, which writes it to the fp64 partial row.
+template <int MB, int KB>
+__device__ __forceinline__ void flush_owned(double *__restrict__ part, int p_off, int fan_in, int fan_out, int ob, int kb0,
+                                            const typename Mma<MB>::acc_t (&dw)[1][KB], int j, int q) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int v = 0; v < Mma<MB>::NA; ++v) {
+            const int o = MB * ob + crow<MB>(v, q), k = MB * (kb0 + kb) + j;
+            if (o < fan_out && k < fan_in) part[p_off + o * fan_in + k] = (double)dw[0][kb][v];
+        }
+    }
+}
+template <int MB>
+__device__ __forceinline__ void flush_owned_bias(double *__restrict__ part, int p_off, int fan_in, int fan_out, int ob,
+                                                 float db, int j, int q) {
+    // lane (j, q) holds the sum over its MB / NQ samples of row MB*ob + j: add the NQ lanes of the row
+    float t = db;
+#pragma unroll
+    for (int m = MB; m < 64; m <<= 1) t += __shfl_xor(t, m, 64);
+    const int o = MB * ob + j;
+    if (q == 0 && o < fan_out) part[p_off + fan_in * fan_out + o] = (double)t;
+}
+
+template <int MB, int IN, int H, int NH, int OUT>
+__global__ __launch_bounds__(64 * kMfmaWaves) void split_mlp_backward_kernel(
+    const float *__restrict__ x, const float *__restrict__ params, const float *__restrict__ gy,
+    float *__restrict__ gx, double *__restrict__ partials, int64_t N) {
+    using S = WideShape<MB, IN, H, NH, OUT>;
+    using M = Mma<MB>;
+    using A = typename M::acc_t;
+    static_assert(S::HB == kMfmaWaves, "one output-row block of the hidden layers per wave");
+    extern __shared__ __align__(16) float smem[];
+    float *s_in = smem + S::lds_weights;             // shared stage: In [MB samples][stage_in_pitch]
+    float *s_dz = s_in + MB * S::stage_in_pitch;     //               dZ [H rows][MB + 1]
+    const int lane = threadIdx.x & 63, i = lane % MB, q = lane / MB, wave = threadIdx.x >> 6;
+    load_weights<S, NH>(smem, params);
+
+    A dw0[1][S::KB0], dw1[1][S::HB], dwo[1][1];
+    float db0[1] = {0.0f}, db1[1] = {0.0f}, dbo[1] = {0.0f};
+#pragma unroll
+    for (int v = 0; v < M::NA; ++v) {
+#pragma unroll
+        for (int b = 0; b < S::KB0; ++b) dw0[0][b][v] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < S::HB; ++b) dw1[0][b][v] = 0.0f;
+        dwo[0][0][v] = 0.0f;
+    }
+    const float *s_dz_own = s_dz + (MB * wave) * (MB + 1);   // this wave's rows of dZ
+
+    const int64_t tiles = (N + MB - 1) / MB;
+    // uniform trip count for the whole workgroup (barriers inside): a wave past the last tile runs on zeros
+    for (int64_t base = (int64_t)blockIdx.x * kMfmaWaves; base < tiles; base += (int64_t)gridDim.x * kMfmaWaves) {
+        const int64_t s = (base + wave) * MB + i;
+        const bool live = s < N;
+        A in0[S::KB0], h0[S::HB], h1[S::HB];
+        load_input<MB, IN, S::KB0>(x, s, live, in0, q);
+        layer_forward<MB, S::KB0, S::HB, true>(smem + S::lds_w_off(0), S::pitch(0), smem + S::lds_b_off(0), in0, h0, i, q);
+        if constexpr (NH == 2)
+            layer_forward<MB, S::HB, S::HB, true>(smem + S::lds_w_off(1), S::pitch(1), smem + S::lds_b_off(1), h0, h1, i,
+                                                  q);
+        A dzo[1];
+#pragma unroll
+        for (int v = 0; v < M::NA; ++v) {
+            const int o = crow<MB>(v, q);
+            dzo[0][v] = (live && o < OUT) ? gy[s * OUT + o] : 0.0f;
+        }
+        const A (&hlast)[S::HB] = (NH == 2) ? h1 : h0;
+        // output layer: wave w accumulates k-block w of dW_out (and everyone the bias; wave 0's copy is written)
+#pragma unroll 1
+        for (int tw = 0; tw < kMfmaWaves; ++tw) {
+            if (wave == tw) {
+                stage_in<MB, S::HB>(s_in, S::stage_in_pitch, hlast, i, q);
+                stage_dz<MB, 1>(s_dz, dzo, i, q);
+            }
+            __syncthreads();
+            accumulate_dw<MB, 1, 1>(s_in + MB * wave, S::stage_in_pitch, s_dz, dwo, dbo, i, q);
+            __syncthreads();
+        }
+        A dcur[S::HB];
+        layer_backward<MB, S::HB, 1>(smem + S::lds_w_off(NH), S::pitch(NH), dzo, dcur, i, q, OUT);
+#pragma unroll
+        for (int b = 0; b < S::HB; ++b)
+#pragma unroll
+            for (int v = 0; v < M::NA; ++v) dcur[b][v] = (hlast[b][v] > 0.0f) ? dcur[b][v] : 0.0f;
+        if constexpr (NH == 2) {
+#pragma unroll 1
+            for (int tw = 0; tw < kMfmaWaves; ++tw) {
+                if (wave == tw) {
+                    stage_in<MB, S::HB>(s_in, S::stage_in_pitch, h0, i, q);
+                    stage_dz<MB, S::HB>(s_dz, dcur, i, q);
+                }
+                __syncthreads();
+                accumulate_dw<MB, S::HB, 1>(s_in, S::stage_in_pitch, s_dz_own, dw1, db1, i, q);
+                __syncthreads();
+            }
+            A dprev[S::HB];
+            layer_backward<MB, S::HB, S::HB>(smem + S::lds_w_off(1), S::pitch(1), dcur, dprev, i, q, H);
+#pragma unroll
+            for (int b = 0; b < S::HB; ++b)
+#pragma unroll
+                for (int v = 0; v < M::NA; ++v) dcur[b][v] = (h0[b][v] > 0.0f) ? dprev[b][v] : 0.0f;
+        }
+        // two hidden layers: the inputs are read again here instead of being kept in 32 registers through both chains
+        // (the compiler spilled 216 B / lane otherwise); x2 is opaque so that the two reads are not merged
+        A in0b[S::KB0];
+        if constexpr (NH == 2) {
+            const float *x2 = x;
+            asm volatile("" : "+s"(x2));
+            load_input<MB, IN, S::KB0>(x2, s, live, in0b, q);
+        }
+        const A (&in_l0)[S::KB0] = (NH == 2) ? in0b : in0;
+#pragma unroll 1
+        for (int tw = 0; tw < kMfmaWaves; ++tw) {
+            if (wave == tw) {
+                stage_in<MB, S::KB0>(s_in, S::stage_in_pitch, in_l0, i, q);
+                stage_dz<MB, S::HB>(s_dz, dcur, i, q);
+            }
+            __syncthreads();
+            accumulate_dw<MB, S::KB0, 1>(s_in, S::stage_in_pitch, s_dz_own, dw0, db0, i, q);
+            __syncthreads();
+        }
+        if (gx != nullptr) {
+            A dx[S::KB0];
+            layer_backward<MB, S::KB0, S::HB>(smem + S::lds_w_off(0), S::pitch(0), dcur, dx, i, q, H);
+            store_rows<MB, IN, S::KB0>(gx, s, live, dx, q);
+        }
+    }
+    double *part = partials + (size_t)blockIdx.x * S::n_params;
+    flush_owned<MB, S::KB0>(part, S::p_off(0), IN, H, wave, 0, dw0, i, q);
+    flush_owned_bias<MB>(part, S::p_off(0), IN, H, wave, db0[0], i, q);
+    if constexpr (NH == 2) {
+        flush_owned<MB, S::HB>(part, S::p_off(1), H, H, wave, 0, dw1, i, q);
+        flush_owned_bias<MB>(part, S::p_off(1), H, H, wave, db1[0], i, q);
+    }
+    flush_owned<MB, 1>(part, S::p_off(NH), H, OUT, 0, wave, dwo, i, q);
+    if (wave == 0) flush_owned_bias<MB>(part, S::p_off(NH), H, OUT, 0, dbo[0], i, q);
+}
+
 // finishing pass (mlp.hip): fp64 block partials -> fp32 gradient, fixed summation tree
 hipError_t mlp_finish_launch(const double *partials, int nblocks, int n, float *out, hipStream_t s);
 
@@ -399,8 +555,7 @@ hipError_t wide_mlp_run(bool bwd, int64_t N, const float *x, const float *params
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     constexpr size_t fwd_lds = (size_t)S::lds_weights * sizeof(float);
-    constexpr size_t bwd_lds =
-        ((size_t)S::lds_weights + (S::n_params + 3) / 4 * 4 + (size_t)kMfmaWaves * S::stage_floats) * sizeof(float);
+    constexpr size_t bwd_lds = S::bwd_lds_floats * sizeof(float);
     static_assert(bwd_lds <= 160 * 1024, "backward LDS plan exceeds the CU's 160 KiB");
     static PerDeviceOnce once;
     const hipError_t attr_err = once.run([]() -> hipError_t {
@@ -408,9 +563,14 @@ hipError_t wide_mlp_run(bool bwd, int64_t N, const float *x, const float *params
         if (fwd_lds > 64 * 1024)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_mlp_forward_kernel<MB, IN, H, NH, OUT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds);
-        if (e == hipSuccess && bwd_lds > 64 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_mlp_backward_kernel<MB, IN, H, NH, OUT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
+        if (e == hipSuccess && bwd_lds > 64 * 1024) {
+            if constexpr (S::kSplit)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&split_mlp_backward_kernel<MB, IN, H, NH, OUT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
+            else
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_mlp_backward_kernel<MB, IN, H, NH, OUT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
+        }
         return e;
     });
     if (attr_err != hipSuccess) return attr_err;
@@ -419,8 +579,12 @@ hipError_t wide_mlp_run(bool bwd, int64_t N, const float *x, const float *params
                            fwd_lds, s, x, params, y, N);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((wide_mlp_backward_kernel<MB, IN, H, NH, OUT>), dim3((uint32_t)blocks), dim3(64 * kMfmaWaves),
-                       bwd_lds, s, x, params, gy, gx, partials, N);
+    if constexpr (S::kSplit)
+        hipLaunchKernelGGL((split_mlp_backward_kernel<MB, IN, H, NH, OUT>), dim3((uint32_t)blocks), dim3(64 * kMfmaWaves),
+                           bwd_lds, s, x, params, gy, gx, partials, N);
+    else
+        hipLaunchKernelGGL((wide_mlp_backward_kernel<MB, IN, H, NH, OUT>), dim3((uint32_t)blocks), dim3(64 * kMfmaWaves),
+                           bwd_lds, s, x, params, gy, gx, partials, N);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return mlp_finish_launch(partials, (int)blocks, S::n_params, gparams, s);
@@ -435,6 +599,8 @@ SHACIRA_WIDE_INST(32, 43, 64, 2, 3)
 SHACIRA_WIDE_INST(32, 32, 64, 2, 3)
 SHACIRA_WIDE_INST(32, 16, 64, 2, 3)
 SHACIRA_WIDE_INST(32, 32, 64, 1, 3)
+SHACIRA_WIDE_INST(32, 96, 128, 1, 16)
+SHACIRA_WIDE_INST(32, 43, 128, 2, 3)
 SHACIRA_WIDE_INST(16, 32, 16, 2, 3)
 SHACIRA_WIDE_INST(16, 24, 16, 2, 3)
 SHACIRA_WIDE_INST(16, 16, 16, 2, 3)

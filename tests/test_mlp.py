@@ -32,7 +32,9 @@ def test_basic_decoder_host_logic_and_names():
 @pytest.mark.parametrize("dims", [(32, 16, 2, 3), (24, 16, 2, 3), (16, 16, 2, 3), (48, 16, 2, 3), (32, 16, 1, 3),
                                   (32, 16, 3, 3), (32, 16, 2, 4),
                                   # hidden width 64: the fp32-MFMA kernels (NeRF density / colour decoders)
-                                  (32, 64, 1, 16), (43, 64, 2, 3), (32, 64, 2, 3), (16, 64, 2, 3)])
+                                  (32, 64, 1, 16), (43, 64, 2, 3), (32, 64, 2, 3), (16, 64, 2, 3),
+                                  # hidden width 128 (nerf_lego.yaml): weight gradients split over the workgroup's waves
+                                  (96, 128, 1, 16), (43, 128, 2, 3)])
 @pytest.mark.parametrize("n", [1, 255, 256, 70_001])
 @pytest.mark.parametrize("variant", [-1, 0])
 def test_fused_mlp_matches_torch_layers(dims, n, variant):
@@ -42,7 +44,7 @@ def test_fused_mlp_matches_torch_layers(dims, n, variant):
     dev = torch.device("cuda:0")
     IN, H, NH, OUT = dims
     if variant == 0 and H != 16:
-        pytest.skip("width-64 decoders exist as MFMA kernels only")
+        pytest.skip("width-64 / width-128 decoders exist as MFMA kernels only")
     _lib.set_option("mlp_variant", variant)
     try:
         _check_fused_mlp(dims, n, dev)
