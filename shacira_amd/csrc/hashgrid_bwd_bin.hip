@@ -64,6 +64,7 @@ struct BinPlan {
     uint32_t chunk;     // items per consumer work unit
     uint32_t nbl;       // number of binned levels
     uint32_t blevel[SHACIRA_MAX_LODS];  // their level indices (grid.y of passes A/B); 32-bit = scalar loads
+    uint32_t bstart[SHACIRA_MAX_LODS];  // first global bucket of binned level q (= lv[blevel[q]].bucket0)
     uint32_t ngroups;   // groups of direct levels
     uint32_t gmask[SHACIRA_MAX_LODS];   // levels of each group (bit l)
     uint32_t grows[SHACIRA_MAX_LODS];   // rows of each group's LDS image
@@ -73,6 +74,17 @@ template <int F> struct alignas(F == 2 ? 16 : 8) Item {
     uint32_t key;
     float fx;
     float a[F];
+};
+
+// One consumer work unit, written by the bucket scan: everything a consume workgroup needs in ONE 32-byte load (it used to
+// chase unit -> bucket -> base / unit_first -> level through four dependent loads and a 15-step scalar search: ~8 us per
+// unit before the first item arrived).
+struct alignas(16) UnitDesc {
+    uint64_t begin, end;   // item range
+    uint32_t bucket;       // global bucket index
+    uint32_t level;
+    uint32_t single;       // 1: the bucket's only unit (rows are written with plain stores)
+    uint32_t pad;
 };
 
 // Workgroup barrier that orders LDS traffic only. __syncthreads() also drains the wave's global loads AND stores
@@ -412,12 +424,12 @@ __global__ __launch_bounds__(64) void bin_scan_tiles_kernel(uint32_t *__restrict
 // single block: bucket bases (exclusive scan of totals) and the consumer work list
 //   base[b]         first item of bucket b in the item array (base[nb] = total)
 //   unit_first[b]   first work unit of bucket b; unit_first[nb] = number of units
-//   unit_bucket[u]  bucket of work unit u
+//   unit_desc[u]    item range, bucket and level of work unit u
 __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *__restrict__ totals,
                                                                 uint64_t *__restrict__ base,
                                                                 uint32_t *__restrict__ unit_first,
-                                                                uint32_t *__restrict__ unit_bucket, uint32_t nb,
-                                                                uint32_t chunk_items) {
+                                                                UnitDesc *__restrict__ unit_desc, uint32_t nb,
+                                                                uint32_t chunk_items, BinPlan plan) {
     __shared__ uint64_t s_items[kMaxBuckets + 2];
     __shared__ uint32_t s_units[kMaxBuckets + 2];
     __shared__ uint64_t s_wave_items[16];
@@ -463,8 +475,23 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const uint32_t b = 2 * t + k;
-        if (b < nb)
-            for (uint32_t q = 0; q < u[k]; ++q) unit_bucket[s_units[b] + q] = b;
+        if (b < nb) {
+            uint32_t lq = 0;
+            for (uint32_t q = 1; q < plan.nbl; ++q)
+                if (plan.bstart[q] <= b) lq = q;
+            const uint32_t lvl = plan.blevel[lq];
+            for (uint32_t q = 0; q < u[k]; ++q) {
+                UnitDesc d;
+                d.begin = s_items[b] + (uint64_t)q * chunk_items;
+                const uint64_t bucket_end = s_items[b] + c[k];
+                d.end = (d.begin + chunk_items < bucket_end) ? (d.begin + chunk_items) : bucket_end;
+                d.bucket = b;
+                d.level = lvl;
+                d.single = u[k] == 1 ? 1u : 0u;
+                d.pad = 0;
+                unit_desc[s_units[b] + q] = d;
+            }
+        }
     }
 }
 
@@ -622,6 +649,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
     __shared__ uint32_t s_hist[SHACIRA_MAX_LODS][kMaxLevelBuckets];
     constexpr int SPT = kTile / kBinThreads;
     const uint32_t tile = blockIdx.x;
+    // gridDim.y workgroups share a tile's levels (bi = blockIdx.y, blockIdx.y + gridDim.y, ...): small batches keep the chip
+    // busy with one level each, large ones load the coordinates once for all levels
     for (uint32_t e = threadIdx.x; e < plan.nbl * kMaxLevelBuckets; e += kBinThreads) (&s_hist[0][0])[e] = 0;
     double t[SPT][DIM];
     bool live[SPT];
@@ -633,7 +662,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
     }
     __syncthreads();
 #pragma unroll 1
-    for (uint32_t bi = 0; bi < plan.nbl; ++bi) {
+    for (uint32_t bi = blockIdx.y; bi < plan.nbl; bi += gridDim.y) {
         const uint32_t lvl = plan.blevel[bi];
         const BinLevel bl = plan.lv[lvl];
         const int32_t res = lt.res[lvl];
@@ -660,7 +689,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
         }
     }
     __syncthreads();
-    for (uint32_t bi = 0; bi < plan.nbl; ++bi) {
+    for (uint32_t bi = blockIdx.y; bi < plan.nbl; bi += gridDim.y) {
         const BinLevel bl = plan.lv[plan.blevel[bi]];
         for (uint32_t b = threadIdx.x; b < bl.nb; b += kBinThreads)
             cnt[(size_t)(bl.bucket0 + b) * plan.num_tiles + tile] = s_hist[bi][b];
@@ -673,7 +702,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
                                                                       const int32_t *__restrict__ first_idx,
                                                                       const uint64_t *__restrict__ base,
                                                                       const uint32_t *__restrict__ unit_first,
-                                                                      const uint32_t *__restrict__ unit_bucket,
+                                                                      const UnitDesc *__restrict__ unit_desc,
                                                                       const Item<F> *__restrict__ items,
                                                                       float *__restrict__ grad_table,
                                                                       int force_atomic,
@@ -682,13 +711,12 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
                                                                       uint32_t bucket_hi) {
     extern __shared__ double s_acc[];  // [rows_pb][F]: fp64, or 64-bit fixed point (same size)
     // this launch consumes the work units of buckets [bucket_lo, bucket_hi) (one group of levels, or all of them)
-    const uint32_t unit = blockIdx.x + unit_first[bucket_lo];
+    const uint32_t unit = blockIdx.x + (bucket_lo ? unit_first[bucket_lo] : 0u);
+    UnitDesc d;
+    if (bucket_lo == 0) d = unit_desc[unit];   // in flight beside the bound below (the array covers a whole-plan grid)
     if (unit >= unit_first[bucket_hi]) return;
-    const uint32_t gb = unit_bucket[unit];
-    // level of the bucket
-    uint32_t lvl = plan.blevel[0];
-    for (uint32_t q = 1; q < plan.nbl; ++q)
-        if (plan.lv[plan.blevel[q]].bucket0 <= gb) lvl = plan.blevel[q];
+    if (bucket_lo != 0) d = unit_desc[unit];
+    const uint32_t gb = d.bucket, lvl = d.level;
     const BinLevel bl = plan.lv[lvl];
     const uint32_t b = gb - bl.bucket0;
     const uint32_t r1 = (uint32_t)lt.res[lvl];
@@ -702,10 +730,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     if constexpr (FX) fx = fx_scale_of(gmax[lvl], headroom);
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
 
-    const uint32_t chunk = unit - unit_first[gb];
-    const uint64_t begin = base[gb] + (uint64_t)chunk * plan.chunk;
-    const uint64_t bucket_end = base[gb + 1];
-    const uint64_t end = (begin + plan.chunk < bucket_end) ? (begin + plan.chunk) : bucket_end;
+    const uint64_t begin = d.begin, end = d.end;
     if constexpr (F == 2) {
         if (bl.compact) {
             // one sample per two slots: {local base row | valid, fx, fy, fz} {-, g0, g1, -}; all 8 corners land here
@@ -794,7 +819,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     }
     __syncthreads();
 
-    const bool single = (unit_first[gb + 1] - unit_first[gb]) == 1 && !force_atomic;
+    const bool single = d.single != 0 && !force_atomic;
     const int64_t grow0 = (int64_t)first_idx[lvl] + row0;
     for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) {
         const int64_t grow = grow0 + e / F;
@@ -1050,6 +1075,7 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
             }
         }
     }
+    for (uint32_t q = 0; q < plan.nbl; ++q) plan.bstart[q] = plan.lv[plan.blevel[q]].bucket0;
     plan.total_buckets = nbk;
     plan.BR = BR;
     plan.num_tiles = (uint32_t)((n_batch + kTile - 1) / kTile);
@@ -1081,7 +1107,7 @@ struct BinWorkspace {
     uint32_t *totals;
     uint64_t *base;
     uint32_t *unit_first;
-    uint32_t *unit_bucket;
+    UnitDesc *unit_desc;
     uint32_t *gmax;  // [SHACIRA_MAX_LODS] bit patterns of max |grad_output| per level
     float *acc32;  // fp32 accumulation image for fp16 tables
     size_t bytes;
@@ -1103,7 +1129,7 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     const size_t o_base = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
     const size_t o_unit = take((size_t)(kMaxBuckets + 2) * sizeof(uint32_t));
     const uint64_t max_items_ws = (uint64_t)nb * plan.nbl * plan.pairs;
-    const size_t o_ub = take((size_t)(max_items_ws / plan.chunk + plan.total_buckets + 2) * sizeof(uint32_t));
+    const size_t o_ub = take((size_t)(max_items_ws / plan.chunk + plan.total_buckets + 2) * sizeof(UnitDesc));
     const size_t o_acc = take(dtype == SHACIRA_F16 ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0);
     BinWorkspace w{};
     unsigned char *p = static_cast<unsigned char *>(ws);
@@ -1114,7 +1140,7 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
         w.totals = reinterpret_cast<uint32_t *>(p + o_tot);
         w.base = reinterpret_cast<uint64_t *>(p + o_base);
         w.unit_first = reinterpret_cast<uint32_t *>(p + o_unit);
-        w.unit_bucket = reinterpret_cast<uint32_t *>(p + o_ub);
+        w.unit_desc = reinterpret_cast<UnitDesc *>(p + o_ub);
         w.gmax = reinterpret_cast<uint32_t *>(p + o_gmax);
         w.acc32 = reinterpret_cast<float *>(p + o_acc);
     }
@@ -1173,6 +1199,13 @@ static hipError_t side_stream(SideStream **out) {
     return hipSuccess;
 }
 
+// pass A grid: tiles x level shares, at least ~1024 workgroups when the batch is small
+static dim3 count_grid(const BinPlan &plan) {
+    uint32_t shares = plan.num_tiles >= 1024 ? 1u : (1024u + plan.num_tiles - 1) / plan.num_tiles;
+    if (shares > plan.nbl) shares = plan.nbl;
+    return dim3(plan.num_tiles, shares < 1 ? 1 : shares);
+}
+
 template <int DIM, int F>
 static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                           const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s,
@@ -1211,14 +1244,14 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             BinPlan plan;
             make_plan(DIM, lt, n, plan, acc_kib);
             const dim3 grid(plan.num_tiles, plan.nbl);
-            hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), dim3(plan.num_tiles), dim3(kBinThreads), 0, ss->stream, lt,
+            hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), count_grid(plan), dim3(kBinThreads), 0, ss->stream, lt,
                                plan, coords, w.cnt, (int64_t)0, n);
             SHACIRA_CHECK_LAUNCH();
             hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, ss->stream, w.cnt,
                                w.totals, plan.num_tiles);
             SHACIRA_CHECK_LAUNCH();
             hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, ss->stream, w.totals, w.base,
-                               w.unit_first, w.unit_bucket, plan.total_buckets, plan.chunk);
+                               w.unit_first, w.unit_desc, plan.total_buckets, plan.chunk, plan);
             SHACIRA_CHECK_LAUNCH();
             if ((e = hipEventRecord(ss->join, ss->stream)) != hipSuccess) return e;
         }
@@ -1260,7 +1293,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                            plan.num_tiles);
         SHACIRA_CHECK_LAUNCH();
         hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
-                           w.unit_bucket, plan.total_buckets, plan.chunk);
+                           w.unit_desc, plan.total_buckets, plan.chunk, plan);
         SHACIRA_CHECK_LAUNCH();
     } else if (need_T && !staged) {
         const int t_lb = stage_all ? 0 : lt.level_begin, t_le = stage_all ? L : lt.level_end;
@@ -1340,12 +1373,12 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         if (use_fx)   // a unit streams <= chunk items
             hipLaunchKernelGGL((bin_consume_kernel<F, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, cs, lt,
-                               plan, first_idx, w.base, w.unit_first, w.unit_bucket,
+                               plan, first_idx, w.base, w.unit_first, w.unit_desc,
                                reinterpret_cast<const Item<F> *>(w.items), acc, force_atomic, w.gmax,
                                fx_headroom((uint64_t)plan.chunk + 1), b_lo, b_hi);
         else
             hipLaunchKernelGGL((bin_consume_kernel<F, false>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, cs, lt,
-                               plan, first_idx, w.base, w.unit_first, w.unit_bucket,
+                               plan, first_idx, w.base, w.unit_first, w.unit_desc,
                                reinterpret_cast<const Item<F> *>(w.items), acc, force_atomic, nullptr, -1, b_lo, b_hi);
         return hipGetLastError();
     };
@@ -1389,14 +1422,14 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         make_plan(DIM, lt, hi - s0, plan, acc_kib);
         const dim3 grid(plan.num_tiles, plan.nbl);
         if (!ss) {
-            hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), dim3(plan.num_tiles), dim3(kBinThreads), 0, s, lt, plan,
+            hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), count_grid(plan), dim3(kBinThreads), 0, s, lt, plan,
                                coords, w.cnt, s0, hi);
             SHACIRA_CHECK_LAUNCH();
             hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, s, w.cnt, w.totals,
                                plan.num_tiles);
             SHACIRA_CHECK_LAUNCH();
             hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
-                               w.unit_bucket, plan.total_buckets, plan.chunk);
+                               w.unit_desc, plan.total_buckets, plan.chunk, plan);
             SHACIRA_CHECK_LAUNCH();
         }
         hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,
