@@ -404,6 +404,10 @@ SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origi
  *   "bwd_groups": 1 (default) = one scatter and one consume launch over all binned levels; g > 1 = the levels in g groups,
  *               the scatter of group k + 1 on the caller's stream beside the consume of group k on the side stream
  *               (an experiment hook: every g measured slower, both passes share the same memory queues).
+ *   "bwd_rows": 0 (default) = the backward transposes grad_output once (gT [L][N][F]); 1 = fp32 batches >= 2^18 scatter
+ *               straight from grad_output on an XCD-affine grid (no transposing pass), 2 = always. Measured slower
+ *               (S1: 0.636 vs 0.608 ms: the strided reads cost the scatter pass more than the transpose saves).
+ *   "bwd_direct_side": 0 (default); 1 = LDS-resident levels accumulate on the side stream beside the scatter pass.
  */
 SHACIRA_API int shacira_set_option(const char *name, int value);
 SHACIRA_API int shacira_get_option(const char *name);

@@ -496,14 +496,21 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
 }
 
 // ------------------------------------------------------------------------------------------------- pass B
-template <int DIM, int F>
+// ROWS = false: gradients from the transposed image gT [L][N][F], grid (tiles, levels).
+// ROWS = true:  gradients straight from grad_output [N, L*F] (8 or 16 bytes of every 128-byte row per level) -- no
+//   transposing pass. Only worth it when the rows are fetched from HBM once: the 1-D grid is numbered so that ALL levels
+//   of a tile run back to back on ONE XCD (workgroup b runs on XCD b % 8): the first level pulls the tile's rows (and
+//   coordinates) into that XCD's L2, the others hit there. Each workgroup also folds max |g| of its level into gmax[]
+//   (the consumer's fixed-point scale, otherwise a by-product of the transpose).
+template <int DIM, int F, bool ROWS>
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt, BinPlan plan,
                                                                   const float *__restrict__ coords,
                                                                   const float *__restrict__ gT,
                                                                   const uint32_t *__restrict__ tile_off,
                                                                   const uint64_t *__restrict__ base,
                                                                   Item<F> *__restrict__ items, int64_t sample0,
-                                                                  int64_t N, int64_t Ntotal, uint32_t lvl_off) {
+                                                                  int64_t N, int64_t Ntotal, uint32_t lvl_off,
+                                                                  uint32_t nlev, uint32_t *__restrict__ gmax) {
     constexpr int NP = 1 << (DIM - 1);
     constexpr int SPT = kTile / kBinThreads;   // samples per thread
     constexpr int kStage = kTile * NP;         // staged items per block
@@ -514,7 +521,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     __shared__ uint32_t s_start[kMaxLevelBuckets + 1];
     __shared__ uint64_t s_gbase[kMaxLevelBuckets];
 
-    const uint32_t tile = blockIdx.x, lvl = plan.blevel[blockIdx.y + lvl_off];
+    uint32_t tile = blockIdx.x, bi = blockIdx.y;
+    if constexpr (ROWS) {   // b -> (XCD, slot); slot -> (tile of that XCD, level)
+        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        tile = (slot / nlev) * 8u + xcd;
+        bi = slot % nlev;
+        if (tile >= plan.num_tiles) return;
+    }
+    const uint32_t lvl = plan.blevel[bi + lvl_off];
     const BinLevel bl = plan.lv[lvl];
     if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -560,7 +574,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
             enumerate_pairs<DIM>(t, res, hi, dense, lt.mask, bl, plan.BR, fx[u], ps[u]);
         }
         if (live) {
-            const float *gp = gT + ((int64_t)lvl * Ntotal + i) * F;
+            const float *gp = ROWS ? gT + (i * lt.num_lods + lvl) * F : gT + ((int64_t)lvl * Ntotal + i) * F;
             if constexpr (F == 2) {
                 const float2 v = *reinterpret_cast<const float2 *>(gp);
                 g[u][0] = v.x; g[u][1] = v.y;
@@ -576,6 +590,28 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         }
     }
     __syncthreads();
+    if constexpr (ROWS) {
+        if (gmax != nullptr) {   // max |g| of the level as an integer max on the float bit patterns (finite < inf < NaN)
+            uint32_t m = 0;
+#pragma unroll
+            for (int u = 0; u < SPT; ++u) {
+                if (sample0 + (int64_t)tile * kTile + threadIdx.x + u * kBinThreads < N) {
+#pragma unroll
+                    for (int j = 0; j < F; ++j) {
+                        const uint32_t b = __float_as_uint(fabsf(g[u][j]));
+                        m = b > m ? b : m;
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = __shfl_xor(m, off, 64);
+                m = o > m ? o : m;
+            }
+            if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(&gmax[lvl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&gmax[lvl], m);
+        }
+    }
     if (threadIdx.x < 64) {  // wave 0: exclusive scan of the <= 128 bucket counts, two per lane
         const uint32_t lane = threadIdx.x;
         const uint32_t c0 = (2 * lane < bl.nb) ? s_hist[2 * lane] : 0u;
@@ -1219,7 +1255,11 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     const bool stage_all = (lt.stage_flags & SHACIRA_BWD_STAGE_ALL_LEVELS) != 0;
     const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
     // only binned levels consume the transposed gradients (a later call on this workspace may, too: stage_all)
-    const bool need_T = whole.nbl > 0 || stage_all || staged;
+    // "rows" mode: the scatter pass reads grad_output itself (XCD-affine grid), no transposed image is built at all
+    const int rows_opt = g_bwd_rows.load();
+    const bool rows_mode = rows_opt != 0 && whole.nbl > 0 && dtype == SHACIRA_F32 && !stage_all && !staged && !multi &&
+                           (rows_opt == 2 || n >= (1 << 18));
+    const bool need_T = !rows_mode && (whole.nbl > 0 || stage_all || staged);
     // single sub-batch (the usual case): a side stream takes what is off the critical path. With a transpose to do,
     // counting is FUSED into it (transpose_count_kernel) and the side stream zeroes the table and runs the direct
     // levels; a call that reuses staged gradients counts + scans on the side stream instead.
@@ -1262,7 +1302,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     }
     // fixed-point images pay off once the accumulation itself dominates; small batches are bound by fixed costs and
     // keep the fp64 image (and skip the gmax bookkeeping): measured 100 vs 107 us at 65 536 samples
-    const bool use_fx = need_T && n >= (1 << 17);
+    const bool use_fx = (need_T || rows_mode) && n >= (1 << 17);
     if (!staged && use_fx) {   // per-level max |grad_output| for the scales (kept in the workspace for REUSE_STAGED)
         hipError_t e = hipMemsetAsync(w.gmax, 0, SHACIRA_MAX_LODS * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
@@ -1319,13 +1359,21 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // 0.082 ms for the whole backward), so those calls keep the fp64 image.
     // direct levels: one pass over the whole batch, no items (they add into the zeroed table)
     hipStream_t ds = s;   // stream of the direct levels
-    if (fuse) {           // side stream: after its memset, once the staged gradients (and gmax) exist
+    // two-stream form without the fused count: the direct levels (LDS bound) follow the count + scans on the side
+    // stream and run beside the scatter pass (write bound) instead of in front of it
+    const bool direct_side = ss && !fuse && need_T && !staged && whole.ngroups > 0 && whole.nbl > 0 &&
+                             g_bwd_direct_side.load() != 0 && g_bwd_groups.load() <= 1;
+    if (direct_side) {
+        hipError_t e = hipEventRecord(ss->staged, s);
+        if (e != hipSuccess) return e;
+    }
+    if (fuse || direct_side) {   // side stream: after its memset, once the staged gradients (and gmax) exist
         hipError_t e = hipStreamWaitEvent(ss->stream, ss->staged, 0);
         if (e != hipSuccess) return e;
         ds = ss->stream;
     }
     if (whole.ngroups > 0) {
-        if (zero_table && ss && !fuse) {
+        if (zero_table && ss && !fuse && !direct_side) {
             hipError_t e = hipStreamWaitEvent(s, ss->zeroed, 0);
             if (e != hipSuccess) return e;
         }
@@ -1340,7 +1388,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         const dim3 grid(bpg, plan.ngroups);
         // a row receives at most (samples walked by one workgroup) x (corners) contributions
-        const int headroom = use_fx ? fx_headroom(((uint64_t)n / bpg + kConsumeThreads) * (1u << DIM)) : -1;
+        const int headroom = (use_fx && need_T) ? fx_headroom(((uint64_t)n / bpg + kConsumeThreads) * (1u << DIM)) : -1;
         if (need_T && use_fx)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, true>), grid, dim3(kConsumeThreads),
                                acc_bytes, ds, lt, plan, first_idx, coords, w.gT, acc, n, w.gmax, headroom);
@@ -1359,6 +1407,10 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     }
     if (fuse) {   // direct levels (and the table zeroing before them) join the caller's stream before the consume pass
         hipError_t e = hipEventRecord(ss->join, ss->stream);
+        if (e != hipSuccess) return e;
+    }
+    if (direct_side) {
+        hipError_t e = hipEventRecord(ss->done, ss->stream);
         if (e != hipSuccess) return e;
     }
     if (whole.nbl == 0) return hipSuccess;
@@ -1399,8 +1451,9 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             while (q1 < plan.nbl && (acc_w < target || g + 1 == G)) acc_w += weight[q1++];
             spent += acc_w;
             const dim3 grid(plan.num_tiles, q1 - q0);
-            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,
-                               w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), (int64_t)0, n, n, q0);
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), grid, dim3(kBinThreads), stage, s, lt, plan, coords,
+                               w.gT, w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), (int64_t)0, n, n, q0, q1 - q0,
+                               (uint32_t *)nullptr);
             SHACIRA_CHECK_LAUNCH();
             hipError_t e = hipEventRecord(ss->group, s);
             if (e != hipSuccess) return e;
@@ -1432,13 +1485,25 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                                w.unit_desc, plan.total_buckets, plan.chunk, plan);
             SHACIRA_CHECK_LAUNCH();
         }
-        hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>), grid, dim3(kBinThreads), stage, s, lt, plan, coords, w.gT,
-                           w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n, 0u);
+        if (rows_mode) {   // 1-D grid, XCD-affine numbering (see the kernel)
+            const uint32_t per_xcd = (plan.num_tiles + 7) / 8;
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), dim3(8u * per_xcd * plan.nbl), dim3(kBinThreads), stage,
+                               s, lt, plan, coords, static_cast<const float *>(grad_out), w.cnt, w.base,
+                               reinterpret_cast<Item<F> *>(w.items), s0, hi, n, 0u, plan.nbl, use_fx ? w.gmax : nullptr);
+        } else {
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), grid, dim3(kBinThreads), stage, s, lt, plan, coords,
+                               w.gT, w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n, 0u, plan.nbl,
+                               (uint32_t *)nullptr);
+        }
         SHACIRA_CHECK_LAUNCH();
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NP;
         const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + plan.total_buckets + 1;
         if (fuse) {
             hipError_t e = hipStreamWaitEvent(s, ss->join, 0);
+            if (e != hipSuccess) return e;
+        }
+        if (direct_side) {
+            hipError_t e = hipStreamWaitEvent(s, ss->done, 0);
             if (e != hipSuccess) return e;
         }
         hipError_t e = consume(plan, max_units, 0u, plan.total_buckets, multi ? 1 : 0, s);
@@ -1479,10 +1544,14 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, true>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2, false>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, false>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4>), (size_t)kTile * 2 * (sizeof(Item<4>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, false>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, true>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, false>), (size_t)kTile * 2 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, true>), (size_t)kTile * 2 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, false>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, true>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, false>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, true>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
         return attr_err;
     });
     if (attr_err != hipSuccess) return attr_err;

@@ -248,6 +248,28 @@ def test_backward_side_stream_fork(dev, name):
         _lib.set_option("bwd_fork", 1)
 
 
+@pytest.mark.parametrize("name", ["D", "Bp"])
+@pytest.mark.parametrize("option,value", [("bwd_rows", 2), ("bwd_groups", 3), ("bwd_direct_side", 1)])
+def test_backward_experiment_hooks_keep_the_gradient(dev, name, option, value):
+    """The measured-and-kept-off orderings of the binned backward (scatter straight from grad_output on an XCD-affine grid;
+    level groups pipelined over two streams; direct levels beside the scatter pass) give the oracle's gradient too."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw = CONFIGS[name]
+    N = (1 << 18) + 333
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, N, seed=23)
+    tc, tg, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(go).to(dev), torch.from_numpy(first).to(dev)
+    ref = oc.backward(coords, go, (T, 2), first, res, bw)
+    default = _lib.get_option(option)
+    try:
+        _lib.set_option(option, value)
+        assert _lib.get_option(option) == value
+        got = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2).cpu().numpy()
+    finally:
+        _lib.set_option(option, default)
+    _assert_grad_close(got, ref, first, sizes)
+
+
 @pytest.mark.parametrize("n", [20_011, (1 << 18) + 5])
 def test_max_levels_and_wide_features(dev, n):
     """SHACIRA_MAX_LODS = 32 levels with F = 4 (largest staging tiles of the transposing passes), 3-D and 2-D; the
