@@ -430,14 +430,15 @@ class _AnalyticNef:
 
 def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwidth=19, max_grid_res=2048,
              num_lods=16, blas_level=5, prune_every=100, val_rays=8192, hidden_dim=64, latent=False,
-             entropy_reg=1.0e-4):
+             entropy_reg=1.0e-4, feature_dim=2):
     """NeRF-style fit of the analytic scene through the full pipeline the reference runs per step
     (multiview_trainer.py:88-150): ray marching on the occupancy grid ('ray' sampler) -> hash-grid lookup -> density /
     colour decoders -> volume integration -> L1 to the target pixels -> Adam; occupancy pruned every `prune_every` steps.
     Targets are rendered from the closed-form scene by the same tracer with 4x the samples.
     `latent=True`: the compressed variant the reference's nerf_lego.yaml trains -- a 3-D LatentGrid (latent_dim 1, SGA
     warm-up with temperature 1.0 until decay_period 0.9, entropy model with one layer, lambda = `entropy_reg`); the
-    result then also carries the size estimate and the bytes of the entropy-coded model file.
+    result then also carries the size estimate and the bytes of the entropy-coded model file. nerf_lego.yaml's shape is
+    feature_dim=4, num_lods=24, max_grid_res=512, hidden_dim=128 (tools/lego_fit.py).
     Returns dict(psnr on held-out rays, ms_per_step, samples_per_step)."""
     import time
     from .optim import FusedAdam
@@ -455,7 +456,7 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
                     clamp_weights=0.0, num_decoders=1, alpha_std=1.0)
         cent = dict(num_prob_layers=1, entropy_reg=entropy_reg, entropy_reg_end=entropy_reg,
                     entropy_reg_sched="cosine", noise_freq=1)
-        grid = LatentGrid.from_geometric(feature_dim=2, num_lods=num_lods, latent_dim=1, multiscale_type="cat",
+        grid = LatentGrid.from_geometric(feature_dim=feature_dim, num_lods=num_lods, latent_dim=1, multiscale_type="cat",
                                          resolution_dim=3, feature_std=0.02, feature_bias=0.0,
                                          codebook_bitwidth=codebook_bitwidth, min_grid_res=16,
                                          max_grid_res=max_grid_res, blas_level=blas_level, init_grid="normal",
@@ -464,7 +465,7 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
                                            {"temperature": cdec["temperature"], "decay_period": cdec["decay_period"]})
         grid.device_noise = True   # 6.1 M uniforms per step: drawn on the device (the reference draws on the host + H2D)
     else:
-        grid = HashGrid.from_geometric(feature_dim=2, num_lods=num_lods, multiscale_type="cat", resolution_dim=3,
+        grid = HashGrid.from_geometric(feature_dim=feature_dim, num_lods=num_lods, multiscale_type="cat", resolution_dim=3,
                                        feature_std=0.01, codebook_bitwidth=codebook_bitwidth, min_grid_res=16,
                                        max_grid_res=max_grid_res, blas_level=blas_level)
     nef = NeuralRadianceField(grid, view_embedder="positional", view_multires=4, hidden_dim=hidden_dim, num_layers=1,
