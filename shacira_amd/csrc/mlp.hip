@@ -259,8 +259,32 @@ __global__ __launch_bounds__(256) void mlp_finish_kernel(const double *__restric
 }
 
 
+// Same sums for long parameter vectors (the width-128 decoders: 22 K parameters x 256 partial rows): a workgroup owns 64
+// consecutive parameters, 16 row groups x 64 columns, so every load instruction reads 512 contiguous bytes of one partial
+// row (the kernel above reads one double per 180 KB stride). Fixed order: rows r, r + 16, ... per group, then the groups.
+__global__ __launch_bounds__(1024) void mlp_finish_cols_kernel(const double *__restrict__ partials, int nblocks, int n,
+                                                               float *__restrict__ out) {
+    __shared__ double s_g[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + c;
+    double v = 0.0;
+    if (q < n)
+        for (int b = g; b < nblocks; b += 16) v += partials[(size_t)b * n + q];
+    s_g[g][c] = v;
+    __syncthreads();
+    if (g == 0 && q < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s_g[k][c];
+        out[q] = (float)t;
+    }
+}
+
 hipError_t mlp_finish_launch(const double *partials, int nblocks, int n, float *out, hipStream_t s) {
-    hipLaunchKernelGGL(mlp_finish_kernel, dim3(n), dim3(256), 0, s, partials, nblocks, n, out);
+    if (n >= 4096)
+        hipLaunchKernelGGL(mlp_finish_cols_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, partials, nblocks, n, out);
+    else
+        hipLaunchKernelGGL(mlp_finish_kernel, dim3(n), dim3(256), 0, s, partials, nblocks, n, out);
     return hipGetLastError();
 }
 
@@ -300,8 +324,7 @@ static hipError_t mlp_run(bool bwd, int64_t N, const float *x, const float *para
                        params, gy, gx, partials, N, tpb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mlp_finish_kernel, dim3(S::n_params), dim3(256), 0, s, partials, (int)blocks, S::n_params, gparams);
-    return hipGetLastError();
+    return mlp_finish_launch(partials, (int)blocks, S::n_params, gparams, s);
 }
 
 typedef hipError_t (*mlp_fn)(bool, int64_t, const float *, const float *, float *, const float *, float *, float *,
