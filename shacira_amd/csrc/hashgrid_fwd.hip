@@ -341,6 +341,53 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
         const uint32_t ux = (uint32_t)p[0] + (uint32_t)dx;
         const uint32_t r = (uint32_t)res;
         const int64_t base = (int64_t)first_idx[l];
+        if constexpr (DIM == 3 && F == 2 && sizeof(T) == 4) {
+            if (dense) {
+                // Dense level: rows x and x + 1 are neighbours in memory, so ONE 16-byte load (8-byte aligned) fetches the
+                // x-pair. The lane pair splits y instead of x: lane dx takes y + dx, two loads (z, z + 1) instead of four;
+                // the partner's four pieces come over DPP and lane 0 runs the corner sum in the reference's order.
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(8)));
+                float w4[2][4];
+#pragma unroll
+                for (int dz = 0; dz < 2; ++dz) {
+                    const uint32_t row = (uint32_t)p[0] + ((uint32_t)p[1] + (uint32_t)dx) * r + ((uint32_t)p[2] + dz) * r * r;
+                    const int64_t grow = base + (int64_t)row;
+                    if (live && (uint64_t)(grow + 1) < (uint64_t)lt.table_rows) {
+                        const f32x4u q4 = *reinterpret_cast<const f32x4u *>(table + grow * 2);
+                        w4[dz][0] = q4.x; w4[dz][1] = q4.y; w4[dz][2] = q4.z; w4[dz][3] = q4.w;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) w4[dz][c] = 0.0f;
+                        if (live && (uint64_t)grow < (uint64_t)lt.table_rows) {   // last row of the table: x only
+                            w4[dz][0] = Scalar<T>::load(table + grow * 2);
+                            w4[dz][1] = Scalar<T>::load(table + grow * 2 + 1);
+                        }
+                    }
+                }
+                float o4[2][4];
+#pragma unroll
+                for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        o4[dz][c] = __builtin_bit_cast(
+                            float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, w4[dz][c]), 0xB1, 0xF, 0xF, true));
+                if (dx == 0) {
+                    float acc[F];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {   // corner k: bit 2 -> x, bit 1 -> y, bit 0 -> z (the reference's order)
+                        const int kx = k >> 2, dy = (k >> 1) & 1, dz = k & 1;
+                        const float w = ((kx ? f[0] : g[0]) * (dy ? f[1] : g[1])) * (dz ? f[2] : g[2]);
+#pragma unroll
+                        for (int j = 0; j < F; ++j) {
+                            const float tv = dy ? o4[dz][2 * kx + j] : w4[dz][2 * kx + j];
+                            acc[j] = (k == 0) ? tv * w : fmaf(tv, w, acc[j]);
+                        }
+                    }
+                    store_row<T, F>(reinterpret_cast<T *>(my + (size_t)sl * pitch) + l * F, acc);
+                }
+                continue;
+            }
+        }
         float v[NH][F];
 #pragma unroll
         for (int q = 0; q < NH; ++q) {
