@@ -1012,3 +1012,45 @@ def test_tiled_forward_other_shapes(dev, dim, F, dtype):
     finally:
         _lib.set_option("fwd_variant", -1)
         _lib.set_option("tiled_lc_fwd", -1)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes_against_the_oracle(dev, seed):
+    """Randomised sweep over the shape space the operators accept (dimension, level count, resolution range, table
+    bitwidth, feature width, batch size incl. ragged tails): forward bit-identical to the oracle on the default path AND on
+    the cell-sorted path forced on (every coarse / fine split), gradients within 1e-5 of each level's largest value."""
+    from shacira_amd import _lib
+    ops = _ops()
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.choice([2, 3]))
+    L = int(rng.integers(1, 25))
+    lo = int(rng.integers(2, 33))
+    hi = int(lo * rng.uniform(1.0, 40.0)) + 1
+    res = geo(lo, hi, L) if L > 1 else [lo]
+    bw = int(rng.integers(4, 20))
+    F = int(rng.choice([2, 4]))
+    N = int(rng.choice([1, 63, 257, 4_097, 30_011, 66_000]))
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, N, F=F, seed=seed)
+    tc, tt, tf = (torch.from_numpy(a).to(dev) for a in (coords, table, first))
+    tg = torch.from_numpy(go).to(dev)
+    fwd = ops.hashgrid_interpolate_cuda if dim == 3 else ops.hashgrid_interpolate2d_cuda
+    ref = oc.forward(coords, table, first, res, bw)
+    assert np.array_equal(fwd(tc, tt, tf, res, bw).cpu().numpy(), ref), (dim, res, bw, F, N)
+    _lib.set_option("fwd_variant", 8)
+    try:
+        for lc in (-1, 0, L // 2, L):
+            _lib.set_option("tiled_lc_fwd", lc)
+            assert np.array_equal(fwd(tc, tt, tf, res, bw).cpu().numpy(), ref), (dim, res, bw, F, N, lc)
+    finally:
+        _lib.set_option("fwd_variant", -1)
+        _lib.set_option("tiled_lc_fwd", -1)
+    got = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, F).cpu().numpy()
+    ref_g = oc.backward(coords, go, (T, F), first, res, bw)
+    _assert_grad_close(got, ref_g, first, sizes)
+    for variant in (0, 1):   # atomic form and the binned form forced (any batch size)
+        _lib.set_option("bwd_variant", variant)
+        try:
+            got = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, F).cpu().numpy()
+        finally:
+            _lib.set_option("bwd_variant", -1)
+        _assert_grad_close(got, ref_g, first, sizes)
