@@ -1054,3 +1054,30 @@ def test_random_shapes_against_the_oracle(dev, seed):
         finally:
             _lib.set_option("bwd_variant", -1)
         _assert_grad_close(got, ref_g, first, sizes)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_large_batches(dev, seed):
+    """The same sweep at batch sizes that take the large-batch machinery (>= 2^18 samples: cell-sorted forward by the
+    automatic rule, side-stream fork, compact items, fixed-point images), fp32 and fp16 tables."""
+    ops = _ops()
+    rng = np.random.default_rng(5000 + seed)
+    dim = int(rng.choice([2, 3]))
+    L = int(rng.integers(4, 20))
+    res = geo(int(rng.integers(4, 20)), int(rng.integers(256, 2049)), L)
+    bw = int(rng.integers(14, 20))
+    F = int(rng.choice([2, 4]))
+    N = int(rng.choice([(1 << 18) + 5, 400_003, (1 << 19) + 77]))
+    dtype = torch.float16 if seed % 3 == 2 else torch.float32
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, N, F=F, seed=seed)
+    stored = table.astype(np.float16).astype(np.float32) if dtype == torch.float16 else table
+    go_s = go.astype(np.float16).astype(np.float32) if dtype == torch.float16 else go
+    tc, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(first).to(dev)
+    tt, tg = torch.from_numpy(table).to(dev).to(dtype), torch.from_numpy(go).to(dev).to(dtype)
+    fwd = ops.hashgrid_interpolate_cuda if dim == 3 else ops.hashgrid_interpolate2d_cuda
+    ref = oc.forward(coords, stored, first, res, bw)
+    want = ref.astype(np.float16) if dtype == torch.float16 else ref
+    assert np.array_equal(fwd(tc, tt, tf, res, bw).cpu().numpy(), want), (dim, res, bw, F, N, dtype)
+    got = ops.hashgrid_backward(dim, tc, tg, T, dtype, tf, res, bw, F).float().cpu().numpy()
+    ref_g = oc.backward(coords, go_s, (T, F), first, res, bw)
+    _assert_grad_close(got, ref_g, first, sizes, rtol=RTOL if dtype == torch.float32 else 2e-3)
