@@ -51,7 +51,7 @@ struct BinLevel {
     uint32_t shift;     // hashed: log2(BR)
     int32_t dgroup;     // >= 0: "direct" level (fits one LDS image): index of its group; -1: binned level
     uint32_t drow0;     // direct: first row of the level inside its group's LDS image
-    uint32_t compact;   // 1: dense 3-D level binned by z-slab with ONE 32-byte item per sample (all 8 corners)
+    uint32_t compact;   // 1: dense 3-D level binned by z-slab with ONE two-slot item per sample (all 8 corners): 32 B (F = 2), 48 B (F = 4)
     uint32_t slab;      // compact: base-cell planes per bucket (its image holds slab + 1 planes)
 };
 
@@ -654,6 +654,20 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                         s_items[pos + 1] = it2;
                         s_bucket[pos] = (uint8_t)ps[u][q].bucket;
                         s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
+                    } else if constexpr (F == 4) {   // two 24-byte slots: {key, fx, fy, fz, g0, g1} {0, g2, g3, -, -, -}
+                        it.a[0] = fyz[u][0];
+                        it.a[1] = fyz[u][1];
+                        it.a[2] = g[u][0];
+                        it.a[3] = g[u][1];
+                        s_items[pos] = it;
+                        Item<F> it2;
+                        it2.key = 0;
+                        it2.fx = g[u][2];
+                        it2.a[0] = g[u][3];
+                        it2.a[1] = 0.0f; it2.a[2] = 0.0f; it2.a[3] = 0.0f;
+                        s_items[pos + 1] = it2;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                        s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
                     }
                 } else {
 #pragma unroll
@@ -767,9 +781,10 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
 
     const uint64_t begin = d.begin, end = d.end;
-    if constexpr (F == 2) {
+    if constexpr (F == 2 || F == 4) {
         if (bl.compact) {
-            // one sample per two slots: {local base row | valid, fx, fy, fz} {-, g0, g1, -}; all 8 corners land here
+            // one sample per two slots: F = 2 {local base row | valid, fx, fy, fz} {-, g0, g1, -}; F = 4 {.., fx, fy, fz, g0, g1}
+            // {-, g2, g3, ...}; all 8 corners land here
             constexpr int UC = 2;
             const uint32_t r2 = r1 * r1;
             for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
@@ -790,19 +805,22 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
                     const uint32_t base_row = ia[u].key & 0x1FFFu;
                     const float fxx = ia[u].fx, fyy = ia[u].a[0], fzz = ia[u].a[1];
                     const float gxx = 1.0f - fxx, gyy = 1.0f - fyy, gzz = 1.0f - fzz;
-                    const float g0 = ib[u].fx, g1 = ib[u].a[0];
+                    float gg[F];
+                    if constexpr (F == 2) {
+                        gg[0] = ib[u].fx; gg[1] = ib[u].a[0];
+                    } else {
+                        gg[0] = ia[u].a[2]; gg[1] = ia[u].a[3]; gg[2] = ib[u].fx; gg[3] = ib[u].a[0];
+                    }
                     const float wxy[4] = {gxx * gyy, gxx * fyy, fxx * gyy, fxx * fyy};   // reference order: (x * y) * z
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const uint32_t row = base_row + ((c >> 2) & 1) + ((c >> 1) & 1) * r1 + (c & 1) * r2;
                         const float w = wxy[c >> 1] * ((c & 1) ? fzz : gzz);
                         if (row >= nrows) continue;   // cannot happen for in-range cells; keeps the image safe
-                        if (FX && fx.fixed) {
-                            atomicAdd(&s_fix[row * 2 + 0], fx_encode(g0 * w, fx.scale));
-                            atomicAdd(&s_fix[row * 2 + 1], fx_encode(g1 * w, fx.scale));
-                        } else {
-                            atomicAdd(&s_acc[row * 2 + 0], (double)(g0 * w));
-                            atomicAdd(&s_acc[row * 2 + 1], (double)(g1 * w));
+#pragma unroll
+                        for (int j = 0; j < F; ++j) {
+                            if (FX && fx.fixed) atomicAdd(&s_fix[row * F + j], fx_encode(gg[j] * w, fx.scale));
+                            else atomicAdd(&s_acc[row * F + j], (double)(gg[j] * w));
                         }
                     }
                 }
@@ -1034,7 +1052,7 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
             // Compact mode (3-D, F = 2): when an image holds at least two z-planes of the level, bucket = slab of base
             // cells in z and the image = that slab plus one halo plane, so all 8 corners of a sample land in ONE
             // bucket and the sample travels as one 32-byte item instead of four 16-byte pair items.
-            const uint64_t planes = (dim == 3 && F == 2 && g_bwd_compact.load() != 0) ? BR / (res * res) : 0;
+            const uint64_t planes = (dim == 3 && (F == 2 || F == 4) && g_bwd_compact.load() != 0) ? BR / (res * res) : 0;
             if (planes >= 2 && res >= 3 && bl.used > BR) {
                 const uint32_t slab = (uint32_t)planes - 1;
                 const uint32_t nbz = ((uint32_t)res - 2u) / slab + 1u;      // base cells: z in [0, res - 2]

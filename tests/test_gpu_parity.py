@@ -865,22 +865,24 @@ def test_level_ranges_share_the_fixed_point_scales(dev):
         np.testing.assert_allclose(full[lo:hi].cpu().numpy(), ref[lo:hi], rtol=RTOL, atol=RTOL * scale)
 
 
+@pytest.mark.parametrize("F", [2, 4])
 @pytest.mark.parametrize("n", [40_000, 1 << 17])
-def test_compact_dense_items_nerf_lego_table(dev, n):
-    """nerf_lego.yaml's table (3-D, 24 levels, res 16..512, bw 19): levels up to res 64 are dense and travel as ONE
-    32-byte item per sample in z-slab buckets with a halo plane (option bwd_compact); same gradient as the pair-item
-    path and as the oracle, small batch (64 KiB images) and large (128 KiB, fixed point)."""
+def test_compact_dense_items_nerf_lego_table(dev, n, F):
+    """nerf_lego.yaml's table (3-D, 24 levels, res 16..512, bw 19; the file's own feature_dim is 4): dense levels whose image
+    holds two z-planes (res <= 64 for F = 2, <= 45 for F = 4) travel as ONE two-slot item per sample (32 / 48 bytes) in
+    z-slab buckets with a halo plane (option bwd_compact); same gradient as the pair-item path and as the oracle, small
+    batch (64 KiB images) and large (128 KiB, fixed point)."""
     from shacira_amd import _lib
     ops = _ops()
     dim, bw = 3, 19
     res = geo(16, 512, 24)
-    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, seed=41)
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, F=F, seed=41)
     tc, tg, tf = (torch.from_numpy(a).to(dev) for a in (coords, go, first))
-    ref = oc.backward(coords, go, (T, 2), first, res, bw)
+    ref = oc.backward(coords, go, (T, F), first, res, bw)
     try:
         for compact in (1, 0):
             _lib.set_option("bwd_compact", compact)
-            got = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2).cpu().numpy()
+            got = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, F).cpu().numpy()
             for l in range(len(res)):
                 lo, hi = int(first[l]), int(first[l]) + sizes[l]
                 np.testing.assert_allclose(got[lo:hi], ref[lo:hi], rtol=RTOL, atol=RTOL * np.abs(ref[lo:hi]).max(),
