@@ -746,6 +746,47 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
     }
 }
 
+// ------------------------------------------------------------------------------------------------- table zeroing
+// at::zeros_like of the reference, minus what the consume pass overwrites anyway: the rows of a HASHED binned level are
+// covered by its buckets, and a bucket with exactly one work unit writes all its rows with plain stores. So only the
+// other rows are zeroed up front (S1: 6.6 of 48.8 MB; the table-sized memset was 13 of config D's 93 us and 40 MB of the
+// write-bound traffic of every call) and the buckets that turn out to have 0 or several units are zeroed once the bucket
+// scan knows them. grid (x, num_lods): segment l = rows [first_idx[l], first_idx[l + 1]) (segment 0 starts at row 0).
+__global__ __launch_bounds__(256) void zero_unowned_rows_kernel(float *__restrict__ acc,
+                                                                const int32_t *__restrict__ first_idx, LevelTable lt,
+                                                                BinPlan plan) {
+    const int l = blockIdx.y, F = lt.feature_dim;
+    const int64_t level0 = first_idx[l];
+    const int64_t start = (l == 0) ? 0 : level0;
+    const int64_t end = (l + 1 < lt.num_lods) ? (int64_t)first_idx[l + 1] : lt.table_rows;
+    const BinLevel bl = plan.lv[l];
+    const bool covered = bl.nb > 0 && bl.dgroup < 0 && lt.dense[l] == 0;   // hashed + binned: rows [level0, level0 + used)
+    // two plain ranges around the covered rows: [start, hole_lo) and [hole_hi, end)
+    const int64_t hole_lo = covered ? level0 : end;
+    int64_t hole_hi = covered ? level0 + (int64_t)bl.used : end;
+    if (hole_hi > end) hole_hi = end;
+    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (int64_t e = start * F + t0; e < hole_lo * F; e += stride) acc[e] = 0.0f;
+    for (int64_t e = hole_hi * F + t0; e < end * F; e += stride) acc[e] = 0.0f;
+}
+
+// after the bucket scan: hashed buckets with 0 units (never written) or several (they add atomically) are zeroed now.
+// grid (kMaxLevelBuckets, nbl)
+__global__ __launch_bounds__(256) void zero_odd_buckets_kernel(float *__restrict__ acc, const int32_t *__restrict__ first_idx,
+                                                               const uint32_t *__restrict__ unit_first, LevelTable lt,
+                                                               BinPlan plan) {
+    const uint32_t lvl = plan.blevel[blockIdx.y];
+    const BinLevel bl = plan.lv[lvl];
+    const uint32_t b = blockIdx.x;
+    if (b >= bl.nb || lt.dense[lvl] != 0) return;
+    const uint32_t gb = bl.bucket0 + b;
+    if (unit_first[gb + 1] - unit_first[gb] == 1u) return;
+    const uint32_t row0 = b * bl.rows_pb;
+    const uint32_t nrows = (bl.used - row0 < bl.rows_pb) ? (bl.used - row0) : bl.rows_pb;
+    float *dst = acc + ((int64_t)first_idx[lvl] + row0) * lt.feature_dim;
+    for (uint32_t e = threadIdx.x; e < nrows * (uint32_t)lt.feature_dim; e += 256) dst[e] = 0.0f;
+}
+
 // ------------------------------------------------------------------------------------------------- pass C
 template <int F, bool FX>
 __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable lt, BinPlan plan,
@@ -1288,14 +1329,29 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     const int fuse_opt = g_bwd_fuse.load();
     const bool fuse = can_fork && need_T && !staged &&
                       (fuse_opt == 2 || (fuse_opt == 1 && n * ((int64_t)1 << (DIM - 1)) <= ((int64_t)1 << 21)));
+    // selective zeroing (see zero_unowned_rows_kernel): a single sub-batch whose plan has hashed binned levels
+    bool any_hashed = false;
+    for (uint32_t q = 0; q < whole.nbl; ++q) any_hashed = any_hashed || lt.dense[whole.blevel[q]] == 0;
+    const bool selective = zero_table && !multi && any_hashed && g_bwd_selective_zero.load() != 0;
+    auto zero_acc = [&](hipStream_t zs) -> hipError_t {
+        if (!selective)
+            return hipMemsetAsync(acc, 0, (size_t)lt.table_rows * lt.feature_dim * sizeof(float), zs);
+        hipLaunchKernelGGL(zero_unowned_rows_kernel, dim3(256, (uint32_t)L), dim3(256), 0, zs, acc, first_idx, lt, whole);
+        return hipGetLastError();
+    };
+    auto zero_odd_buckets = [&](const BinPlan &plan, hipStream_t zs) -> hipError_t {   // after bin_scan_buckets_kernel
+        if (!selective) return hipSuccess;
+        hipLaunchKernelGGL(zero_odd_buckets_kernel, dim3(kMaxLevelBuckets, plan.nbl), dim3(256), 0, zs, acc, first_idx,
+                           w.unit_first, lt, plan);
+        return hipGetLastError();
+    };
     if (can_fork) {
         hipError_t e = side_stream(&ss);
         if (e != hipSuccess) return e;
         if ((e = hipEventRecord(ss->fork, s)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(ss->stream, ss->fork, 0)) != hipSuccess) return e;
         if (zero_table) {   // at::zeros_like of the reference: off the critical path, next to the transpose
-            e = hipMemsetAsync(acc, 0, (size_t)lt.table_rows * lt.feature_dim * sizeof(float), ss->stream);
-            if (e != hipSuccess) return e;
+            if ((e = zero_acc(ss->stream)) != hipSuccess) return e;
             if ((e = hipEventRecord(ss->zeroed, ss->stream)) != hipSuccess) return e;
         }
         if (!fuse) {
@@ -1311,11 +1367,12 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, ss->stream, w.totals, w.base,
                                w.unit_first, w.unit_desc, plan.total_buckets, plan.chunk, plan);
             SHACIRA_CHECK_LAUNCH();
+            if ((e = zero_odd_buckets(plan, ss->stream)) != hipSuccess) return e;
             if ((e = hipEventRecord(ss->join, ss->stream)) != hipSuccess) return e;
         }
     }
     if (zero_table && !ss) {
-        hipError_t e = hipMemsetAsync(acc, 0, (size_t)lt.table_rows * lt.feature_dim * sizeof(float), s);
+        hipError_t e = zero_acc(s);
         if (e != hipSuccess) return e;
     }
     // fixed-point images pay off once the accumulation itself dominates; small batches are bound by fixed costs and
@@ -1353,6 +1410,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
                            w.unit_desc, plan.total_buckets, plan.chunk, plan);
         SHACIRA_CHECK_LAUNCH();
+        if ((e = zero_odd_buckets(plan, s)) != hipSuccess) return e;
     } else if (need_T && !staged) {
         const int t_lb = stage_all ? 0 : lt.level_begin, t_le = stage_all ? L : lt.level_end;
         // pass T over the whole batch (also gathers gmax)
@@ -1502,6 +1560,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
                                w.unit_desc, plan.total_buckets, plan.chunk, plan);
             SHACIRA_CHECK_LAUNCH();
+            hipError_t ze = zero_odd_buckets(plan, s);
+            if (ze != hipSuccess) return ze;
         }
         if (rows_mode) {   // 1-D grid, XCD-affine numbering (see the kernel)
             const uint32_t per_xcd = (plan.num_tiles + 7) / 8;

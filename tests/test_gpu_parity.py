@@ -1083,3 +1083,29 @@ def test_random_shapes_large_batches(dev, seed):
     got = ops.hashgrid_backward(dim, tc, tg, T, dtype, tf, res, bw, F).float().cpu().numpy()
     ref_g = oc.backward(coords, go_s, (T, F), first, res, bw)
     _assert_grad_close(got, ref_g, first, sizes, rtol=RTOL if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("n", [50_000, (1 << 18) + 9])
+@pytest.mark.parametrize("selective", [1, 0])
+def test_zeroing_with_empty_and_overfull_buckets(dev, n, selective):
+    """The backward zeroes only rows its last pass does not overwrite (option bwd_selective_zero). Half of the samples sit on
+    ONE point (its hashed buckets receive several work units -> atomic flush), the rest in a corner of the cube (most hashed
+    buckets stay empty -> no unit at all): with the output buffer pre-filled with garbage every row must still come out as the
+    oracle's, zeros included."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, seed=61)
+    coords[: n // 2] = np.float32(0.3217)
+    coords[n // 2:] = coords[n // 2:] * np.float32(0.01) - np.float32(0.9)
+    tc, tg, tf = (torch.from_numpy(a).to(dev) for a in (coords, go, first))
+    out = torch.full((T, 2), 7.0, device=dev)
+    _lib.set_option("bwd_selective_zero", selective)
+    try:
+        ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, out=out)
+    finally:
+        _lib.set_option("bwd_selective_zero", 1)
+    ref = oc.backward(coords, go, (T, 2), first, res, bw)
+    got = out.cpu().numpy()
+    assert np.array_equal(got == 0.0, ref == 0.0) or np.abs(got[ref == 0.0]).max() < 1e-30   # untouched rows are exactly zero
+    _assert_grad_close(got, ref, first, sizes)
