@@ -1109,3 +1109,40 @@ def test_zeroing_with_empty_and_overfull_buckets(dev, n, selective):
     got = out.cpu().numpy()
     assert np.array_equal(got == 0.0, ref == 0.0) or np.abs(got[ref == 0.0]).max() < 1e-30   # untouched rows are exactly zero
     _assert_grad_close(got, ref, first, sizes)
+
+
+def test_forward_and_backward_replay_from_one_graph(dev):
+    """A training step's operator pair captured ONCE into a HIP graph (cell-sorted forward: sort + fine + rows kernels;
+    forked backward: side stream, events, selective zeroing) and replayed on NEW coordinates and gradients written into the
+    same buffers: every data-dependent quantity (sort offsets, bucket counts, work units, fixed-point scales) is recomputed
+    on the device, so the replay must match the oracle on the new data."""
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    N = (1 << 19) + 100
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, N, seed=71)
+    tc, tt, tg, tf = (torch.from_numpy(a).to(dev) for a in (coords, table, go, first))
+    out = torch.empty((T, 2), device=dev)
+    ws = ops.backward_workspace(dim, N, T, torch.float32, res, bw, 2, dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):          # one eager call creates the library's side-stream objects / kernel attributes
+        ops.hashgrid_interpolate_cuda(tc, tt, tf, res, bw)
+        ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, out=out, workspace=ws)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        feats = ops.hashgrid_interpolate_cuda(tc, tt, tf, res, bw)
+        ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, out=out, workspace=ws)
+    rng = np.random.default_rng(72)
+    coords2 = (rng.uniform(-1, 1, (N, dim)) ** 3).astype(np.float32)          # a different, clustered distribution
+    go2 = rng.standard_normal(go.shape).astype(np.float32) * 3.0
+    tc.copy_(torch.from_numpy(coords2))
+    tg.copy_(torch.from_numpy(go2))
+    out.fill_(-3.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    n_or = 1 << 16
+    ref_f = oc.forward(coords2[:n_or], table, first, res, bw)
+    assert np.array_equal(feats[:n_or].cpu().numpy(), ref_f)
+    ref_g = oc.backward(coords2, go2, (T, 2), first, res, bw)
+    _assert_grad_close(out.cpu().numpy(), ref_g, first, sizes)
