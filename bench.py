@@ -421,6 +421,28 @@ def main():
                                 f"({rec.get('kernel_source_hash')} != {kernel_source_hash()}): not attached")
         achieved = dom[2] * n_local / (dom[1] * 1e-3) / 1e9
         path_gbs = (b_fwd + b_bwd) * n_local / ((ms_fwd + ms_bwd) * 1e-3) / 1e9
+        # what this chip's memory system sustains on plain streams, measured in the same run (SURVEY 8d asks for the
+        # nominal AND the measured peak): a 1 GiB device-to-device copy (read + write), a fill (write only) and a
+        # reduction (read only), bytes moved / time. The nominal 8 TB/s stays the `peak` of the contract.
+        def stream_gbs(fn, nbytes, it=5):
+            fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(it):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return nbytes * it / (a.elapsed_time(b) * 1e-3) / 1e9
+        src = torch.empty(1 << 28, dtype=torch.float32, device=device).normal_()
+        dst = torch.empty_like(src)
+        measured = {"copy_read+write": stream_gbs(lambda: dst.copy_(src), 2 * src.numel() * 4),
+                    "write_only": stream_gbs(lambda: dst.fill_(1.0), src.numel() * 4),
+                    "read_only": stream_gbs(lambda: src.sum(), src.numel() * 4),
+                    "unit": "GB/s", "how": "torch copy_/fill_/sum over 1 GiB fp32, HIP events, 5 repetitions"}
+        del src, dst
+        if traffic is not None:
+            measured["operator_traffic_over_time_GBps"] = traffic / (dom[1] * 1e-3) / 1e9
         out = {
             "metric": "hash-grid samples/sec fwd+bwd (16 lvl, F=2)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -443,7 +465,8 @@ def main():
                          "algorithmic_bytes_per_launch": dom[2] * n_local,
                          "ms_per_launch": dom[1],
                          "fwd_bwd_path": {"achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS,
-                                          "bytes_per_sample": b_fwd + b_bwd}},
+                                          "bytes_per_sample": b_fwd + b_bwd},
+                         "measured_stream_rates": measured},
             "ms": {"forward": ms_fwd, "backward": ms_bwd, "allreduce": ms_ar,
                    "fwd+bwd_p10_p50_p90": [float(np.percentile(per_step, q)) for q in (10, 50, 90)],
                    "adam_table": ms_adam,
