@@ -7,7 +7,7 @@
 // it by "partition, then accumulate on chip":
 //
 //   pass T  transpose   grad_output [N, L*F] -> gT [L][N][F]            (coalesced both ways through LDS)
-//   pass A  count       per (level, tile of samples): how many items fall into each bucket  -> cnt[bucket][tile]
+//   pass A  count       per (level, tile of samples): how many items fall into each bucket  -> cnt[tile][bucket]
 //   pass S  scan        exclusive scans: per bucket over tiles, then over buckets; builds the consumer work list
 //   pass B  bin         recompute the corners, stage the tile's items in LDS sorted by bucket, write each bucket's
 //                       run to its exact slot in HBM with coalesced 16-byte stores
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kFuseThreads) void transpose_count_kernel(LevelTabl
     for (uint32_t k = threadIdx.x; k < plan.nbl * (uint32_t)kMaxLevelBuckets; k += kFuseThreads) {
         const uint32_t li = k / kMaxLevelBuckets, b = k % kMaxLevelBuckets;
         const BinLevel &bl = plan.lv[plan.blevel[li]];
-        if (b < bl.nb) cnt[(size_t)(bl.bucket0 + b) * plan.num_tiles + tile] = s_hist[li][b];
+        if (b < bl.nb) cnt[(size_t)tile * plan.total_buckets + bl.bucket0 + b] = s_hist[li][b];
     }
     if constexpr (GMAX) {
         if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x])
@@ -392,33 +392,43 @@ __global__ __launch_bounds__(kFuseThreads) void transpose_count_kernel(LevelTabl
 }
 
 // ------------------------------------------------------------------------------------------------- pass S
-// one wave per bucket: exclusive scan of cnt[bucket][0..num_tiles) in place; total -> totals[bucket]
-__global__ __launch_bounds__(64) void bin_scan_tiles_kernel(uint32_t *__restrict__ cnt, uint32_t *__restrict__ totals,
-                                                            uint32_t num_tiles) {
-    uint32_t *row = cnt + (size_t)blockIdx.x * num_tiles;
-    const uint32_t lane = threadIdx.x;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < num_tiles; base += 256) {   // 4 consecutive counters per lane and round
-        const uint32_t idx = base + lane * 4;
-        uint32_t v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (idx + k < num_tiles) ? row[idx + k] : 0u;
-        const uint32_t sum = (v[0] + v[1]) + (v[2] + v[3]);
-        uint32_t incl = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t n = __shfl_up(incl, off, 64);
-            if (lane >= (uint32_t)off) incl += n;
-        }
-        uint32_t run = carry + incl - sum;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (idx + k < num_tiles) row[idx + k] = run;
-            run += v[k];
-        }
-        carry += __shfl(incl, 63, 64);
+// cnt is TILE-major, cnt[tile][bucket] (a tile's counts of one level are contiguous: the count pass writes and the scatter
+// pass reads them as one 256-byte piece instead of one dword per 128-byte line). One workgroup per 16 buckets: thread =
+// (bucket, chunk of tiles), 64 chunks: per-chunk sums, prefix over the chunks, exclusive offsets in place; total ->
+// totals[bucket]. Every access is a 64-byte row piece shared by 16 lanes.
+constexpr int kScanWaves = 16, kScanBuckets = 16, kScanChunks = 64 * kScanWaves / kScanBuckets;
+__global__ __launch_bounds__(64 * kScanWaves) void bin_scan_tiles_kernel(uint32_t *__restrict__ cnt,
+                                                                          uint32_t *__restrict__ totals, uint32_t num_tiles,
+                                                                          uint32_t nbuckets) {
+    __shared__ uint32_t s_sum[kScanChunks][kScanBuckets];
+    const uint32_t bl = threadIdx.x % kScanBuckets, chunk = threadIdx.x / kScanBuckets;
+    const uint32_t gb = blockIdx.x * kScanBuckets + bl;
+    const bool ok = gb < nbuckets;
+    const uint32_t tpc = (num_tiles + kScanChunks - 1) / kScanChunks;
+    const uint32_t t0 = chunk * tpc < num_tiles ? chunk * tpc : num_tiles;
+    const uint32_t t1 = (t0 + tpc < num_tiles) ? t0 + tpc : num_tiles;
+    uint32_t sum = 0;
+    if (ok) {
+#pragma unroll 8
+        for (uint32_t t = t0; t < t1; ++t) sum += cnt[(size_t)t * nbuckets + gb];
     }
-    if (lane == 0) totals[blockIdx.x] = carry;
+    s_sum[chunk][bl] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+    for (uint32_t c = 0; c < (uint32_t)kScanChunks; ++c) {
+        const uint32_t v = s_sum[c][bl];
+        if (c < chunk) run += v;
+        total += v;
+    }
+    if (ok) {
+        for (uint32_t t = t0; t < t1; ++t) {
+            uint32_t *p = cnt + (size_t)t * nbuckets + gb;
+            const uint32_t v = *p;
+            *p = run;
+            run += v;
+        }
+        if (chunk == 0) totals[gb] = total;
+    }
 }
 
 // single block: bucket bases (exclusive scan of totals) and the consumer work list
@@ -629,7 +639,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     }
     if (threadIdx.x < bl.nb) {
         const size_t gb = bl.bucket0 + threadIdx.x;
-        s_gbase[threadIdx.x] = base[gb] + tile_off[gb * plan.num_tiles + tile];
+        s_gbase[threadIdx.x] = base[gb] + tile_off[(size_t)tile * plan.total_buckets + gb];
     }
     __syncthreads();
 #pragma unroll
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
     for (uint32_t bi = blockIdx.y; bi < plan.nbl; bi += gridDim.y) {
         const BinLevel bl = plan.lv[plan.blevel[bi]];
         for (uint32_t b = threadIdx.x; b < bl.nb; b += kBinThreads)
-            cnt[(size_t)(bl.bucket0 + b) * plan.num_tiles + tile] = s_hist[bi][b];
+            cnt[(size_t)tile * plan.total_buckets + bl.bucket0 + b] = s_hist[bi][b];
     }
 }
 
@@ -1361,8 +1371,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), count_grid(plan), dim3(kBinThreads), 0, ss->stream, lt,
                                plan, coords, w.cnt, (int64_t)0, n);
             SHACIRA_CHECK_LAUNCH();
-            hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, ss->stream, w.cnt,
-                               w.totals, plan.num_tiles);
+            hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3((plan.total_buckets + kScanBuckets - 1) / kScanBuckets), dim3(64 * kScanWaves), 0,
+                               ss->stream, w.cnt, w.totals, plan.num_tiles, plan.total_buckets);
             SHACIRA_CHECK_LAUNCH();
             hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, ss->stream, w.totals, w.base,
                                w.unit_first, w.unit_desc, plan.total_buckets, plan.chunk, plan);
@@ -1404,8 +1414,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         SHACIRA_CHECK_LAUNCH();
         hipError_t e;
         if ((e = hipEventRecord(ss->staged, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, s, w.cnt, w.totals,
-                           plan.num_tiles);
+        hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3((plan.total_buckets + kScanBuckets - 1) / kScanBuckets), dim3(64 * kScanWaves), 0, s,
+                           w.cnt, w.totals, plan.num_tiles, plan.total_buckets);
         SHACIRA_CHECK_LAUNCH();
         hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
                            w.unit_desc, plan.total_buckets, plan.chunk, plan);
@@ -1554,8 +1564,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), count_grid(plan), dim3(kBinThreads), 0, s, lt, plan,
                                coords, w.cnt, s0, hi);
             SHACIRA_CHECK_LAUNCH();
-            hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(plan.total_buckets), dim3(64), 0, s, w.cnt, w.totals,
-                               plan.num_tiles);
+            hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3((plan.total_buckets + kScanBuckets - 1) / kScanBuckets), dim3(64 * kScanWaves), 0, s,
+                               w.cnt, w.totals, plan.num_tiles, plan.total_buckets);
             SHACIRA_CHECK_LAUNCH();
             hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
                                w.unit_desc, plan.total_buckets, plan.chunk, plan);
