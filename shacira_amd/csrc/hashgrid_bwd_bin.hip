@@ -1334,11 +1334,12 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // levels; a call that reuses staged gradients counts + scans on the side stream instead.
     SideStream *ss = nullptr;
     const bool can_fork = whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 && n >= (1 << 18);   // a loss at 64 K and 128 K (also fused)
-    // measured (tools/fuse_check.py): fused wins by 4-9 % up to 2^19 3-D samples, loses 3-4 % at 2^20 ("bwd_fuse": 0 = never,
-    // 1 = by that rule, 2 = always)
+    // measured (tools/fuse_check.py, re-measured at the end of round 2): 3-D: fused wins by 2-4 % up to 786 K samples and
+    // loses 3 % at 2^20; 2-D: fused wins by 2-8 % at every size tried (2^18 ... 2^21) ("bwd_fuse": 0 = never, 1 = by that
+    // rule, 2 = always)
     const int fuse_opt = g_bwd_fuse.load();
-    const bool fuse = can_fork && need_T && !staged &&
-                      (fuse_opt == 2 || (fuse_opt == 1 && n * ((int64_t)1 << (DIM - 1)) <= ((int64_t)1 << 21)));
+    const bool fuse_rule = (DIM == 2) ? n <= ((int64_t)1 << 22) : n <= ((int64_t)3 << 18);
+    const bool fuse = can_fork && need_T && !staged && (fuse_opt == 2 || (fuse_opt == 1 && fuse_rule));
     // selective zeroing (see zero_unowned_rows_kernel): a single sub-batch whose plan has hashed binned levels
     bool any_hashed = false;
     for (uint32_t q = 0; q < whole.nbl; ++q) any_hashed = any_hashed || lt.dense[whole.blevel[q]] == 0;
