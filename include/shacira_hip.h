@@ -393,11 +393,12 @@ SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origi
  *   "bin_batch_mib": cap (MiB) of the backward's item array; larger batches are processed in sub-batches.
  *   "bin_acc_kib": LDS accumulator image per consumer workgroup: 64, 128, or 0 = chosen from the batch size (default).
  *   "bwd_fuse": bucket counting fused into the transpose pass: 0 = never, 1 (default) = for batches where it measured
- *               faster (up to 2^19 3-D / 2^20 2-D samples), 2 = always.
+ *               faster (up to 786 K 3-D / 2^22 2-D samples), 2 = always.
  *   "bwd_compact": 1 (default) = dense 3-D levels travel as one 32-byte item per sample (z-slab buckets), 0 = pair items.
  *   "mlp_variant": -1 (default) = decoder MLPs on the fp32 matrix cores wherever instantiated, 0 = VALU kernels.
  *   "tiled": -1 (default) = the cell-sorted forward (hashgrid_tiled.hip: counting sort of the samples by spatial block,
- *            coarse levels gathered out of L1 in that order) for batches where it measured faster (>= 2^19 samples),
+ *            coarse levels gathered out of L1 in that order) for batches where it measured faster (tables > 8 MB; 3-D: from 2^18
+ *            samples for F = 2, 80 K for F = 4; 2-D: from 192 K),
  *            0 = never, 1 = whenever the shape allows it. "fwd_variant" 8 also forces it; other explicit variants exclude it.
  *   "tiled_lc_fwd": its number of coarse levels, -1 (default) = planner's choice.
  *   "bwd_fork": 1 (default) = the backward's count + scan passes are issued on a library-owned side stream, forked

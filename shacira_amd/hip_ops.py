@@ -47,6 +47,14 @@ def _need_gpu(*tensors):
             raise RuntimeError("shacira_amd: operands must be on the MI355X (HIP) device; there is no CPU fallback")
 
 
+def _check_coords(dim, coords):
+    # the reference reads coords as a flat [N, dim] array without looking at its shape (a [N, 2] tensor handed to the
+    # 3-D op is read past its end): a wrong shape is refused here instead of faulting on the device
+    if coords.dim() != 2 or coords.shape[1] != dim or not coords.is_contiguous():
+        raise RuntimeError(f"shacira_amd: coords must be a contiguous [N, {dim}] tensor for the {dim}-D operator, got "
+                           f"{tuple(coords.shape)}")
+
+
 def _dtype_code(t):
     try:
         return _DTYPES[t.dtype]
@@ -58,6 +66,7 @@ def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, cod
     _need_gpu(coords, codebook, codebook_first_idx)
     if coords.dtype != torch.float32:
         raise RuntimeError("expected scalar type Float for coords")  # data_ptr<float>() in the reference
+    _check_coords(dim, coords)
     res = tuple(int(r) for r in resolution)
     N, T, F = coords.shape[0], codebook.shape[0], codebook.shape[1]
     feats = torch.empty((N, F * len(res)), dtype=codebook.dtype, device=codebook.device)
@@ -83,6 +92,7 @@ def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codeboo
     calls can share ``workspace`` (see ``backward_workspace``) with ``flags`` BWD_STAGE_ALL_LEVELS on the first and
     BWD_REUSE_STAGED on the following ones, so the gradients are transposed once."""
     _need_gpu(coords, grad_output, codebook_first_idx)
+    _check_coords(dim, coords)
     res = tuple(int(r) for r in resolution)
     N, T, F = coords.shape[0], int(table_rows), int(feature_dim)
     if table_dtype not in _DTYPES:

@@ -1146,3 +1146,19 @@ def test_forward_and_backward_replay_from_one_graph(dev):
     assert np.array_equal(feats[:n_or].cpu().numpy(), ref_f)
     ref_g = oc.backward(coords2, go2, (T, 2), first, res, bw)
     _assert_grad_close(out.cpu().numpy(), ref_g, first, sizes)
+
+
+def test_wrong_coordinate_shape_is_refused(dev):
+    """[N, 2] coordinates handed to the 3-D operator (or the reverse) would be read past their end on the device: the
+    wrappers refuse them."""
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, 1000)
+    tt, tf = torch.from_numpy(table).to(dev), torch.from_numpy(first).to(dev)
+    bad = torch.rand(1000, 2, device=dev)
+    with pytest.raises(RuntimeError, match="coords"):
+        ops.hashgrid_interpolate_cuda(bad, tt, tf, res, bw)
+    with pytest.raises(RuntimeError, match="coords"):
+        ops.hashgrid_backward(3, bad, torch.from_numpy(go).to(dev), T, torch.float32, tf, res, bw, 2)
+    with pytest.raises(RuntimeError, match="coords"):
+        ops.hashgrid_interpolate2d_cuda(torch.rand(1000, 3, device=dev), tt, tf, res, bw)
