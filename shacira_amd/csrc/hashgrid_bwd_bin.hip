@@ -1333,7 +1333,9 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // counting is FUSED into it (transpose_count_kernel) and the side stream zeroes the table and runs the direct
     // levels; a call that reuses staged gradients counts + scans on the side stream instead.
     SideStream *ss = nullptr;
-    const bool can_fork = whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 && n >= (1 << 18);   // a loss at 64 K and 128 K (also fused)
+    // measured (tools/bwd_rules_sweep.py): 3-D: the one-stream order is 4-5 % faster at 256 K - 320 K samples, equal at 400 K,
+    // 3-5 % slower from 2^19; 2-D: the fork wins from 2^18 (equal at 192 K); a loss at 64 K and 128 K (also fused)
+    const bool can_fork = whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 && n >= (DIM == 3 ? (3 << 17) : (1 << 18));
     // measured (tools/fuse_check.py, re-measured at the end of round 2): 3-D: fused wins by 2-4 % up to 786 K samples and
     // loses 3 % at 2^20; 2-D: fused wins by 2-8 % at every size tried (2^18 ... 2^21) ("bwd_fuse": 0 = never, 1 = by that
     // rule, 2 = always)

@@ -211,12 +211,12 @@ def test_backward_by_level_ranges(dev, name, bvar):
 
 @pytest.mark.parametrize("name", ["D", "Bp"])
 def test_backward_side_stream_fork(dev, name):
-    """N >= 2^18: count + scans run on the library's side stream. Same gradient as the single-stream order and as
+    """Large batches: count + scans run on the library's side stream. Same gradient as the single-stream order and as
     the oracle; the forked call is also capturable into a HIP graph (after one eager call) and replays correctly."""
     from shacira_amd import _lib
     ops = _ops()
     dim, res, bw = CONFIGS[name]
-    N = 1 << 18
+    N = (3 << 17) + 64          # 3-D batches fork from 3 * 2^17 samples, 2-D from 2^18
     sizes, first, T, coords, table, go = _problem(dim, res, bw, N, seed=11)
     tc, tg, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(go).to(dev), torch.from_numpy(first).to(dev)
     ref = oc.backward(coords, go, (T, 2), first, res, bw)
@@ -256,7 +256,7 @@ def test_backward_experiment_hooks_keep_the_gradient(dev, name, option, value):
     from shacira_amd import _lib
     ops = _ops()
     dim, res, bw = CONFIGS[name]
-    N = (1 << 18) + 333
+    N = (3 << 17) + 333
     sizes, first, T, coords, table, go = _problem(dim, res, bw, N, seed=23)
     tc, tg, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(go).to(dev), torch.from_numpy(first).to(dev)
     ref = oc.backward(coords, go, (T, 2), first, res, bw)
