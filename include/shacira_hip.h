@@ -12,7 +12,7 @@
  * Conventions (all entry points):
  *   - every buffer is CALLER-OWNED device memory (hipMalloc / the PyTorch caching allocator) unless the name
  *     ends in _host; the library never allocates or frees device memory and never synchronises the host (the backward
- *     of large batches (3-D: >= 3 * 2^17 samples, 2-D: >= 2^18) creates, once per host thread and device, one non-blocking side stream and six
+ *     of large batches (3-D: n * L * F >= 7 * 2^21, 2-D: >= 2^23) creates, once per host thread and device, one non-blocking side stream and six
  *     events that it forks from / joins back into `stream`: stream semantics are unchanged, HIP-graph capture works
  *     after one eager call). Those objects belong to the CURRENT device (hipGetDevice): like every HIP launch, a call
  *     must be made with the device of `stream` and of its buffers current;

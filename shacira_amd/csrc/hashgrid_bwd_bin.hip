@@ -98,11 +98,14 @@ template <int F> __device__ __forceinline__ void store_item_nt(Item<F> *p, const
         u32x4 v;
         __builtin_memcpy(&v, &it, 16);
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
-    } else {
-        uint32_t *q = reinterpret_cast<uint32_t *>(p);
-        const uint32_t *d = reinterpret_cast<const uint32_t *>(&it);
+    } else {   // 24-byte items (F = 4, 8-byte aligned): three 8-byte stores instead of six dwords
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        static_assert(sizeof(Item<F>) % 8 == 0, "item size");
+        u32x2 *q = reinterpret_cast<u32x2 *>(p);
+        u32x2 d[sizeof(Item<F>) / 8];
+        __builtin_memcpy(d, &it, sizeof(Item<F>));
 #pragma unroll
-        for (int k = 0; k < (int)(sizeof(Item<F>) / 4); ++k) __builtin_nontemporal_store(d[k], q + k);
+        for (int k = 0; k < (int)(sizeof(Item<F>) / 8); ++k) __builtin_nontemporal_store(d[k], q + k);
     }
 }
 
@@ -112,11 +115,12 @@ template <int F> __device__ __forceinline__ Item<F> load_item_nt(const Item<F> *
     if constexpr (sizeof(Item<F>) == 16) {
         const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
         __builtin_memcpy(&it, &v, 16);
-    } else {
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
-        uint32_t d[sizeof(Item<F>) / 4];
+    } else {   // 24-byte items: three 8-byte loads
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 *q = reinterpret_cast<const u32x2 *>(p);
+        u32x2 d[sizeof(Item<F>) / 8];
 #pragma unroll
-        for (int k = 0; k < (int)(sizeof(Item<F>) / 4); ++k) d[k] = __builtin_nontemporal_load(q + k);
+        for (int k = 0; k < (int)(sizeof(Item<F>) / 8); ++k) d[k] = __builtin_nontemporal_load(q + k);
         __builtin_memcpy(&it, d, sizeof(Item<F>));
     }
     return it;
@@ -1333,9 +1337,13 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // counting is FUSED into it (transpose_count_kernel) and the side stream zeroes the table and runs the direct
     // levels; a call that reuses staged gradients counts + scans on the side stream instead.
     SideStream *ss = nullptr;
-    // measured (tools/bwd_rules_sweep.py): 3-D: the one-stream order is 4-5 % faster at 256 K - 320 K samples, equal at 400 K,
-    // 3-5 % slower from 2^19; 2-D: the fork wins from 2^18 (equal at 192 K); a loss at 64 K and 128 K (also fused)
-    const bool can_fork = whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 && n >= (DIM == 3 ? (3 << 17) : (1 << 18));
+    // measured (tools/bwd_rules_sweep.py, S1 table): 3-D: the one-stream order is 4-5 % faster at 256 K - 320 K samples, equal at
+    // 400 K, 3-5 % slower from 2^19; 2-D: the fork wins from 2^18 (equal at 192 K); a loss at 64 K and 128 K (also fused)
+    // (thresholds in units of n * L * F so that heavier tables fork earlier: nerf_lego.yaml's 24-level F = 4 table gains 7 %
+    // from the fork at 256 K samples, where the 16-level F = 2 table loses 5 %)
+    const int64_t fork_work = n * lt.num_lods * lt.feature_dim;
+    const bool can_fork = whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 &&
+                          fork_work >= (DIM == 3 ? ((int64_t)7 << 21) : ((int64_t)1 << 23));
     // measured (tools/fuse_check.py, re-measured at the end of round 2): 3-D: fused wins by 2-4 % up to 786 K samples and
     // loses 3 % at 2^20; 2-D: fused wins by 2-8 % at every size tried (2^18 ... 2^21) ("bwd_fuse": 0 = never, 1 = by that
     // rule, 2 = always)

@@ -216,7 +216,7 @@ def test_backward_side_stream_fork(dev, name):
     from shacira_amd import _lib
     ops = _ops()
     dim, res, bw = CONFIGS[name]
-    N = (3 << 17) + 64          # 3-D batches fork from 3 * 2^17 samples, 2-D from 2^18
+    N = (1 << 19) + 64          # the S1-sized tables fork from ~460 K (3-D) / 2^18 (2-D) samples
     sizes, first, T, coords, table, go = _problem(dim, res, bw, N, seed=11)
     tc, tg, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(go).to(dev), torch.from_numpy(first).to(dev)
     ref = oc.backward(coords, go, (T, 2), first, res, bw)
@@ -256,7 +256,7 @@ def test_backward_experiment_hooks_keep_the_gradient(dev, name, option, value):
     from shacira_amd import _lib
     ops = _ops()
     dim, res, bw = CONFIGS[name]
-    N = (3 << 17) + 333
+    N = (1 << 19) + 333
     sizes, first, T, coords, table, go = _problem(dim, res, bw, N, seed=23)
     tc, tg, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(go).to(dev), torch.from_numpy(first).to(dev)
     ref = oc.backward(coords, go, (T, 2), first, res, bw)
