@@ -410,6 +410,8 @@ SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origi
  *               straight from grad_output on an XCD-affine grid (no transposing pass), 2 = always. Measured slower
  *               (S1: 0.636 vs 0.608 ms: the strided reads cost the scatter pass more than the transpose saves).
  *   "bwd_direct_side": 0 (default); 1 = LDS-resident levels accumulate on the side stream beside the scatter pass.
+ *   "bwd_persistent": 1 (default) = the backward's last pass runs as persistent workgroups that fetch their work units from a
+ *               counter (batches >= 2^17 samples); 0 = one workgroup per unit.
  *   "bwd_selective_zero": 1 (default) = the backward zeroes only the gradient rows its last pass does not overwrite with
  *               plain stores (all rows outside the hashed levels, plus hashed buckets that received 0 or several work
  *               units); 0 = one memset of the whole table first. Same result either way.

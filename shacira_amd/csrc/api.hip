@@ -15,6 +15,7 @@ std::atomic<int> g_bwd_compact{1};        // dense 3-D levels: one 32-byte item 
 std::atomic<int> g_bwd_fuse{1};           // bucket counting fused into the transpose pass
 std::atomic<int> g_bwd_groups{1};         // > 1: binned levels in that many groups, scatter of group g + 1 beside consume of group g (measured slower)
 std::atomic<int> g_bwd_selective_zero{1};  // 1: zero only the rows the consume pass does not overwrite (0: memset of the whole table)
+std::atomic<int> g_bwd_persistent{1};     // consume pass: persistent workgroups fetching units from a counter (0: one unit per workgroup)
 std::atomic<int> g_bwd_direct_side{0};    // 1: direct levels on the side stream beside the scatter pass (two-stream form; no gain measured)
 std::atomic<int> g_bwd_rows{0};           // 1: fp32 batches >= 2^18 scatter straight from grad_output (no transposing pass); 2: always; 0: never
 std::atomic<int> g_bwd_fork{1};           // 1: count + scans of the backward on a side stream next to the transpose
@@ -82,6 +83,7 @@ int shacira_set_option(const char *name, int value) {
     }
     if (!std::strcmp(name, "bwd_fork")) { g_bwd_fork = value ? 1 : 0; return 0; }
     if (!std::strcmp(name, "bwd_direct_side")) { g_bwd_direct_side = value ? 1 : 0; return 0; }
+    if (!std::strcmp(name, "bwd_persistent")) { g_bwd_persistent = value ? 1 : 0; return 0; }
     if (!std::strcmp(name, "bwd_selective_zero")) { g_bwd_selective_zero = value ? 1 : 0; return 0; }
     if (!std::strcmp(name, "bwd_rows")) { g_bwd_rows = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     if (!std::strcmp(name, "bwd_groups")) { g_bwd_groups = value < 0 ? 0 : (value > 16 ? 16 : value); return 0; }
@@ -115,6 +117,7 @@ int shacira_get_option(const char *name) {
     if (!std::strcmp(name, "bwd_fork")) return g_bwd_fork;
     if (!std::strcmp(name, "bwd_rows")) return g_bwd_rows;
     if (!std::strcmp(name, "bwd_direct_side")) return g_bwd_direct_side;
+    if (!std::strcmp(name, "bwd_persistent")) return g_bwd_persistent;
     if (!std::strcmp(name, "bwd_selective_zero")) return g_bwd_selective_zero;
     if (!std::strcmp(name, "bwd_groups")) return g_bwd_groups;
     if (!std::strcmp(name, "mlp_variant")) return g_mlp_variant;

@@ -136,6 +136,7 @@ extern std::atomic<int> g_bin_acc_kib;
 extern std::atomic<int> g_bwd_groups;
 extern std::atomic<int> g_bwd_rows;
 extern std::atomic<int> g_bwd_direct_side;
+extern std::atomic<int> g_bwd_persistent;
 extern std::atomic<int> g_bwd_selective_zero;
 extern std::atomic<int> g_bwd_fork;
 extern std::atomic<int> g_bwd_fuse;

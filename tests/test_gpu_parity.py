@@ -249,7 +249,7 @@ def test_backward_side_stream_fork(dev, name):
 
 
 @pytest.mark.parametrize("name", ["D", "Bp"])
-@pytest.mark.parametrize("option,value", [("bwd_rows", 2), ("bwd_groups", 3), ("bwd_direct_side", 1)])
+@pytest.mark.parametrize("option,value", [("bwd_rows", 2), ("bwd_groups", 3), ("bwd_direct_side", 1), ("bwd_persistent", 0)])
 def test_backward_experiment_hooks_keep_the_gradient(dev, name, option, value):
     """The measured-and-kept-off orderings of the binned backward (scatter straight from grad_output on an XCD-affine grid;
     level groups pipelined over two streams; direct levels beside the scatter pass) give the oracle's gradient too."""
