@@ -22,7 +22,8 @@ std::atomic<int> g_bwd_fork{1};           // 1: count + scans of the backward on
 std::atomic<int> g_bin_acc_kib{0};        // LDS accumulator image per consumer workgroup, KiB: 64, 128, 0 = by batch size
 std::atomic<int> g_bin_batch_mib{1536};   // cap of the backward's item array per sub-batch, MiB
 std::atomic<int> g_tiled{-1};             // cell-sorted forward (hashgrid_tiled.hip): -1 = by batch size, 0 = never, 1 = always
-std::atomic<int> g_tiled_lc_fwd{-1};      // its number of coarse levels (rows kernel), -1 = planner
+std::atomic<int> g_tiled_lc_fwd{-1};
+std::atomic<int> g_exp[8] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};   // development knobs "exp0".."exp7" (-1 = default)      // its number of coarse levels (rows kernel), -1 = planner
 
 static int build_level_table(int dim, int num_lods, int feature_dim, int bw, const int32_t *res_host,
                              int64_t table_rows, LevelTable &lt) {
@@ -105,6 +106,7 @@ int shacira_set_option(const char *name, int value) {
         g_bin_batch_mib = value;
         return 0;
     }
+    if (!std::strncmp(name, "exp", 3) && name[3] >= '0' && name[3] <= '7' && !name[4]) { g_exp[name[3] - '0'] = value; return 0; }
     return SHACIRA_EINVAL;
 }
 
@@ -125,6 +127,7 @@ int shacira_get_option(const char *name) {
     if (!std::strcmp(name, "bwd_compact")) return g_bwd_compact;
     if (!std::strcmp(name, "tiled")) return g_tiled;
     if (!std::strcmp(name, "tiled_lc_fwd")) return g_tiled_lc_fwd;
+    if (!std::strncmp(name, "exp", 3) && name[3] >= '0' && name[3] <= '7' && !name[4]) return g_exp[name[3] - '0'];
     return SHACIRA_EINVAL;
 }
 

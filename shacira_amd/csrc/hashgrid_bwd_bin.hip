@@ -53,6 +53,7 @@ struct BinLevel {
     uint32_t drow0;     // direct: first row of the level inside its group's LDS image
     uint32_t compact;   // 1: dense 3-D level binned by z-slab with ONE two-slot item per sample (all 8 corners): 32 B (F = 2), 48 B (F = 4)
     uint32_t slab;      // compact: base-cell planes per bucket (its image holds slab + 1 planes)
+    uint32_t chunk;     // items per consumer work unit of this level
 };
 
 struct BinPlan {
@@ -62,6 +63,9 @@ struct BinPlan {
     uint32_t num_tiles;
     uint32_t pairs;     // items per (sample, level) = 2^(dim-1)
     uint32_t chunk;     // items per consumer work unit
+    uint32_t chunk_c;   // same for compact levels (smaller: they are consumed last and even out the tail)
+    uint32_t rotf;      // 1: consumers rotate the feature order by lane (LDS bank spreading)
+    uint32_t rot_bucket; // first bucket of the first HASHED binned level: the persistent consume pass starts there
     uint32_t nbl;       // number of binned levels
     uint32_t blevel[SHACIRA_MAX_LODS];  // their level indices (grid.y of passes A/B); 32-bit = scalar loads
     uint32_t bstart[SHACIRA_MAX_LODS];  // first global bucket of binned level q (= lv[blevel[q]].bucket0)
@@ -281,6 +285,101 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
     }
 }
 
+// 16-byte form of pass T (round 3): the 8-byte accesses above ran at 2.5 TB/s, half the chip's copy rate (the guide prices
+// 8-byte accesses at 0.54-0.70x the 16-byte rate). Rows whose byte size is a multiple of 16 are read as 16-byte vectors
+// (K = 16 / (sizeof(T) * F) level pieces of one sample per lane, every load of the tile issued before the first LDS write),
+// kept LEVEL-major in LDS, and leave as 16-byte non-temporal vectors of M = 16 / (4 F) consecutive samples of one level.
+// Tile = TS samples (a multiple of 128); pitch = TS + 2 pieces keeps the 16-byte LDS reads aligned (2-way conflicts on the
+// writes only). Requires (l * N + tile start) * F * 4 to be 16-byte aligned for every level: N even when F == 2.
+template <typename T, int F, bool GMAX>
+__global__ __launch_bounds__(256) void transpose_grad16_kernel(const T *__restrict__ go, float *__restrict__ gT,
+                                                               int64_t N, int L, int lb, int le, int TS,
+                                                               uint32_t *__restrict__ gmax) {
+    constexpr int K = 16 / (int)(sizeof(T) * F);   // level pieces per 16-byte input vector
+    constexpr int M = 16 / (4 * F);                // samples per 16-byte output vector
+    static_assert(K >= 1 && M >= 1, "16-byte transpose: F <= 4");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    struct alignas(sizeof(float) * F) PieceOut { float v[F]; };
+    __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
+    extern __shared__ __align__(16) unsigned char s_raw_g[];
+    PieceOut *s_tile = reinterpret_cast<PieceOut *>(s_raw_g);   // [L][TS + 2]
+    if (GMAX && threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
+    const int pitch = TS + 2;
+    const int VPR = L / K;                                      // input vectors per row
+    const int64_t s0 = (int64_t)blockIdx.x * TS;
+    const int ns = (int)((N - s0 < TS) ? (N - s0) : TS);
+    const u32x4 *in = reinterpret_cast<const u32x4 *>(go) + s0 * VPR;
+    const int total = ns * VPR;
+    constexpr int UL = 8;                                       // loads in flight per thread
+    for (int e0 = threadIdx.x; e0 < total; e0 += 256 * UL) {
+        u32x4 raw[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const int e = e0 + u * 256;
+            if (e < total) raw[u] = __builtin_nontemporal_load(in + e);
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const int e = e0 + u * 256;
+            if (e >= total) continue;
+            const int sm = e / VPR, v = e - sm * VPR;
+            T tv[K * F];
+            __builtin_memcpy(tv, &raw[u], 16);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                PieceOut q;
+#pragma unroll
+                for (int j = 0; j < F; ++j) q.v[j] = Scalar<T>::load(&tv[k * F + j]);
+                s_tile[(v * K + k) * pitch + sm] = q;
+            }
+        }
+    }
+    __syncthreads();
+    const int nvec = TS / M;
+    for (int l = lb; l < le; ++l) {
+        uint32_t m = 0;
+        for (int q = threadIdx.x; q < nvec; q += 256) {
+            const int sm = q * M;
+            if (sm >= ns) break;
+            const f32x4 val = *reinterpret_cast<const f32x4 *>(&s_tile[l * pitch + sm]);
+            float *dst = gT + ((int64_t)l * N + s0 + sm) * F;
+            if (sm + M <= ns) {
+                __builtin_nontemporal_store(val, reinterpret_cast<f32x4 *>(dst));
+                if constexpr (GMAX) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t b = __float_as_uint(fabsf(val[j]));
+                        m = b > m ? b : m;
+                    }
+                }
+            } else {   // last sample of an odd tail (M == 2)
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    dst[j] = val[j];
+                    if constexpr (GMAX) {
+                        const uint32_t b = __float_as_uint(fabsf(val[j]));
+                        m = b > m ? b : m;
+                    }
+                }
+            }
+        }
+        if constexpr (GMAX) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = __shfl_xor(m, off, 64);
+                m = o > m ? o : m;
+            }
+            if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_max[l], m);
+        }
+    }
+    if constexpr (GMAX) {
+        __syncthreads();
+        if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x])
+            atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------- passes T + A fused
 // One workgroup = one 1024-sample tile of passes A / B: four 256-sample rounds of the transpose (memory bound) with
 // the bucket counting of the same samples (ALU bound: corner hashing of every binned level) in between, so the two
@@ -453,12 +552,17 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) work_counter[0] = 0;   // the persistent consume pass fetches its units from here
     uint64_t c[2];
-    uint32_t u[2];
+    uint32_t u[2], lv_of[2], ck[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const uint32_t b = 2 * t + k;
         c[k] = (b < nb) ? totals[b] : 0u;
-        u[k] = (uint32_t)((c[k] + chunk_items - 1) / chunk_items);
+        uint32_t lq = 0;
+        for (uint32_t q = 1; q < plan.nbl; ++q)
+            if (plan.bstart[q] <= b) lq = q;
+        lv_of[k] = plan.blevel[lq];
+        ck[k] = plan.lv[lv_of[k]].chunk;
+        u[k] = (uint32_t)((c[k] + ck[k] - 1) / ck[k]);
     }
     uint64_t ci = c[0] + c[1];
     uint32_t ui = u[0] + u[1];
@@ -492,15 +596,12 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
     for (int k = 0; k < 2; ++k) {
         const uint32_t b = 2 * t + k;
         if (b < nb) {
-            uint32_t lq = 0;
-            for (uint32_t q = 1; q < plan.nbl; ++q)
-                if (plan.bstart[q] <= b) lq = q;
-            const uint32_t lvl = plan.blevel[lq];
+            const uint32_t lvl = lv_of[k];
             for (uint32_t q = 0; q < u[k]; ++q) {
                 UnitDesc d;
-                d.begin = s_items[b] + (uint64_t)q * chunk_items;
+                d.begin = s_items[b] + (uint64_t)q * ck[k];
                 const uint64_t bucket_end = s_items[b] + c[k];
-                d.end = (d.begin + chunk_items < bucket_end) ? (d.begin + chunk_items) : bucket_end;
+                d.end = (d.begin + ck[k] < bucket_end) ? (d.begin + ck[k]) : bucket_end;
                 d.bucket = b;
                 d.level = lvl;
                 d.single = u[k] == 1 ? 1u : 0u;
@@ -803,6 +904,15 @@ __global__ __launch_bounds__(256) void zero_odd_buckets_kernel(float *__restrict
     for (uint32_t e = threadIdx.x; e < nrows * (uint32_t)lt.feature_dim; e += 256) dst[e] = 0.0f;
 }
 
+// a[j] for a lane-dependent j without a scratch array (select chain)
+template <int F> __device__ __forceinline__ float pick(const float (&a)[F], int j) {
+    float v = a[0];
+#pragma unroll
+    for (int k = 1; k < F; ++k) v = (j == k) ? a[k] : v;
+    return v;
+}
+__device__ __forceinline__ bool g_rot_enabled(const BinPlan &plan) { return plan.rotf != 0; }
+
 // ------------------------------------------------------------------------------------------------- pass C
 // one work unit (a bucket, or a chunk of an over-full one) on the calling workgroup
 template <int F, bool FX>
@@ -831,6 +941,7 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
             // {-, g2, g3, ...}; all 8 corners land here
             constexpr int UC = 2;
             const uint32_t r2 = r1 * r1;
+            const int rotc = plan.rotf ? (int)(threadIdx.x & (F - 1)) : 0;
             for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
                 Item<F> ia[UC], ib[UC];
 #pragma unroll
@@ -862,9 +973,11 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
                         const float w = wxy[c >> 1] * ((c & 1) ? fzz : gzz);
                         if (row >= nrows) continue;   // cannot happen for in-range cells; keeps the image safe
 #pragma unroll
-                        for (int j = 0; j < F; ++j) {
-                            if (FX && fx.fixed) atomicAdd(&s_fix[row * F + j], fx_encode(gg[j] * w, fx.scale));
-                            else atomicAdd(&s_acc[row * F + j], (double)(gg[j] * w));
+                        for (int jj = 0; jj < F; ++jj) {
+                            const int j = (jj + rotc) & (F - 1);
+                            const float gj = pick<F>(gg, j);
+                            if (FX && fx.fixed) atomicAdd(&s_fix[row * F + j], fx_encode(gj * w, fx.scale));
+                            else atomicAdd(&s_acc[row * F + j], (double)(gj * w));
                         }
                     }
                 }
@@ -882,6 +995,7 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
         }
     }
     constexpr int UN = 8;  // items in flight per thread (4: -1 %, 16: +3 % with the fixed-point atomics)
+    const int rotf = g_rot_enabled(plan) ? (int)(threadIdx.x & (F - 1)) : 0;
     for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
         Item<F> it[UN];
 #pragma unroll
@@ -895,13 +1009,22 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
             const uint32_t ra = it[u].key & 0x1FFFu, rb = (it[u].key >> 13) & 0x1FFFu;
             const float gx = 1.0f - it[u].fx;
             if (FX && fx.fixed) {
+                // feature order rotated by lane: the F slots of a row are consecutive 8-byte words, so with every lane adding
+                // feature j in the same instruction only 1 / F of the LDS banks were addressed (half of the pass's LDS
+                // cycles were bank conflicts)
                 if (it[u].key & (1u << 26)) {
 #pragma unroll
-                    for (int j = 0; j < F; ++j) atomicAdd(&s_fix[ra * F + j], fx_encode(it[u].a[j] * gx, fx.scale));
+                    for (int jj = 0; jj < F; ++jj) {
+                        const int j = (jj + rotf) & (F - 1);
+                        atomicAdd(&s_fix[ra * F + j], fx_encode(pick<F>(it[u].a, j) * gx, fx.scale));
+                    }
                 }
                 if (it[u].key & (1u << 27)) {
 #pragma unroll
-                    for (int j = 0; j < F; ++j) atomicAdd(&s_fix[rb * F + j], fx_encode(it[u].a[j] * it[u].fx, fx.scale));
+                    for (int jj = 0; jj < F; ++jj) {
+                        const int j = (jj + rotf) & (F - 1);
+                        atomicAdd(&s_fix[rb * F + j], fx_encode(pick<F>(it[u].a, j) * it[u].fx, fx.scale));
+                    }
                 }
             } else {
                 if (it[u].key & (1u << 26)) {
@@ -959,11 +1082,16 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         consume_unit<F, FX>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
         return;
     }
+    // fetch order: the hashed levels' units (one whole bucket each: equal, large) first, the dense levels' smaller chunks
+    // last, so that the last round of units is made of small ones (persistent launches always cover the whole plan)
+    const uint32_t rot = (plan.rot_bucket == 0xFFFFFFFFu ? 0u : unit_first[plan.rot_bucket]) - unit0, nunits = unit_end - unit0;
     for (;;) {
         if (threadIdx.x == 0) s_unit = atomicAdd(work_counter, 1u);
         lds_barrier();
-        const uint32_t unit = s_unit + unit0;
-        if (unit >= unit_end) return;
+        if (s_unit >= nunits) return;
+        const uint32_t unit = plan.rot_bucket == 0xFFFFFFFFu
+                                  ? unit_end - 1u - s_unit
+                                  : unit0 + (s_unit + rot < nunits ? s_unit + rot : s_unit + rot - nunits);
         consume_unit<F, FX>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
         lds_barrier();   // the image and s_unit are free again; the flush stores keep draining
     }
@@ -1006,6 +1134,7 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
     const bool fixed = FX && s_all_fixed != 0;
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
     const int64_t stride = (int64_t)gridDim.x * kConsumeThreads;
+    const int rotd = plan.rotf ? (int)(threadIdx.x & (F - 1)) : 0;
     for (int64_t i = (int64_t)blockIdx.x * kConsumeThreads + threadIdx.x; i < N; i += stride) {
         double t[DIM];
 #pragma unroll
@@ -1026,7 +1155,10 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
                     const size_t slot = (size_t)(bl.drow0 + c.row[k]) * F;
                     if (fixed) {
 #pragma unroll
-                        for (int j = 0; j < F; ++j) atomicAdd(s_fix + slot + j, fx_encode(g[j] * c.w[k], scale));
+                        for (int jj = 0; jj < F; ++jj) {   // feature order rotated by lane (LDS bank spreading)
+                            const int j = (jj + rotd) & (F - 1);
+                            atomicAdd(s_fix + slot + j, fx_encode(pick<F>(g, j) * c.w[k], scale));
+                        }
                     } else {
 #pragma unroll
                         for (int j = 0; j < F; ++j) atomicAdd(s_acc + slot + j, (double)(g[j] * c.w[k]));
@@ -1224,6 +1356,35 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
     if (chunk < 8192) chunk = 8192;
     if (chunk > (1u << 22)) chunk = 1u << 22;
     plan.chunk = (uint32_t)chunk & ~1u;   // even: a compact item (two 16-byte slots) never straddles two work units
+    const int cdiv = g_exp[1].load() > 0 ? g_exp[1].load() : 1;
+    uint64_t cc = chunk / (uint64_t)cdiv;
+    if (cc < 8192) cc = 8192;
+    if (cc > chunk) cc = chunk;
+    plan.chunk_c = (uint32_t)cc & ~1u;
+    // The consume pass hands out units in bucket order to one persistent workgroup per CU: the units of the LAST levels are
+    // its tail. An evenly loaded hashed bucket is one unit (~45 us on S1); the last `tail_levels` levels are cut into
+    // `tail_div` chunks per bucket instead (atomic flush onto rows zeroed by zero_odd_buckets_kernel), so that the
+    // workgroups run out of work within ~10 us of each other.
+    {
+        const int tail_levels = g_exp[3].load() >= 0 ? g_exp[3].load() : 2;
+        const int tail_div = g_exp[4].load() > 0 ? g_exp[4].load() : 4;
+        for (uint32_t q = 0; q < plan.nbl; ++q) {
+            BinLevel &bl = plan.lv[plan.blevel[q]];
+            bl.chunk = bl.compact ? plan.chunk_c : plan.chunk;
+            if (q + (uint32_t)tail_levels >= plan.nbl && !bl.compact && n_batch >= (1 << 17)) {
+                uint64_t c = ((uint64_t)n_batch * plan.pairs / bl.nb) / (uint64_t)tail_div + 1024;   // per-bucket mean / div, + slack
+                if (c < 8192) c = 8192;
+                if (c < bl.chunk) bl.chunk = (uint32_t)c & ~1u;
+            }
+            if (bl.chunk < plan.chunk_c) plan.chunk_c = bl.chunk;   // smallest unit size of the plan (sizes the unit list)
+        }
+    }
+    plan.rot_bucket = 0;
+    plan.rotf = g_exp[5].load() != 0 ? 1u : 0u;
+    if (g_exp[2].load() == 2) plan.rot_bucket = 0xFFFFFFFFu;   // reverse order: the items written last are read first
+    if (g_exp[2].load() == 1)
+        for (uint32_t q = 0; q < plan.nbl; ++q)
+            if (lt.dense[plan.blevel[q]] == 0) { plan.rot_bucket = plan.bstart[q]; break; }
 }
 
 // sub-batch so that the item array stays below the cap (default 1.5 GiB, option "bin_batch_mib")
@@ -1268,7 +1429,7 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     const size_t o_base = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
     const size_t o_unit = take((size_t)(kMaxBuckets + 2) * sizeof(uint32_t));
     const uint64_t max_items_ws = (uint64_t)nb * plan.nbl * plan.pairs;
-    const size_t o_ub = take((size_t)(max_items_ws / plan.chunk + plan.total_buckets + 2) * sizeof(UnitDesc));
+    const size_t o_ub = take((size_t)(max_items_ws / plan.chunk_c + plan.total_buckets + 2) * sizeof(UnitDesc));
     const size_t o_wc = take(256);
     const size_t o_acc = take(dtype == SHACIRA_F16 ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0);
     BinWorkspace w{};
@@ -1469,7 +1630,30 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         // pass T over the whole batch (also gathers gmax)
         const uint32_t blocks = (uint32_t)((n + 255) / 256);
         const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
-        if (dtype == SHACIRA_F32 && use_fx)
+        // 16-byte form: rows of whole 16-byte vectors, 16-byte aligned input, N even for the two-sample output vectors
+        const size_t esz = dtype == SHACIRA_F32 ? 4 : 2;
+        const int kvec = (int)(16 / (esz * F));
+        int ts16 = g_exp[0].load();   // samples per tile (exp0: 0 = 8-byte kernel, else tile size)
+        if (ts16 < 0) ts16 = 512;
+        while (ts16 >= 128 && (size_t)L * (ts16 + 2) * F * sizeof(float) > (size_t)72 * 1024) ts16 /= 2;
+        const bool t16 = ts16 >= 128 && ts16 % 128 == 0 && (L % kvec) == 0 && (F == 4 || (n % 2) == 0) &&
+                         (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0;
+        if (t16) {
+            const uint32_t blocks16 = (uint32_t)((n + ts16 - 1) / ts16);
+            const size_t shmem16 = (size_t)L * (ts16 + 2) * F * sizeof(float);
+            if (dtype == SHACIRA_F32 && use_fx)
+                hipLaunchKernelGGL((transpose_grad16_kernel<float, F, true>), dim3(blocks16), dim3(256), shmem16, s,
+                                   static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, ts16, w.gmax);
+            else if (dtype == SHACIRA_F32)
+                hipLaunchKernelGGL((transpose_grad16_kernel<float, F, false>), dim3(blocks16), dim3(256), shmem16, s,
+                                   static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, ts16, nullptr);
+            else if (use_fx)
+                hipLaunchKernelGGL((transpose_grad16_kernel<__half, F, true>), dim3(blocks16), dim3(256), shmem16, s,
+                                   static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, ts16, w.gmax);
+            else
+                hipLaunchKernelGGL((transpose_grad16_kernel<__half, F, false>), dim3(blocks16), dim3(256), shmem16, s,
+                                   static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, ts16, nullptr);
+        } else if (dtype == SHACIRA_F32 && use_fx)
             hipLaunchKernelGGL((transpose_grad_kernel<float, F, true>), dim3(blocks), dim3(256), shmem, s,
                                static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax);
         else if (dtype == SHACIRA_F32)
@@ -1596,7 +1780,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             const BinLevel &first = plan.lv[plan.blevel[q0]], &last = plan.lv[plan.blevel[q1 - 1]];
             const uint32_t b_lo = first.bucket0, b_hi = last.bucket0 + last.nb;
             const uint64_t max_items = (uint64_t)n * NP * (q1 - q0);
-            const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + (b_hi - b_lo) + 1;
+            const uint32_t max_units = (uint32_t)(max_items / plan.chunk_c) + (b_hi - b_lo) + 1;
             if ((e = consume(plan, max_units, b_lo, b_hi, 0, ss->stream)) != hipSuccess) return e;
             q0 = q1;
         }
@@ -1634,7 +1818,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         }
         SHACIRA_CHECK_LAUNCH();
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NP;
-        const uint32_t max_units = (uint32_t)(max_items / plan.chunk) + plan.total_buckets + 1;
+        const uint32_t max_units = (uint32_t)(max_items / plan.chunk_c) + plan.total_buckets + 1;
         if (fuse) {
             hipError_t e = hipStreamWaitEvent(s, ss->join, 0);
             if (e != hipSuccess) return e;
@@ -1664,6 +1848,8 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
 #define SHACIRA_T_ATTR(TT, FF)                                                                           \
         set(reinterpret_cast<const void *>(&transpose_grad_kernel<TT, FF, true>), 140 * 1024);          \
         set(reinterpret_cast<const void *>(&transpose_grad_kernel<TT, FF, false>), 140 * 1024);         \
+        set(reinterpret_cast<const void *>(&transpose_grad16_kernel<TT, FF, true>), 72 * 1024);         \
+        set(reinterpret_cast<const void *>(&transpose_grad16_kernel<TT, FF, false>), 72 * 1024);        \
         set(reinterpret_cast<const void *>(&transpose_count_kernel<2, TT, FF, true>), 140 * 1024);      \
         set(reinterpret_cast<const void *>(&transpose_count_kernel<2, TT, FF, false>), 140 * 1024);     \
         set(reinterpret_cast<const void *>(&transpose_count_kernel<3, TT, FF, true>), 140 * 1024);      \

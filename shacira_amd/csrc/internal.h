@@ -144,5 +144,6 @@ extern std::atomic<int> g_bwd_compact;
 extern std::atomic<int> g_mlp_variant;
 extern std::atomic<int> g_tiled;          // cell-sorted forward: -1 by batch size, 0 never, 1 whenever the shape allows
 extern std::atomic<int> g_tiled_lc_fwd;   // its number of coarse levels (rows kernel), -1 = planner
+extern std::atomic<int> g_exp[8];         // development knobs
 
 }  // namespace shacira
