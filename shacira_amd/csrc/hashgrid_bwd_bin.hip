@@ -40,6 +40,7 @@ constexpr int kBinThreads = SHACIRA_KBIN;  // threads of passes A and B
 constexpr int kConsumeThreads = 1024;
 constexpr int kMaxBuckets = 2048;     // over all levels
 constexpr int kMaxLevelBuckets = 128; // per level (LDS histogram size)
+constexpr int kTotalShards = 16;      // bucket totals are accumulated in this many copies (same-address atomic contention)
 
 struct BinLevel {
     uint32_t nb;        // buckets in this level
@@ -56,16 +57,27 @@ struct BinLevel {
     uint32_t chunk;     // items per consumer work unit of this level
 };
 
+// What the counting needs to know about binned level q, dense in q (one unchained scalar load per level: reading the fields
+// through blevel[q] -> lv[lvl] / lt.res[lvl] chained four scalar-load round trips per level and made the fused front kernel
+// latency bound).
+struct CountLevel {
+    int32_t res;
+    float hi;
+    uint32_t kind;      // 0 hashed, 1 compact (z slab), 2 dense x-lines
+    uint32_t shift;     // hashed: log2(rows per bucket)
+    uint32_t m_lo, m_hi; // compact: m_lo = ceil(2^18 / slab) (pz / slab == (pz * m_lo) >> 18, checked by make_plan); dense: magicG
+};
+
 struct BinPlan {
     BinLevel lv[SHACIRA_MAX_LODS];
+    CountLevel cl[SHACIRA_MAX_LODS];
     uint32_t total_buckets;
     uint32_t BR;
     uint32_t num_tiles;
     uint32_t pairs;     // items per (sample, level) = 2^(dim-1)
     uint32_t chunk;     // items per consumer work unit
-    uint32_t chunk_c;   // same for compact levels (smaller: they are consumed last and even out the tail)
-    uint32_t rotf;      // 1: consumers rotate the feature order by lane (LDS bank spreading)
-    uint32_t rot_bucket; // first bucket of the first HASHED binned level: the persistent consume pass starts there
+    uint32_t chunk_min; // smallest unit size of the plan (sizes the unit list)
+    uint32_t level_fastest;
     uint32_t nbl;       // number of binned levels
     uint32_t blevel[SHACIRA_MAX_LODS];  // their level indices (grid.y of passes A/B); 32-bit = scalar loads
     uint32_t bstart[SHACIRA_MAX_LODS];  // first global bucket of binned level q (= lv[blevel[q]].bucket0)
@@ -186,6 +198,95 @@ __device__ __forceinline__ void enumerate_pairs(const double (&t)[DIM], int32_t 
     }
 }
 
+// Buckets of the 2^(DIM-1) x-pairs of one (sample, level) WITHOUT the x axis: a pair's bucket and validity depend on its
+// (y[, z]) line only (hashed: x < 2^shift never reaches the bucket bits; dense: buckets hold whole x-lines, and a pair is
+// dropped only when its line lies outside the level). Same result as enumerate_pairs(...).bucket / (key >> 26 != 0) at a
+// third of the arithmetic: this is what the counting passes run.
+template <int DIM>
+__device__ __forceinline__ void enumerate_buckets(const double (&t)[DIM], int32_t res, float hi, bool dense, uint32_t mask,
+                                                  const BinLevel &bl, uint32_t (&bucket)[1 << (DIM - 1)],
+                                                  bool (&valid)[1 << (DIM - 1)]) {
+    int32_t p[DIM];
+    float f, g;
+#pragma unroll
+    for (int a = 1; a < DIM; ++a) axis_transform(t[a], res, hi, p[a], f, g);
+    const uint32_t r = (uint32_t)res;
+    constexpr int NP = 1 << (DIM - 1);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int dy = (DIM == 3) ? ((q >> 1) & 1) : (q & 1);
+        const int dz = (DIM == 3) ? (q & 1) : 0;
+        const uint32_t uy = (uint32_t)p[1] + dy;
+        uint32_t uz = 0;
+        if constexpr (DIM == 3) uz = (uint32_t)p[2] + dz;
+        if (dense) {
+            bool ok = uy < r;
+            uint32_t line = uy;
+            if constexpr (DIM == 3) {
+                ok = ok && uz < r;
+                line += uz * r;
+            }
+            valid[q] = ok;
+            bucket[q] = ok ? (uint32_t)(((uint64_t)line * bl.magicG) >> 40) : 0u;
+        } else {
+            uint32_t h = uy * kPrimeY;
+            if constexpr (DIM == 3) h ^= uz * kPrimeZ;
+            valid[q] = true;
+            bucket[q] = (h & mask) >> bl.shift;
+        }
+    }
+}
+
+// position along one axis only (axis_transform without the fractions)
+__device__ __forceinline__ uint32_t axis_pos(double t, int32_t res, float hi) {
+    float x = (float)((double)res * t);
+    x = fmaxf(0.0f, fminf(hi, x));
+    return (uint32_t)(int32_t)floorf(x);
+}
+
+// bucket counts of one (sample, binned level) into the level's LDS histogram -- the same buckets / validity as
+// enumerate_pairs (hashed, dense) and the compact scatter path, from the dense per-level record
+template <int DIM>
+__device__ __forceinline__ void count_level(const double (&t)[DIM], const CountLevel cl, uint32_t mask, uint32_t *hist) {
+    if (cl.kind == 1u) {
+        if constexpr (DIM == 3) {
+            const uint32_t pz = axis_pos(t[2], cl.res, cl.hi);
+            const uint32_t b = cl.m_lo ? (__umul24(pz, cl.m_lo) >> 18) : pz / cl.m_hi;
+            atomicAdd(hist + b, 2u);
+        }
+    } else if (cl.kind == 0u) {
+        const uint32_t hy0 = axis_pos(t[1], cl.res, cl.hi) * kPrimeY, hy1 = hy0 + kPrimeY;
+        if constexpr (DIM == 3) {
+            const uint32_t hz0 = axis_pos(t[2], cl.res, cl.hi) * kPrimeZ, hz1 = hz0 + kPrimeZ;
+            atomicAdd(hist + (((hy0 ^ hz0) & mask) >> cl.shift), 1u);
+            atomicAdd(hist + (((hy0 ^ hz1) & mask) >> cl.shift), 1u);
+            atomicAdd(hist + (((hy1 ^ hz0) & mask) >> cl.shift), 1u);
+            atomicAdd(hist + (((hy1 ^ hz1) & mask) >> cl.shift), 1u);
+        } else {
+            atomicAdd(hist + ((hy0 & mask) >> cl.shift), 1u);
+            atomicAdd(hist + ((hy1 & mask) >> cl.shift), 1u);
+        }
+    } else {
+        const uint64_t magic = ((uint64_t)cl.m_hi << 32) | cl.m_lo;
+        const uint32_t r = (uint32_t)cl.res;
+        const uint32_t py = axis_pos(t[1], cl.res, cl.hi);
+        uint32_t pz = 0;
+        if constexpr (DIM == 3) pz = axis_pos(t[2], cl.res, cl.hi);
+#pragma unroll
+        for (int q = 0; q < (1 << (DIM - 1)); ++q) {
+            const uint32_t uy = py + ((DIM == 3) ? ((q >> 1) & 1) : (q & 1));
+            bool ok = uy < r;
+            uint32_t line = uy;
+            if constexpr (DIM == 3) {
+                const uint32_t uz = pz + (q & 1);
+                ok = ok && uz < r;
+                line += uz * r;
+            }
+            if (ok) atomicAdd(hist + (uint32_t)(((uint64_t)line * magic) >> 40), 1u);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ fixed point
 // LDS integer atomics run 1.6x faster than ds_add_f64 (2.1-2.5 vs 1.3-1.4 T op/s, profiles/r01_microbench2), so the
 // accumulator images hold 64-bit fixed-point numbers. Scale per level: gmax[l] = max |grad_output| over the level's
@@ -222,10 +323,11 @@ static inline int fx_headroom(uint64_t n_max) {
 }
 
 // ------------------------------------------------------------------------------------------------- pass T
-// grad_output [N, L*F] (T) -> gT [L][N][F] fp32, through LDS, F scalars per lane per access. Block: 256 samples.
+// grad_output [N, L*F] (T) -> gT [L][NP][F] fp32 (NP = N rounded up to even), through LDS, F scalars per lane per access.
+// Block: 256 samples. Generic fallback: rows that are not whole 16-byte vectors (odd level counts), unaligned input.
 template <typename T, int F, bool GMAX>
 __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict__ go, float *__restrict__ gT,
-                                                             int64_t N, int L, int lb, int le,
+                                                             int64_t N, int64_t NP, int L, int lb, int le,
                                                              uint32_t *__restrict__ gmax) {
     __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
     if (GMAX && threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
@@ -259,7 +361,7 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
                     m = b > m ? b : m;
                 }
             }
-            float *dst = reinterpret_cast<float *>(out + (int64_t)l * N + s0 + threadIdx.x);
+            float *dst = reinterpret_cast<float *>(out + (int64_t)l * NP + s0 + threadIdx.x);
             if constexpr (F == 2) {
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
                 f32x2 v = {q.v[0], q.v[1]};
@@ -285,47 +387,92 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
     }
 }
 
-// 16-byte form of pass T (round 3): the 8-byte accesses above ran at 2.5 TB/s, half the chip's copy rate (the guide prices
-// 8-byte accesses at 0.54-0.70x the 16-byte rate). Rows whose byte size is a multiple of 16 are read as 16-byte vectors
-// (K = 16 / (sizeof(T) * F) level pieces of one sample per lane, every load of the tile issued before the first LDS write),
-// kept LEVEL-major in LDS, and leave as 16-byte non-temporal vectors of M = 16 / (4 F) consecutive samples of one level.
-// Tile = TS samples (a multiple of 128); pitch = TS + 2 pieces keeps the 16-byte LDS reads aligned (2-way conflicts on the
-// writes only). Requires (l * N + tile start) * F * 4 to be 16-byte aligned for every level: N even when F == 2.
-template <typename T, int F, bool GMAX>
-__global__ __launch_bounds__(256) void transpose_grad16_kernel(const T *__restrict__ go, float *__restrict__ gT,
-                                                               int64_t N, int L, int lb, int le, int TS,
-                                                               uint32_t *__restrict__ gmax) {
+// 16-byte form of pass T, fused with pass A (round 3). The 8-byte kernel above ran at 2.5 TB/s, half the chip's copy rate
+// (the guide prices 8-byte accesses at 0.54-0.70x the 16-byte rate), and the bucket counting ran as a separate kernel on a
+// side stream that slowed it down further (105 us together on S1). Here a workgroup of 512 threads walks `rounds` tiles of
+// TS samples: it issues every 16-byte load of a tile's gradient rows (K = 16 / (sizeof(T) * F) level pieces of one sample
+// per lane), COUNTs the buckets of that tile's samples while the rows are in flight (corner hashing: pure ALU + LDS
+// atomics; COUNT = true), parks the rows LEVEL-major in LDS and writes them out as 16-byte non-temporal vectors of
+// M = 16 / (4 F) consecutive samples of one level. The staging image gT is [L][NP][F] with the level pitch NP = N rounded
+// up to even, so that every vector is 16-byte aligned for any batch size. Bucket counts leave as ONE global atomic per
+// (workgroup, non-empty bucket) into totals[] -- the per-(tile, bucket) matrix and its scan are gone: the scatter pass
+// reserves its runs with returning atomics on per-bucket cursors instead.
+constexpr int kFrontThreads = 512;
+template <int DIM, typename T, int F, bool GMAX, bool COUNT>
+__global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, BinPlan plan, const T *__restrict__ go,
+                                                                float *__restrict__ gT, const float *__restrict__ coords,
+                                                                uint32_t *__restrict__ totals, int64_t N, int64_t NP,
+                                                                int lb, int le, int ts_log2, int rounds,
+                                                                uint32_t *__restrict__ gmax) {
     constexpr int K = 16 / (int)(sizeof(T) * F);   // level pieces per 16-byte input vector
     constexpr int M = 16 / (4 * F);                // samples per 16-byte output vector
-    static_assert(K >= 1 && M >= 1, "16-byte transpose: F <= 4");
+    constexpr int M_LOG2 = (M == 2) ? 1 : 0;
+    constexpr int UL = 8;                          // 16-byte loads in flight per thread and round
+    static_assert(K >= 1 && (M == 1 || M == 2), "16-byte transpose: F = 2 or 4");
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     struct alignas(sizeof(float) * F) PieceOut { float v[F]; };
     __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
     extern __shared__ __align__(16) unsigned char s_raw_g[];
-    PieceOut *s_tile = reinterpret_cast<PieceOut *>(s_raw_g);   // [L][TS + 2]
+    const int L = lt.num_lods;
+    const int TS = 1 << ts_log2;                   // samples per tile: a power of two in [128, 512]
+    const int pitch = TS + 2;                      // even: 16-byte LDS reads stay aligned; 2-way conflicts on the writes only
+    PieceOut *s_tile = reinterpret_cast<PieceOut *>(s_raw_g);                                    // [L][TS + 2]
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_raw_g + (size_t)L * pitch * sizeof(PieceOut));   // [nbl][128]
     if (GMAX && threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
-    const int pitch = TS + 2;
-    const int VPR = L / K;                                      // input vectors per row
-    const int64_t s0 = (int64_t)blockIdx.x * TS;
-    const int ns = (int)((N - s0 < TS) ? (N - s0) : TS);
-    const u32x4 *in = reinterpret_cast<const u32x4 *>(go) + s0 * VPR;
-    const int total = ns * VPR;
-    constexpr int UL = 8;                                       // loads in flight per thread
-    for (int e0 = threadIdx.x; e0 < total; e0 += 256 * UL) {
+    if constexpr (COUNT)
+        for (uint32_t k = threadIdx.x; k < plan.nbl * (uint32_t)kMaxLevelBuckets; k += kFrontThreads) s_hist[k] = 0;
+    __syncthreads();
+    const int VPR = L / K;                         // input vectors per row
+    const int nvec_log2 = ts_log2 - M_LOG2;        // output vectors per level and tile (a multiple of 64)
+    // input vector e = tid + u * 512 of a tile belongs to sample e / VPR, level group e % VPR: divided once here, then
+    // stepped (no integer division inside the rounds -- the kernel is bound by its vector ALU work, not by memory)
+    const int q512 = kFrontThreads / VPR, r512 = kFrontThreads % VPR;
+    const int sm_first = (int)threadIdx.x / VPR, v_first = (int)threadIdx.x % VPR;
+    // counting: thread = (sample of the tile, level slot); tiles smaller than the workgroup split a sample's levels over
+    // 512 / TS threads. A wave's threads share the slot (TS >= 128): readfirstlane keeps the level loop uniform.
+    const int cslots = kFrontThreads >> ts_log2, csm = (int)threadIdx.x & (TS - 1);
+    const int cslot = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> ts_log2);
+    const int64_t tile0 = (int64_t)blockIdx.x * rounds;
+    const int64_t tiles = (N + TS - 1) >> ts_log2;
+    for (int r = 0; r < rounds && tile0 + r < tiles; ++r) {
+        const int64_t s0 = (tile0 + r) << ts_log2;
+        const int ns = (int)((N - s0 < TS) ? (N - s0) : TS);
+        const int total = ns * VPR;
+        // the sample's coordinates FIRST (vmcnt counts in order: the counting then waits for them only), then the row
+        // vectors; all loads unconditional with clamped indices (a branch around a load makes the compiler wait with
+        // vmcnt(0) in front of the counting, which would serialise it with the row loads)
+        float cc[DIM];
+        if constexpr (COUNT) {
+            const int64_t ci = s0 + (csm < ns ? csm : ns - 1);
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) cc[a] = coords[ci * DIM + a];
+        }
+        const u32x4 *in = reinterpret_cast<const u32x4 *>(go) + s0 * VPR;
         u32x4 raw[UL];
 #pragma unroll
         for (int u = 0; u < UL; ++u) {
-            const int e = e0 + u * 256;
-            if (e < total) raw[u] = __builtin_nontemporal_load(in + e);
+            const int e = (int)threadIdx.x + u * kFrontThreads;
+            raw[u] = __builtin_nontemporal_load(in + (e < total ? e : total - 1));   // idle lanes: one merged request
         }
+        if constexpr (COUNT) {
+#ifndef ABL_NO_COUNT
+            if (csm < ns) {
+#else
+            if (csm < ns && N < 0) {
+#endif
+                double t[DIM];
 #pragma unroll
-        for (int u = 0; u < UL; ++u) {
-            const int e = e0 + u * 256;
-            if (e >= total) continue;
-            const int sm = e / VPR, v = e - sm * VPR;
+                for (int a = 0; a < DIM; ++a) t[a] = axis_unit(cc[a]);
+#pragma unroll 2
+                for (uint32_t li = (uint32_t)cslot; li < plan.nbl; li += (uint32_t)cslots)
+                    count_level<DIM>(t, plan.cl[li], lt.mask, s_hist + li * kMaxLevelBuckets);
+            }
+        }
+        // rows -> LEVEL-major LDS image
+        auto park1 = [&](const u32x4 &rv, int sm, int v) {
             T tv[K * F];
-            __builtin_memcpy(tv, &raw[u], 16);
+            __builtin_memcpy(tv, &rv, 16);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 PieceOut q;
@@ -333,142 +480,48 @@ __global__ __launch_bounds__(256) void transpose_grad16_kernel(const T *__restri
                 for (int j = 0; j < F; ++j) q.v[j] = Scalar<T>::load(&tv[k * F + j]);
                 s_tile[(v * K + k) * pitch + sm] = q;
             }
+        };
+        int sm = sm_first, v = v_first;
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            if ((int)threadIdx.x + u * kFrontThreads < total) park1(raw[u], sm, v);
+            sm += q512;
+            v += r512;
+            if (v >= VPR) { v -= VPR; ++sm; }
         }
-    }
-    __syncthreads();
-    const int nvec = TS / M;
-    for (int l = lb; l < le; ++l) {
-        uint32_t m = 0;
-        for (int q = threadIdx.x; q < nvec; q += 256) {
-            const int sm = q * M;
-            if (sm >= ns) break;
-            const f32x4 val = *reinterpret_cast<const f32x4 *>(&s_tile[l * pitch + sm]);
-            float *dst = gT + ((int64_t)l * N + s0 + sm) * F;
-            if (sm + M <= ns) {
-                __builtin_nontemporal_store(val, reinterpret_cast<f32x4 *>(dst));
-                if constexpr (GMAX) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t b = __float_as_uint(fabsf(val[j]));
-                        m = b > m ? b : m;
-                    }
-                }
-            } else {   // last sample of an odd tail (M == 2)
-#pragma unroll
-                for (int j = 0; j < F; ++j) {
-                    dst[j] = val[j];
-                    if constexpr (GMAX) {
-                        const uint32_t b = __float_as_uint(fabsf(val[j]));
-                        m = b > m ? b : m;
-                    }
-                }
-            }
+        for (int e = (int)threadIdx.x + kFrontThreads * UL; e < total; e += kFrontThreads) {   // rows wider than 8 vectors
+            park1(__builtin_nontemporal_load(in + e), sm, v);
+            sm += q512;
+            v += r512;
+            if (v >= VPR) { v -= VPR; ++sm; }
         }
-        if constexpr (GMAX) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t o = __shfl_xor(m, off, 64);
-                m = o > m ? o : m;
-            }
-            if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_max[l], m);
-        }
-    }
-    if constexpr (GMAX) {
-        __syncthreads();
-        if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x])
-            atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------- passes T + A fused
-// One workgroup = one 1024-sample tile of passes A / B: four 256-sample rounds of the transpose (memory bound) with
-// the bucket counting of the same samples (ALU bound: corner hashing of every binned level) in between, so the two
-// overlap inside every CU -- issued as two kernels on two streams they mostly ran one after the other.
-constexpr int kFuseSlots = 4;                    // level slots per sample in the fused transpose + count kernel
-constexpr int kFuseThreads = 256 * kFuseSlots;
-template <int DIM, typename T, int F, bool GMAX>
-__global__ __launch_bounds__(kFuseThreads) void transpose_count_kernel(LevelTable lt, BinPlan plan, const T *__restrict__ go,
-                                                              float *__restrict__ gT, const float *__restrict__ coords,
-                                                              uint32_t *__restrict__ cnt, int64_t N, int lb, int le,
-                                                              uint32_t *__restrict__ gmax) {
-    __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
-    __shared__ uint32_t s_hist[SHACIRA_MAX_LODS][kMaxLevelBuckets];
-    struct alignas(sizeof(T) * F) PieceIn { T v[F]; };
-    struct alignas(sizeof(float) * F) PieceOut { float v[F]; };
-    extern __shared__ __align__(16) unsigned char s_raw_g[];
-    PieceOut *s_tile = reinterpret_cast<PieceOut *>(s_raw_g);  // [256][L + 1]
-    const int L = lt.num_lods, pitch = L + 1;
-    const uint32_t tile = blockIdx.x;
-    // thread = (sample sm of the round, level slot q): the transpose stores and the counting loop take every
-    // kFuseSlots-th level, so a round keeps 16 waves busy
-    const int sm_t = threadIdx.x & 255, q_t = threadIdx.x >> 8;
-    if (threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
-    for (uint32_t k = threadIdx.x; k < plan.nbl * (uint32_t)kMaxLevelBuckets; k += kFuseThreads) (&s_hist[0][0])[k] = 0;
-    __syncthreads();
-    PieceOut *out = reinterpret_cast<PieceOut *>(gT);
-    for (int sub = 0; sub < kTile / 256; ++sub) {
-        const int64_t s0 = (int64_t)tile * kTile + sub * 256;
-        if (s0 >= N) break;
-        const int ns = (int)((N - s0 < 256) ? (N - s0) : 256);
-        const PieceIn *in = reinterpret_cast<const PieceIn *>(go) + s0 * L;
-        const int total = ns * L;
-        for (int e = threadIdx.x; e < total; e += kFuseThreads) {
-            const int sm = e / L, l = e - sm * L;
-            const PieceIn p = in[e];
-            PieceOut q;
-#pragma unroll
-            for (int j = 0; j < F; ++j) q.v[j] = Scalar<T>::load(&p.v[j]);
-            s_tile[sm * pitch + l] = q;
-        }
-        // bucket counts of this round's sample while the rows above are in flight
-        if (sm_t < ns) {
-            const int64_t i = s0 + sm_t;
-            double t[DIM];
-#pragma unroll
-            for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
-            for (uint32_t li = (uint32_t)q_t; li < plan.nbl; li += kFuseSlots) {
-                const uint32_t lvl = plan.blevel[li];
-                const BinLevel bl = plan.lv[lvl];
-                bool done = false;
-                if constexpr (DIM == 3) {
-                    if (bl.compact) {
-                        int32_t pz;
-                        float fz, gz;
-                        axis_transform(t[2], lt.res[lvl], lt.hi[lvl], pz, fz, gz);
-                        atomicAdd(&s_hist[li][(uint32_t)pz / bl.slab], 2u);
-                        done = true;
-                    }
-                }
-                if (!done) {
-                    float fx;
-                    PairSlot ps[1 << (DIM - 1)];
-                    enumerate_pairs<DIM>(t, lt.res[lvl], lt.hi[lvl], lt.dense[lvl] != 0, lt.mask, bl, plan.BR, fx, ps);
-#pragma unroll
-                    for (int q = 0; q < (1 << (DIM - 1)); ++q)
-                        if (ps[q].key >> 26) atomicAdd(&s_hist[li][ps[q].bucket], 1u);
-                }
-            }
-        }
-        __syncthreads();
-        for (int l = lb + q_t; l < le; l += kFuseSlots) {
+        lds_barrier();
+        // LDS image -> gT: (level, vector) pairs over all threads; a wave stays inside one level per trip
+        const int work = (le - lb) << nvec_log2;
+        for (int idx = threadIdx.x; idx < work; idx += kFrontThreads) {
+            const int l = lb + (idx >> nvec_log2), smo = (idx & ((1 << nvec_log2) - 1)) << M_LOG2;
             uint32_t m = 0;
-            if (sm_t < ns) {
-                const PieceOut q = s_tile[sm_t * pitch + l];
-                if constexpr (GMAX) {
+            if (smo < ns) {
+                const f32x4 val = *reinterpret_cast<const f32x4 *>(&s_tile[l * pitch + smo]);
+                float *dst = gT + ((int64_t)l * NP + s0 + smo) * F;
+                if (smo + M <= ns) {
+                    __builtin_nontemporal_store(val, reinterpret_cast<f32x4 *>(dst));
+                    if constexpr (GMAX) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t b = __float_as_uint(fabsf(val[j]));
+                            m = b > m ? b : m;
+                        }
+                    }
+                } else {   // last sample of an odd tail (M == 2)
 #pragma unroll
                     for (int j = 0; j < F; ++j) {
-                        const uint32_t b = __float_as_uint(fabsf(q.v[j]));
-                        m = b > m ? b : m;
+                        dst[j] = val[j];
+                        if constexpr (GMAX) {
+                            const uint32_t b = __float_as_uint(fabsf(val[j]));
+                            m = b > m ? b : m;
+                        }
                     }
-                }
-                float *dst = reinterpret_cast<float *>(out + (int64_t)l * N + s0 + sm_t);
-                if constexpr (F == 2) {
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    f32x2 v = {q.v[0], q.v[1]};
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x2 *>(dst));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < F; ++j) __builtin_nontemporal_store(q.v[j], dst + j);
                 }
             }
             if constexpr (GMAX) {
@@ -480,13 +533,25 @@ __global__ __launch_bounds__(kFuseThreads) void transpose_count_kernel(LevelTabl
                 if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_max[l], m);
             }
         }
-        __syncthreads();   // s_tile is refilled by the next round
+        lds_barrier();   // s_tile is refilled by the next round (the stores keep draining)
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < plan.nbl * (uint32_t)kMaxLevelBuckets; k += kFuseThreads) {
-        const uint32_t li = k / kMaxLevelBuckets, b = k % kMaxLevelBuckets;
-        const BinLevel &bl = plan.lv[plan.blevel[li]];
-        if (b < bl.nb) cnt[(size_t)tile * plan.total_buckets + bl.bucket0 + b] = s_hist[li][b];
+    if constexpr (COUNT) {
+        // level index uniform, lanes = consecutive buckets: contiguous atomics into one of kTotalShards copies of the
+        // totals (512 workgroups adding to the same word serialise at the memory side: 18 us of the 30 this kernel took
+        // on 65 536 samples); the bucket scan adds the copies up
+        uint32_t *mine = totals + (size_t)(blockIdx.x % kTotalShards) * kMaxBuckets;
+        for (uint32_t li = 0; li < plan.nbl; ++li) {
+            const uint32_t nbk = plan.lv[plan.blevel[li]].nb, b0 = plan.bstart[li];
+            for (uint32_t b = threadIdx.x; b < nbk; b += kFrontThreads) {
+                const uint32_t c = s_hist[li * kMaxLevelBuckets + b];
+#ifndef ABL_NO_FLUSH
+                if (c) atomicAdd(&mine[b0 + b], c);
+#else
+                if (c && N < 0) atomicAdd(&mine[b0 + b], c);
+#endif
+            }
+        }
     }
     if constexpr (GMAX) {
         if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x])
@@ -495,45 +560,6 @@ __global__ __launch_bounds__(kFuseThreads) void transpose_count_kernel(LevelTabl
 }
 
 // ------------------------------------------------------------------------------------------------- pass S
-// cnt is TILE-major, cnt[tile][bucket] (a tile's counts of one level are contiguous: the count pass writes and the scatter
-// pass reads them as one 256-byte piece instead of one dword per 128-byte line). One workgroup per 16 buckets: thread =
-// (bucket, chunk of tiles), 64 chunks: per-chunk sums, prefix over the chunks, exclusive offsets in place; total ->
-// totals[bucket]. Every access is a 64-byte row piece shared by 16 lanes.
-constexpr int kScanWaves = 16, kScanBuckets = 16, kScanChunks = 64 * kScanWaves / kScanBuckets;
-__global__ __launch_bounds__(64 * kScanWaves) void bin_scan_tiles_kernel(uint32_t *__restrict__ cnt,
-                                                                          uint32_t *__restrict__ totals, uint32_t num_tiles,
-                                                                          uint32_t nbuckets) {
-    __shared__ uint32_t s_sum[kScanChunks][kScanBuckets];
-    const uint32_t bl = threadIdx.x % kScanBuckets, chunk = threadIdx.x / kScanBuckets;
-    const uint32_t gb = blockIdx.x * kScanBuckets + bl;
-    const bool ok = gb < nbuckets;
-    const uint32_t tpc = (num_tiles + kScanChunks - 1) / kScanChunks;
-    const uint32_t t0 = chunk * tpc < num_tiles ? chunk * tpc : num_tiles;
-    const uint32_t t1 = (t0 + tpc < num_tiles) ? t0 + tpc : num_tiles;
-    uint32_t sum = 0;
-    if (ok) {
-#pragma unroll 8
-        for (uint32_t t = t0; t < t1; ++t) sum += cnt[(size_t)t * nbuckets + gb];
-    }
-    s_sum[chunk][bl] = sum;
-    __syncthreads();
-    uint32_t run = 0, total = 0;
-    for (uint32_t c = 0; c < (uint32_t)kScanChunks; ++c) {
-        const uint32_t v = s_sum[c][bl];
-        if (c < chunk) run += v;
-        total += v;
-    }
-    if (ok) {
-        for (uint32_t t = t0; t < t1; ++t) {
-            uint32_t *p = cnt + (size_t)t * nbuckets + gb;
-            const uint32_t v = *p;
-            *p = run;
-            run += v;
-        }
-        if (chunk == 0) totals[gb] = total;
-    }
-}
-
 // single block: bucket bases (exclusive scan of totals) and the consumer work list
 //   base[b]         first item of bucket b in the item array (base[nb] = total)
 //   unit_first[b]   first work unit of bucket b; unit_first[nb] = number of units
@@ -542,8 +568,9 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
                                                                 uint64_t *__restrict__ base,
                                                                 uint32_t *__restrict__ unit_first,
                                                                 UnitDesc *__restrict__ unit_desc, uint32_t nb,
-                                                                uint32_t chunk_items, BinPlan plan,
-                                                                uint32_t *__restrict__ work_counter) {
+                                                                BinPlan plan,
+                                                                uint32_t *__restrict__ work_counter,
+                                                                unsigned long long *__restrict__ cursor) {
     __shared__ uint64_t s_items[kMaxBuckets + 2];
     __shared__ uint32_t s_units[kMaxBuckets + 2];
     __shared__ uint64_t s_wave_items[16];
@@ -556,7 +583,9 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const uint32_t b = 2 * t + k;
-        c[k] = (b < nb) ? totals[b] : 0u;
+        c[k] = 0u;
+        if (b < nb)
+            for (int sh = 0; sh < kTotalShards; ++sh) c[k] += totals[(size_t)sh * kMaxBuckets + b];
         uint32_t lq = 0;
         for (uint32_t q = 1; q < plan.nbl; ++q)
             if (plan.bstart[q] <= b) lq = q;
@@ -590,6 +619,7 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
     __syncthreads();
     for (uint32_t b = t; b <= nb; b += 1024) {
         base[b] = s_items[b];          // entries >= nb hold the grand totals (zero counts beyond nb)
+        cursor[b] = s_items[b];        // the scatter pass reserves its runs from here (returning atomics)
         unit_first[b] = s_units[b];
     }
 #pragma unroll
@@ -613,21 +643,16 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
 }
 
 // ------------------------------------------------------------------------------------------------- pass B
-// ROWS = false: gradients from the transposed image gT [L][N][F], grid (tiles, levels).
-// ROWS = true:  gradients straight from grad_output [N, L*F] (8 or 16 bytes of every 128-byte row per level) -- no
-//   transposing pass. Only worth it when the rows are fetched from HBM once: the 1-D grid is numbered so that ALL levels
-//   of a tile run back to back on ONE XCD (workgroup b runs on XCD b % 8): the first level pulls the tile's rows (and
-//   coordinates) into that XCD's L2, the others hit there. Each workgroup also folds max |g| of its level into gmax[]
-//   (the consumer's fixed-point scale, otherwise a by-product of the transpose).
-template <int DIM, int F, bool ROWS>
+// Gradients from the transposed image gT [L][NP][F], grid (tiles, binned levels). A (tile, bucket) run is reserved with one
+// returning atomic on the bucket's cursor (set to the bucket's base by the bucket scan): runs of different tiles land in
+// the bucket in arrival order -- the consumer's fixed-point sums do not depend on it.
+template <int DIM, int F>
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt, BinPlan plan,
                                                                   const float *__restrict__ coords,
                                                                   const float *__restrict__ gT,
-                                                                  const uint32_t *__restrict__ tile_off,
-                                                                  const uint64_t *__restrict__ base,
+                                                                  unsigned long long *__restrict__ cursor,
                                                                   Item<F> *__restrict__ items, int64_t sample0,
-                                                                  int64_t N, int64_t Ntotal, uint32_t lvl_off,
-                                                                  uint32_t nlev, uint32_t *__restrict__ gmax) {
+                                                                  int64_t N, int64_t gpitch) {
     constexpr int NP = 1 << (DIM - 1);
     constexpr int SPT = kTile / kBinThreads;   // samples per thread
     constexpr int kStage = kTile * NP;         // staged items per block
@@ -638,14 +663,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     __shared__ uint32_t s_start[kMaxLevelBuckets + 1];
     __shared__ uint64_t s_gbase[kMaxLevelBuckets];
 
-    uint32_t tile = blockIdx.x, bi = blockIdx.y;
-    if constexpr (ROWS) {   // b -> (XCD, slot); slot -> (tile of that XCD, level)
-        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-        tile = (slot / nlev) * 8u + xcd;
-        bi = slot % nlev;
-        if (tile >= plan.num_tiles) return;
-    }
-    const uint32_t lvl = plan.blevel[bi + lvl_off];
+    // level-fastest numbering: the workgroups in flight at any time span every binned level, so that their run
+    // reservations (returning atomics) spread over all buckets' cursors instead of hammering one level's 64 words, and a
+    // tile's coordinates are re-read by its levels back to back (L2 hits)
+    const uint32_t tile = plan.level_fastest ? blockIdx.y : blockIdx.x, bi = plan.level_fastest ? blockIdx.x : blockIdx.y;
+    const uint32_t lvl = plan.blevel[bi];
     const BinLevel bl = plan.lv[lvl];
     if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -691,7 +713,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
             enumerate_pairs<DIM>(t, res, hi, dense, lt.mask, bl, plan.BR, fx[u], ps[u]);
         }
         if (live) {
-            const float *gp = ROWS ? gT + (i * lt.num_lods + lvl) * F : gT + ((int64_t)lvl * Ntotal + i) * F;
+            const float *gp = gT + ((int64_t)lvl * gpitch + i) * F;
             if constexpr (F == 2) {
                 const float2 v = *reinterpret_cast<const float2 *>(gp);
                 g[u][0] = v.x; g[u][1] = v.y;
@@ -707,28 +729,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         }
     }
     __syncthreads();
-    if constexpr (ROWS) {
-        if (gmax != nullptr) {   // max |g| of the level as an integer max on the float bit patterns (finite < inf < NaN)
-            uint32_t m = 0;
-#pragma unroll
-            for (int u = 0; u < SPT; ++u) {
-                if (sample0 + (int64_t)tile * kTile + threadIdx.x + u * kBinThreads < N) {
-#pragma unroll
-                    for (int j = 0; j < F; ++j) {
-                        const uint32_t b = __float_as_uint(fabsf(g[u][j]));
-                        m = b > m ? b : m;
-                    }
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t o = __shfl_xor(m, off, 64);
-                m = o > m ? o : m;
-            }
-            if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(&gmax[lvl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMax(&gmax[lvl], m);
-        }
-    }
     if (threadIdx.x < 64) {  // wave 0: exclusive scan of the <= 128 bucket counts, two per lane
         const uint32_t lane = threadIdx.x;
         const uint32_t c0 = (2 * lane < bl.nb) ? s_hist[2 * lane] : 0u;
@@ -744,11 +744,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         if (2 * lane + 1 < bl.nb) s_start[2 * lane + 1] = excl + c0;
         if (lane == 63) s_start[bl.nb] = incl;
     }
-    if (threadIdx.x < bl.nb) {
-        const size_t gb = bl.bucket0 + threadIdx.x;
-        s_gbase[threadIdx.x] = base[gb] + tile_off[(size_t)tile * plan.total_buckets + gb];
+    // waves 1, 2 reserve this tile's runs (wave 0 scans meanwhile); the returned offsets are parked in a register and only
+    // written to LDS after the staging phase, so that the atomic's round trip hides behind it (LDS-only barrier here)
+    const bool reserver = threadIdx.x >= 64 && threadIdx.x - 64 < bl.nb;
+    unsigned long long run_base = 0ull;
+    if (reserver) {
+        const uint32_t c = s_hist[threadIdx.x - 64];
+        if (c) run_base = atomicAdd(&cursor[bl.bucket0 + threadIdx.x - 64], (unsigned long long)c);
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
 #pragma unroll
@@ -795,6 +799,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
             }
         }
     }
+    if (reserver) s_gbase[threadIdx.x - 64] = run_base;
     __syncthreads();
     const uint32_t staged = s_start[bl.nb];
     for (uint32_t pos = threadIdx.x; pos < staged; pos += kBinThreads) {
@@ -805,13 +810,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
 }
 
 // ------------------------------------------------------------------------------------------------- pass A
-// One workgroup per TILE counting every binned level: the coordinates are loaded once (all loads of the block in flight
-// together) and there are 10-15x fewer workgroups than one per (tile, level): 55 vs 88 us on S1. The same restructuring of
-// pass B measured slower (283 vs 247 us): profiles/r02_bwd_ablation.md.
+// Standalone counting pass (calls that do not transpose: sub-batches, level-range calls on staged gradients, rows the
+// 16-byte front kernel cannot read). One workgroup per TILE counting every binned level: the coordinates are loaded once;
+// counts leave as one global atomic per (workgroup, non-empty bucket) into totals[].
 template <int DIM>
 __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTable lt, BinPlan plan,
                                                                        const float *__restrict__ coords,
-                                                                       uint32_t *__restrict__ cnt, int64_t sample0,
+                                                                       uint32_t *__restrict__ totals, int64_t sample0,
                                                                        int64_t N) {
     __shared__ uint32_t s_hist[SHACIRA_MAX_LODS][kMaxLevelBuckets];
     constexpr int SPT = kTile / kBinThreads;
@@ -847,19 +852,20 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
                     continue;
                 }
             }
-            float fx;
-            PairSlot ps[1 << (DIM - 1)];
-            enumerate_pairs<DIM>(t[u], res, hi, dense, lt.mask, bl, plan.BR, fx, ps);
+            uint32_t bk[1 << (DIM - 1)];
+            bool ok[1 << (DIM - 1)];
+            enumerate_buckets<DIM>(t[u], res, hi, dense, lt.mask, bl, bk, ok);
 #pragma unroll
             for (int q = 0; q < (1 << (DIM - 1)); ++q)
-                if (ps[q].key >> 26) atomicAdd(&s_hist[bi][ps[q].bucket], 1u);
+                if (ok[q]) atomicAdd(&s_hist[bi][bk[q]], 1u);
         }
     }
     __syncthreads();
     for (uint32_t bi = blockIdx.y; bi < plan.nbl; bi += gridDim.y) {
         const BinLevel bl = plan.lv[plan.blevel[bi]];
         for (uint32_t b = threadIdx.x; b < bl.nb; b += kBinThreads)
-            cnt[(size_t)tile * plan.total_buckets + bl.bucket0 + b] = s_hist[bi][b];
+            if (s_hist[bi][b])
+                atomicAdd(&totals[(size_t)((blockIdx.x + blockIdx.y) % kTotalShards) * kMaxBuckets + bl.bucket0 + b], s_hist[bi][b]);
     }
 }
 
@@ -911,7 +917,6 @@ template <int F> __device__ __forceinline__ float pick(const float (&a)[F], int 
     for (int k = 1; k < F; ++k) v = (j == k) ? a[k] : v;
     return v;
 }
-__device__ __forceinline__ bool g_rot_enabled(const BinPlan &plan) { return plan.rotf != 0; }
 
 // ------------------------------------------------------------------------------------------------- pass C
 // one work unit (a bucket, or a chunk of an over-full one) on the calling workgroup
@@ -941,7 +946,7 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
             // {-, g2, g3, ...}; all 8 corners land here
             constexpr int UC = 2;
             const uint32_t r2 = r1 * r1;
-            const int rotc = plan.rotf ? (int)(threadIdx.x & (F - 1)) : 0;
+            const int rotc = (int)(threadIdx.x & (F - 1));
             for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
                 Item<F> ia[UC], ib[UC];
 #pragma unroll
@@ -995,7 +1000,7 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
         }
     }
     constexpr int UN = 8;  // items in flight per thread (4: -1 %, 16: +3 % with the fixed-point atomics)
-    const int rotf = g_rot_enabled(plan) ? (int)(threadIdx.x & (F - 1)) : 0;
+    const int rotf = (int)(threadIdx.x & (F - 1));
     for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
         Item<F> it[UN];
 #pragma unroll
@@ -1029,11 +1034,17 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
             } else {
                 if (it[u].key & (1u << 26)) {
 #pragma unroll
-                    for (int j = 0; j < F; ++j) atomicAdd(&s_acc[ra * F + j], (double)(it[u].a[j] * gx));
+                    for (int jj = 0; jj < F; ++jj) {
+                        const int j = (jj + rotf) & (F - 1);
+                        atomicAdd(&s_acc[ra * F + j], (double)(pick<F>(it[u].a, j) * gx));
+                    }
                 }
                 if (it[u].key & (1u << 27)) {
 #pragma unroll
-                    for (int j = 0; j < F; ++j) atomicAdd(&s_acc[rb * F + j], (double)(it[u].a[j] * it[u].fx));
+                    for (int jj = 0; jj < F; ++jj) {
+                        const int j = (jj + rotf) & (F - 1);
+                        atomicAdd(&s_acc[rb * F + j], (double)(pick<F>(it[u].a, j) * it[u].fx));
+                    }
                 }
             }
         }
@@ -1068,30 +1079,22 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
                                                                       float *__restrict__ grad_table,
                                                                       int force_atomic,
                                                                       const uint32_t *__restrict__ gmax,
-                                                                      int headroom, uint32_t bucket_lo,
-                                                                      uint32_t bucket_hi,
+                                                                      int headroom,
                                                                       uint32_t *__restrict__ work_counter) {
     extern __shared__ double s_acc[];  // [rows_pb][F]: fp64, or 64-bit fixed point (same size)
     __shared__ uint32_t s_unit;
-    // this launch consumes the work units of buckets [bucket_lo, bucket_hi) (one group of levels, or all of them)
-    const uint32_t unit0 = bucket_lo ? unit_first[bucket_lo] : 0u;
-    const uint32_t unit_end = unit_first[bucket_hi];
+    const uint32_t unit0 = 0u, unit_end = unit_first[plan.total_buckets];
     if (work_counter == nullptr) {
         const uint32_t unit = blockIdx.x + unit0;
         if (unit >= unit_end) return;
         consume_unit<F, FX>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
         return;
     }
-    // fetch order: the hashed levels' units (one whole bucket each: equal, large) first, the dense levels' smaller chunks
-    // last, so that the last round of units is made of small ones (persistent launches always cover the whole plan)
-    const uint32_t rot = (plan.rot_bucket == 0xFFFFFFFFu ? 0u : unit_first[plan.rot_bucket]) - unit0, nunits = unit_end - unit0;
     for (;;) {
         if (threadIdx.x == 0) s_unit = atomicAdd(work_counter, 1u);
         lds_barrier();
-        if (s_unit >= nunits) return;
-        const uint32_t unit = plan.rot_bucket == 0xFFFFFFFFu
-                                  ? unit_end - 1u - s_unit
-                                  : unit0 + (s_unit + rot < nunits ? s_unit + rot : s_unit + rot - nunits);
+        const uint32_t unit = s_unit + unit0;
+        if (unit >= unit_end) return;
         consume_unit<F, FX>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
         lds_barrier();   // the image and s_unit are free again; the flush stores keep draining
     }
@@ -1109,7 +1112,7 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
                                                                             const float *__restrict__ coords,
                                                                             const GT *__restrict__ gT,
                                                                             float *__restrict__ grad_table,
-                                                                            int64_t N,
+                                                                            int64_t N, int64_t gpitch,
                                                                             const uint32_t *__restrict__ gmax,
                                                                             int headroom) {
     constexpr int NC = 1 << DIM;
@@ -1134,7 +1137,7 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
     const bool fixed = FX && s_all_fixed != 0;
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
     const int64_t stride = (int64_t)gridDim.x * kConsumeThreads;
-    const int rotd = plan.rotf ? (int)(threadIdx.x & (F - 1)) : 0;
+    const int rotd = (int)(threadIdx.x & (F - 1));
     for (int64_t i = (int64_t)blockIdx.x * kConsumeThreads + threadIdx.x; i < N; i += stride) {
         double t[DIM];
 #pragma unroll
@@ -1144,7 +1147,7 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
             const BinLevel bl = plan.lv[l];
             Corners<DIM> c;
             compute_corners<DIM>(t, lt.res[l], lt.hi[l], lt.dense[l] != 0, lt.mask, c);
-            const GT *gp = TRANSPOSED ? gT + ((int64_t)l * N + i) * F : gT + (i * lt.num_lods + l) * F;
+            const GT *gp = TRANSPOSED ? gT + ((int64_t)l * gpitch + i) * F : gT + (i * lt.num_lods + l) * F;
             float g[F];
 #pragma unroll
             for (int j = 0; j < F; ++j) g[j] = Scalar<GT>::load(gp + j);
@@ -1161,7 +1164,10 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
                         }
                     } else {
 #pragma unroll
-                        for (int j = 0; j < F; ++j) atomicAdd(s_acc + slot + j, (double)(g[j] * c.w[k]));
+                        for (int jj = 0; jj < F; ++jj) {
+                            const int j = (jj + rotd) & (F - 1);
+                            atomicAdd(s_acc + slot + j, (double)(pick<F>(g, j) * c.w[k]));
+                        }
                     }
                 }
             }
@@ -1185,7 +1191,11 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
 // ------------------------------------------------------------------------------------------------- host side
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib);
+// `one_image_compact`: a dense 3-D level that fits ONE image travels as compact items too (one bucket whose units flush
+// atomically) instead of the direct pass in front of the scatter pass; decided per CALL from the total batch (below), so
+// that every plan of a call classifies the levels alike
+static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib, bool one_image_compact);
+static inline bool one_image_compact_rule(int64_t n_total) { return g_exp[2].load() != 0 && n_total >= ((int64_t)1 << 17); }
 
 // can the table be partitioned with an LDS accumulator image of `acc_kib` KiB per consumer workgroup?
 static bool bin_feasible(int dim, const LevelTable &lt, int acc_kib) {
@@ -1204,8 +1214,8 @@ static bool bin_feasible(int dim, const LevelTable &lt, int acc_kib) {
         }
     }
     BinPlan plan;
-    make_plan(dim, lt, kTile, plan, acc_kib);
-    if (plan.total_buckets > (uint32_t)kMaxBuckets) return false;
+    make_plan(dim, lt, kTile, plan, acc_kib, false);
+    if (plan.total_buckets + (uint32_t)lt.num_lods > (uint32_t)kMaxBuckets) return false;   // (+ one-image compact levels)
     for (int l = 0; l < lt.num_lods; ++l)
         if (plan.lv[l].nb > (uint32_t)kMaxLevelBuckets) return false;
     return true;
@@ -1222,7 +1232,7 @@ static int choose_acc_kib(int dim, const LevelTable &lt, int64_t n) {
     // tables whose levels are all "direct" (config B: every level fits an LDS image) want the big image: fewer level
     // groups, hence fewer walks over the samples (measured 82 vs 124 us on the 393 216-pixel batch)
     BinPlan big;
-    make_plan(dim, lt, kTile, big, 128);
+    make_plan(dim, lt, kTile, big, 128, false);
     return big.nbl == 0 ? 128 : 64;
 }
 
@@ -1231,7 +1241,11 @@ bool bin_supported(int dim, const LevelTable &lt) {
     return bin_feasible(dim, lt, opt ? opt : 128);
 }
 
-static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib) {
+static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib, bool one_image_compact) {
+    if (one_image_compact) {   // tables whose levels are ALL direct stay that way (no transposing pass at all)
+        make_plan(dim, lt, n_batch, plan, acc_kib, false);
+        if (plan.nbl == 0) return;
+    }
     const int F = lt.feature_dim;
     const uint32_t BR = (uint32_t)acc_kib * 128u / (uint32_t)F;
     uint32_t shift = 0;
@@ -1269,7 +1283,9 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
             // cells in z and the image = that slab plus one halo plane, so all 8 corners of a sample land in ONE
             // bucket and the sample travels as one 32-byte item instead of four 16-byte pair items.
             const uint64_t planes = (dim == 3 && (F == 2 || F == 4) && g_bwd_compact.load() != 0) ? BR / (res * res) : 0;
-            if (planes >= 2 && res >= 3 && bl.used > BR) {
+            // (exp2: a level that fits ONE image may also travel as compact items -- one bucket, its units flush atomically --
+            // instead of the direct pass that walks the whole batch in front of the scatter pass)
+            if (planes >= 2 && res >= 3 && (bl.used > BR || one_image_compact)) {
                 const uint32_t slab = (uint32_t)planes - 1;
                 const uint32_t nbz = ((uint32_t)res - 2u) / slab + 1u;      // base cells: z in [0, res - 2]
                 if (nbz <= (uint32_t)kMaxLevelBuckets) {
@@ -1286,7 +1302,7 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
             bl.G = 1;
             bl.magicG = 0;
         }
-        if (bl.nb == 1 && bl.used <= BR) {
+        if (bl.nb == 1 && bl.used <= BR && !bl.compact) {
             // direct level: first group with room (greedy); groups hold <= BR rows
             uint32_t gi = 0;
             while (gi < plan.ngroups && plan.grows[gi] + bl.used > BR) ++gi;
@@ -1356,42 +1372,37 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
     if (chunk < 8192) chunk = 8192;
     if (chunk > (1u << 22)) chunk = 1u << 22;
     plan.chunk = (uint32_t)chunk & ~1u;   // even: a compact item (two 16-byte slots) never straddles two work units
-    const int cdiv = g_exp[1].load() > 0 ? g_exp[1].load() : 1;
-    uint64_t cc = chunk / (uint64_t)cdiv;
-    if (cc < 8192) cc = 8192;
-    if (cc > chunk) cc = chunk;
-    plan.chunk_c = (uint32_t)cc & ~1u;
-    // The consume pass hands out units in bucket order to one persistent workgroup per CU: the units of the LAST levels are
-    // its tail. An evenly loaded hashed bucket is one unit (~45 us on S1); the last `tail_levels` levels are cut into
-    // `tail_div` chunks per bucket instead (atomic flush onto rows zeroed by zero_odd_buckets_kernel), so that the
-    // workgroups run out of work within ~10 us of each other.
-    {
-        const int tail_levels = g_exp[3].load() >= 0 ? g_exp[3].load() : 2;
-        const int tail_div = g_exp[4].load() > 0 ? g_exp[4].load() : 4;
-        for (uint32_t q = 0; q < plan.nbl; ++q) {
-            BinLevel &bl = plan.lv[plan.blevel[q]];
-            bl.chunk = bl.compact ? plan.chunk_c : plan.chunk;
-            if (q + (uint32_t)tail_levels >= plan.nbl && !bl.compact && n_batch >= (1 << 17)) {
-                uint64_t c = ((uint64_t)n_batch * plan.pairs / bl.nb) / (uint64_t)tail_div + 1024;   // per-bucket mean / div, + slack
-                if (c < 8192) c = 8192;
-                if (c < bl.chunk) bl.chunk = (uint32_t)c & ~1u;
-            }
-            if (bl.chunk < plan.chunk_c) plan.chunk_c = bl.chunk;   // smallest unit size of the plan (sizes the unit list)
+    // Unit order = bucket order (dense compact levels first, then the hashed levels, coarse to fine) is the measured best for
+    // the persistent consume pass: hashed levels first or reverse order cost +45 us on S1, smaller units for the dense levels
+    // or for the last hashed levels changed nothing (round 3, tools/r3_ab.py).
+    for (uint32_t q = 0; q < plan.nbl; ++q) {
+        BinLevel &bl = plan.lv[plan.blevel[q]];
+        bl.chunk = plan.chunk;
+        CountLevel &c = plan.cl[q];
+        c.res = lt.res[plan.blevel[q]];
+        c.hi = lt.hi[plan.blevel[q]];
+        c.shift = bl.shift;
+        c.m_lo = (uint32_t)bl.magicG;
+        c.m_hi = (uint32_t)(bl.magicG >> 32);
+        c.kind = lt.dense[plan.blevel[q]] ? 2u : 0u;
+        if (bl.compact) {
+            const uint32_t m = ((1u << 18) + bl.slab - 1u) / bl.slab;
+            bool exact = m < (1u << 18) || bl.slab == 1;
+            for (uint32_t pz = 0; pz < (uint32_t)c.res && exact; ++pz) exact = ((pz * m) >> 18) == pz / bl.slab;
+            c.kind = 1u;
+            c.m_lo = exact ? m : 0u;   // 0: divide
+            c.m_hi = bl.slab;
         }
     }
-    plan.rot_bucket = 0;
-    plan.rotf = g_exp[5].load() != 0 ? 1u : 0u;
-    if (g_exp[2].load() == 2) plan.rot_bucket = 0xFFFFFFFFu;   // reverse order: the items written last are read first
-    if (g_exp[2].load() == 1)
-        for (uint32_t q = 0; q < plan.nbl; ++q)
-            if (lt.dense[plan.blevel[q]] == 0) { plan.rot_bucket = plan.bstart[q]; break; }
+    plan.chunk_min = plan.chunk;
+    plan.level_fastest = g_exp[1].load() == 1 ? 1u : 0u;
 }
 
 // sub-batch so that the item array stays below the cap (default 1.5 GiB, option "bin_batch_mib")
 static int64_t bin_batch_samples(int dim, const LevelTable &lt, int64_t n) {
     const size_t item = 8 + 4 * (size_t)lt.feature_dim;
     BinPlan plan;
-    make_plan(dim, lt, kTile, plan, choose_acc_kib(dim, lt, n));
+    make_plan(dim, lt, kTile, plan, choose_acc_kib(dim, lt, n), one_image_compact_rule(n));
     const size_t per_sample = (size_t)(plan.nbl ? plan.nbl : 1) * (1u << (dim - 1)) * item;
     int64_t cap = (int64_t)(((size_t)g_bin_batch_mib.load() << 20) / per_sample);
     cap = cap / kTile * kTile;
@@ -1400,36 +1411,37 @@ static int64_t bin_batch_samples(int dim, const LevelTable &lt, int64_t n) {
 }
 
 struct BinWorkspace {
-    float *gT;
+    float *gT;                    // [L][NP][F] transposed gradients, NP = n rounded up to even
     unsigned char *items;
-    uint32_t *cnt;
-    uint32_t *totals;
+    uint32_t *totals;             // [kTotalShards][kMaxBuckets] items per bucket (global atomics of the counting pass)
+    uint32_t *gmax;               // [SHACIRA_MAX_LODS] bit patterns of max |grad_output| per level (right behind totals)
     uint64_t *base;
+    unsigned long long *cursor;   // [kMaxBuckets + 2] next free item slot of each bucket (scatter pass)
     uint32_t *unit_first;
     UnitDesc *unit_desc;
-    uint32_t *work_counter;   // next unit of the persistent consume pass (zeroed by the bucket scan)
-    uint32_t *gmax;  // [SHACIRA_MAX_LODS] bit patterns of max |grad_output| per level
-    float *acc32;  // fp32 accumulation image for fp16 tables
+    uint32_t *work_counter;       // next unit of the persistent consume pass (zeroed by the bucket scan)
+    float *acc32;                 // fp32 accumulation image for fp16 tables
     size_t bytes;
 };
+
+static inline int64_t level_pitch(int64_t n) { return (n + 1) & ~(int64_t)1; }
 
 static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, void *ws) {
     BinPlan plan;
     const int64_t nb = bin_batch_samples(dim, lt, n);
-    make_plan(dim, lt, nb, plan, choose_acc_kib(dim, lt, n));
+    make_plan(dim, lt, nb, plan, choose_acc_kib(dim, lt, n), one_image_compact_rule(n));
     const size_t item = 8 + 4 * (size_t)lt.feature_dim;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     // gT and gmax first: their offsets must not depend on the level range of the call (REUSE_STAGED calls share them)
-    const size_t o_gT = take((size_t)n * lt.num_lods * lt.feature_dim * sizeof(float));
-    const size_t o_gmax = take(SHACIRA_MAX_LODS * sizeof(uint32_t));
+    const size_t o_gT = take((size_t)level_pitch(n) * lt.num_lods * lt.feature_dim * sizeof(float));
+    const size_t o_ctrl = take((size_t)(kTotalShards * kMaxBuckets + SHACIRA_MAX_LODS) * sizeof(uint32_t));   // totals | gmax: one memset
     const size_t o_items = take((size_t)nb * plan.nbl * plan.pairs * item);
-    const size_t o_cnt = take((size_t)plan.total_buckets * plan.num_tiles * sizeof(uint32_t));
-    const size_t o_tot = take((size_t)(plan.total_buckets + 1) * sizeof(uint32_t));
     const size_t o_base = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
+    const size_t o_cur = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
     const size_t o_unit = take((size_t)(kMaxBuckets + 2) * sizeof(uint32_t));
     const uint64_t max_items_ws = (uint64_t)nb * plan.nbl * plan.pairs;
-    const size_t o_ub = take((size_t)(max_items_ws / plan.chunk_c + plan.total_buckets + 2) * sizeof(UnitDesc));
+    const size_t o_ub = take((size_t)(max_items_ws / plan.chunk_min + plan.total_buckets + 2) * sizeof(UnitDesc));
     const size_t o_wc = take(256);
     const size_t o_acc = take(dtype == SHACIRA_F16 ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0);
     BinWorkspace w{};
@@ -1437,13 +1449,13 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     if (p) {
         w.gT = reinterpret_cast<float *>(p + o_gT);
         w.items = p + o_items;
-        w.cnt = reinterpret_cast<uint32_t *>(p + o_cnt);
-        w.totals = reinterpret_cast<uint32_t *>(p + o_tot);
+        w.totals = reinterpret_cast<uint32_t *>(p + o_ctrl);
+        w.gmax = w.totals + (size_t)kTotalShards * kMaxBuckets;
         w.base = reinterpret_cast<uint64_t *>(p + o_base);
+        w.cursor = reinterpret_cast<unsigned long long *>(p + o_cur);
         w.unit_first = reinterpret_cast<uint32_t *>(p + o_unit);
         w.unit_desc = reinterpret_cast<UnitDesc *>(p + o_ub);
         w.work_counter = reinterpret_cast<uint32_t *>(p + o_wc);
-        w.gmax = reinterpret_cast<uint32_t *>(p + o_gmax);
         w.acc32 = reinterpret_cast<float *>(p + o_acc);
     }
     w.bytes = off;
@@ -1463,49 +1475,63 @@ float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *work
         hipError_t e_ = hipGetLastError();     \
         if (e_ != hipSuccess) return e_;       \
     } while (0)
+#define SHACIRA_CHECK(expr)                    \
+    do {                                       \
+        hipError_t e_ = (expr);                \
+        if (e_ != hipSuccess) return e_;       \
+    } while (0)
 
-// Side stream for the passes that do not depend on the transposed gradient (count + scans): they are compute/LDS
-// bound while the transpose and the direct levels are memory/LDS bound, so they share the chip well. One per host
-// thread and device; fork/join with events keeps the caller's stream semantics (and is capturable in a HIP graph once
-// the objects exist -- they are created on the first eager call).
+// Side stream for what does not sit on the critical path transpose -> bucket scan -> scatter -> consume: the table
+// zeroing and the direct levels (LDS bound; they run beside the bucket scan and the write-bound scatter pass). One per host
+// thread and device; fork/join with events keeps the caller's stream semantics (and is capturable in a HIP graph once the
+// objects exist -- they are created on the first eager call).
 struct SideStream {
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, zeroed = nullptr, staged = nullptr, group = nullptr, done = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, staged = nullptr;
 };
 static hipError_t side_stream(SideStream **out) {
-    static thread_local SideStream per_device[16];
+    static thread_local SideStream per_device[kMaxDevices];
     int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    SHACIRA_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
     SideStream &ss = per_device[dev];
     if (!ss.stream) {
         hipStream_t st;
-        hipEvent_t a, b, c, d, g2, d2;
-        if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return e;
-        if ((e = hipEventCreateWithFlags(&a, hipEventDisableTiming)) != hipSuccess) return e;
-        if ((e = hipEventCreateWithFlags(&b, hipEventDisableTiming)) != hipSuccess) return e;
-        if ((e = hipEventCreateWithFlags(&c, hipEventDisableTiming)) != hipSuccess) return e;
-        if ((e = hipEventCreateWithFlags(&d, hipEventDisableTiming)) != hipSuccess) return e;
-        if ((e = hipEventCreateWithFlags(&g2, hipEventDisableTiming)) != hipSuccess) return e;
-        if ((e = hipEventCreateWithFlags(&d2, hipEventDisableTiming)) != hipSuccess) return e;
+        hipEvent_t a, b, c;
+        SHACIRA_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        SHACIRA_CHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        SHACIRA_CHECK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        SHACIRA_CHECK(hipEventCreateWithFlags(&c, hipEventDisableTiming));
         ss.fork = a;
         ss.join = b;
-        ss.zeroed = c;
-        ss.staged = d;
-        ss.group = g2;
-        ss.done = d2;
+        ss.staged = c;
         ss.stream = st;
     }
     *out = &ss;
     return hipSuccess;
 }
 
-// pass A grid: tiles x level shares, at least ~1024 workgroups when the batch is small
+// standalone pass A grid: tiles x level shares, at least ~1024 workgroups when the batch is small
 static dim3 count_grid(const BinPlan &plan) {
     uint32_t shares = plan.num_tiles >= 1024 ? 1u : (1024u + plan.num_tiles - 1) / plan.num_tiles;
     if (shares > plan.nbl) shares = plan.nbl;
     return dim3(plan.num_tiles, shares < 1 ? 1 : shares);
+}
+
+// tile size of the 16-byte front kernel: the largest multiple of 128 samples (<= 512) whose staging image + bucket
+// histograms leave room for two workgroups per CU
+static int front_tile(int L, int F, uint32_t nbl, int64_t n, size_t *shmem) {
+    int ts = 512;
+    for (;;) {
+        const size_t bytes = (size_t)L * (ts + 2) * F * sizeof(float) + (size_t)nbl * kMaxLevelBuckets * sizeof(uint32_t);
+        // small batches: smaller tiles, so that at least ~512 workgroups share the counting (one sample per thread)
+        const bool enough = (n + ts - 1) / ts >= 512;
+        if ((bytes <= (size_t)78 * 1024 && enough) || ts == 128) {
+            *shmem = bytes;
+            return bytes <= (size_t)156 * 1024 ? ts : 0;
+        }
+        ts /= 2;
+    }
 }
 
 template <int DIM, int F>
@@ -1513,183 +1539,108 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                           const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s,
                           bool zero_table) {
     const int L = lt.num_lods;
+    const int64_t NP = level_pitch(n);
     BinPlan whole;
     const int acc_kib = choose_acc_kib(DIM, lt, n);
-    make_plan(DIM, lt, n, whole, acc_kib);
+    const bool oic = one_image_compact_rule(n);
+    make_plan(DIM, lt, n, whole, acc_kib, oic);
     const int64_t nb = bin_batch_samples(DIM, lt, n);
     const bool multi = nb < n;
     const bool stage_all = (lt.stage_flags & SHACIRA_BWD_STAGE_ALL_LEVELS) != 0;
     const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
     // only binned levels consume the transposed gradients (a later call on this workspace may, too: stage_all)
-    // "rows" mode: the scatter pass reads grad_output itself (XCD-affine grid), no transposed image is built at all
-    const int rows_opt = g_bwd_rows.load();
-    const bool rows_mode = rows_opt != 0 && whole.nbl > 0 && dtype == SHACIRA_F32 && !stage_all && !staged && !multi &&
-                           (rows_opt == 2 || n >= (1 << 18));
-    const bool need_T = !rows_mode && (whole.nbl > 0 || stage_all || staged);
-    // single sub-batch (the usual case): a side stream takes what is off the critical path. With a transpose to do,
-    // counting is FUSED into it (transpose_count_kernel) and the side stream zeroes the table and runs the direct
-    // levels; a call that reuses staged gradients counts + scans on the side stream instead.
-    SideStream *ss = nullptr;
-    // measured (tools/bwd_rules_sweep.py, S1 table): 3-D: the one-stream order is 4-5 % faster at 256 K - 320 K samples, equal at
-    // 400 K, 3-5 % slower from 2^19; 2-D: the fork wins from 2^18 (equal at 192 K); a loss at 64 K and 128 K (also fused)
-    // (thresholds in units of n * L * F so that heavier tables fork earlier: nerf_lego.yaml's 24-level F = 4 table gains 7 %
-    // from the fork at 256 K samples, where the 16-level F = 2 table loses 5 %)
+    const bool need_T = whole.nbl > 0 || stage_all || staged;
+    // fixed-point images pay off once the accumulation itself dominates; small batches are bound by fixed costs and
+    // keep the fp64 image (and skip the gmax bookkeeping): measured 100 vs 107 us at 65 536 samples
+    const bool use_fx = need_T && n >= (1 << 17);
+    // the 16-byte front kernel needs rows of whole 16-byte vectors and a 16-byte aligned input
+    const size_t esz = dtype == SHACIRA_F32 ? 4 : 2;
+    const int kvec = (int)(16 / (esz * F));
+    size_t front_shmem = 0;
+    const int ts16 = front_tile(L, F, whole.nbl, n, &front_shmem);
+    const bool t16 = ts16 > 0 && (L % kvec) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0;
+    // counting fused into the front kernel: a call that transposes, single sub-batch
+    const bool front_counts = need_T && !staged && !multi && t16 && whole.nbl > 0;
+    // side stream (option bwd_fork): table zeroing + direct levels beside the critical path. Worth an event pair once the
+    // batch is large (threshold in units of n * L * F: heavier tables fork earlier)
     const int64_t fork_work = n * lt.num_lods * lt.feature_dim;
-    const bool can_fork = whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 &&
-                          fork_work >= (DIM == 3 ? ((int64_t)7 << 21) : ((int64_t)1 << 23));
-    // measured (tools/fuse_check.py, re-measured at the end of round 2): 3-D: fused wins by 2-4 % up to 786 K samples and
-    // loses 3 % at 2^20; 2-D: fused wins by 2-8 % at every size tried (2^18 ... 2^21) ("bwd_fuse": 0 = never, 1 = by that
-    // rule, 2 = always)
-    const int fuse_opt = g_bwd_fuse.load();
-    const bool fuse_rule = (DIM == 2) ? n <= ((int64_t)1 << 22) : n <= ((int64_t)3 << 18);
-    const bool fuse = can_fork && need_T && !staged && (fuse_opt == 2 || (fuse_opt == 1 && fuse_rule));
+    const int64_t fork_min = g_exp[0].load() >= 0 ? (int64_t)g_exp[0].load() << 16 : (DIM == 3 ? ((int64_t)7 << 21) : ((int64_t)1 << 23));
+    const bool fork = whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 && fork_work >= fork_min;
     // selective zeroing (see zero_unowned_rows_kernel): a single sub-batch whose plan has hashed binned levels
     bool any_hashed = false;
     for (uint32_t q = 0; q < whole.nbl; ++q) any_hashed = any_hashed || lt.dense[whole.blevel[q]] == 0;
     const bool selective = zero_table && !multi && any_hashed && g_bwd_selective_zero.load() != 0;
-    auto zero_acc = [&](hipStream_t zs) -> hipError_t {
-        if (!selective)
-            return hipMemsetAsync(acc, 0, (size_t)lt.table_rows * lt.feature_dim * sizeof(float), zs);
-        hipLaunchKernelGGL(zero_unowned_rows_kernel, dim3(256, (uint32_t)L), dim3(256), 0, zs, acc, first_idx, lt, whole);
-        return hipGetLastError();
-    };
-    auto zero_odd_buckets = [&](const BinPlan &plan, hipStream_t zs) -> hipError_t {   // after bin_scan_buckets_kernel
-        if (!selective) return hipSuccess;
-        hipLaunchKernelGGL(zero_odd_buckets_kernel, dim3(kMaxLevelBuckets, plan.nbl), dim3(256), 0, zs, acc, first_idx,
-                           w.unit_first, lt, plan);
-        return hipGetLastError();
-    };
-    if (can_fork) {
-        hipError_t e = side_stream(&ss);
-        if (e != hipSuccess) return e;
-        if ((e = hipEventRecord(ss->fork, s)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(ss->stream, ss->fork, 0)) != hipSuccess) return e;
-        if (zero_table) {   // at::zeros_like of the reference: off the critical path, next to the transpose
-            if ((e = zero_acc(ss->stream)) != hipSuccess) return e;
-            if ((e = hipEventRecord(ss->zeroed, ss->stream)) != hipSuccess) return e;
-        }
-        if (!fuse) {
-            BinPlan plan;
-            make_plan(DIM, lt, n, plan, acc_kib);
-            const dim3 grid(plan.num_tiles, plan.nbl);
-            hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), count_grid(plan), dim3(kBinThreads), 0, ss->stream, lt,
-                               plan, coords, w.cnt, (int64_t)0, n);
+    SideStream *ss = nullptr;
+    hipStream_t zs = s;   // stream of the table zeroing and the direct levels
+    if (fork) {
+        SHACIRA_CHECK(side_stream(&ss));
+        SHACIRA_CHECK(hipEventRecord(ss->fork, s));
+        SHACIRA_CHECK(hipStreamWaitEvent(ss->stream, ss->fork, 0));
+        zs = ss->stream;
+    }
+    if (zero_table) {   // at::zeros_like of the reference
+        if (!selective) {
+            SHACIRA_CHECK(hipMemsetAsync(acc, 0, (size_t)lt.table_rows * lt.feature_dim * sizeof(float), zs));
+        } else {
+            hipLaunchKernelGGL(zero_unowned_rows_kernel, dim3(256, (uint32_t)L), dim3(256), 0, zs, acc, first_idx, lt, whole);
             SHACIRA_CHECK_LAUNCH();
-            hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3((plan.total_buckets + kScanBuckets - 1) / kScanBuckets), dim3(64 * kScanWaves), 0,
-                               ss->stream, w.cnt, w.totals, plan.num_tiles, plan.total_buckets);
-            SHACIRA_CHECK_LAUNCH();
-            hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, ss->stream, w.totals, w.base,
-                               w.unit_first, w.unit_desc, plan.total_buckets, plan.chunk, plan, w.work_counter);
-            SHACIRA_CHECK_LAUNCH();
-            if ((e = zero_odd_buckets(plan, ss->stream)) != hipSuccess) return e;
-            if ((e = hipEventRecord(ss->join, ss->stream)) != hipSuccess) return e;
         }
     }
-    if (zero_table && !ss) {
-        hipError_t e = zero_acc(s);
-        if (e != hipSuccess) return e;
-    }
-    // fixed-point images pay off once the accumulation itself dominates; small batches are bound by fixed costs and
-    // keep the fp64 image (and skip the gmax bookkeeping): measured 100 vs 107 us at 65 536 samples
-    const bool use_fx = (need_T || rows_mode) && n >= (1 << 17);
-    if (!staged && use_fx) {   // per-level max |grad_output| for the scales (kept in the workspace for REUSE_STAGED)
-        hipError_t e = hipMemsetAsync(w.gmax, 0, SHACIRA_MAX_LODS * sizeof(uint32_t), s);
-        if (e != hipSuccess) return e;
-    }
-    if (fuse) {
-        // passes T + A in one kernel, then the scans, all on the caller's stream
+    // bucket totals (and, when this call transposes, the per-level max |grad_output| right behind them) start at zero
+    if (whole.nbl > 0 || (!staged && use_fx))
+        SHACIRA_CHECK(hipMemsetAsync(w.totals, 0, ((size_t)kTotalShards * kMaxBuckets + ((!staged && use_fx) ? SHACIRA_MAX_LODS : 0)) * sizeof(uint32_t), s));
+    if (need_T && !staged) {
         const int t_lb = stage_all ? 0 : lt.level_begin, t_le = stage_all ? L : lt.level_end;
-        const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
-        BinPlan plan;
-        make_plan(DIM, lt, n, plan, acc_kib);
-        const dim3 grid(plan.num_tiles);
-        if (dtype == SHACIRA_F32 && use_fx)
-            hipLaunchKernelGGL((transpose_count_kernel<DIM, float, F, true>), grid, dim3(kFuseThreads), shmem, s, lt, plan,
-                               static_cast<const float *>(grad_out), w.gT, coords, w.cnt, n, t_lb, t_le, w.gmax);
-        else if (dtype == SHACIRA_F32)
-            hipLaunchKernelGGL((transpose_count_kernel<DIM, float, F, false>), grid, dim3(kFuseThreads), shmem, s, lt, plan,
-                               static_cast<const float *>(grad_out), w.gT, coords, w.cnt, n, t_lb, t_le, nullptr);
-        else if (use_fx)
-            hipLaunchKernelGGL((transpose_count_kernel<DIM, __half, F, true>), grid, dim3(kFuseThreads), shmem, s, lt, plan,
-                               static_cast<const __half *>(grad_out), w.gT, coords, w.cnt, n, t_lb, t_le, w.gmax);
-        else
-            hipLaunchKernelGGL((transpose_count_kernel<DIM, __half, F, false>), grid, dim3(kFuseThreads), shmem, s, lt, plan,
-                               static_cast<const __half *>(grad_out), w.gT, coords, w.cnt, n, t_lb, t_le, nullptr);
-        SHACIRA_CHECK_LAUNCH();
-        hipError_t e;
-        if ((e = hipEventRecord(ss->staged, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3((plan.total_buckets + kScanBuckets - 1) / kScanBuckets), dim3(64 * kScanWaves), 0, s,
-                           w.cnt, w.totals, plan.num_tiles, plan.total_buckets);
-        SHACIRA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
-                           w.unit_desc, plan.total_buckets, plan.chunk, plan, w.work_counter);
-        SHACIRA_CHECK_LAUNCH();
-        if ((e = zero_odd_buckets(plan, s)) != hipSuccess) return e;
-    } else if (need_T && !staged) {
-        const int t_lb = stage_all ? 0 : lt.level_begin, t_le = stage_all ? L : lt.level_end;
-        // pass T over the whole batch (also gathers gmax)
-        const uint32_t blocks = (uint32_t)((n + 255) / 256);
-        const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
-        // 16-byte form: rows of whole 16-byte vectors, 16-byte aligned input, N even for the two-sample output vectors
-        const size_t esz = dtype == SHACIRA_F32 ? 4 : 2;
-        const int kvec = (int)(16 / (esz * F));
-        int ts16 = g_exp[0].load();   // samples per tile (exp0: 0 = 8-byte kernel, else tile size)
-        if (ts16 < 0) ts16 = 512;
-        while (ts16 >= 128 && (size_t)L * (ts16 + 2) * F * sizeof(float) > (size_t)72 * 1024) ts16 /= 2;
-        const bool t16 = ts16 >= 128 && ts16 % 128 == 0 && (L % kvec) == 0 && (F == 4 || (n % 2) == 0) &&
-                         (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0;
         if (t16) {
-            const uint32_t blocks16 = (uint32_t)((n + ts16 - 1) / ts16);
-            const size_t shmem16 = (size_t)L * (ts16 + 2) * F * sizeof(float);
+            // ~512 workgroups (two per CU, all resident) when the batch allows; never fewer than one tile per workgroup
+            const int64_t tiles = (n + ts16 - 1) / ts16;
+            int ts_log2 = 7;
+            while ((1 << ts_log2) < ts16) ++ts_log2;
+            const int rounds = (int)((tiles + 511) / 512);
+            const uint32_t blocks = (uint32_t)((tiles + rounds - 1) / rounds);
+#define SHACIRA_FRONT(TT, GM, CN)                                                                                         \
+            hipLaunchKernelGGL((front16_kernel<DIM, TT, F, GM, CN>), dim3(blocks), dim3(kFrontThreads), front_shmem, s, lt, \
+                               whole, static_cast<const TT *>(grad_out), w.gT, coords, w.totals, n, NP, t_lb, t_le, ts_log2, \
+                               rounds, GM ? w.gmax : nullptr)
+            if (dtype == SHACIRA_F32) {
+                if (use_fx && front_counts) SHACIRA_FRONT(float, true, true);
+                else if (use_fx) SHACIRA_FRONT(float, true, false);
+                else if (front_counts) SHACIRA_FRONT(float, false, true);
+                else SHACIRA_FRONT(float, false, false);
+            } else {
+                if (use_fx && front_counts) SHACIRA_FRONT(__half, true, true);
+                else if (use_fx) SHACIRA_FRONT(__half, true, false);
+                else if (front_counts) SHACIRA_FRONT(__half, false, true);
+                else SHACIRA_FRONT(__half, false, false);
+            }
+#undef SHACIRA_FRONT
+        } else {
+            const uint32_t blocks = (uint32_t)((n + 255) / 256);
+            const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
             if (dtype == SHACIRA_F32 && use_fx)
-                hipLaunchKernelGGL((transpose_grad16_kernel<float, F, true>), dim3(blocks16), dim3(256), shmem16, s,
-                                   static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, ts16, w.gmax);
+                hipLaunchKernelGGL((transpose_grad_kernel<float, F, true>), dim3(blocks), dim3(256), shmem, s,
+                                   static_cast<const float *>(grad_out), w.gT, n, NP, L, t_lb, t_le, w.gmax);
             else if (dtype == SHACIRA_F32)
-                hipLaunchKernelGGL((transpose_grad16_kernel<float, F, false>), dim3(blocks16), dim3(256), shmem16, s,
-                                   static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, ts16, nullptr);
+                hipLaunchKernelGGL((transpose_grad_kernel<float, F, false>), dim3(blocks), dim3(256), shmem, s,
+                                   static_cast<const float *>(grad_out), w.gT, n, NP, L, t_lb, t_le, nullptr);
             else if (use_fx)
-                hipLaunchKernelGGL((transpose_grad16_kernel<__half, F, true>), dim3(blocks16), dim3(256), shmem16, s,
-                                   static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, ts16, w.gmax);
+                hipLaunchKernelGGL((transpose_grad_kernel<__half, F, true>), dim3(blocks), dim3(256), shmem, s,
+                                   static_cast<const __half *>(grad_out), w.gT, n, NP, L, t_lb, t_le, w.gmax);
             else
-                hipLaunchKernelGGL((transpose_grad16_kernel<__half, F, false>), dim3(blocks16), dim3(256), shmem16, s,
-                                   static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, ts16, nullptr);
-        } else if (dtype == SHACIRA_F32 && use_fx)
-            hipLaunchKernelGGL((transpose_grad_kernel<float, F, true>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax);
-        else if (dtype == SHACIRA_F32)
-            hipLaunchKernelGGL((transpose_grad_kernel<float, F, false>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const float *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr);
-        else if (use_fx)
-            hipLaunchKernelGGL((transpose_grad_kernel<__half, F, true>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, w.gmax);
-        else
-            hipLaunchKernelGGL((transpose_grad_kernel<__half, F, false>), dim3(blocks), dim3(256), shmem, s,
-                               static_cast<const __half *>(grad_out), w.gT, n, L, t_lb, t_le, nullptr);
+                hipLaunchKernelGGL((transpose_grad_kernel<__half, F, false>), dim3(blocks), dim3(256), shmem, s,
+                                   static_cast<const __half *>(grad_out), w.gT, n, NP, L, t_lb, t_le, nullptr);
+        }
         SHACIRA_CHECK_LAUNCH();
+    }
+    if (fork) {   // the direct levels need the staged gradients (and gmax)
+        SHACIRA_CHECK(hipEventRecord(ss->staged, s));
+        SHACIRA_CHECK(hipStreamWaitEvent(ss->stream, ss->staged, 0));
     }
     // When nothing is transposed (every level is direct: the image configs) gmax would cost an extra read of grad_output
     // (tried: a streaming abs-max kernel); measured on config B it costs more than the faster atomics return (0.103 vs
     // 0.082 ms for the whole backward), so those calls keep the fp64 image.
     // direct levels: one pass over the whole batch, no items (they add into the zeroed table)
-    hipStream_t ds = s;   // stream of the direct levels
-    // two-stream form without the fused count: the direct levels (LDS bound) follow the count + scans on the side
-    // stream and run beside the scatter pass (write bound) instead of in front of it
-    const bool direct_side = ss && !fuse && need_T && !staged && whole.ngroups > 0 && whole.nbl > 0 &&
-                             g_bwd_direct_side.load() != 0 && g_bwd_groups.load() <= 1;
-    if (direct_side) {
-        hipError_t e = hipEventRecord(ss->staged, s);
-        if (e != hipSuccess) return e;
-    }
-    if (fuse || direct_side) {   // side stream: after its memset, once the staged gradients (and gmax) exist
-        hipError_t e = hipStreamWaitEvent(ss->stream, ss->staged, 0);
-        if (e != hipSuccess) return e;
-        ds = ss->stream;
-    }
     if (whole.ngroups > 0) {
-        if (zero_table && ss && !fuse && !direct_side) {
-            hipError_t e = hipStreamWaitEvent(s, ss->zeroed, 0);
-            if (e != hipSuccess) return e;
-        }
         const BinPlan &plan = whole;
         // one level group (S1's level 0): ~512 workgroups measured best; several groups (the all-direct image tables,
         // 128 KiB images = one resident workgroup per CU): 256 in total = one wave of workgroups, no tail
@@ -1704,131 +1655,67 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const int headroom = (use_fx && need_T) ? fx_headroom(((uint64_t)n / bpg + kConsumeThreads) * (1u << DIM)) : -1;
         if (need_T && use_fx)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, true>), grid, dim3(kConsumeThreads),
-                               acc_bytes, ds, lt, plan, first_idx, coords, w.gT, acc, n, w.gmax, headroom);
+                               acc_bytes, zs, lt, plan, first_idx, coords, w.gT, acc, n, NP, w.gmax, headroom);
         else if (need_T)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, false>), grid, dim3(kConsumeThreads),
-                               acc_bytes, ds, lt, plan, first_idx, coords, w.gT, acc, n, nullptr, headroom);
+                               acc_bytes, zs, lt, plan, first_idx, coords, w.gT, acc, n, NP, nullptr, headroom);
         else if (dtype == SHACIRA_F32)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, false, false>), grid, dim3(kConsumeThreads),
-                               acc_bytes, ds, lt, plan, first_idx, coords, static_cast<const float *>(grad_out), acc, n,
-                               nullptr, headroom);
+                               acc_bytes, zs, lt, plan, first_idx, coords, static_cast<const float *>(grad_out), acc, n,
+                               NP, nullptr, headroom);
         else
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, __half, false, false>), grid, dim3(kConsumeThreads),
-                               acc_bytes, ds, lt, plan, first_idx, coords, static_cast<const __half *>(grad_out), acc, n,
-                               nullptr, headroom);
+                               acc_bytes, zs, lt, plan, first_idx, coords, static_cast<const __half *>(grad_out), acc, n,
+                               NP, nullptr, headroom);
         SHACIRA_CHECK_LAUNCH();
     }
-    if (fuse) {   // direct levels (and the table zeroing before them) join the caller's stream before the consume pass
-        hipError_t e = hipEventRecord(ss->join, ss->stream);
-        if (e != hipSuccess) return e;
-    }
-    if (direct_side) {
-        hipError_t e = hipEventRecord(ss->done, ss->stream);
-        if (e != hipSuccess) return e;
-    }
-    if (whole.nbl == 0) return hipSuccess;
-    if (ss && !fuse) {
-        hipError_t e = hipStreamWaitEvent(s, ss->join, 0);
-        if (e != hipSuccess) return e;
-    }
-    constexpr int NP = 1 << (DIM - 1);
-    const size_t stage = (size_t)kTile * NP * (sizeof(Item<F>) + 1);
-    auto consume = [&](const BinPlan &plan, uint32_t grid_units, uint32_t b_lo, uint32_t b_hi, int force_atomic,
-                       hipStream_t cs) -> hipError_t {
-        const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
-        // whole-plan launches are persistent: as many workgroups as the chip holds fetch units from the work counter
-        // (measured: S1 backward 0.611 -> 0.595 ms, 2-D 0.375 -> 0.369; at 65 536 samples the hardware's own dispatch of
-        // 1 400 tiny workgroups is 5 us faster, so small batches keep it)
-        uint32_t *wc = (b_lo == 0 && b_hi == plan.total_buckets && g_bwd_persistent.load() != 0 && n >= (1 << 17))
-                           ? w.work_counter : nullptr;
-        if (wc != nullptr && grid_units > 512u) grid_units = 512u;
-        if (use_fx)   // a unit streams <= chunk items
-            hipLaunchKernelGGL((bin_consume_kernel<F, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, cs, lt,
-                               plan, first_idx, w.base, w.unit_first, w.unit_desc,
-                               reinterpret_cast<const Item<F> *>(w.items), acc, force_atomic, w.gmax,
-                               fx_headroom((uint64_t)plan.chunk + 1), b_lo, b_hi, wc);
-        else
-            hipLaunchKernelGGL((bin_consume_kernel<F, false>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, cs, lt,
-                               plan, first_idx, w.base, w.unit_first, w.unit_desc,
-                               reinterpret_cast<const Item<F> *>(w.items), acc, force_atomic, nullptr, -1, b_lo, b_hi, wc);
-        return hipGetLastError();
-    };
-    // Level groups: the scatter pass is bound by the chip's WRITE rate (3.4 TB/s: a kernel that only stores the items
-    // takes 195 of its 254 us), the consume pass by reads and LDS atomics -- opposite directions of the fabric. With the
-    // binned levels cut into groups, the caller's stream scatters group g + 1 while the side stream consumes group g.
-    const int groups_opt = g_bwd_groups.load();
-    if (ss && !multi && groups_opt > 1 && whole.nbl >= 2) {
-        const BinPlan &plan = whole;
-        const uint32_t G = (uint32_t)groups_opt < plan.nbl ? (uint32_t)groups_opt : plan.nbl;
-        // equal item bytes per group (a compact level moves half of what a pair level does)
-        uint32_t weight[SHACIRA_MAX_LODS], total = 0;
-        for (uint32_t q = 0; q < plan.nbl; ++q) total += (weight[q] = plan.lv[plan.blevel[q]].compact ? 1u : 2u);
-        uint32_t q0 = 0, spent = 0;
-        for (uint32_t g = 0; g < G && q0 < plan.nbl; ++g) {
-            uint32_t q1 = q0, acc_w = 0;
-            const uint32_t target = (total - spent + (G - g) - 1) / (G - g);
-            while (q1 < plan.nbl && (acc_w < target || g + 1 == G)) acc_w += weight[q1++];
-            spent += acc_w;
-            const dim3 grid(plan.num_tiles, q1 - q0);
-            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), grid, dim3(kBinThreads), stage, s, lt, plan, coords,
-                               w.gT, w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), (int64_t)0, n, n, q0, q1 - q0,
-                               (uint32_t *)nullptr);
-            SHACIRA_CHECK_LAUNCH();
-            hipError_t e = hipEventRecord(ss->group, s);
-            if (e != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(ss->stream, ss->group, 0)) != hipSuccess) return e;
-            const BinLevel &first = plan.lv[plan.blevel[q0]], &last = plan.lv[plan.blevel[q1 - 1]];
-            const uint32_t b_lo = first.bucket0, b_hi = last.bucket0 + last.nb;
-            const uint64_t max_items = (uint64_t)n * NP * (q1 - q0);
-            const uint32_t max_units = (uint32_t)(max_items / plan.chunk_c) + (b_hi - b_lo) + 1;
-            if ((e = consume(plan, max_units, b_lo, b_hi, 0, ss->stream)) != hipSuccess) return e;
-            q0 = q1;
-        }
-        hipError_t e = hipEventRecord(ss->done, ss->stream);   // the side stream carries everything the table waits for:
-        if (e != hipSuccess) return e;                         // its zeroing, (fused mode) the direct levels, the consumes
-        return hipStreamWaitEvent(s, ss->done, 0);
-    }
+    if (fork) SHACIRA_CHECK(hipEventRecord(ss->join, ss->stream));
+    if (whole.nbl == 0) return hipSuccess;   // (fork implies binned levels)
+    constexpr int NPAIR = 1 << (DIM - 1);
+    const size_t stage = (size_t)kTile * NPAIR * (sizeof(Item<F>) + 1);
+    bool first_batch = true;
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
         BinPlan plan;
-        make_plan(DIM, lt, hi - s0, plan, acc_kib);
-        const dim3 grid(plan.num_tiles, plan.nbl);
-        if (!ss) {
-            hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), count_grid(plan), dim3(kBinThreads), 0, s, lt, plan,
-                               coords, w.cnt, s0, hi);
+        make_plan(DIM, lt, hi - s0, plan, acc_kib, oic);
+        if (!first_batch) SHACIRA_CHECK(hipMemsetAsync(w.totals, 0, (size_t)kTotalShards * kMaxBuckets * sizeof(uint32_t), s));
+        if (!(front_counts && first_batch)) {
+            hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), count_grid(plan), dim3(kBinThreads), 0, s, lt, plan, coords,
+                               w.totals, s0, hi);
             SHACIRA_CHECK_LAUNCH();
-            hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3((plan.total_buckets + kScanBuckets - 1) / kScanBuckets), dim3(64 * kScanWaves), 0, s,
-                               w.cnt, w.totals, plan.num_tiles, plan.total_buckets);
-            SHACIRA_CHECK_LAUNCH();
-            hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first,
-                               w.unit_desc, plan.total_buckets, plan.chunk, plan, w.work_counter);
-            SHACIRA_CHECK_LAUNCH();
-            hipError_t ze = zero_odd_buckets(plan, s);
-            if (ze != hipSuccess) return ze;
         }
-        if (rows_mode) {   // 1-D grid, XCD-affine numbering (see the kernel)
-            const uint32_t per_xcd = (plan.num_tiles + 7) / 8;
-            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), dim3(8u * per_xcd * plan.nbl), dim3(kBinThreads), stage,
-                               s, lt, plan, coords, static_cast<const float *>(grad_out), w.cnt, w.base,
-                               reinterpret_cast<Item<F> *>(w.items), s0, hi, n, 0u, plan.nbl, use_fx ? w.gmax : nullptr);
-        } else {
-            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), grid, dim3(kBinThreads), stage, s, lt, plan, coords,
-                               w.gT, w.cnt, w.base, reinterpret_cast<Item<F> *>(w.items), s0, hi, n, 0u, plan.nbl,
-                               (uint32_t *)nullptr);
-        }
+        first_batch = false;
+        hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first, w.unit_desc,
+                           plan.total_buckets, plan, w.work_counter, w.cursor);
         SHACIRA_CHECK_LAUNCH();
-        const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NP;
-        const uint32_t max_units = (uint32_t)(max_items / plan.chunk_c) + plan.total_buckets + 1;
-        if (fuse) {
-            hipError_t e = hipStreamWaitEvent(s, ss->join, 0);
-            if (e != hipSuccess) return e;
+        if (selective) {   // hashed buckets with 0 or several units are zeroed now (the others are overwritten)
+            hipLaunchKernelGGL(zero_odd_buckets_kernel, dim3(kMaxLevelBuckets, plan.nbl), dim3(256), 0, s, acc, first_idx,
+                               w.unit_first, lt, plan);
+            SHACIRA_CHECK_LAUNCH();
         }
-        if (direct_side) {
-            hipError_t e = hipStreamWaitEvent(s, ss->done, 0);
-            if (e != hipSuccess) return e;
-        }
-        hipError_t e = consume(plan, max_units, 0u, plan.total_buckets, multi ? 1 : 0, s);
-        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>),
+                           plan.level_fastest ? dim3(plan.nbl, plan.num_tiles) : dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads), stage, s, lt,
+                           plan, coords, w.gT, w.cursor, reinterpret_cast<Item<F> *>(w.items), s0, hi, NP);
+        SHACIRA_CHECK_LAUNCH();
+        if (fork) SHACIRA_CHECK(hipStreamWaitEvent(s, ss->join, 0));   // table zeroed, direct levels in
+        const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NPAIR;
+        uint32_t grid_units = (uint32_t)(max_items / plan.chunk_min) + plan.total_buckets + 1;
+        const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
+        // persistent: as many workgroups as the chip holds fetch units from the work counter (measured: S1 backward
+        // 0.611 -> 0.595 ms, 2-D 0.375 -> 0.369; at 65 536 samples the hardware's own dispatch of 1 400 tiny workgroups
+        // is 5 us faster, so small batches keep it)
+        uint32_t *wc = (g_bwd_persistent.load() != 0 && n >= (1 << 17)) ? w.work_counter : nullptr;
+        if (wc != nullptr && grid_units > 512u) grid_units = 512u;
+        if (use_fx)   // a unit streams <= chunk items
+            hipLaunchKernelGGL((bin_consume_kernel<F, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,
+                               plan, first_idx, w.base, w.unit_first, w.unit_desc,
+                               reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, w.gmax,
+                               fx_headroom((uint64_t)plan.chunk + 1), wc);
+        else
+            hipLaunchKernelGGL((bin_consume_kernel<F, false>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,
+                               plan, first_idx, w.base, w.unit_first, w.unit_desc,
+                               reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, nullptr, -1, wc);
+        SHACIRA_CHECK_LAUNCH();
     }
     return hipSuccess;
 }
@@ -1848,12 +1735,14 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
 #define SHACIRA_T_ATTR(TT, FF)                                                                           \
         set(reinterpret_cast<const void *>(&transpose_grad_kernel<TT, FF, true>), 140 * 1024);          \
         set(reinterpret_cast<const void *>(&transpose_grad_kernel<TT, FF, false>), 140 * 1024);         \
-        set(reinterpret_cast<const void *>(&transpose_grad16_kernel<TT, FF, true>), 72 * 1024);         \
-        set(reinterpret_cast<const void *>(&transpose_grad16_kernel<TT, FF, false>), 72 * 1024);        \
-        set(reinterpret_cast<const void *>(&transpose_count_kernel<2, TT, FF, true>), 140 * 1024);      \
-        set(reinterpret_cast<const void *>(&transpose_count_kernel<2, TT, FF, false>), 140 * 1024);     \
-        set(reinterpret_cast<const void *>(&transpose_count_kernel<3, TT, FF, true>), 140 * 1024);      \
-        set(reinterpret_cast<const void *>(&transpose_count_kernel<3, TT, FF, false>), 140 * 1024);
+        set(reinterpret_cast<const void *>(&front16_kernel<2, TT, FF, true, true>), 156 * 1024);        \
+        set(reinterpret_cast<const void *>(&front16_kernel<2, TT, FF, true, false>), 156 * 1024);       \
+        set(reinterpret_cast<const void *>(&front16_kernel<2, TT, FF, false, true>), 156 * 1024);       \
+        set(reinterpret_cast<const void *>(&front16_kernel<2, TT, FF, false, false>), 156 * 1024);      \
+        set(reinterpret_cast<const void *>(&front16_kernel<3, TT, FF, true, true>), 156 * 1024);        \
+        set(reinterpret_cast<const void *>(&front16_kernel<3, TT, FF, true, false>), 156 * 1024);       \
+        set(reinterpret_cast<const void *>(&front16_kernel<3, TT, FF, false, true>), 156 * 1024);       \
+        set(reinterpret_cast<const void *>(&front16_kernel<3, TT, FF, false, false>), 156 * 1024);
         SHACIRA_T_ATTR(float, 2) SHACIRA_T_ATTR(float, 4) SHACIRA_T_ATTR(__half, 2) SHACIRA_T_ATTR(__half, 4)
 #undef SHACIRA_T_ATTR
 #define SHACIRA_DIRECT_ATTR(D, FF)                                                                              \
@@ -1867,14 +1756,10 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, true>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2, false>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, false>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, false>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, true>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, false>), (size_t)kTile * 2 * (sizeof(Item<4>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, true>), (size_t)kTile * 2 * (sizeof(Item<4>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, false>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, true>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, false>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, true>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4>), (size_t)kTile * 2 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
         return attr_err;
     });
     if (attr_err != hipSuccess) return attr_err;

@@ -11,14 +11,15 @@ namespace shacira {
 // hipFuncSetAttribute (the opt-in for > 64 KiB of dynamic LDS) is a per-DEVICE setting: the opt-ins run once for every
 // device this process launches on (the current device must be the one the caller's stream belongs to; the PyTorch
 // wrappers enter `torch.cuda.device(tensor.device)` around every call).
+constexpr int kMaxDevices = 64;
 struct PerDeviceOnce {
-    std::once_flag flag[16];
-    hipError_t err[16] = {};
+    std::once_flag flag[kMaxDevices];
+    hipError_t err[kMaxDevices] = {};
     template <typename Fn> hipError_t run(Fn &&fn) {
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+        if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
         std::call_once(flag[dev], [&] { err[dev] = fn(); });
         return err[dev];
     }
