@@ -86,6 +86,29 @@ __global__ __launch_bounds__(256) void zero_level_rows_kernel(float *__restrict_
     for (int64_t e = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; e < hi; e += stride) acc[e] = 0.0f;
 }
 
+// Streaming zero fill as a kernel of the library (16 bytes per lane, scalar head / tail). Used instead of hipMemsetAsync on
+// every path that may be captured into a HIP graph: a captured memset node was seen not to take effect on replay (round 3).
+__global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, int64_t n) {
+    const int64_t head = (int64_t)((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) / 4;   // floats up to 16-byte alignment
+    const int64_t h = head < n ? head : n;
+    const int64_t nv = (n - h) / 4;
+    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t0 < h) p[t0] = 0.0f;
+    float4 *v = reinterpret_cast<float4 *>(p + h);
+    for (int64_t e = t0; e < nv; e += stride) v[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int64_t tail0 = h + nv * 4;
+    if (tail0 + t0 < n) p[tail0 + t0] = 0.0f;
+}
+
+hipError_t zero_fill_async(float *p, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, p, n);
+    return hipGetLastError();
+}
+
 template <int DIM, typename T, int F>
 static hipError_t launch_bwd_atomic(const LevelTable &lt, const int32_t *first_idx, const float *coords,
                                     const void *grad_out, float *acc, int64_t num_coords, hipStream_t stream) {
@@ -150,7 +173,7 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
     if (full && bin) {
         // zeroed inside bin_backward (on its side stream, next to the transpose, when it forks)
     } else if (full) {
-        e = hipMemsetAsync(acc, 0, (size_t)numel * sizeof(float), s);  // at::zeros_like, .cpp:81/:167
+        e = zero_fill_async(acc, numel, s);  // at::zeros_like, .cpp:81/:167
     } else {
         hipLaunchKernelGGL(zero_level_rows_kernel, dim3(2048), dim3(256), 0, s, acc, first_idx, lt.level_begin,
                            lt.level_end, lt.num_lods, lt.table_rows, lt.feature_dim);

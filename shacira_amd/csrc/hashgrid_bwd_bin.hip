@@ -401,10 +401,11 @@ constexpr int kFrontThreads = 512;
 template <int DIM, typename T, int F, bool GMAX, bool COUNT>
 __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, BinPlan plan, const T *__restrict__ go,
                                                                 float *__restrict__ gT, const float *__restrict__ coords,
-                                                                uint32_t *__restrict__ totals, int64_t N, int64_t NP,
-                                                                int lb, int le, int ts_log2, int rounds,
-                                                                uint32_t *__restrict__ gmax) {
+                                                                uint32_t *__restrict__ totals, uint32_t *__restrict__ cnt,
+                                                                int64_t N, int64_t NP, int lb, int le, int ts_log2,
+                                                                int rounds, uint32_t *__restrict__ gmax) {
     constexpr int K = 16 / (int)(sizeof(T) * F);   // level pieces per 16-byte input vector
+    constexpr int HE = SHACIRA_MAX_LODS * kMaxLevelBuckets / kFrontThreads;   // histogram words per thread (<= 8)
     constexpr int M = 16 / (4 * F);                // samples per 16-byte output vector
     constexpr int M_LOG2 = (M == 2) ? 1 : 0;
     constexpr int UL = 8;                          // 16-byte loads in flight per thread and round
@@ -435,6 +436,19 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
     const int cslot = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> ts_log2);
     const int64_t tile0 = (int64_t)blockIdx.x * rounds;
     const int64_t tiles = (N + TS - 1) >> ts_log2;
+    // the histogram is per ROUND: after each tile a thread moves its words (k = tid + j * 512 <-> (level k / 128, bucket
+    // k % 128)) to the tile's row of cnt[tile][bucket] -- what lets the scatter pass reserve its runs before it has ranked
+    // anything -- and keeps the workgroup's sums in registers for the totals
+    int hcol[HE];
+    uint32_t hsum[HE];
+    if constexpr (COUNT) {
+#pragma unroll
+        for (int j = 0; j < HE; ++j) {
+            const uint32_t k = threadIdx.x + j * kFrontThreads, li = k / kMaxLevelBuckets, b = k % kMaxLevelBuckets;
+            hcol[j] = (li < plan.nbl && b < plan.lv[plan.blevel[li < plan.nbl ? li : 0]].nb) ? (int)(plan.bstart[li] + b) : -1;
+            hsum[j] = 0;
+        }
+    }
     for (int r = 0; r < rounds && tile0 + r < tiles; ++r) {
         const int64_t s0 = (tile0 + r) << ts_log2;
         const int ns = (int)((N - s0 < TS) ? (N - s0) : TS);
@@ -456,11 +470,7 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
             raw[u] = __builtin_nontemporal_load(in + (e < total ? e : total - 1));   // idle lanes: one merged request
         }
         if constexpr (COUNT) {
-#ifndef ABL_NO_COUNT
             if (csm < ns) {
-#else
-            if (csm < ns && N < 0) {
-#endif
                 double t[DIM];
 #pragma unroll
                 for (int a = 0; a < DIM; ++a) t[a] = axis_unit(cc[a]);
@@ -496,6 +506,18 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
             if (v >= VPR) { v -= VPR; ++sm; }
         }
         lds_barrier();
+        if constexpr (COUNT) {
+            uint32_t *row = cnt + (size_t)(tile0 + r) * plan.total_buckets;
+#pragma unroll
+            for (int j = 0; j < HE; ++j) {
+                if (hcol[j] >= 0) {
+                    const uint32_t h = s_hist[threadIdx.x + j * kFrontThreads];
+                    s_hist[threadIdx.x + j * kFrontThreads] = 0;
+                    row[hcol[j]] = h;
+                    hsum[j] += h;
+                }
+            }
+        }
         // LDS image -> gT: (level, vector) pairs over all threads; a wave stays inside one level per trip
         const int work = (le - lb) << nvec_log2;
         for (int idx = threadIdx.x; idx < work; idx += kFrontThreads) {
@@ -537,21 +559,12 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
     }
     __syncthreads();
     if constexpr (COUNT) {
-        // level index uniform, lanes = consecutive buckets: contiguous atomics into one of kTotalShards copies of the
-        // totals (512 workgroups adding to the same word serialise at the memory side: 18 us of the 30 this kernel took
+        // lanes = consecutive buckets: contiguous atomics into one of kTotalShards copies of the totals (512 workgroups adding to the same word serialise at the memory side: 18 us of the 30 this kernel took
         // on 65 536 samples); the bucket scan adds the copies up
         uint32_t *mine = totals + (size_t)(blockIdx.x % kTotalShards) * kMaxBuckets;
-        for (uint32_t li = 0; li < plan.nbl; ++li) {
-            const uint32_t nbk = plan.lv[plan.blevel[li]].nb, b0 = plan.bstart[li];
-            for (uint32_t b = threadIdx.x; b < nbk; b += kFrontThreads) {
-                const uint32_t c = s_hist[li * kMaxLevelBuckets + b];
-#ifndef ABL_NO_FLUSH
-                if (c) atomicAdd(&mine[b0 + b], c);
-#else
-                if (c && N < 0) atomicAdd(&mine[b0 + b], c);
-#endif
-            }
-        }
+#pragma unroll
+        for (int j = 0; j < HE; ++j)
+            if (hcol[j] >= 0 && hsum[j]) atomicAdd(&mine[hcol[j]], hsum[j]);
     }
     if constexpr (GMAX) {
         if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x])
@@ -651,6 +664,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                                                                   const float *__restrict__ coords,
                                                                   const float *__restrict__ gT,
                                                                   unsigned long long *__restrict__ cursor,
+                                                                  const uint32_t *__restrict__ cnt, uint32_t cps,
+                                                                  uint32_t cnt_rows,
                                                                   Item<F> *__restrict__ items, int64_t sample0,
                                                                   int64_t N, int64_t gpitch) {
     constexpr int NP = 1 << (DIM - 1);
@@ -681,6 +696,36 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     float g[SPT][F];
     float fyz[SPT][2];   // compact levels: y / z fractions travel with the item
     const bool compact = (DIM == 3) && bl.compact != 0;
+    // every global load of the workgroup up front, unconditional (indices clamped into the batch): coordinates and
+    // gradients of the thread's samples, then -- waves 1 and 2 -- the tile's bucket counts (rows of cnt[tile][bucket]
+    // written by the counting pass) and straight away the returning atomic that reserves the bucket's run: it is the
+    // YOUNGEST memory operation of the wave, so nothing below waits for it until the run offsets are needed (after the
+    // staging phase); issued after the ranking instead, its round trip cost 23 us on S1
+    float craw[SPT][DIM], graw[SPT][F];
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+        int64_t i = sample0 + (int64_t)tile * kTile + threadIdx.x + u * kBinThreads;
+        i = i < N ? i : N - 1;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) craw[u][a] = coords[i * DIM + a];
+        const float *gp = gT + ((int64_t)lvl * gpitch + i) * F;
+        if constexpr (F == 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(gp);
+            graw[u][0] = v.x; graw[u][1] = v.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < F; ++j) graw[u][j] = gp[j];
+        }
+    }
+    const bool reserver = threadIdx.x >= 64 && threadIdx.x - 64 < bl.nb;
+    unsigned long long run_base = 0ull;
+    if (reserver) {
+        const uint32_t gb = bl.bucket0 + threadIdx.x - 64;
+        const uint32_t *row = cnt + (size_t)tile * cps * plan.total_buckets + gb;
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < cps && tile * cps + k < cnt_rows; ++k) c += row[(size_t)k * plan.total_buckets];
+        if (c) run_base = atomicAdd(&cursor[gb], (unsigned long long)c);
+    }
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
         const int k = threadIdx.x + u * kBinThreads;
@@ -688,7 +733,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         const bool live = i < N;
         double t[DIM];
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(live ? coords[i * DIM + a] : 0.0f);
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(craw[u][a]);
+#pragma unroll
+        for (int j = 0; j < F; ++j) g[u][j] = graw[u][j];
         if (compact) {
             if constexpr (DIM == 3) {
                 // slot key = local row of the base corner inside the bucket's image (slab + halo planes) | valid bit
@@ -712,23 +759,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         } else {
             enumerate_pairs<DIM>(t, res, hi, dense, lt.mask, bl, plan.BR, fx[u], ps[u]);
         }
-        if (live) {
-            const float *gp = gT + ((int64_t)lvl * gpitch + i) * F;
-            if constexpr (F == 2) {
-                const float2 v = *reinterpret_cast<const float2 *>(gp);
-                g[u][0] = v.x; g[u][1] = v.y;
-            } else {
-#pragma unroll
-                for (int j = 0; j < F; ++j) g[u][j] = gp[j];
-            }
-        }
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             if (!live) ps[u][q].key = 0;
             rank[u][q] = (ps[u][q].key >> 26) ? atomicAdd(&s_hist[ps[u][q].bucket], compact ? 2u : 1u) : 0u;
         }
     }
-    __syncthreads();
+    lds_barrier();   // (not __syncthreads(): its vmcnt(0) would wait for the reservation)
     if (threadIdx.x < 64) {  // wave 0: exclusive scan of the <= 128 bucket counts, two per lane
         const uint32_t lane = threadIdx.x;
         const uint32_t c0 = (2 * lane < bl.nb) ? s_hist[2 * lane] : 0u;
@@ -743,14 +780,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         if (2 * lane < bl.nb) s_start[2 * lane] = excl;
         if (2 * lane + 1 < bl.nb) s_start[2 * lane + 1] = excl + c0;
         if (lane == 63) s_start[bl.nb] = incl;
-    }
-    // waves 1, 2 reserve this tile's runs (wave 0 scans meanwhile); the returned offsets are parked in a register and only
-    // written to LDS after the staging phase, so that the atomic's round trip hides behind it (LDS-only barrier here)
-    const bool reserver = threadIdx.x >= 64 && threadIdx.x - 64 < bl.nb;
-    unsigned long long run_base = 0ull;
-    if (reserver) {
-        const uint32_t c = s_hist[threadIdx.x - 64];
-        if (c) run_base = atomicAdd(&cursor[bl.bucket0 + threadIdx.x - 64], (unsigned long long)c);
     }
     lds_barrier();
 #pragma unroll
@@ -816,7 +845,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
 template <int DIM>
 __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTable lt, BinPlan plan,
                                                                        const float *__restrict__ coords,
-                                                                       uint32_t *__restrict__ totals, int64_t sample0,
+                                                                       uint32_t *__restrict__ totals,
+                                                                       uint32_t *__restrict__ cnt, int64_t sample0,
                                                                        int64_t N) {
     __shared__ uint32_t s_hist[SHACIRA_MAX_LODS][kMaxLevelBuckets];
     constexpr int SPT = kTile / kBinThreads;
@@ -864,8 +894,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
     for (uint32_t bi = blockIdx.y; bi < plan.nbl; bi += gridDim.y) {
         const BinLevel bl = plan.lv[plan.blevel[bi]];
         for (uint32_t b = threadIdx.x; b < bl.nb; b += kBinThreads)
+        {
+            cnt[(size_t)tile * plan.total_buckets + bl.bucket0 + b] = s_hist[bi][b];
             if (s_hist[bi][b])
                 atomicAdd(&totals[(size_t)((blockIdx.x + blockIdx.y) % kTotalShards) * kMaxBuckets + bl.bucket0 + b], s_hist[bi][b]);
+        }
     }
 }
 
@@ -891,6 +924,13 @@ __global__ __launch_bounds__(256) void zero_unowned_rows_kernel(float *__restric
     const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     for (int64_t e = start * F + t0; e < hole_lo * F; e += stride) acc[e] = 0.0f;
     for (int64_t e = hole_hi * F + t0; e < end * F; e += stride) acc[e] = 0.0f;
+}
+
+// control words of a call (bucket totals, per-level max |grad_output|): a kernel of our own rather than hipMemsetAsync -- a
+// memset node captured into a HIP graph after an eager call on ANOTHER stream was seen not to take effect on replay
+// (round 3: stale totals -> wrong bucket bases)
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__restrict__ p, uint32_t n) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0u;
 }
 
 // after the bucket scan: hashed buckets with 0 units (never written) or several (they add atomically) are zeroed now.
@@ -1417,6 +1457,7 @@ struct BinWorkspace {
     uint32_t *gmax;               // [SHACIRA_MAX_LODS] bit patterns of max |grad_output| per level (right behind totals)
     uint64_t *base;
     unsigned long long *cursor;   // [kMaxBuckets + 2] next free item slot of each bucket (scatter pass)
+    uint32_t *cnt;                // [tiles of the counting pass][total_buckets] items per (tile, bucket)
     uint32_t *unit_first;
     UnitDesc *unit_desc;
     uint32_t *work_counter;       // next unit of the persistent consume pass (zeroed by the bucket scan)
@@ -1439,6 +1480,7 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     const size_t o_items = take((size_t)nb * plan.nbl * plan.pairs * item);
     const size_t o_base = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
     const size_t o_cur = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
+    const size_t o_cnt = take((size_t)(nb / 128 + 8) * plan.total_buckets * sizeof(uint32_t));   // smallest counting tile: 128
     const size_t o_unit = take((size_t)(kMaxBuckets + 2) * sizeof(uint32_t));
     const uint64_t max_items_ws = (uint64_t)nb * plan.nbl * plan.pairs;
     const size_t o_ub = take((size_t)(max_items_ws / plan.chunk_min + plan.total_buckets + 2) * sizeof(UnitDesc));
@@ -1453,6 +1495,7 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
         w.gmax = w.totals + (size_t)kTotalShards * kMaxBuckets;
         w.base = reinterpret_cast<uint64_t *>(p + o_base);
         w.cursor = reinterpret_cast<unsigned long long *>(p + o_cur);
+        w.cnt = reinterpret_cast<uint32_t *>(p + o_cnt);
         w.unit_first = reinterpret_cast<uint32_t *>(p + o_unit);
         w.unit_desc = reinterpret_cast<UnitDesc *>(p + o_ub);
         w.work_counter = reinterpret_cast<uint32_t *>(p + o_wc);
@@ -1565,7 +1608,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // batch is large (threshold in units of n * L * F: heavier tables fork earlier)
     const int64_t fork_work = n * lt.num_lods * lt.feature_dim;
     const int64_t fork_min = g_exp[0].load() >= 0 ? (int64_t)g_exp[0].load() << 16 : (DIM == 3 ? ((int64_t)7 << 21) : ((int64_t)1 << 23));
-    const bool fork = whole.nbl > 0 && !multi && g_bwd_fork.load() != 0 && fork_work >= fork_min;
+    // (an event pair costs ~10-20 us of cross-stream latency here: only worth it with direct levels to hide)
+    const bool fork = whole.nbl > 0 && whole.ngroups > 0 && !multi && g_bwd_fork.load() != 0 && fork_work >= fork_min;
     // selective zeroing (see zero_unowned_rows_kernel): a single sub-batch whose plan has hashed binned levels
     bool any_hashed = false;
     for (uint32_t q = 0; q < whole.nbl; ++q) any_hashed = any_hashed || lt.dense[whole.blevel[q]] == 0;
@@ -1580,15 +1624,18 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     }
     if (zero_table) {   // at::zeros_like of the reference
         if (!selective) {
-            SHACIRA_CHECK(hipMemsetAsync(acc, 0, (size_t)lt.table_rows * lt.feature_dim * sizeof(float), zs));
+            SHACIRA_CHECK(zero_fill_async(acc, (int64_t)lt.table_rows * lt.feature_dim, zs));
         } else {
             hipLaunchKernelGGL(zero_unowned_rows_kernel, dim3(256, (uint32_t)L), dim3(256), 0, zs, acc, first_idx, lt, whole);
             SHACIRA_CHECK_LAUNCH();
         }
     }
     // bucket totals (and, when this call transposes, the per-level max |grad_output| right behind them) start at zero
-    if (whole.nbl > 0 || (!staged && use_fx))
-        SHACIRA_CHECK(hipMemsetAsync(w.totals, 0, ((size_t)kTotalShards * kMaxBuckets + ((!staged && use_fx) ? SHACIRA_MAX_LODS : 0)) * sizeof(uint32_t), s));
+    if (whole.nbl > 0 || (!staged && use_fx)) {
+        const uint32_t words = (uint32_t)kTotalShards * kMaxBuckets + ((!staged && use_fx) ? SHACIRA_MAX_LODS : 0);
+        hipLaunchKernelGGL(zero_words_kernel, dim3(32), dim3(256), 0, s, w.totals, words);
+        SHACIRA_CHECK_LAUNCH();
+    }
     if (need_T && !staged) {
         const int t_lb = stage_all ? 0 : lt.level_begin, t_le = stage_all ? L : lt.level_end;
         if (t16) {
@@ -1600,7 +1647,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             const uint32_t blocks = (uint32_t)((tiles + rounds - 1) / rounds);
 #define SHACIRA_FRONT(TT, GM, CN)                                                                                         \
             hipLaunchKernelGGL((front16_kernel<DIM, TT, F, GM, CN>), dim3(blocks), dim3(kFrontThreads), front_shmem, s, lt, \
-                               whole, static_cast<const TT *>(grad_out), w.gT, coords, w.totals, n, NP, t_lb, t_le, ts_log2, \
+                               whole, static_cast<const TT *>(grad_out), w.gT, coords, w.totals, w.cnt, n, NP, t_lb, t_le, ts_log2, \
                                rounds, GM ? w.gmax : nullptr)
             if (dtype == SHACIRA_F32) {
                 if (use_fx && front_counts) SHACIRA_FRONT(float, true, true);
@@ -1678,10 +1725,14 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
         BinPlan plan;
         make_plan(DIM, lt, hi - s0, plan, acc_kib, oic);
-        if (!first_batch) SHACIRA_CHECK(hipMemsetAsync(w.totals, 0, (size_t)kTotalShards * kMaxBuckets * sizeof(uint32_t), s));
-        if (!(front_counts && first_batch)) {
+        if (!first_batch) {
+            hipLaunchKernelGGL(zero_words_kernel, dim3(32), dim3(256), 0, s, w.totals, (uint32_t)kTotalShards * kMaxBuckets);
+            SHACIRA_CHECK_LAUNCH();
+        }
+        const bool fused_now = front_counts && first_batch;
+        if (!fused_now) {
             hipLaunchKernelGGL((bin_count_levels_kernel<DIM>), count_grid(plan), dim3(kBinThreads), 0, s, lt, plan, coords,
-                               w.totals, s0, hi);
+                               w.totals, w.cnt, s0, hi);
             SHACIRA_CHECK_LAUNCH();
         }
         first_batch = false;
@@ -1695,7 +1746,9 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         }
         hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>),
                            plan.level_fastest ? dim3(plan.nbl, plan.num_tiles) : dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads), stage, s, lt,
-                           plan, coords, w.gT, w.cursor, reinterpret_cast<Item<F> *>(w.items), s0, hi, NP);
+                           plan, coords, w.gT, w.cursor, w.cnt, fused_now ? (uint32_t)(kTile / ts16) : 1u,
+                           fused_now ? (uint32_t)((n + ts16 - 1) / ts16) : plan.num_tiles,
+                           reinterpret_cast<Item<F> *>(w.items), s0, hi, NP);
         SHACIRA_CHECK_LAUNCH();
         if (fork) SHACIRA_CHECK(hipStreamWaitEvent(s, ss->join, 0));   // table zeroed, direct levels in
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NPAIR;

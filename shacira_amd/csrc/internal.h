@@ -49,6 +49,7 @@ size_t cell_sort_workspace_bytes(int dim, int64_t n);
 hipError_t cell_sort(int dim, const float *coords, int64_t n, void *ws, uint32_t **perm_out, float **sorted_out,
                      hipStream_t s);
 // hashgrid_bwd.hip
+hipError_t zero_fill_async(float *p, int64_t n, hipStream_t s);   // zero fill as a kernel (graph-capture safe)
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
 hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                       const float *coords, const void *grad_out, void *grad_table, void *workspace,
