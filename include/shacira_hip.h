@@ -12,8 +12,8 @@
  * Conventions (all entry points):
  *   - every buffer is CALLER-OWNED device memory (hipMalloc / the PyTorch caching allocator) unless the name
  *     ends in _host; the library never allocates or frees device memory and never synchronises the host (the backward
- *     of large batches (3-D: n * L * F >= 7 * 2^21, 2-D: >= 2^23) creates, once per host thread and device, one non-blocking side stream and six
- *     events that it forks from / joins back into `stream`: stream semantics are unchanged, HIP-graph capture works
+ *     of large batches with LDS-resident levels (3-D: n * L * F >= 7 * 2^21, 2-D: >= 2^23) creates, once per host thread and
+ *     device, one non-blocking side stream and three events that it forks from / joins back into `stream`: stream semantics are unchanged, HIP-graph capture works
  *     after one eager call). Those objects belong to the CURRENT device (hipGetDevice): like every HIP launch, a call
  *     must be made with the device of `stream` and of its buffers current;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and the call
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SHACIRA_ABI_VERSION 6
+#define SHACIRA_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define SHACIRA_API __attribute__((visibility("default")))
@@ -388,33 +388,30 @@ SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origi
                                 int32_t *pidx, float *depth, void *stream);
 
 /*
- * Tunables (process-wide, read at call time; for benchmarking and A/B only).
- *   "fwd_variant", "bwd_variant": integer algorithm selectors, -1 = automatic.
+ * Tunables (for benchmarking and A/B only). Process-wide atomics; every entry point takes ONE snapshot of them when it is
+ * entered and uses that for the whole call (its workspace-size check included), so changing an option from another thread
+ * never makes a running call inconsistent -- it applies to calls entered later. Unknown names / values -> SHACIRA_EINVAL.
+ *   "fwd_variant": -1 (default) = measured rule; 0 = one gather per corner, the reference's kernel shape (any even F);
+ *               3 = lane pairs, sample-major; 6 = one level per XCD + level-major staging; 8 = cell-sorted forward.
+ *   "bwd_variant": -1 (default) = by batch size; 0 = scattered atomics (the reference's design); 1 = binned.
  *   "bin_batch_mib": cap (MiB) of the backward's item array; larger batches are processed in sub-batches.
  *   "bin_acc_kib": LDS accumulator image per consumer workgroup: 64, 128, or 0 = chosen from the batch size (default).
- *   "bwd_fuse": bucket counting fused into the transpose pass: 0 = never, 1 (default) = for batches where it measured
- *               faster (up to 786 K 3-D / 2^22 2-D samples), 2 = always.
- *   "bwd_compact": 1 (default) = dense 3-D levels travel as one 32-byte item per sample (z-slab buckets), 0 = pair items.
+ *   "bwd_compact": 1 (default) = dense 3-D levels travel as one two-slot item per sample (z-slab buckets), 0 = pair items.
  *   "mlp_variant": -1 (default) = decoder MLPs on the fp32 matrix cores wherever instantiated, 0 = VALU kernels.
- *   "tiled": -1 (default) = the cell-sorted forward (hashgrid_tiled.hip: counting sort of the samples by spatial block,
- *            coarse levels gathered out of L1 in that order) for batches where it measured faster (tables > 8 MB; 3-D: from 2^18
- *            samples for F = 2, 80 K for F = 4; 2-D: from 192 K),
- *            0 = never, 1 = whenever the shape allows it. "fwd_variant" 8 also forces it; other explicit variants exclude it.
+ *   "tiled": -1 (default) = the cell-sorted forward (hashgrid_tiled.hip) for batches where it measured faster (tables
+ *            > 8 MB; 3-D: from 2^18 samples for F = 2, 80 K for F = 4; 2-D: from 192 K), 0 = never, 1 = whenever the shape
+ *            allows it. "fwd_variant" 8 also forces it; other explicit variants exclude it.
  *   "tiled_lc_fwd": its number of coarse levels, -1 (default) = planner's choice.
- *   "bwd_fork": 1 (default) = the backward's count + scan passes are issued on a library-owned side stream, forked
- *               from and joined back into the caller's stream with events (stream semantics unchanged); 0 = one stream.
- *   "bwd_groups": 1 (default) = one scatter and one consume launch over all binned levels; g > 1 = the levels in g groups,
- *               the scatter of group k + 1 on the caller's stream beside the consume of group k on the side stream
- *               (an experiment hook: every g measured slower, both passes share the same memory queues).
- *   "bwd_rows": 0 (default) = the backward transposes grad_output once (gT [L][N][F]); 1 = fp32 batches >= 2^18 scatter
- *               straight from grad_output on an XCD-affine grid (no transposing pass), 2 = always. Measured slower
- *               (S1: 0.636 vs 0.608 ms: the strided reads cost the scatter pass more than the transpose saves).
- *   "bwd_direct_side": 0 (default); 1 = LDS-resident levels accumulate on the side stream beside the scatter pass.
+ *   "bwd_fork": 1 (default) = large batches with LDS-resident ("direct") levels zero the table and accumulate those levels
+ *               on a library-owned side stream, forked from and joined back into the caller's stream with events (stream
+ *               semantics unchanged, capturable); 0 = one stream.
  *   "bwd_persistent": 1 (default) = the backward's last pass runs as persistent workgroups that fetch their work units from a
  *               counter (batches >= 2^17 samples); 0 = one workgroup per unit.
  *   "bwd_selective_zero": 1 (default) = the backward zeroes only the gradient rows its last pass does not overwrite with
  *               plain stores (all rows outside the hashed levels, plus hashed buckets that received 0 or several work
- *               units); 0 = one memset of the whole table first. Same result either way.
+ *               units); 0 = the whole table first. Same result either way.
+ * (ABI 7 removed "bwd_fuse", "bwd_groups", "bwd_rows", "bwd_direct_side" and forward variants 1, 2, 4, 5, 7 -- code paths
+ * that measured slower in rounds 1-2; they are recorded by git hash in profiles/.)
  */
 SHACIRA_API int shacira_set_option(const char *name, int value);
 SHACIRA_API int shacira_get_option(const char *name);

@@ -1,5 +1,6 @@
 // api.hip -- the extern "C" entry points declared in include/shacira_hip.h: argument validation, level-table
-// construction and dispatch. No allocation, no synchronisation, no global mutable state besides the tunables.
+// construction and dispatch. No allocation, no synchronisation, no global mutable state besides the tunables (atomics,
+// snapshotted once per call).
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -8,22 +9,37 @@
 
 namespace shacira {
 
-std::atomic<int> g_fwd_variant{-1};
-std::atomic<int> g_bwd_variant{-1};
-std::atomic<int> g_mlp_variant{-1};       // -1: MFMA decoders wherever instantiated, 0: VALU kernels
-std::atomic<int> g_bwd_compact{1};        // dense 3-D levels: one 32-byte item per sample, z-slab buckets with a halo plane
-std::atomic<int> g_bwd_fuse{1};           // bucket counting fused into the transpose pass
-std::atomic<int> g_bwd_groups{1};         // > 1: binned levels in that many groups, scatter of group g + 1 beside consume of group g (measured slower)
-std::atomic<int> g_bwd_selective_zero{1};  // 1: zero only the rows the consume pass does not overwrite (0: memset of the whole table)
-std::atomic<int> g_bwd_persistent{1};     // consume pass: persistent workgroups fetching units from a counter (0: one unit per workgroup)
-std::atomic<int> g_bwd_direct_side{0};    // 1: direct levels on the side stream beside the scatter pass (two-stream form; no gain measured)
-std::atomic<int> g_bwd_rows{0};           // 1: fp32 batches >= 2^18 scatter straight from grad_output (no transposing pass); 2: always; 0: never
-std::atomic<int> g_bwd_fork{1};           // 1: count + scans of the backward on a side stream next to the transpose
-std::atomic<int> g_bin_acc_kib{0};        // LDS accumulator image per consumer workgroup, KiB: 64, 128, 0 = by batch size
-std::atomic<int> g_bin_batch_mib{1536};   // cap of the backward's item array per sub-batch, MiB
-std::atomic<int> g_tiled{-1};             // cell-sorted forward (hashgrid_tiled.hip): -1 = by batch size, 0 = never, 1 = always
-std::atomic<int> g_tiled_lc_fwd{-1};
-std::atomic<int> g_exp[8] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};   // development knobs "exp0".."exp7" (-1 = default)      // its number of coarse levels (rows kernel), -1 = planner
+// ---- tunables: process-wide atomics, one snapshot per API call (internal.h) ------------------------------------------
+struct OptionSlot {
+    const char *name;
+    int Options::*field;
+    int lo, hi;           // accepted range (inclusive)
+    std::atomic<int> value;
+};
+static OptionSlot g_slots[] = {
+    {"fwd_variant", &Options::fwd_variant, -1, 8, {-1}},
+    {"bwd_variant", &Options::bwd_variant, -1, 1, {-1}},
+    {"mlp_variant", &Options::mlp_variant, -1, 1, {-1}},
+    {"bwd_compact", &Options::bwd_compact, 0, 1, {1}},
+    {"bwd_selective_zero", &Options::bwd_selective_zero, 0, 1, {1}},
+    {"bwd_persistent", &Options::bwd_persistent, 0, 1, {1}},
+    {"bwd_fork", &Options::bwd_fork, 0, 1, {1}},
+    {"bin_acc_kib", &Options::bin_acc_kib, 0, 128, {0}},
+    {"bin_batch_mib", &Options::bin_batch_mib, 1, 1 << 20, {1536}},
+    {"tiled", &Options::tiled, -1, 1, {-1}},
+    {"tiled_lc_fwd", &Options::tiled_lc_fwd, -1, SHACIRA_MAX_LODS, {-1}},
+};
+static thread_local Options tl_options;
+const Options &opt() { return tl_options; }
+void options_snapshot() {
+    for (OptionSlot &sl : g_slots) tl_options.*(sl.field) = sl.value.load(std::memory_order_relaxed);
+}
+static bool option_value_ok(const OptionSlot &sl, int v) {
+    if (v < sl.lo || v > sl.hi) return false;
+    if (!std::strcmp(sl.name, "fwd_variant")) return v == -1 || v == 0 || v == 3 || v == 6 || v == 8;
+    if (!std::strcmp(sl.name, "bin_acc_kib")) return v == 0 || v == 64 || v == 128;
+    return true;
+}
 
 static int build_level_table(int dim, int num_lods, int feature_dim, int bw, const int32_t *res_host,
                              int64_t table_rows, LevelTable &lt) {
@@ -75,65 +91,26 @@ const char *shacira_strerror(int code) {
 
 int shacira_set_option(const char *name, int value) {
     if (!name) return SHACIRA_EINVAL;
-    if (!std::strcmp(name, "fwd_variant")) { g_fwd_variant = value; return 0; }
-    if (!std::strcmp(name, "bwd_variant")) { g_bwd_variant = value; return 0; }
-    if (!std::strcmp(name, "bin_acc_kib")) {
-        if (value != 0 && value != 64 && value != 128) return SHACIRA_EINVAL;
-        g_bin_acc_kib = value;
+    for (OptionSlot &sl : g_slots) {
+        if (std::strcmp(name, sl.name)) continue;
+        if (!option_value_ok(sl, value)) return SHACIRA_EINVAL;
+        sl.value.store(value, std::memory_order_relaxed);
         return 0;
     }
-    if (!std::strcmp(name, "bwd_fork")) { g_bwd_fork = value ? 1 : 0; return 0; }
-    if (!std::strcmp(name, "bwd_direct_side")) { g_bwd_direct_side = value ? 1 : 0; return 0; }
-    if (!std::strcmp(name, "bwd_persistent")) { g_bwd_persistent = value ? 1 : 0; return 0; }
-    if (!std::strcmp(name, "bwd_selective_zero")) { g_bwd_selective_zero = value ? 1 : 0; return 0; }
-    if (!std::strcmp(name, "bwd_rows")) { g_bwd_rows = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
-    if (!std::strcmp(name, "bwd_groups")) { g_bwd_groups = value < 0 ? 0 : (value > 16 ? 16 : value); return 0; }
-    if (!std::strcmp(name, "mlp_variant")) { g_mlp_variant = value; return 0; }
-    if (!std::strcmp(name, "bwd_fuse")) {
-        if (value < 0 || value > 2) return SHACIRA_EINVAL;
-        g_bwd_fuse = value;
-        return 0;
-    }
-    if (!std::strcmp(name, "bwd_compact")) { g_bwd_compact = value ? 1 : 0; return 0; }
-    if (!std::strcmp(name, "tiled")) {
-        if (value < -1 || value > 1) return SHACIRA_EINVAL;
-        g_tiled = value;
-        return 0;
-    }
-    if (!std::strcmp(name, "tiled_lc_fwd")) { g_tiled_lc_fwd = value < 0 ? -1 : value; return 0; }
-    if (!std::strcmp(name, "bin_batch_mib")) {
-        if (value < 1) return SHACIRA_EINVAL;
-        g_bin_batch_mib = value;
-        return 0;
-    }
-    if (!std::strncmp(name, "exp", 3) && name[3] >= '0' && name[3] <= '7' && !name[4]) { g_exp[name[3] - '0'] = value; return 0; }
     return SHACIRA_EINVAL;
 }
 
 int shacira_get_option(const char *name) {
     if (!name) return SHACIRA_EINVAL;
-    if (!std::strcmp(name, "fwd_variant")) return g_fwd_variant;
-    if (!std::strcmp(name, "bwd_variant")) return g_bwd_variant;
-    if (!std::strcmp(name, "bin_batch_mib")) return g_bin_batch_mib;
-    if (!std::strcmp(name, "bin_acc_kib")) return g_bin_acc_kib;
-    if (!std::strcmp(name, "bwd_fork")) return g_bwd_fork;
-    if (!std::strcmp(name, "bwd_rows")) return g_bwd_rows;
-    if (!std::strcmp(name, "bwd_direct_side")) return g_bwd_direct_side;
-    if (!std::strcmp(name, "bwd_persistent")) return g_bwd_persistent;
-    if (!std::strcmp(name, "bwd_selective_zero")) return g_bwd_selective_zero;
-    if (!std::strcmp(name, "bwd_groups")) return g_bwd_groups;
-    if (!std::strcmp(name, "mlp_variant")) return g_mlp_variant;
-    if (!std::strcmp(name, "bwd_fuse")) return g_bwd_fuse;
-    if (!std::strcmp(name, "bwd_compact")) return g_bwd_compact;
-    if (!std::strcmp(name, "tiled")) return g_tiled;
-    if (!std::strcmp(name, "tiled_lc_fwd")) return g_tiled_lc_fwd;
-    if (!std::strncmp(name, "exp", 3) && name[3] >= '0' && name[3] <= '7' && !name[4]) return g_exp[name[3] - '0'];
+    for (OptionSlot &sl : g_slots)
+        if (!std::strcmp(name, sl.name)) return sl.value.load(std::memory_order_relaxed);
     return SHACIRA_EINVAL;
 }
 
 size_t shacira_hashgrid_forward_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
                                                 int codebook_bitwidth, const int32_t *resolutions_host,
                                                 int64_t table_rows, int dtype) {
+    options_snapshot();
     LevelTable lt;
     if (build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt)) return 0;
     return hashgrid_forward_workspace(dim, dtype, lt, num_coords);
@@ -143,6 +120,7 @@ int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feat
                              const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
                              const float *coords, const void *codebook, int dtype, void *feats, void *workspace,
                              size_t workspace_bytes, void *stream) {
+    options_snapshot();
     LevelTable lt;
     int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
     if (rc) return rc;
@@ -170,6 +148,7 @@ int shacira_hashgrid_debug_corners(int dim, int64_t num_coords, int num_lods, in
 size_t shacira_hashgrid_backward_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
                                                  int codebook_bitwidth, const int32_t *resolutions_host,
                                                  int64_t table_rows, int dtype) {
+    options_snapshot();
     LevelTable lt;
     if (build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt)) return 0;
     return hashgrid_backward_workspace(dim, dtype, lt, num_coords);
@@ -189,6 +168,7 @@ int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, int num_lods, 
                                      int64_t table_rows, const float *coords, const void *grad_output, int dtype,
                                      void *grad_codebook, int level_begin, int level_end, int flags, void *workspace,
                                      size_t workspace_bytes, void *stream) {
+    options_snapshot();
     LevelTable lt;
     int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
     if (rc) return rc;
@@ -553,16 +533,19 @@ int shacira_adam_step_multi(int num_tensors, const int64_t *numel_host, float *c
 }
 
 int shacira_mlp_supported(int in_dim, int hidden_dim, int num_hidden, int out_dim) {
+    options_snapshot();
     return mlp_supported(in_dim, hidden_dim, num_hidden, out_dim) ? 1 : 0;
 }
 
 size_t shacira_mlp_backward_workspace_bytes(int in_dim, int hidden_dim, int num_hidden, int out_dim) {
+    options_snapshot();
     return mlp_supported(in_dim, hidden_dim, num_hidden, out_dim)
                ? mlp_workspace_bytes(in_dim, hidden_dim, num_hidden, out_dim) : 0;
 }
 
 int shacira_mlp_forward(int64_t num_rows, int in_dim, int hidden_dim, int num_hidden, int out_dim, const float *x,
                         const float *params, float *y, void *stream) {
+    options_snapshot();
     if (num_rows < 0) return SHACIRA_EINVAL;
     if (!mlp_supported(in_dim, hidden_dim, num_hidden, out_dim)) return SHACIRA_EDTYPE;
     if (num_rows == 0) return 0;
@@ -574,6 +557,7 @@ int shacira_mlp_forward(int64_t num_rows, int in_dim, int hidden_dim, int num_hi
 int shacira_mlp_backward(int64_t num_rows, int in_dim, int hidden_dim, int num_hidden, int out_dim, const float *x,
                          const float *params, const float *grad_y, float *grad_x, float *grad_params, void *workspace,
                          size_t workspace_bytes, void *stream) {
+    options_snapshot();
     if (num_rows < 0) return SHACIRA_EINVAL;
     if (!mlp_supported(in_dim, hidden_dim, num_hidden, out_dim)) return SHACIRA_EDTYPE;
     if (!workspace || workspace_bytes < mlp_workspace_bytes(in_dim, hidden_dim, num_hidden, out_dim))

@@ -142,7 +142,7 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
 
 // variant 1 ("bin") whenever the shape allows it and the batch is big enough to amortise its fixed passes
 static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
-    const int v = g_bwd_variant.load();
+    const int v = opt().bwd_variant;
     if (v == 0 || !bin_supported(dim, lt)) return false;
     if (v == 1) return true;
     return n >= 8192;

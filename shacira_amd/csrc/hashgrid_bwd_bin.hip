@@ -77,7 +77,6 @@ struct BinPlan {
     uint32_t pairs;     // items per (sample, level) = 2^(dim-1)
     uint32_t chunk;     // items per consumer work unit
     uint32_t chunk_min; // smallest unit size of the plan (sizes the unit list)
-    uint32_t level_fastest;
     uint32_t nbl;       // number of binned levels
     uint32_t blevel[SHACIRA_MAX_LODS];  // their level indices (grid.y of passes A/B); 32-bit = scalar loads
     uint32_t bstart[SHACIRA_MAX_LODS];  // first global bucket of binned level q (= lv[blevel[q]].bucket0)
@@ -678,10 +677,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     __shared__ uint32_t s_start[kMaxLevelBuckets + 1];
     __shared__ uint64_t s_gbase[kMaxLevelBuckets];
 
-    // level-fastest numbering: the workgroups in flight at any time span every binned level, so that their run
-    // reservations (returning atomics) spread over all buckets' cursors instead of hammering one level's 64 words, and a
-    // tile's coordinates are re-read by its levels back to back (L2 hits)
-    const uint32_t tile = plan.level_fastest ? blockIdx.y : blockIdx.x, bi = plan.level_fastest ? blockIdx.x : blockIdx.y;
+    // (tile-fastest numbering; level-fastest -- a tile's levels back to back -- measured 3 % slower, round 3)
+    const uint32_t tile = blockIdx.x, bi = blockIdx.y;
     const uint32_t lvl = plan.blevel[bi];
     const BinLevel bl = plan.lv[lvl];
     if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
@@ -1235,7 +1232,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // atomically) instead of the direct pass in front of the scatter pass; decided per CALL from the total batch (below), so
 // that every plan of a call classifies the levels alike
 static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib, bool one_image_compact);
-static inline bool one_image_compact_rule(int64_t n_total) { return g_exp[2].load() != 0 && n_total >= ((int64_t)1 << 17); }
+static inline bool one_image_compact_rule(int64_t n_total) { return n_total >= ((int64_t)1 << 17); }
 
 // can the table be partitioned with an LDS accumulator image of `acc_kib` KiB per consumer workgroup?
 static bool bin_feasible(int dim, const LevelTable &lt, int acc_kib) {
@@ -1265,8 +1262,8 @@ static bool bin_feasible(int dim, const LevelTable &lt, int acc_kib) {
 // alike). Option "bin_acc_kib": 64 / 128 force it, 0 (default) = measured rule: 64 KiB images (two consumer workgroups
 // per CU overlap their zero / stream / flush phases) win up to 2^19 3-D samples, 128 KiB (half as many buckets) beyond.
 static int choose_acc_kib(int dim, const LevelTable &lt, int64_t n) {
-    const int opt = g_bin_acc_kib.load();
-    if (opt != 0) return opt;
+    const int kib = opt().bin_acc_kib;
+    if (kib != 0) return kib;
     const int64_t pairs = (int64_t)1 << (dim - 1);
     if (n * pairs > ((int64_t)1 << 21) || !bin_feasible(dim, lt, 64)) return 128;
     // tables whose levels are all "direct" (config B: every level fits an LDS image) want the big image: fewer level
@@ -1277,8 +1274,8 @@ static int choose_acc_kib(int dim, const LevelTable &lt, int64_t n) {
 }
 
 bool bin_supported(int dim, const LevelTable &lt) {
-    const int opt = g_bin_acc_kib.load();
-    return bin_feasible(dim, lt, opt ? opt : 128);
+    const int kib = opt().bin_acc_kib;
+    return bin_feasible(dim, lt, kib ? kib : 128);
 }
 
 static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib, bool one_image_compact) {
@@ -1322,7 +1319,7 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
             // Compact mode (3-D, F = 2): when an image holds at least two z-planes of the level, bucket = slab of base
             // cells in z and the image = that slab plus one halo plane, so all 8 corners of a sample land in ONE
             // bucket and the sample travels as one 32-byte item instead of four 16-byte pair items.
-            const uint64_t planes = (dim == 3 && (F == 2 || F == 4) && g_bwd_compact.load() != 0) ? BR / (res * res) : 0;
+            const uint64_t planes = (dim == 3 && (F == 2 || F == 4) && opt().bwd_compact != 0) ? BR / (res * res) : 0;
             // (exp2: a level that fits ONE image may also travel as compact items -- one bucket, its units flush atomically --
             // instead of the direct pass that walks the whole batch in front of the scatter pass)
             if (planes >= 2 && res >= 3 && (bl.used > BR || one_image_compact)) {
@@ -1435,7 +1432,6 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
         }
     }
     plan.chunk_min = plan.chunk;
-    plan.level_fastest = g_exp[1].load() == 1 ? 1u : 0u;
 }
 
 // sub-batch so that the item array stays below the cap (default 1.5 GiB, option "bin_batch_mib")
@@ -1444,7 +1440,7 @@ static int64_t bin_batch_samples(int dim, const LevelTable &lt, int64_t n) {
     BinPlan plan;
     make_plan(dim, lt, kTile, plan, choose_acc_kib(dim, lt, n), one_image_compact_rule(n));
     const size_t per_sample = (size_t)(plan.nbl ? plan.nbl : 1) * (1u << (dim - 1)) * item;
-    int64_t cap = (int64_t)(((size_t)g_bin_batch_mib.load() << 20) / per_sample);
+    int64_t cap = (int64_t)(((size_t)opt().bin_batch_mib << 20) / per_sample);
     cap = cap / kTile * kTile;
     if (cap < kTile) cap = kTile;
     return n < cap ? n : cap;
@@ -1607,13 +1603,13 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // side stream (option bwd_fork): table zeroing + direct levels beside the critical path. Worth an event pair once the
     // batch is large (threshold in units of n * L * F: heavier tables fork earlier)
     const int64_t fork_work = n * lt.num_lods * lt.feature_dim;
-    const int64_t fork_min = g_exp[0].load() >= 0 ? (int64_t)g_exp[0].load() << 16 : (DIM == 3 ? ((int64_t)7 << 21) : ((int64_t)1 << 23));
+    const int64_t fork_min = DIM == 3 ? ((int64_t)7 << 21) : ((int64_t)1 << 23);
     // (an event pair costs ~10-20 us of cross-stream latency here: only worth it with direct levels to hide)
-    const bool fork = whole.nbl > 0 && whole.ngroups > 0 && !multi && g_bwd_fork.load() != 0 && fork_work >= fork_min;
+    const bool fork = whole.nbl > 0 && whole.ngroups > 0 && !multi && opt().bwd_fork != 0 && fork_work >= fork_min;
     // selective zeroing (see zero_unowned_rows_kernel): a single sub-batch whose plan has hashed binned levels
     bool any_hashed = false;
     for (uint32_t q = 0; q < whole.nbl; ++q) any_hashed = any_hashed || lt.dense[whole.blevel[q]] == 0;
-    const bool selective = zero_table && !multi && any_hashed && g_bwd_selective_zero.load() != 0;
+    const bool selective = zero_table && !multi && any_hashed && opt().bwd_selective_zero != 0;
     SideStream *ss = nullptr;
     hipStream_t zs = s;   // stream of the table zeroing and the direct levels
     if (fork) {
@@ -1745,7 +1741,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             SHACIRA_CHECK_LAUNCH();
         }
         hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>),
-                           plan.level_fastest ? dim3(plan.nbl, plan.num_tiles) : dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads), stage, s, lt,
+                           dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads), stage, s, lt,
                            plan, coords, w.gT, w.cursor, w.cnt, fused_now ? (uint32_t)(kTile / ts16) : 1u,
                            fused_now ? (uint32_t)((n + ts16 - 1) / ts16) : plan.num_tiles,
                            reinterpret_cast<Item<F> *>(w.items), s0, hi, NP);
@@ -1757,7 +1753,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         // persistent: as many workgroups as the chip holds fetch units from the work counter (measured: S1 backward
         // 0.611 -> 0.595 ms, 2-D 0.375 -> 0.369; at 65 536 samples the hardware's own dispatch of 1 400 tiny workgroups
         // is 5 us faster, so small batches keep it)
-        uint32_t *wc = (g_bwd_persistent.load() != 0 && n >= (1 << 17)) ? w.work_counter : nullptr;
+        uint32_t *wc = (opt().bwd_persistent != 0 && n >= (1 << 17)) ? w.work_counter : nullptr;
         if (wc != nullptr && grid_units > 512u) grid_units = 512u;
         if (use_fx)   // a unit streams <= chunk items
             hipLaunchKernelGGL((bin_consume_kernel<F, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,

@@ -8,12 +8,11 @@
 // it touches, and lines fetched from beyond the XCD's L2 cost a full Infinity-Cache request. The kernels below differ
 // in how they keep that count down; all of them produce bit-identical results (same fp64 coordinate scale, same
 // corner order, same fmaf chain as the reference):
-//   variant 0  lane = (sample, level)                                     (round-1 first version, kept for A/B)
-//   variant 1  thread = sample, rolled loop over levels, LDS-staged rows
-//   variant 2  block = (level, tile), one level per XCD at a time
+//   variant 0  lane = (sample, level), one gather per corner: the reference's own kernel shape (any even F; kept for A/B)
 //   variant 3  lane pair = sample (x / x+1 corners merge into one request), sample-major   [default: 2-D, small N]
-//   variant 4/5 variant 2's schedule + variant 3's lane pairing, feats written in place
-//   variant 6  variant 4 writing a level-major staging buffer + transposing copy             [default: 3-D, N >= 16 K]
+//   variant 6  one level per XCD at a time + lane pairing, level-major staging + transposing copy [default: 3-D, N >= 16 K]
+//   variant 8  cell-sorted forward (hashgrid_tiled.hip) over this file's rows / level-pair kernels [default: large batches]
+// (option "fwd_variant"; -1 = the measured rule. Variants 1, 2, 4, 5, 7 of rounds 1-2 lost and were removed: git 4a7dfa7)
 // HBM-bound: algorithmic bytes per sample = 4*DIM + L*2^DIM*F*s + L*F*s.
 #include <mutex>
 
@@ -119,72 +118,6 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(LevelTable lt, const 
                 Scalar<T>::store(feats + (i * L + lvl) * Fr + j, acc);
             }
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Variant 1 ("sample per thread"): a thread walks the levels of ONE sample, stages the L*F results in wave-private
-// LDS and the wave writes its 64 feats rows with full-width vector stores. All waves of the chip advance through the levels at about
-// the same pace, so at any moment the gathers of the whole chip target one or two level tables (<= 4 MiB each:
-// L2-resident) instead of all of them (48.8 MiB: Infinity-Cache bound, profiles/r01_microbench2_lds_gather.txt).
-// Level parameters are wave-uniform (scalar registers). MAXL bounds the register array.
-template <int DIM, typename T, int F>
-__global__ __launch_bounds__(256) void hashgrid_fwd_sample_kernel(LevelTable lt, const int32_t *__restrict__ first_idx,
-                                                                  const float *__restrict__ coords,
-                                                                  const T *__restrict__ table, T *__restrict__ feats,
-                                                                  int64_t N) {
-    constexpr int NC = 1 << DIM;
-    extern __shared__ __align__(16) float s_out[];  // [4 waves][64 samples][LFP], wave-private: no block barrier
-    const int L = lt.num_lods;
-    const int LF = L * F;
-    const int LFP = (LF + 3) / 4 * 4 + 4;  // row pitch in floats: 16-byte aligned rows, +4 to spread banks
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *my = s_out + (size_t)wave * 64 * LFP;
-    const int64_t wave_s0 = (int64_t)blockIdx.x * 256 + wave * 64;
-    const int64_t i = wave_s0 + lane;
-    const bool live = i < N;
-    double t[DIM];
-    load_unit_coords<DIM>(coords, i, N, t);
-#pragma unroll 1
-    for (int l = 0; l < L; ++l) {
-        Corners<DIM> c;
-        compute_corners<DIM>(t, lt.res[l], lt.hi[l], lt.dense[l] != 0, lt.mask, c);
-        const int64_t base = (int64_t)first_idx[l];
-        float acc[F];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            const int64_t row = base + (int64_t)c.row[k];
-            float v[F];
-            if (live && (uint64_t)row < (uint64_t)lt.table_rows) {
-                load_row<T, F>(table + row * F, v);
-            } else {
-#pragma unroll
-                for (int j = 0; j < F; ++j) v[j] = 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < F; ++j) acc[j] = (k == 0) ? v[j] * c.w[0] : fmaf(v[j], c.w[k], acc[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < F; ++j) my[lane * LFP + l * F + j] = acc[j];
-    }
-    // the wave's 64 rows are contiguous in feats: write them with lane-consecutive addresses
-    const int64_t rows = (N - wave_s0 < 64) ? (N - wave_s0) : 64;
-    if (rows <= 0) return;
-    T *dst = feats + wave_s0 * LF;
-    const int total = (int)rows * LF;
-    if constexpr (sizeof(T) == 4) {
-        if ((LF & 3) == 0) {
-            const int q4 = LF >> 2;
-            for (int e = lane; e < total / 4; e += 64) {
-                const int r = e / q4, c4 = e - r * q4;
-                reinterpret_cast<float4 *>(dst)[e] = *reinterpret_cast<const float4 *>(my + r * LFP + c4 * 4);
-            }
-            return;
-        }
-    }
-    for (int e = lane; e < total; e += 64) {
-        const int r = e / LF, cc = e - r * LF;
-        Scalar<T>::store(dst + e, my[r * LFP + cc]);
     }
 }
 
@@ -309,17 +242,25 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
                                                                 const float4 *__restrict__ sorted4,
                                                                 const T *__restrict__ table,
                                                                 const T *__restrict__ staged, T *__restrict__ feats,
-                                                                int64_t N, int lc) {
+                                                                int64_t N, int lc, uint32_t xcd_affine) {
     constexpr int NH = 1 << (DIM - 1);
     struct alignas(sizeof(T) * F) Piece { T v[F]; };
     extern __shared__ __align__(16) unsigned char s_rows_raw[];   // [4 waves][32 samples][pitch]
+    // XCD-affine numbering (round-robin dispatch, workgroup b on XCD b % 8 -- a speed assumption only): XCD k walks the
+    // k-th eighth of the SORTED samples, i.e. one slab of space, so its L2 holds that slab's share of the coarse tables
+    // instead of every XCD pulling every table through the fabric (the kernel fetched 390 MB for ~100 MB of inputs)
+    uint32_t vb = blockIdx.x;
+    if (xcd_affine) {
+        const uint32_t per = gridDim.x >> 3;
+        vb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    }
     const int L = lt.num_lods;
     const uint32_t row_bytes = (uint32_t)(L * F * sizeof(T));
     const uint32_t pitch = (row_bytes + 15u) / 16u * 16u + 16u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dx = lane & 1, sl = lane >> 1;
     unsigned char *my = s_rows_raw + (size_t)wave * 32 * pitch;
-    const int64_t wave_s0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t wave_s0 = (int64_t)vb * 128 + wave * 32;
     const int64_t i = wave_s0 + sl;
     const bool live = i < N;
     // one 16-byte record per sample: {x, y, z (0 in 2-D), bit pattern of the sample's original index}
@@ -470,54 +411,15 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Variant 2 ("level per XCD"): block = (level, tile of 256 samples). Blocks are numbered so that the blocks an
-// XCD receives under round-robin dispatch (blockIdx % 8, a speed assumption only) all work on the same level:
-// XCD k walks levels k, k+8, k+16, ... one after the other, so its 4 MiB L2 holds exactly one level table and
-// every table is pulled from the Infinity Cache by one XCD only.
-template <int DIM, typename T, int F>
-__global__ __launch_bounds__(256) void hashgrid_fwd_level_kernel(LevelTable lt, const int32_t *__restrict__ first_idx,
-                                                                 const float *__restrict__ coords,
-                                                                 const T *__restrict__ table, T *__restrict__ feats,
-                                                                 int64_t N, uint32_t tiles) {
-    constexpr int NC = 1 << DIM;
-    const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t q = blockIdx.x >> 3;
-    const uint32_t lvl = xcd + 8u * (q / tiles);
-    const uint32_t tile = q % tiles;
-    if (lvl >= (uint32_t)lt.num_lods) return;
-    const int64_t i = (int64_t)tile * 256 + threadIdx.x;
-    if (i >= N) return;
-    double t[DIM];
-#pragma unroll
-    for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
-    Corners<DIM> c;
-    compute_corners<DIM>(t, lt.res[lvl], lt.hi[lvl], lt.dense[lvl] != 0, lt.mask, c);
-    const int64_t base = (int64_t)first_idx[lvl];
-    float acc[F];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        const int64_t row = base + (int64_t)c.row[k];
-        float v[F];
-        if ((uint64_t)row < (uint64_t)lt.table_rows) {
-            load_row<T, F>(table + row * F, v);
-        } else {
-#pragma unroll
-            for (int j = 0; j < F; ++j) v[j] = 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < F; ++j) acc[j] = (k == 0) ? v[j] * c.w[0] : fmaf(v[j], c.w[k], acc[j]);
-    }
-    store_row<T, F>(feats + (i * lt.num_lods + lvl) * F, acc);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Variant 4 = variant 2's schedule (one level per XCD at a time, so the XCD's 4 MiB L2 holds exactly that level's
-// table) + variant 3's lane pairing (corners x / x+1 in one instruction -> one L2 request). The per-level feature
-// piece of a sample (F scalars) is written with a non-temporal store and coords are read non-temporally so that
-// the streams do not evict the table from L2 (a plain 8-byte store allocates a whole 128-byte line).
+// Level-per-XCD pair kernel (variant 6, and the fine levels of the cell-sorted forward): one level per XCD at a time, so
+// the XCD's 4 MiB L2 holds exactly that level's table and every table is pulled from the Infinity Cache by one XCD only
+// (measured: fabric reads 50 M -> 8 M), + variant 3's lane pairing (corners x / x+1 in one instruction -> one L2
+// request). The per-level feature piece of a sample (F scalars) goes to a level-major staging image [L][N][F] with a
+// non-temporal store (a plain 8-byte store into [N, L*F] allocates a whole 128-byte line per piece: 0.2 ms on S1).
 // PACKED: `coords` is an array of 16-byte records {x, y, z (0 in 2-D), bits} (the cell-sorted copy of hashgrid_tiled.hip):
 // one dwordx4 load per sample instead of DIM dword loads -- the kernel is bound by vector-memory instructions.
-template <int DIM, typename T, int F, int U, bool TRANSPOSED = false, bool PACKED = false>
+// (Round 3 pruned the unstaged forms of this kernel and the per-sample / per-level variants 1, 2, 4, 5, 7: git 4a7dfa7.)
+template <int DIM, typename T, int F, bool PACKED = false>
 __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable lt,
                                                                       const int32_t *__restrict__ first_idx,
                                                                       const float *__restrict__ coords,
@@ -525,6 +427,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
                                                                       T *__restrict__ feats, int64_t N,
                                                                       uint32_t tiles) {
     constexpr int NH = 1 << (DIM - 1);
+    constexpr int U = 1;   // samples per lane pair
     // work list = (level, tile) pairs, level-major, of levels [level_begin, level_end); XCD k (round-robin dispatch,
     // blockIdx % 8 -- a speed assumption only) takes the k-th eighth of it and walks it in order, so that at any moment its
     // L2 holds the table of one level (two at a slice boundary), whatever the number of levels
@@ -613,17 +516,14 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
                     acc[j] = (k == 0) ? tv * w : fmaf(tv, w, acc[j]);
                 }
             }
-            if constexpr (TRANSPOSED) {
-                T *dstT = feats + ((int64_t)lvl * N + idx[u]) * F;
-                if constexpr (sizeof(T) == 4 && F == 2) {   // staging stream: written once, read once
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    f32x2 o = {acc[0], acc[1]};
-                    __builtin_nontemporal_store(o, reinterpret_cast<f32x2 *>(dstT));
-                } else {
-                    store_row<T, F>(dstT, acc);
-                }
+            T *dstT = feats + ((int64_t)lvl * N + idx[u]) * F;
+            if constexpr (sizeof(T) == 4 && F == 2) {   // staging stream: written once, read once
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 o = {acc[0], acc[1]};
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x2 *>(dstT));
+            } else {
+                store_row<T, F>(dstT, acc);
             }
-            else store_row<T, F>(feats + (idx[u] * lt.num_lods + lvl) * F, acc);
         }
     }
 }
@@ -632,8 +532,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
 // (fp32, F == 2) or F*sizeof(T)-byte piece per lane, lanes consecutive.
 template <typename T, int F>
 __global__ __launch_bounds__(256) void untranspose_feats_kernel(const T *__restrict__ src, T *__restrict__ dst,
-                                                                int64_t N, int L,
-                                                                const uint32_t *__restrict__ perm) {
+                                                                int64_t N, int L) {
     struct alignas(sizeof(T) * F) Piece { T v[F]; };
     extern __shared__ __align__(16) unsigned char s_raw_t[];
     Piece *s_tile = reinterpret_cast<Piece *>(s_raw_t);  // [256][L + 1] pieces
@@ -645,14 +544,6 @@ __global__ __launch_bounds__(256) void untranspose_feats_kernel(const T *__restr
         if ((int)threadIdx.x < ns) s_tile[threadIdx.x * pitch + l] = in[(int64_t)l * N + s0 + threadIdx.x];
     __syncthreads();
     const int total = ns * L;
-    if (perm) {   // staged rows are in cell-sorted order: row j belongs to sample perm[j] (whole rows stay contiguous)
-        Piece *out = reinterpret_cast<Piece *>(dst);
-        for (int e = threadIdx.x; e < total; e += 256) {
-            const int sm = e / L, l = e - sm * L;
-            out[(int64_t)perm[s0 + sm] * L + l] = s_tile[sm * pitch + l];
-        }
-        return;
-    }
     Piece *out = reinterpret_cast<Piece *>(dst) + s0 * L;
     for (int e = threadIdx.x; e < total; e += 256) {
         const int sm = e / L, l = e - sm * L;
@@ -660,7 +551,6 @@ __global__ __launch_bounds__(256) void untranspose_feats_kernel(const T *__restr
     }
 }
 
-static bool use_sorted(int dim, const LevelTable &lt, int64_t n);
 template <typename T> static size_t staged_bytes(const LevelTable &lt, int64_t n) {
     return ((size_t)n * lt.num_lods * lt.feature_dim * sizeof(T) + 255) / 256 * 256;
 }
@@ -668,26 +558,15 @@ template <typename T> static size_t staged_bytes(const LevelTable &lt, int64_t n
 template <int DIM, typename T, int F>
 static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, const float *coords, const void *table,
                              void *feats, void *workspace, int64_t num_coords, hipStream_t stream) {
-    const int variant = g_fwd_variant.load();
+    const int variant = opt().fwd_variant;
     if constexpr (F > 0) {
         if (use_staged(DIM, lt, num_coords) && workspace) {
             // variant 6: level-per-XCD schedule with lane pairing, features staged level-major (coalesced stores),
             // then one transposing copy into the caller's [N, L*F] layout
             const uint32_t tiles = (uint32_t)((num_coords + 127) / 128);
             const uint32_t grid_v6 = 8u * (uint32_t)(((uint64_t)lt.num_lods * tiles + 7) / 8);
-            const uint32_t *perm = nullptr;
             hipError_t e;
-            if (use_sorted(DIM, lt, num_coords)) {
-                // variant 7: the same kernels walking the samples in cell-sorted order (cell_sort.hip)
-                uint32_t *perm_w;
-                float *sorted;
-                unsigned char *sort_ws = static_cast<unsigned char *>(workspace) + staged_bytes<T>(lt, num_coords);
-                e = cell_sort(DIM, coords, num_coords, sort_ws, &perm_w, &sorted, stream);
-                if (e != hipSuccess) return e;
-                perm = perm_w;
-                coords = sorted;
-            }
-            hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true>), dim3(grid_v6),
+            hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F>), dim3(grid_v6),
                                dim3(256), 0, stream, lt, first_idx, coords, static_cast<const T *>(table),
                                static_cast<T *>(workspace), num_coords, tiles);
             e = hipGetLastError();
@@ -701,19 +580,8 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((untranspose_feats_kernel<T, F>), dim3((uint32_t)((num_coords + 255) / 256)), dim3(256),
                                shmem, stream, static_cast<const T *>(workspace), static_cast<T *>(feats), num_coords,
-                               lt.num_lods, perm);
+                               lt.num_lods);
             return hipGetLastError();
-        }
-        if (variant == 1) {
-            const uint32_t blocks = (uint32_t)((num_coords + 255) / 256);
-            const int LFP = (lt.num_lods * F + 3) / 4 * 4 + 4;
-            const size_t shmem = (size_t)256 * LFP * sizeof(float);
-            if (shmem <= 64 * 1024) {
-                hipLaunchKernelGGL((hashgrid_fwd_sample_kernel<DIM, T, F>), dim3(blocks), dim3(256), shmem, stream, lt,
-                                   first_idx, coords, static_cast<const T *>(table), static_cast<T *>(feats),
-                                   num_coords);
-                return hipGetLastError();
-            }
         }
         if (variant == 3 || variant < 0) {
             const uint32_t blocks = (uint32_t)((num_coords + 127) / 128);
@@ -725,30 +593,6 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
                                    num_coords);
                 return hipGetLastError();
             }
-        }
-        if (variant == 4 || variant == 5) {
-            if (variant == 4) {
-                const uint32_t tiles = (uint32_t)((num_coords + 127) / 128);
-                hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1>),
-                                   dim3(8u * (uint32_t)(((uint64_t)lt.num_lods * tiles + 7) / 8)), dim3(256),
-                                   0, stream, lt, first_idx, coords, static_cast<const T *>(table),
-                                   static_cast<T *>(feats), num_coords, tiles);
-            } else {
-                const uint32_t tiles = (uint32_t)((num_coords + 511) / 512);
-                hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 4>),
-                                   dim3(8u * (uint32_t)(((uint64_t)lt.num_lods * tiles + 7) / 8)), dim3(256),
-                                   0, stream, lt, first_idx, coords, static_cast<const T *>(table),
-                                   static_cast<T *>(feats), num_coords, tiles);
-            }
-            return hipGetLastError();
-        }
-        if (variant == 2) {
-            const uint32_t tiles = (uint32_t)((num_coords + 255) / 256);
-            const uint32_t groups = (uint32_t)((lt.num_lods + 7) / 8);
-            hipLaunchKernelGGL((hashgrid_fwd_level_kernel<DIM, T, F>), dim3(8u * tiles * groups), dim3(256), 0, stream,
-                               lt, first_idx, coords, static_cast<const T *>(table), static_cast<T *>(feats),
-                               num_coords, tiles);
-            return hipGetLastError();
         }
     }
     // items are indexed with 32 bits inside a launch; chunk the samples so that samples*L < 2^31
@@ -776,28 +620,20 @@ static hipError_t dispatch_f(const LevelTable &lt, const int32_t *first_idx, con
     }
 }
 
-// level-major staging buffer [L][N][F] of the table's scalar type (variants 6 and 7)
+// level-major staging buffer [L][N][F] of the table's scalar type (variant 6)
 static bool use_staged(int dim, const LevelTable &lt, int64_t n) {
-    const int v = g_fwd_variant.load();
+    const int v = opt().fwd_variant;
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return false;
-    if (v == 6 || v == 7) return true;
+    if (v == 6) return true;
     return v < 0 && dim == 3 && n >= 16384;   // measured: 3-D large batches; 2-D and small batches: variant 3
 }
 
-static bool use_sorted(int dim, const LevelTable &lt, int64_t n) {
-    (void)dim;
-    (void)lt;
-    return g_fwd_variant.load() == 7 && n > 0;
-}
-
-// levels [lt.level_begin, lt.level_end) of the level-per-XCD pair kernel into a level-major staging buffer [L][N][F]
-// (used by hashgrid_tiled.hip for the fine levels; `coords` = its cell-sorted 16-byte sample records)
 template <int DIM, typename T, int F>
 static hipError_t launch_levels_staged(const LevelTable &lt, const int32_t *first_idx, const float *coords,
                                        const void *table, void *staged, int64_t n, hipStream_t s) {
     const uint32_t nl = (uint32_t)(lt.level_end - lt.level_begin);
     const uint32_t tiles = (uint32_t)((n + 127) / 128);
-    hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, 1, true, true>),
+    hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, true>),
                        dim3(8u * (uint32_t)(((uint64_t)nl * tiles + 7) / 8)), dim3(256), 0, s,
                        lt, first_idx, coords, static_cast<const T *>(table), static_cast<T *>(staged), n, tiles);
     return hipGetLastError();
@@ -832,9 +668,10 @@ static hipError_t launch_rows(const LevelTable &lt, const int32_t *first_idx, co
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     });
     if (oe != hipSuccess) return oe;
-    hipLaunchKernelGGL((hashgrid_fwd_rows_kernel<DIM, T, F>), dim3((uint32_t)((n + 127) / 128)), dim3(256), shmem, s, lt,
+    const uint32_t blocks = ((uint32_t)((n + 127) / 128) + 7u) & ~7u;   // a multiple of 8 (surplus workgroups find no samples)
+    hipLaunchKernelGGL((hashgrid_fwd_rows_kernel<DIM, T, F>), dim3(blocks), dim3(256), shmem, s, lt,
                        first_idx, reinterpret_cast<const float4 *>(sorted4), static_cast<const T *>(table),
-                       static_cast<const T *>(staged), static_cast<T *>(feats), n, lc);
+                       static_cast<const T *>(staged), static_cast<T *>(feats), n, lc, 1u);
     return hipGetLastError();
 }
 
@@ -854,31 +691,6 @@ hipError_t hashgrid_forward_rows(int dim, int dtype, const LevelTable &lt, const
                       : launch_rows<2, float, 4>(lt, first_idx, sorted4, table, staged, feats, n, lc, s);
     return F == 2 ? launch_rows<2, __half, 2>(lt, first_idx, sorted4, table, staged, feats, n, lc, s)
                   : launch_rows<2, __half, 4>(lt, first_idx, sorted4, table, staged, feats, n, lc, s);
-}
-
-template <typename T, int F>
-static hipError_t launch_untranspose(const void *staged, void *feats, int64_t n, int L, const uint32_t *perm,
-                                     hipStream_t s) {
-    const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(T);
-    static PerDeviceOnce once;
-    const hipError_t oe = once.run([]() -> hipError_t {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&untranspose_feats_kernel<T, F>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    });
-    if (oe != hipSuccess) return oe;
-    hipLaunchKernelGGL((untranspose_feats_kernel<T, F>), dim3((uint32_t)((n + 255) / 256)), dim3(256), shmem, s,
-                       static_cast<const T *>(staged), static_cast<T *>(feats), n, L, perm);
-    return hipGetLastError();
-}
-
-// staging [L][N][F] -> feats [N, L*F]; perm != NULL: staged row j belongs to sample perm[j]
-hipError_t hashgrid_untranspose(int dtype, int F, const void *staged, void *feats, int64_t n, int L,
-                                const uint32_t *perm, hipStream_t s) {
-    if (dtype == SHACIRA_F32)
-        return F == 2 ? launch_untranspose<float, 2>(staged, feats, n, L, perm, s)
-                      : launch_untranspose<float, 4>(staged, feats, n, L, perm, s);
-    return F == 2 ? launch_untranspose<__half, 2>(staged, feats, n, L, perm, s)
-                  : launch_untranspose<__half, 4>(staged, feats, n, L, perm, s);
 }
 
 // Test hook: the level-local corner rows and interpolation weights exactly as the kernels compute them
@@ -921,7 +733,6 @@ size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int6
     if (tiled_supported(dim, dtype, lt, n)) return tiled_forward_workspace(dim, dtype, lt, n);
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return 0;
     size_t b = ((size_t)n * lt.num_lods * lt.feature_dim * (dtype == SHACIRA_F32 ? 4 : 2) + 255) / 256 * 256;
-    if (use_sorted(dim, lt, n)) b += cell_sort_workspace_bytes(dim, n);
     return b;
 }
 

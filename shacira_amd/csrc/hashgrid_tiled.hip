@@ -104,8 +104,8 @@ static void make_tile_plan(int dim, const LevelTable &lt, int64_t n, TilePlan &t
         if (dim == 3 && cells > 4.0 * (double)n) break;
         ++lc;
     }
-    const int opt = g_tiled_lc_fwd.load();
-    if (opt >= 0 && opt <= lt.num_lods) lc = opt;
+    const int lc_opt = opt().tiled_lc_fwd;
+    if (lc_opt >= 0 && lc_opt <= lt.num_lods) lc = lc_opt;
     tp.lc = lc;
 }
 
@@ -289,14 +289,14 @@ static hipError_t sort_samples(int dim, const TilePlan &tp, const float *coords,
 
 // ----------------------------------------------------------------------------------------------- host side
 bool tiled_supported(int dim, int dtype, const LevelTable &lt, int64_t n) {
-    const int opt = g_tiled.load();
-    if (opt == 0) return false;
+    const int t_opt = opt().tiled;
+    if (t_opt == 0) return false;
     // explicit algorithm selectors win: forward variant 8 forces this path, any other explicit variant excludes it
-    const int v = g_fwd_variant.load();
+    const int v = opt().fwd_variant;
     if (v >= 0 && v != 8) return false;
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return false;
     if (n < 1 || n >= ((int64_t)1 << 31)) return false;
-    if (opt == 1 || v == 8) return true;
+    if (t_opt == 1 || v == 8) return true;
     // measured rule (tools/tiled_check.py, tools/lego_fwd_check.py): tables that do not fit an XCD's L2 (the Kodak tables of
     // configs B / C are L1 / LDS resident: sorting only costs there); 3-D F = 2 batches from 2^18 samples (equal there, -6 %
     // at 320 K, -20 % at 2^20), 3-D F = 4 (nerf_lego.yaml's 24-level table: 16-byte rows) from 80 K (-15 % at 96 K, -35 %

@@ -44,10 +44,6 @@ hipError_t tiled_forward(int dim, int dtype, const LevelTable &lt, const int32_t
                          const void *table, void *feats, void *workspace, int64_t n, hipStream_t s);
 hipError_t hashgrid_debug_corners(int dim, const LevelTable &lt, const float *coords, int64_t n, int32_t *idx, float *w,
                                   hipStream_t s);
-// cell_sort.hip
-size_t cell_sort_workspace_bytes(int dim, int64_t n);
-hipError_t cell_sort(int dim, const float *coords, int64_t n, void *ws, uint32_t **perm_out, float **sorted_out,
-                     hipStream_t s);
 // hashgrid_bwd.hip
 hipError_t zero_fill_async(float *p, int64_t n, hipStream_t s);   // zero fill as a kernel (graph-capture safe)
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
@@ -130,22 +126,23 @@ size_t mlp_workspace_bytes(int in, int h, int nh, int out);
 hipError_t mlp_dispatch(bool bwd, int in, int h, int nh, int out, int64_t N, const float *x, const float *params,
                         float *y, const float *gy, float *gx, float *gparams, double *partials, hipStream_t s);
 
-// api.hip: tunables
-extern std::atomic<int> g_fwd_variant;
-extern std::atomic<int> g_bwd_variant;
-extern std::atomic<int> g_bin_batch_mib;
-extern std::atomic<int> g_bin_acc_kib;
-extern std::atomic<int> g_bwd_groups;
-extern std::atomic<int> g_bwd_rows;
-extern std::atomic<int> g_bwd_direct_side;
-extern std::atomic<int> g_bwd_persistent;
-extern std::atomic<int> g_bwd_selective_zero;
-extern std::atomic<int> g_bwd_fork;
-extern std::atomic<int> g_bwd_fuse;
-extern std::atomic<int> g_bwd_compact;
-extern std::atomic<int> g_mlp_variant;
-extern std::atomic<int> g_tiled;          // cell-sorted forward: -1 by batch size, 0 never, 1 whenever the shape allows
-extern std::atomic<int> g_tiled_lc_fwd;   // its number of coarse levels (rows kernel), -1 = planner
-extern std::atomic<int> g_exp[8];         // development knobs
+// api.hip: tunables. shacira_set_option() stores process-wide atomics; every API entry point takes ONE snapshot of them
+// into a thread-local Options and everything below reads that snapshot (opt()), so a call -- its workspace-size check
+// included -- sees one consistent set of values even while another thread changes an option.
+struct Options {
+    int fwd_variant = -1;         // -1 measured rule, 0 reference-shaped kernel, 3 lane pairs, 6 level-per-XCD staged, 8 cell-sorted
+    int bwd_variant = -1;         // -1 by batch size, 0 scattered atomics (the reference's design), 1 binned
+    int mlp_variant = -1;         // -1 MFMA decoders wherever instantiated, 0 VALU kernels
+    int bwd_compact = 1;          // dense 3-D levels: one two-slot item per sample, z-slab buckets with a halo plane
+    int bwd_selective_zero = 1;   // zero only the rows the consume pass does not overwrite (0: the whole table)
+    int bwd_persistent = 1;       // consume pass: persistent workgroups fetching units from a counter
+    int bwd_fork = 1;             // table zeroing + direct levels on a side stream when the batch is large
+    int bin_acc_kib = 0;          // LDS accumulator image per consumer workgroup: 64, 128, 0 = by batch size
+    int bin_batch_mib = 1536;     // cap of the backward's item array per sub-batch
+    int tiled = -1;               // cell-sorted forward: -1 by batch size, 0 never, 1 whenever the shape allows
+    int tiled_lc_fwd = -1;        // its number of coarse levels (rows kernel), -1 = planner
+};
+const Options &opt();             // the calling thread's snapshot
+void options_snapshot();          // taken at every extern "C" entry point that reads options
 
 }  // namespace shacira

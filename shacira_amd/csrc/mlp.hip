@@ -331,7 +331,7 @@ typedef hipError_t (*mlp_fn)(bool, int64_t, const float *, const float *, float 
                              double *, hipStream_t);
 
 static mlp_fn mlp_lookup(int in, int h, int nh, int out) {
-    const bool valu_only = g_mlp_variant.load() == 0;
+    const bool valu_only = opt().mlp_variant == 0;
 #define SHACIRA_WIDE(MB, IN, H, NH, OUT) \
     if (!valu_only && in == IN && h == H && nh == NH && out == OUT) return &wide_mlp_run<MB, IN, H, NH, OUT>;
     SHACIRA_WIDE(32, 32, 64, 1, 16)  // NeRF density decoder: 16 levels x F=2 -> 64 -> 16   (nerf.py:121-130, hidden_dim 64)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(handle, name), name
-    assert _lib.lib().shacira_abi_version() == 6
+    assert _lib.lib().shacira_abi_version() == 7
 
 
 def test_argument_validation_codes():
@@ -55,6 +55,14 @@ def test_argument_validation_codes():
     assert L.shacira_hashgrid_backward_workspace_bytes(3, 0, 2, 2, 8, res, 100, 0) == 0
     assert b"multiple of 2" in L.shacira_strerror(_lib.EODD)
     assert L.shacira_set_option(b"nope", 1) == _lib.EINVAL
+    # pruned in ABI 7 (round 3): the lost code paths' switches are gone, and forward variants 1, 2, 4, 5, 7 are refused
+    for name in (b"bwd_rows", b"bwd_groups", b"bwd_direct_side", b"bwd_fuse"):
+        assert L.shacira_set_option(name, 1) == _lib.EINVAL
+    for v in (1, 2, 4, 5, 7, 9):
+        assert L.shacira_set_option(b"fwd_variant", v) == _lib.EINVAL
+    assert L.shacira_set_option(b"bin_acc_kib", 96) == _lib.EINVAL
+    for v in (0, 3, 6, 8, -1):
+        assert L.shacira_set_option(b"fwd_variant", v) == 0 and L.shacira_get_option(b"fwd_variant") == v
     with pytest.raises(Exception, match="multiple of 2"):
         _lib.check(_lib.EODD)
     with pytest.raises(RuntimeError):

@@ -74,7 +74,7 @@ def _assert_grad_close(got, ref, first, sizes, rtol=RTOL):
 
 
 @pytest.mark.parametrize("name", ["A", "B", "Bp", "D"])
-@pytest.mark.parametrize("variant", [(-1, -1), (0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1)])
+@pytest.mark.parametrize("variant", [(-1, -1), (0, 0), (3, 1), (6, 1), (8, 1)])
 def test_forward_bit_exact_backward_within_tolerance(dev, name, variant):
     from shacira_amd import _lib
     dim, res, bw = CONFIGS[name]
@@ -211,8 +211,10 @@ def test_backward_by_level_ranges(dev, name, bvar):
 
 @pytest.mark.parametrize("name", ["D", "Bp"])
 def test_backward_side_stream_fork(dev, name):
-    """Large batches: count + scans run on the library's side stream. Same gradient as the single-stream order and as
-    the oracle; the forked call is also capturable into a HIP graph (after one eager call) and replays correctly."""
+    """Large batches with LDS-resident (direct) levels: the table zeroing and those levels run on the library's side stream
+    (Bp: 2-D, levels 0-5; D: its level 0 travels as compact items at this size, so the call stays on one stream). Same
+    gradient as the single-stream order and as the oracle; the call is also capturable into a HIP graph (after one eager
+    call on another stream) and replays correctly."""
     from shacira_amd import _lib
     ops = _ops()
     dim, res, bw = CONFIGS[name]
@@ -249,10 +251,10 @@ def test_backward_side_stream_fork(dev, name):
 
 
 @pytest.mark.parametrize("name", ["D", "Bp"])
-@pytest.mark.parametrize("option,value", [("bwd_rows", 2), ("bwd_groups", 3), ("bwd_direct_side", 1), ("bwd_persistent", 0)])
-def test_backward_experiment_hooks_keep_the_gradient(dev, name, option, value):
-    """The measured-and-kept-off orderings of the binned backward (scatter straight from grad_output on an XCD-affine grid;
-    level groups pipelined over two streams; direct levels beside the scatter pass) give the oracle's gradient too."""
+@pytest.mark.parametrize("option,value", [("bwd_persistent", 0), ("bin_acc_kib", 64), ("bwd_compact", 0)])
+def test_backward_options_keep_the_gradient(dev, name, option, value):
+    """The remaining A/B switches of the binned backward (one workgroup per work unit instead of persistent ones; 64 KiB
+    accumulator images; pair items instead of compact ones) give the oracle's gradient too."""
     from shacira_amd import _lib
     ops = _ops()
     dim, res, bw = CONFIGS[name]
