@@ -174,6 +174,71 @@ def psnr_parity(device, steps=200, height=64, width=96, seed=2):
             "bpp_gpu": gpu["bpp"], "bpp_cpu_restatement": cpu["bpp"], "cpu_seconds": time.perf_counter() - t0}
 
 
+def build_step(device, rank, world, dim, res, bw, F, n_local, ar_chunks=1, collective="allreduce"):
+    """The benchmark step on this rank: synthetic inputs resident on `device` (parameters replicated: same seed; samples
+    per rank), forward operator, backward operator into the communication buffer, gradient reduction. Used by main() and,
+    on CPU with the oracle standing in for the operators, by tests/test_dist_cpu.py (world-size-4 gloo run of the same loop)."""
+    from shacira_amd import _lib
+    from shacira_amd import dist as sdist
+    from shacira_amd import hip_ops
+    L = len(res)
+    sizes = [min(2 ** bw, r ** dim) for r in res]
+    first_np = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)
+    T = int(sum(sizes))
+    gp = torch.Generator().manual_seed(0)
+    table = (torch.randn(T, F, generator=gp) * 0.01).to(device)            # reference init: randn * feature_std
+    gs = torch.Generator().manual_seed(1000 + rank)
+    coords = (torch.rand(n_local, dim, generator=gs) * 2 - 1).to(device)   # U(-1,1)^d, full-entropy mantissas
+    grad_out = torch.randn(n_local, L * F, generator=gs).to(device)
+    first = torch.from_numpy(first_np).to(device)
+    fwd = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
+
+    # N > 1: the codebook gradient is still reduced exactly once per step, but in `chunks` row ranges: the backward
+    # is issued per level group and each group's (contiguous) rows start their all-reduce on RCCL's stream while
+    # the next group is computed (xGMI transfer hidden behind compute). N = 1: one call, no collective.
+    groups = sdist.level_groups(L, ar_chunks)
+    row_of = lambda l: int(first_np[l]) if l < L else T
+    reducer = sdist.GradientReducer(collective)
+    # the gradient buffer: [T, F] view of a flat tensor padded to a multiple of the world size (rs_ag shards it evenly)
+    grad_flat = torch.zeros(sdist.GradientReducer.padded_numel(T * F, world), dtype=table.dtype, device=device)
+    grad_buf = grad_flat[:T * F].view(T, F)
+    ws_shared = (hip_ops.backward_workspace(dim, n_local, T, table.dtype, res, bw, F, device)
+                 if (len(groups) > 1 or world > 1) else None)
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        feats = fwd(coords, table, first, res, bw)
+        if ev:
+            ev[1].record()
+        if len(groups) == 1 and world == 1:
+            grad = hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F)
+            if ev:
+                ev[2].record()
+        else:
+            # N > 1: the backward writes straight into the (padded) communication buffer; one collective per step, or one
+            # per level group overlapped with the next group's backward (shacira_amd.dist.backward_in_groups)
+            grad = grad_buf
+
+            def backward_levels(lb, le, first_group):
+                if len(groups) == 1:
+                    hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F, out=grad,
+                                              workspace=ws_shared)
+                else:
+                    hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F, levels=(lb, le),
+                                              out=grad, workspace=ws_shared,
+                                              flags=_lib.BWD_STAGE_ALL_LEVELS if first_group else _lib.BWD_REUSE_STAGED)
+                if ev and le == L:
+                    ev[2].record()
+            sdist.backward_in_groups(backward_levels, grad_flat if len(groups) == 1 else grad, groups, row_of, reducer)
+        if ev:
+            ev[3].record()
+        return feats, grad
+
+    return {"step": step, "groups": groups, "first_np": first_np, "T": T, "table": table, "coords": coords,
+            "grad_out": grad_out, "first": first}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +254,10 @@ def main():
                          "asynchronously while the next group is computed. Default 1: measured on one GPU the split "
                          "costs ~0.11 ms per extra group, about what it can hide at 8 GPUs; kept opt-in until it "
                          "has been measured on a multi-GPU node")
+    ap.add_argument("--collective", choices=["allreduce", "rs_ag"], default="allreduce",
+                    help="N > 1: how the codebook gradient is summed: one all_reduce (RCCL chooses the algorithm; steer it "
+                         "with NCCL_ALGO=Ring|Tree for the comparison SURVEY.md section 5 asks for), or reduce_scatter + "
+                         "all_gather on the flat buffer (every xGMI link carries 1/world of each phase)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the quick figures for the other BASELINE configs")
     ap.add_argument("--psnr-steps", type=int, default=1000, help="image-fit steps for the PSNR figure (0 = skip)")
     ap.add_argument("--nerf-steps", type=int, default=500,
@@ -204,22 +273,29 @@ def main():
     # --gpus N launched plainly (no torchrun environment): start the N rank processes ourselves, BEFORE anything in this
     # process touches the GPU (a process that has initialised HIP must never be replaced or forked into ranks); this
     # parent only waits and relays the children's output (rank 0 prints the JSON line) and exit code.
+    if args.ar_chunks > 1 and args.collective != "allreduce":
+        raise SystemExit("bench.py: --ar-chunks > 1 overlaps all-reduces of row ranges; it needs --collective allreduce")
     if args.gpus > 1 and "RANK" not in os.environ:
         import socket
         import subprocess
+        from shacira_amd import dist as sdist_launch
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        visible = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        # The parent never touches the HIP runtime: GPUs are counted from the environment / sysfs (torch's device_count()
+        # can fall through to hipGetDeviceCount), and the ranks are fresh CHILD processes -- never an exec of this one.
+        visible = 0 if args.selftest_launch else sdist_launch.visible_gpu_count()
+        assert not torch.cuda.is_initialized(), "the launcher parent must not initialise the GPU before it spawns the ranks"
         if not args.selftest_launch and visible == 1:
             # one visible GPU: all ranks share it over gloo -- exercises the control flow only, not a scaling figure
             print(f"bench.py: --gpus {args.gpus} with 1 visible GPU: ranks share cuda:0 over gloo "
                   "(SHACIRA_TEST_SINGLE_GPU=1); control-flow check only", file=sys.stderr)
             env["SHACIRA_TEST_SINGLE_GPU"] = "1"
-        elif not args.selftest_launch and visible < args.gpus:
+        elif not args.selftest_launch and 1 < visible < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but only {visible} GPUs are visible")
+        # (visible == 0: nothing could be counted without the runtime -- let the ranks fail loudly if there is no GPU)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
@@ -261,60 +337,9 @@ def main():
         lo, hi = sdist.shard_bounds(n_local, rank, world)
         n_local = hi - lo
     L = len(res)
-    sizes = [min(2 ** bw, r ** dim) for r in res]
-    first_np = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)
-    T = int(sum(sizes))
-
-    # synthetic inputs, resident in HBM before the timed region: parameters replicated (same seed), samples per rank
-    gp = torch.Generator().manual_seed(0)
-    table = (torch.randn(T, F, generator=gp) * 0.01).to(device)            # reference init: randn * feature_std
-    gs = torch.Generator().manual_seed(1000 + rank)
-    coords = (torch.rand(n_local, dim, generator=gs) * 2 - 1).to(device)   # U(-1,1)^d, full-entropy mantissas
-    grad_out = torch.randn(n_local, L * F, generator=gs).to(device)
-    first = torch.from_numpy(first_np).to(device)
-    fwd = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
-
-    # N > 1: the codebook gradient is still reduced exactly once per step, but in `chunks` row ranges: the backward
-    # is issued per level group and each group's (contiguous) rows start their all-reduce on RCCL's stream while
-    # the next group is computed (xGMI transfer hidden behind compute). N = 1: one call, no collective.
-    chunks = max(1, min(args.ar_chunks, L))
-    if chunks == 1:
-        groups = [(0, L)]
-    else:
-        cuts = [0] + [max(1, min(L - 1, round(L * (5 + 3 * k / (chunks - 1)) / 8))) for k in range(chunks - 1)] + [L]
-        cuts = sorted(set(cuts))
-        groups = list(zip(cuts[:-1], cuts[1:]))
-    row_of = lambda l: int(first_np[l]) if l < L else T
-
-    def step(ev=None):
-        if ev:
-            ev[0].record()
-        feats = fwd(coords, table, first, res, bw)
-        if ev:
-            ev[1].record()
-        if len(groups) == 1:
-            grad = hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F)
-            if ev:
-                ev[2].record()
-            if dist.is_initialized():
-                dist.all_reduce(grad)                                      # one RCCL all-reduce (sum) per step
-        else:
-            grad = torch.empty((T, F), dtype=table.dtype, device=device)
-            ws = hip_ops.backward_workspace(dim, n_local, T, table.dtype, res, bw, F, device)
-            pending = []
-            for gi, (lb, le) in enumerate(groups):
-                hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F, levels=(lb, le),
-                                          out=grad, workspace=ws,
-                                          flags=_lib.BWD_STAGE_ALL_LEVELS if gi == 0 else _lib.BWD_REUSE_STAGED)
-                if dist.is_initialized():
-                    pending.append(dist.all_reduce(grad[row_of(lb):row_of(le)], async_op=True))
-            if ev:
-                ev[2].record()
-            for wk in pending:
-                wk.wait()
-        if ev:
-            ev[3].record()
-        return feats, grad
+    st = build_step(device, rank, world, dim, res, bw, F, n_local, args.ar_chunks, args.collective)
+    step, groups, first_np, T, table, coords, grad_out = (st["step"], st["groups"], st["first_np"], st["T"], st["table"],
+                                                          st["coords"], st["grad_out"])
 
     def fence():
         if dist.is_initialized():
@@ -392,7 +417,8 @@ def main():
 
     secondary = None
     if rank == 0 and not args.no_secondary:
-        del coords, grad_out
+        st.clear()
+        del coords, grad_out, step
         torch.cuda.empty_cache()
         secondary = {name: quick_measure(name, device) for name in SECONDARY if name != args.workload}
 
@@ -450,8 +476,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "dim": dim, "levels": L, "feature_dim": F, "bitwidth": bw,
                        "table_rows": T, "samples_per_gpu": n_local, "scaling": args.scaling,
+                       "collective": args.collective if world > 1 else None,
                        "parallelism": f"dp{world}" + ("" if world == 1 else
-                                                      "+one allreduce(grad_codebook) after the backward"
+                                                      (f"+one {args.collective}(grad_codebook) after the backward")
                                                       if len(groups) == 1 else
                                                       f"+allreduce(grad_codebook) in {len(groups)} level groups "
                                                       f"{groups}, overlapped with the backward")},

@@ -16,3 +16,25 @@ def test_bench_self_launches_ranks():
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["config"]["scaling"] == "strong"
     assert rec["config"]["allreduce_check"] is True
+
+
+def test_bench_self_launch_eight_ranks_never_touches_the_gpu_in_the_parent():
+    """--gpus 8: the launcher counts devices without the HIP runtime (shacira_amd.dist.visible_gpu_count) and spawns its
+    ranks as child processes; rank 0's line reports the all-reduce over 8 ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--selftest-launch"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 8 and rec["config"]["allreduce_check"] is True
+
+
+def test_visible_gpu_count_reads_the_environment(monkeypatch):
+    from shacira_amd import dist as sdist
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2,3,4,5,6,7")
+    assert sdist.visible_gpu_count() == 8
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert sdist.visible_gpu_count() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2")
+    assert sdist.visible_gpu_count() == 1

@@ -71,6 +71,70 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     assert got["nbytes"] >= (table.numel() + extra.numel()) * 4
 
 
+# ------------------------------------------------------------------------------------------------ bench.py's step loop
+def _patch_oracle_ops_levels():
+    """Test-only stand-ins with the level-range / out / workspace / flags arguments of hip_ops.hashgrid_backward (the
+    product has no CPU path): the torch oracle computes the whole gradient, the rows of the requested levels are written."""
+    from shacira_amd import hip_ops
+
+    def fwd(coords, codebook, first_idx, resolution, bw):
+        return ot.hashgrid_forward(coords, codebook, first_idx.numpy(), list(resolution), bw)
+
+    def bwd(dim, coords, grad_output, table_rows, table_dtype, first_idx, resolution, bw, feature_dim, levels=None,
+            out=None, workspace=None, flags=0):
+        table = torch.zeros(table_rows, feature_dim, requires_grad=True)
+        feats = ot.hashgrid_forward(coords, table, first_idx.numpy(), list(resolution), bw)
+        (g,) = torch.autograd.grad(feats, table, grad_output)
+        if out is None:
+            return g
+        first = first_idx.tolist() + [table_rows]
+        lb, le = (0, len(resolution)) if levels is None else levels
+        out[first[lb]:first[le]] = g[first[lb]:first[le]]
+        return out
+
+    hip_ops.hashgrid_interpolate2d_cuda = fwd
+    hip_ops.hashgrid_interpolate_cuda = fwd
+    hip_ops.hashgrid_backward = bwd
+    hip_ops.backward_workspace = lambda *a, **k: None
+
+
+def _bench_step_worker(rank, world, port, out, chunks, collective):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    _patch_oracle_ops_levels()
+    sdist.init_from_env("gloo")
+    dim, res, bw = CONFIGS["A"]
+    st = bench.build_step(torch.device("cpu"), rank, world, dim, res, bw, 2, 257, ar_chunks=chunks, collective=collective)
+    for _ in range(2):                      # twice: the communication buffer is reused across steps
+        feats, grad = st["step"]()
+    torch.save({"grad": grad.clone(), "coords": st["coords"], "go": st["grad_out"], "groups": st["groups"]},
+               f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunks,collective", [(3, "allreduce"), (1, "rs_ag"), (1, "allreduce")])
+def test_bench_step_loop_four_ranks(tmp_path, chunks, collective):
+    """bench.py's real step (build_step: level groups with overlapped all-reduces of row ranges, or reduce-scatter +
+    all-gather on the padded flat buffer) on 4 gloo ranks: the reduced gradient equals the single-process gradient of the
+    concatenated batch, on every rank."""
+    out = str(tmp_path / "step")
+    mp.spawn(_bench_step_worker, args=(4, _free_port(), out, chunks, collective), nprocs=4, join=True)
+    recs = [torch.load(f"{out}.{r}") for r in range(4)]
+    dim, res, bw = CONFIGS["A"]
+    _, first, T = table_layout(res, bw, dim)
+    coords = torch.cat([r["coords"] for r in recs])
+    go = torch.cat([r["go"] for r in recs])
+    table = torch.zeros(T, 2, requires_grad=True)
+    (ref,) = torch.autograd.grad(ot.hashgrid_forward(coords, table, first, res, bw), table, go)
+    assert len(recs[0]["groups"]) == (3 if chunks == 3 else 1)
+    for r in recs:
+        np.testing.assert_allclose(r["grad"].numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_shard_bounds_cover_batch_exactly():
     for n in (0, 1, 7, 1001, 1 << 20):
         for world in (1, 2, 3, 8):
