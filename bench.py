@@ -140,16 +140,16 @@ def cpu_baseline(dim, res, bw, F, first, T, n_samples, budget_s, seed=0):
             "s_per_pass": dt, "c_oracle_1thread_samples_per_s": n_c / dt_c}
 
 
-def psnr_parity(device, steps=200, height=64, width=96, seed=2):
+def psnr_parity(device, steps=200, height=64, width=96, seeds=(2, 3, 4, 5)):
     """PSNR at a fixed step, HIP path vs the CPU restatement of the reference kernels (the C
     oracle behind the same host code), same init / batches / entropy noise. A reduced image so that the scalar CPU leg
-    stays within seconds; both values are REPORTED (level = mean over the last 20 steps; rounding makes single steps
-    chaotic in their last bits). Part of the cpu_baseline leg: the only place the product code runs on the oracle."""
+    stays within seconds; both values are REPORTED per seed (level = mean over the last 20 steps; rounding makes single
+    steps chaotic in their last bits) and the 0.05 dB bar of SURVEY 8d is applied to the mean difference over the seeds
+    (`delta_flag` = 1 when it is exceeded). Part of the cpu_baseline leg: the only place the product code runs on the oracle."""
     import numpy as _np
     from oracle import hashgrid_c as oc
     from shacira_amd import harness, hip_ops
     torch.set_num_threads(min(os.cpu_count() or 1, 8))   # tiny tensors: many threads only oversubscribe (measured 30x)
-    gpu = harness.fit_image(device, steps=steps, height=height, width=width, seed=seed, log_every=1)
     saved = (hip_ops.hashgrid_interpolate_cuda, hip_ops.hashgrid_interpolate2d_cuda, hip_ops.hashgrid_backward)
 
     def fwd(coords, codebook, first_idx, resolution, bw):
@@ -160,18 +160,25 @@ def psnr_parity(device, steps=200, height=64, width=96, seed=2):
         g = oc.backward(coords.detach().numpy(), grad_output.detach().numpy(), (table_rows, feature_dim),
                         first_idx.numpy(), list(resolution), bw)
         return torch.from_numpy(g.astype(_np.float32))
-    t0 = time.perf_counter()
-    try:
-        hip_ops.hashgrid_interpolate_cuda = hip_ops.hashgrid_interpolate2d_cuda = fwd
-        hip_ops.hashgrid_backward = bwd
-        cpu = harness.fit_image(torch.device("cpu"), steps=steps, height=height, width=width, seed=seed, log_every=1)
-    finally:
-        hip_ops.hashgrid_interpolate_cuda, hip_ops.hashgrid_interpolate2d_cuda, hip_ops.hashgrid_backward = saved
     tail = lambda r: float(_np.mean([h[2] for h in r["history"][-20:]]))
-    return {"config": f"config-B LatentGrid image fit, {height}x{width} procedural image, {steps} steps, seed {seed}",
-            "gpu_db": tail(gpu), "cpu_restatement_db": tail(cpu), "delta_db": tail(gpu) - tail(cpu),
-            "gpu_at_step_db": gpu["psnr"], "cpu_restatement_at_step_db": cpu["psnr"],
-            "bpp_gpu": gpu["bpp"], "bpp_cpu_restatement": cpu["bpp"], "cpu_seconds": time.perf_counter() - t0}
+    t0 = time.perf_counter()
+    per_seed = []
+    for seed in seeds:
+        gpu = harness.fit_image(device, steps=steps, height=height, width=width, seed=seed, log_every=1)
+        try:
+            hip_ops.hashgrid_interpolate_cuda = hip_ops.hashgrid_interpolate2d_cuda = fwd
+            hip_ops.hashgrid_backward = bwd
+            cpu = harness.fit_image(torch.device("cpu"), steps=steps, height=height, width=width, seed=seed, log_every=1)
+        finally:
+            hip_ops.hashgrid_interpolate_cuda, hip_ops.hashgrid_interpolate2d_cuda, hip_ops.hashgrid_backward = saved
+        per_seed.append({"seed": seed, "gpu_db": tail(gpu), "cpu_restatement_db": tail(cpu),
+                         "delta_db": tail(gpu) - tail(cpu), "bpp_gpu": gpu["bpp"], "bpp_cpu_restatement": cpu["bpp"]})
+    mean_delta = float(_np.mean([p["delta_db"] for p in per_seed]))
+    return {"config": f"config-B LatentGrid image fit, {height}x{width} procedural image, {steps} steps, seeds {list(seeds)}",
+            "gpu_db": float(_np.mean([p["gpu_db"] for p in per_seed])),
+            "cpu_restatement_db": float(_np.mean([p["cpu_restatement_db"] for p in per_seed])),
+            "delta_db": mean_delta, "bar_db": 0.05, "delta_flag": int(abs(mean_delta) > 0.05), "per_seed": per_seed,
+            "cpu_seconds": time.perf_counter() - t0}
 
 
 def build_step(device, rank, world, dim, res, bw, F, n_local, ar_chunks=1, collective="allreduce"):

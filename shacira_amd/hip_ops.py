@@ -131,6 +131,9 @@ def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codeboo
 def hashgrid_debug_corners(dim, coords, resolution, codebook_bitwidth):
     """Test hook: (rows int32 [N, L, 2^dim], weights fp32 [N, L, 2^dim]) exactly as the kernels compute them."""
     _need_gpu(coords)
+    if coords.dtype != torch.float32:
+        raise RuntimeError("expected scalar type Float for coords")
+    _check_coords(dim, coords)      # [N, dim], contiguous: the kernel reads dim floats per sample
     res = tuple(int(r) for r in resolution)
     N = coords.shape[0]
     rows = torch.empty((N, len(res), 1 << dim), dtype=torch.int32, device=coords.device)

@@ -71,6 +71,22 @@ class FusedAdam(torch.optim.Optimizer):
         pending = {}      # (device, b1, b2, eps, step key) -> (host step, device step tensor, [tensors])
         bumped = set()    # device counters already advanced in this call
         born = {}
+        if self.capturable:
+            # A device counter is shared by the parameters that have been stepped TOGETHER so far. When only some of its
+            # sharers have a gradient in this step (the others were skipped: grad None), the stepping ones move to a copy of
+            # the counter first, so that a skipped parameter's count -- and its later bias correction -- stays its own
+            # (torch.optim.Adam semantics). Eager bookkeeping: under graph replay the set of stepped parameters is fixed.
+            by_counter = {}
+            for group in self.param_groups:
+                for p in group["params"]:
+                    st = self.state.get(p)
+                    if st and "step" in st and torch.is_tensor(st["step"]) and st["step"].is_cuda:
+                        by_counter.setdefault(st["step"].data_ptr(), (st["step"], [], []))[1 if p.grad is not None else 2].append(p)
+            for sd, stepping, skipped in by_counter.values():
+                if stepping and skipped:
+                    fresh = sd.clone()
+                    for p in stepping:
+                        self.state[p]["step"] = fresh
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:

@@ -66,8 +66,16 @@ class HierarchicalLatentDecoder(nn.Module):
             colscale = torch.stack([c.reshape(-1) for _, c, _ in ops]) if ops[0][1] is not None else None
             shift = torch.stack([s.reshape(-1) for _, _, s in ops]) if ops[0][2] is not None else None
             uniforms = None
-            if d0.use_sga:   # one draw for the whole table (the reference draws per level, in level order)
-                uniforms = torch.rand(input.shape + (2,), dtype=input.dtype, device=input.device)
+            if d0.use_sga:
+                # the sampler's uniforms drawn PER LEVEL, in level order, exactly as the per-level decoders of the unfused
+                # path (and the reference) consume the generator: a seeded run sees the same noise on either path. Rows no
+                # level owns decode to 0 and draw nothing.
+                uniforms = torch.zeros(input.shape + (2,), dtype=input.dtype, device=input.device)
+                for l in range(self.num_decoders):
+                    lo, hi = bounds[l], bounds[l + 1]
+                    if hi > lo:
+                        uniforms[lo:hi] = torch.rand((hi - lo,) + tuple(input.shape[1:]) + (2,), dtype=input.dtype,
+                                                     device=input.device)
             return _FusedLevelsDecode.apply(input, uniforms, div, matrix, colscale, shift, tuple(bounds),
                                             float(d0.temperature), bool(d0.diff_sampling), float(d0.clamp_weights))
         pieces, row = [], 0

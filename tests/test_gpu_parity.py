@@ -956,6 +956,31 @@ def test_fused_hierarchical_decoder_sga_matches_per_level_kernels(dev):
         torch.testing.assert_close(g_sh[l], gs1.reshape(-1), rtol=1e-5, atol=1e-6)
 
 
+def test_hierarchical_decoder_sga_draws_the_same_noise_on_both_paths(dev):
+    """the fused per-level decoder draws the sampler's uniforms per level in level order -- a seeded SGA run gives
+    the same table through the one-launch path and through the per-level modules (the unfused fallback / the reference)."""
+    from shacira_amd.wisp.models.latent_decoders import HierarchicalLatentDecoder
+    conf = dict(latent_dim=2, feature_dim=2, norm="none", ldecode_matrix="sq", use_shift=True, use_sga=True,
+                diff_sampling=True, ldec_std=0.5)
+    offs = [0, 300, 300, 1500, 2200]            # an empty level and rows no level owns behind the last boundary
+    torch.manual_seed(5)
+    dec = HierarchicalLatentDecoder(4, offs, conf).to(dev)
+    for d in dec.decoders:
+        d.temperature = 0.5
+    lat = ((torch.rand(2500, 2) - 0.5) * 6).to(dev)
+    torch.manual_seed(99)
+    fused = dec(lat)
+    saved = HierarchicalLatentDecoder._fusable
+    try:
+        HierarchicalLatentDecoder._fusable = lambda self, x: False
+        torch.manual_seed(99)
+        unfused = dec(lat)
+    finally:
+        HierarchicalLatentDecoder._fusable = saved
+    torch.testing.assert_close(fused, unfused, rtol=1e-6, atol=1e-7)
+    assert float(fused[2200:].abs().sum()) == 0.0
+
+
 def test_fused_multi_decoder_against_reference_vectors(dev, golden):
     """Row f4: MultiLatentDecoder (softmax / straight-through selector over K decoders, 'sq' with the reference's double
     mixing and 'dft') as ONE fused kernel each way, against the vectors of the reference's executed module."""

@@ -59,18 +59,23 @@ def test_fit_improves_psnr_on_cpu_restatement(oracle_op):
 @pytest.mark.gpu
 def test_psnr_at_fixed_step_gpu_vs_cpu_restatement(oracle_op, monkeypatch):
     """Same init, same batches, same (CPU-drawn) entropy noise: the HIP path and the CPU restatement of the
-    reference kernels must reach the same PSNR at step 300 (fp32 summation order differs, so not bit-equal)."""
-    cpu = harness.fit_image(torch.device("cpu"), steps=300, height=96, width=128, seed=2, log_every=1)
-    monkeypatch.undo()                                      # the real HIP operators
-    gpu = harness.fit_image(torch.device("cuda:0"), steps=300, height=96, width=128, seed=2, log_every=1)
-    # rounding (STE) makes the trajectory chaotic in its last bits (the torch MLP GEMMs differ between the devices
-    # too), so compare the level reached -- mean over the last 20 steps -- not one noisy sample
+    reference kernels must reach the same PSNR at a fixed step (BASELINE.md section 2 / SURVEY 8d: |delta| <= 0.05 dB).
+    fp32 summation order differs and rounding (STE) makes a single trajectory chaotic in its last bits (the torch MLP
+    GEMMs differ between the devices too), so the LEVEL is compared -- the mean PSNR over the last 20 steps -- and the
+    0.05 dB bar is held on its mean over four seeds (a single seed scatters by up to ~0.1 dB either way: 0.2 dB bar)."""
+    seeds, deltas = (2, 3, 4, 5), []
     tail = lambda r: float(np.mean([h[2] for h in r["history"][-20:]]))
-    assert abs(tail(gpu) - tail(cpu)) <= 0.25, (tail(gpu), tail(cpu))
     first10 = lambda r: np.array([h[2] for h in r["history"][:10]])
-    np.testing.assert_allclose(first10(gpu), first10(cpu), atol=0.02)   # early steps: still the same trajectory
-    assert gpu["psnr"] > 20.0
-    assert abs(gpu["bpp"] - cpu["bpp"]) / cpu["bpp"] < 0.05
+    cpu = {sd: harness.fit_image(torch.device("cpu"), steps=200, height=64, width=96, seed=sd, log_every=1) for sd in seeds}
+    monkeypatch.undo()                                      # the real HIP operators
+    for sd in seeds:
+        gpu = harness.fit_image(torch.device("cuda:0"), steps=200, height=64, width=96, seed=sd, log_every=1)
+        deltas.append(tail(gpu) - tail(cpu[sd]))
+        np.testing.assert_allclose(first10(gpu), first10(cpu[sd]), atol=0.02)   # early steps: still the same trajectory
+        assert gpu["psnr"] > 20.0
+        assert abs(gpu["bpp"] - cpu[sd]["bpp"]) / cpu[sd]["bpp"] < 0.05
+    assert max(abs(d) for d in deltas) <= 0.2, deltas
+    assert abs(float(np.mean(deltas))) <= 0.05, deltas
 
 
 @pytest.mark.gpu

@@ -85,3 +85,28 @@ def test_fused_adam_resume_and_late_gradient_cpu():
 @pytest.mark.parametrize("capturable", [False, True])
 def test_fused_adam_resume_and_late_gradient_gpu(capturable):
     _resume_and_late_grad("cuda:0", capturable=capturable)
+
+
+@pytest.mark.gpu
+def test_capturable_counter_splits_when_a_sharer_is_skipped():
+    """Two parameters born in the same step share one device counter; when one of them is skipped (grad None) while the
+    other steps, its count must not advance: both follow torch.optim.Adam exactly."""
+    import torch
+    from shacira_amd.optim import FusedAdam
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    init = [torch.randn(257, generator=g), torch.randn(65, generator=g)]
+    grads = [[torch.randn(257, generator=g), torch.randn(65, generator=g)] for _ in range(6)]
+    def run(cls, **kw):
+        ps = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+        opt = cls(ps, lr=1e-2, **kw)
+        for k, gs in enumerate(grads):
+            ps[0].grad = gs[0].to(dev)
+            ps[1].grad = None if k in (2, 3) else gs[1].to(dev)     # skipped after birth, twice
+            opt.step()
+        return ps, opt
+    pa, oa = run(torch.optim.Adam)
+    pb, ob = run(FusedAdam, capturable=True)
+    for x, y in zip(pa, pb):
+        torch.testing.assert_close(x, y, rtol=2e-6, atol=1e-7)
+    assert int(ob.state[pb[0]]["step"].item()) == 6 and int(ob.state[pb[1]]["step"].item()) == 4
