@@ -40,9 +40,15 @@ WORKLOADS = {
     "B_kodak_2d_L16_F2_bw11_N393216": (2, geo(16, 512, 16), 11, 2, 393216),
     "C_kodak24_2d_L16_F2_bw11_N9437184": (2, geo(16, 512, 16), 11, 2, 24 * 393216),
     "D_nerf_lego_3d_L16_F2_bw19_N65536": (3, geo(16, 2048, 16), 19, 2, 65536),
+    # the reference's SHIPPED configurations (not BASELINE's 16-level F = 2 metric shape): kodak.yaml's table as the operator
+    # sees it (24 levels, feature_dim 1 repeated to F = 2, bw 11) and nerf_lego.yaml's (24 levels, F = 4, bw 19; 4096 rays x
+    # 100 steps)
+    "kodak_yaml_2d_L24_F1rep2_bw11_N393216": (2, geo(16, 512, 24), 11, 2, 393216),
+    "nerf_lego_yaml_3d_L24_F4_bw19_N409600": (3, geo(16, 512, 24), 19, 4, 409600),
 }
 SECONDARY = ["S2_kodak_2d_L16_F2_bw19_N2^20", "B_kodak_2d_L16_F2_bw11_N393216", "C_kodak24_2d_L16_F2_bw11_N9437184",
-             "D_nerf_lego_3d_L16_F2_bw19_N65536"]
+             "D_nerf_lego_3d_L16_F2_bw19_N65536", "kodak_yaml_2d_L24_F1rep2_bw11_N393216",
+             "nerf_lego_yaml_3d_L24_F4_bw19_N409600"]
 
 
 def quick_measure(name, device, iters=10):

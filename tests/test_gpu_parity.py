@@ -893,6 +893,58 @@ def test_compact_dense_items_nerf_lego_table(dev, n, F):
         _lib.set_option("bwd_compact", 1)
 
 
+def test_shipped_kodak_yaml_shape_through_latent_grid(dev):
+    """kodak.yaml as shipped (app/image/configs/kodak.yaml:29-33: 24 levels, feature_dim 1 -> the repeat-to-2 trick of
+    latent_grid.py:361-370, bw 11, res 16..512, latent_dim 1) at the full image batch of 393 216 pixels, through
+    LatentGrid.interpolate: features and the codebook gradient against the oracle fed with the module's own decoded table."""
+    from shacira_amd.wisp.models.grids import LatentGrid
+    cdec, cent = _conf(1)
+    torch.manual_seed(3)
+    grid = LatentGrid.from_geometric(feature_dim=1, num_lods=24, latent_dim=1, multiscale_type="cat", resolution_dim=2,
+                                     feature_std=2.0, codebook_bitwidth=11, min_grid_res=16, max_grid_res=512,
+                                     init_grid="uniform", blas_level=3, conf_latent_decoder=cdec,
+                                     conf_entropy_reg=cent).to(dev)
+    res, first = list(grid.resolutions), grid.codebook_lod_first_idx.cpu().numpy()
+    assert len(res) == 24 and grid.codebook.shape == (40282, 1)        # SURVEY 8: kodak.yaml's table
+    H, W = 512, 768
+    rr, cc = np.meshgrid((np.arange(H) / H - 0.5) * 2, (np.arange(W) / W - 0.5) * 2, indexing="ij")
+    coords = np.stack([rr, cc], -1).reshape(-1, 2).astype(np.float32)[np.random.default_rng(0).permutation(H * W)]
+    tc = torch.from_numpy(coords).to(dev)
+    feats = grid.interpolate(tc, 0)
+    assert feats.shape == (H * W, 24)
+    with torch.no_grad():
+        table1 = grid.latent_dec(grid.codebook)                          # [T, 1] decoded
+    table2 = table1.repeat(1, 2).cpu().numpy()                           # the reference's repeat trick
+    ref = oc.forward(coords, table2, first, res, 11)[:, ::2]
+    assert np.array_equal(feats.detach().cpu().numpy(), ref)
+    go = np.random.default_rng(1).standard_normal((H * W, 24)).astype(np.float32)
+    (g_table,) = torch.autograd.grad(feats, grid.codebook, torch.from_numpy(go).to(dev))
+    # chain rule of the repeat trick: d/d table1 = column 0 of the F = 2 table gradient (odd output columns get no gradient)
+    go2 = np.zeros((H * W, 48), np.float32)
+    go2[:, ::2] = go
+    ref_g2 = oc.backward(coords, go2, (40282, 2), first, res, 11)
+    scale = float(grid.latent_dec.layers[0].scale.detach().reshape(-1)[0]) / float(grid.latent_dec.div.reshape(-1)[0])
+    ref_g = (ref_g2[:, 0] + ref_g2[:, 1]) * scale                        # through decode (round/STE: identity) to the latents
+    np.testing.assert_allclose(g_table.cpu().numpy().reshape(-1), ref_g, rtol=1e-4, atol=1e-5 * np.abs(ref_g).max())
+
+
+def test_shipped_nerf_lego_yaml_shape_forward_and_backward(dev):
+    """nerf_lego.yaml's table (app/nerf/configs/nerf_lego.yaml:26-30: 24 levels, feature_dim 4, bw 19, res 16..512) at
+    2^18 + 3 samples on the DEFAULT paths (cell-sorted forward from 80 K samples; binned backward with two 24-byte slots
+    on the compact levels): features bit-identical to the oracle, gradients within 1e-5 of each level's largest value."""
+    ops = _ops()
+    dim, bw, F, n = 3, 19, 4, (1 << 18) + 3
+    res = geo(16, 512, 24)
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, F=F, seed=61)
+    assert T == 7879908                                                  # SURVEY 8: nerf_lego.yaml's table
+    tc, tt, tg, tf = (torch.from_numpy(a).to(dev) for a in (coords, table, go, first))
+    feats = ops.hashgrid_interpolate_cuda(tc, tt, tf, res, bw)
+    assert np.array_equal(feats.cpu().numpy(), oc.forward(coords, table, first, res, bw))
+    got = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, F).cpu().numpy()
+    ref = oc.backward(coords, go, (T, F), first, res, bw)
+    _assert_grad_close(got, ref, first, sizes)
+
+
 @pytest.mark.parametrize("n", [30_000, 200_000])
 def test_power_of_two_resolutions(dev, n):
     """`from_octree` tables (res = 2^k): res 64 is the largest level whose two z-planes fill the 8192-row image exactly
