@@ -449,14 +449,14 @@ def main():
         # the same operators and workload; see the note inside the file). Only valid for the workload it was taken on.
         # Attached ONLY when the file was measured on exactly these kernel sources (kernel_source_hash); else null.
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if args.workload.startswith("S1_") and os.path.exists(tpath):
             with open(tpath) as fh:
                 rec = json.load(fh)
             if rec.get("kernel_source_hash") == kernel_source_hash():
                 traffic = rec["operators"].get(dom[0], {}).get("hbm_bytes_per_launch")
             else:
-                traffic_note = ("profiles/r02_pmc_traffic.json was measured on other kernel sources "
+                traffic_note = ("profiles/r03_pmc_traffic.json was measured on other kernel sources "
                                 f"({rec.get('kernel_source_hash')} != {kernel_source_hash()}): not attached")
         achieved = dom[2] * n_local / (dom[1] * 1e-3) / 1e9
         path_gbs = (b_fwd + b_bwd) * n_local / ((ms_fwd + ms_bwd) * 1e-3) / 1e9
@@ -475,13 +475,52 @@ def main():
             return nbytes * it / (a.elapsed_time(b) * 1e-3) / 1e9
         src = torch.empty(1 << 28, dtype=torch.float32, device=device).normal_()
         dst = torch.empty_like(src)
-        measured = {"copy_read+write": stream_gbs(lambda: dst.copy_(src), 2 * src.numel() * 4),
-                    "write_only": stream_gbs(lambda: dst.fill_(1.0), src.numel() * 4),
-                    "read_only": stream_gbs(lambda: src.sum(), src.numel() * 4),
-                    "unit": "GB/s", "how": "torch copy_/fill_/sum over 1 GiB fp32, HIP events, 5 repetitions"}
+        nb = src.numel() * 4
+        Lh = _lib.lib()
+        strm = torch.cuda.current_stream(device).cuda_stream
+
+        def probe(kind):
+            _lib.check(Lh.shacira_stream_probe(kind, src.data_ptr(), dst.data_ptr(), nb, strm), "stream_probe")
+        measured = {"copy_read+write": stream_gbs(lambda: probe(2), 2 * nb),
+                    "write_only": stream_gbs(lambda: probe(1), nb),
+                    "read_only": stream_gbs(lambda: probe(0), nb),
+                    "torch_copy_read+write": stream_gbs(lambda: dst.copy_(src), 2 * nb),
+                    "unit": "GB/s", "how": "shacira_stream_probe (16 B per lane, 8 in flight, non-temporal: the access shape of "
+                                           "the hash-grid kernels) over 1 GiB, HIP events, 5 repetitions; torch copy_ beside it"}
         del src, dst
         if traffic is not None:
             measured["operator_traffic_over_time_GBps"] = traffic / (dom[1] * 1e-3) / 1e9
+        # What actually binds the two operators on this access pattern: next to the contract's HBM
+        # fraction (algorithmic bytes / 8 TB/s), the floor each operator has on the resource that limits it, and how close
+        # the measured time is to that floor.
+        #  forward: a hashed level's x-pair of corners is one 128-byte line; with uniformly random samples every pair of a
+        #   level finer than the batch's density is its own line, and a CU's L2 -> L1 path moves 64 B/clk: 2 clk per line
+        #   (measured: 38 TCP->TCC requests and 81 TA-busy cycles per gather instruction, profiles/r02_fwd_counters.md).
+        #  backward: the traffic its kernels move (PMC counters, profiles/r03_pmc_traffic.json; without them: algorithmic
+        #   bytes x the 1.93 measured in round 2) at the copy rate this chip sustains in the same run.
+        n_fine = sum(1 for r in res if float(r) ** dim > 4.0 * n_local) if dim == 3 else 0
+        lines = n_fine * n_local * (2 ** (dim - 1))
+        cus, clk_ghz = 256, 2.4
+        fwd_floor_ms = lines * 2.0 / (cus * clk_ghz * 1e9) * 1e3
+        bwd_traffic = None
+        if args.workload.startswith("S1_") and os.path.exists(tpath):
+            with open(tpath) as fh:
+                rec2 = json.load(fh)
+            if rec2.get("kernel_source_hash") == kernel_source_hash():
+                bwd_traffic = rec2["operators"].get("backward", {}).get("hbm_bytes_per_launch")
+        bwd_bytes = bwd_traffic if bwd_traffic is not None else 1.93 * b_bwd * n_local
+        bwd_floor_ms = bwd_bytes / (measured["copy_read+write"] * 1e9) * 1e3
+        bound_model = {
+            "forward": {"resource": "L2 -> L1 line path of the CUs: 64 B/clk/CU = 2 clk per 128-byte line, 256 CUs at 2.4 GHz",
+                        "what": f"{n_fine} fine levels x {n_local} samples x {2 ** (dim - 1)} lines (one per x-pair of corners)",
+                        "ms": fwd_floor_ms, "operator_ms": ms_fwd,
+                        "frac_of_floor": (fwd_floor_ms / ms_fwd) if ms_fwd > 0 else None},
+            "backward": {"resource": "copy rate measured in this run (shacira_stream_probe, read + write)",
+                         "what": ("PMC traffic of the backward's kernels" if bwd_traffic is not None else
+                                  "algorithmic bytes x 1.93 (round-2 PMC ratio; no counters for these kernel sources)"),
+                         "bytes": bwd_bytes, "GBps": measured["copy_read+write"], "ms": bwd_floor_ms, "operator_ms": ms_bwd,
+                         "frac_of_floor": (bwd_floor_ms / ms_bwd) if ms_bwd > 0 else None},
+        }
         out = {
             "metric": "hash-grid samples/sec fwd+bwd (16 lvl, F=2)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -497,8 +536,8 @@ def main():
                                                       f"{groups}, overlapped with the backward")},
             "roofline": {"bound": "hbm",
                          "kernel": (f"hashgrid_{dom[0]} operator = one C-ABI call, HIP events on its stream; kernels: "
-                                    + ("transpose_grad + bin_count + 2 scans + bin_scatter + bin_consume + "
-                                       "direct_accumulate" if dom[0] == "backward" else
+                                    + ("front16 (transpose + bucket counts) + bucket scan + bin_scatter + bin_consume"
+                                       if dom[0] == "backward" else
                                        "sample sort + hashgrid_fwd_level_pair (fine levels) + hashgrid_fwd_rows")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_note": traffic_note,
@@ -506,6 +545,7 @@ def main():
                          "ms_per_launch": dom[1],
                          "fwd_bwd_path": {"achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS,
                                           "bytes_per_sample": b_fwd + b_bwd},
+                         "bound_model": bound_model,
                          "measured_stream_rates": measured},
             "ms": {"forward": ms_fwd, "backward": ms_bwd, "allreduce": ms_ar,
                    "fwd+bwd_p10_p50_p90": [float(np.percentile(per_step, q)) for q in (10, 50, 90)],

@@ -388,6 +388,13 @@ SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origi
                                 int32_t *pidx, float *depth, void *stream);
 
 /*
+ * Diagnostics: one streaming pass over `bytes` (a multiple of 16; 16-byte aligned buffers) with the access shape of the
+ * hash-grid kernels -- 16 bytes per lane, 8 in flight, non-temporal. kind 0 = read `src` (`dst` may be NULL or a 4-byte
+ * scratch word), 1 = write `dst`, 2 = copy `src` -> `dst`. bench.py times it for `roofline.measured_stream_rates`.
+ */
+SHACIRA_API int shacira_stream_probe(int kind, const void *src, void *dst, size_t bytes, void *stream);
+
+/*
  * Tunables (for benchmarking and A/B only). Process-wide atomics; every entry point takes ONE snapshot of them when it is
  * entered and uses that for the whole call (its workspace-size check included), so changing an option from another thread
  * never makes a running call inconsistent -- it applies to calls entered later. Unknown names / values -> SHACIRA_EINVAL.

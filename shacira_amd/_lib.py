@@ -26,6 +26,7 @@ SIGNATURES = {
     "shacira_strerror": (ctypes.c_char_p, [_i]),
     "shacira_set_option": (_i, [ctypes.c_char_p, _i]),
     "shacira_get_option": (_i, [ctypes.c_char_p]),
+    "shacira_stream_probe": (_i, [_i, _p, _p, _sz, _p]),
     "shacira_hashgrid_forward_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i, _p, _i64, _i]),
     "shacira_hashgrid_forward": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p]),
     "shacira_hashgrid_debug_corners": (_i, [_i, _i64, _i, _i, _p, _p, _p, _p, _p]),

@@ -532,6 +532,15 @@ int shacira_adam_step_multi(int num_tensors, const int64_t *numel_host, float *c
                                   (hipStream_t)stream);
 }
 
+int shacira_stream_probe(int kind, const void *src, void *dst, size_t bytes, void *stream) {
+    if (kind < 0 || kind > 2 || (bytes & 15u)) return SHACIRA_EINVAL;
+    if (bytes == 0) return 0;
+    if ((kind != 1 && !src) || (kind != 0 && !dst)) return SHACIRA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) return SHACIRA_EINVAL;
+    return (int)stream_probe_launch(kind, src, dst, bytes, kind == 0 ? static_cast<uint32_t *>(dst) : nullptr,
+                                    (hipStream_t)stream);
+}
+
 int shacira_mlp_supported(int in_dim, int hidden_dim, int num_hidden, int out_dim) {
     options_snapshot();
     return mlp_supported(in_dim, hidden_dim, num_hidden, out_dim) ? 1 : 0;

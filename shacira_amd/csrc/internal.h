@@ -109,6 +109,9 @@ hipError_t raytrace_dense_launch(bool emit, int64_t num_rays, const float *origi
                                  const uint8_t *occ, int level, int32_t *counts, const int64_t *offsets, int32_t *ridx,
                                  int32_t *pidx, float *depth, hipStream_t s);
 
+// probe.hip
+hipError_t stream_probe_launch(int kind, const void *a, void *b, size_t bytes, uint32_t *sink, hipStream_t s);
+
 // adam.hip
 hipError_t adam_step_launch(float *p, float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps,
                             float wd, int step, const int32_t *step_dev, int zero_grad, hipStream_t s);
