@@ -35,7 +35,11 @@ namespace shacira {
 #ifndef SHACIRA_KBIN
 #define SHACIRA_KBIN 512
 #endif
-constexpr int kTile = SHACIRA_KTILE;       // samples per (level, tile) block in passes A and B
+constexpr int kTile = SHACIRA_KTILE;       // samples per (level, tile) block in passes A and B, 3-D
+// 2-D samples have half as many x-pairs: tiles of twice as many samples fill the same LDS staging buffer and halve the number
+// of scatter workgroups (each pays the same latencies and barriers whatever it carries: 16 us per level either way before)
+template <int DIM> struct TileOf { static constexpr int value = (DIM == 2) ? 2 * kTile : kTile; };
+static inline int tile_samples(int dim) { return dim == 2 ? 2 * kTile : kTile; }
 constexpr int kBinThreads = SHACIRA_KBIN;  // threads of passes A and B
 constexpr int kConsumeThreads = 1024;
 constexpr int kMaxBuckets = 2048;     // over all levels
@@ -668,8 +672,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                                                                   Item<F> *__restrict__ items, int64_t sample0,
                                                                   int64_t N, int64_t gpitch) {
     constexpr int NP = 1 << (DIM - 1);
-    constexpr int SPT = kTile / kBinThreads;   // samples per thread
-    constexpr int kStage = kTile * NP;         // staged items per block
+    constexpr int kTileD = TileOf<DIM>::value;
+    constexpr int SPT = kTileD / kBinThreads;  // samples per thread
+    constexpr int kStage = kTileD * NP;        // staged items per block
     extern __shared__ __align__(16) unsigned char s_raw[];
     Item<F> *s_items = reinterpret_cast<Item<F> *>(s_raw);
     uint8_t *s_bucket = reinterpret_cast<uint8_t *>(s_items + kStage);
@@ -701,7 +706,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     float craw[SPT][DIM], graw[SPT][F];
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
-        int64_t i = sample0 + (int64_t)tile * kTile + threadIdx.x + u * kBinThreads;
+        int64_t i = sample0 + (int64_t)tile * kTileD + threadIdx.x + u * kBinThreads;
         i = i < N ? i : N - 1;
 #pragma unroll
         for (int a = 0; a < DIM; ++a) craw[u][a] = coords[i * DIM + a];
@@ -726,7 +731,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
         const int k = threadIdx.x + u * kBinThreads;
-        const int64_t i = sample0 + (int64_t)tile * kTile + k;
+        const int64_t i = sample0 + (int64_t)tile * kTileD + k;
         const bool live = i < N;
         double t[DIM];
 #pragma unroll
@@ -846,7 +851,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
                                                                        uint32_t *__restrict__ cnt, int64_t sample0,
                                                                        int64_t N) {
     __shared__ uint32_t s_hist[SHACIRA_MAX_LODS][kMaxLevelBuckets];
-    constexpr int SPT = kTile / kBinThreads;
+    constexpr int kTileD = TileOf<DIM>::value;
+    constexpr int SPT = kTileD / kBinThreads;
     const uint32_t tile = blockIdx.x;
     // gridDim.y workgroups share a tile's levels (bi = blockIdx.y, blockIdx.y + gridDim.y, ...): small batches keep the chip
     // busy with one level each, large ones load the coordinates once for all levels
@@ -855,7 +861,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
     bool live[SPT];
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
-        const int64_t i = sample0 + (int64_t)tile * kTile + threadIdx.x + u * kBinThreads;
+        const int64_t i = sample0 + (int64_t)tile * kTileD + threadIdx.x + u * kBinThreads;
         live[u] = i < N;
         load_unit_coords<DIM>(coords, i, N, t[u]);
     }
@@ -1401,7 +1407,7 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
     for (uint32_t q = 0; q < plan.nbl; ++q) plan.bstart[q] = plan.lv[plan.blevel[q]].bucket0;
     plan.total_buckets = nbk;
     plan.BR = BR;
-    plan.num_tiles = (uint32_t)((n_batch + kTile - 1) / kTile);
+    plan.num_tiles = (uint32_t)((n_batch + tile_samples(dim) - 1) / tile_samples(dim));
     plan.pairs = 1u << (dim - 1);
     // work-unit size: 1/48 of ONE level's items, so that an evenly loaded hashed bucket (1/64 of a level) is ONE unit
     // (plain-store flush) with 33 % slack, while over-full coarse buckets split into equal chunks that keep all CUs busy
@@ -1441,8 +1447,8 @@ static int64_t bin_batch_samples(int dim, const LevelTable &lt, int64_t n) {
     make_plan(dim, lt, kTile, plan, choose_acc_kib(dim, lt, n), one_image_compact_rule(n));
     const size_t per_sample = (size_t)(plan.nbl ? plan.nbl : 1) * (1u << (dim - 1)) * item;
     int64_t cap = (int64_t)(((size_t)opt().bin_batch_mib << 20) / per_sample);
-    cap = cap / kTile * kTile;
-    if (cap < kTile) cap = kTile;
+    cap = cap / tile_samples(dim) * tile_samples(dim);
+    if (cap < tile_samples(dim)) cap = tile_samples(dim);
     return n < cap ? n : cap;
 }
 
@@ -1715,7 +1721,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     if (fork) SHACIRA_CHECK(hipEventRecord(ss->join, ss->stream));
     if (whole.nbl == 0) return hipSuccess;   // (fork implies binned levels)
     constexpr int NPAIR = 1 << (DIM - 1);
-    const size_t stage = (size_t)kTile * NPAIR * (sizeof(Item<F>) + 1);
+    const size_t stage = (size_t)TileOf<DIM>::value * NPAIR * (sizeof(Item<F>) + 1);
     bool first_batch = true;
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
@@ -1742,7 +1748,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         }
         hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>),
                            dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads), stage, s, lt,
-                           plan, coords, w.gT, w.cursor, w.cnt, fused_now ? (uint32_t)(kTile / ts16) : 1u,
+                           plan, coords, w.gT, w.cursor, w.cnt, fused_now ? (uint32_t)(TileOf<DIM>::value / ts16) : 1u,
                            fused_now ? (uint32_t)((n + ts16 - 1) / ts16) : plan.num_tiles,
                            reinterpret_cast<Item<F> *>(w.items), s0, hi, NP);
         SHACIRA_CHECK_LAUNCH();
@@ -1805,8 +1811,8 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, true>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2, false>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, false>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2>), (size_t)kTile * 2 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4>), (size_t)kTile * 2 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<4>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
         return attr_err;

@@ -4,7 +4,7 @@ name=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$name
-rocprofv3 --kernel-trace --stats -d gpurun_out/$name -o $name --output-format csv -- python3 "$@" > gpurun_out/$name/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/$name -o $name --output-format csv -- python3 "$@" > gpurun_out/$name/log.txt 2>&1
 f=$(find gpurun_out/$name -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
