@@ -419,6 +419,10 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
 // PACKED: `coords` is an array of 16-byte records {x, y, z (0 in 2-D), bits} (the cell-sorted copy of hashgrid_tiled.hip):
 // one dwordx4 load per sample instead of DIM dword loads -- the kernel is bound by vector-memory instructions.
 // (Round 3 pruned the unstaged forms of this kernel and the per-sample / per-level variants 1, 2, 4, 5, 7: git 4a7dfa7.)
+#ifndef SHACIRA_LEVEL_PAIR_U
+#define SHACIRA_LEVEL_PAIR_U 1
+#endif
+constexpr int kLevelPairU = SHACIRA_LEVEL_PAIR_U;
 template <int DIM, typename T, int F, bool PACKED = false>
 __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable lt,
                                                                       const int32_t *__restrict__ first_idx,
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
                                                                       T *__restrict__ feats, int64_t N,
                                                                       uint32_t tiles) {
     constexpr int NH = 1 << (DIM - 1);
-    constexpr int U = 1;   // samples per lane pair
+    constexpr int U = kLevelPairU;   // samples per lane pair
     // work list = (level, tile) pairs, level-major, of levels [level_begin, level_end); XCD k (round-robin dispatch,
     // blockIdx % 8 -- a speed assumption only) takes the k-th eighth of it and walks it in order, so that at any moment its
     // L2 holds the table of one level (two at a slice boundary), whatever the number of levels
@@ -563,7 +567,7 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
         if (use_staged(DIM, lt, num_coords) && workspace) {
             // variant 6: level-per-XCD schedule with lane pairing, features staged level-major (coalesced stores),
             // then one transposing copy into the caller's [N, L*F] layout
-            const uint32_t tiles = (uint32_t)((num_coords + 127) / 128);
+            const uint32_t tiles = (uint32_t)((num_coords + 128 * kLevelPairU - 1) / (128 * kLevelPairU));
             const uint32_t grid_v6 = 8u * (uint32_t)(((uint64_t)lt.num_lods * tiles + 7) / 8);
             hipError_t e;
             hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F>), dim3(grid_v6),
@@ -632,7 +636,7 @@ template <int DIM, typename T, int F>
 static hipError_t launch_levels_staged(const LevelTable &lt, const int32_t *first_idx, const float *coords,
                                        const void *table, void *staged, int64_t n, hipStream_t s) {
     const uint32_t nl = (uint32_t)(lt.level_end - lt.level_begin);
-    const uint32_t tiles = (uint32_t)((n + 127) / 128);
+    const uint32_t tiles = (uint32_t)((n + 128 * kLevelPairU - 1) / (128 * kLevelPairU));
     hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, true>),
                        dim3(8u * (uint32_t)(((uint64_t)nl * tiles + 7) / 8)), dim3(256), 0, s,
                        lt, first_idx, coords, static_cast<const T *>(table), static_cast<T *>(staged), n, tiles);

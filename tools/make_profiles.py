@@ -4,8 +4,8 @@ usage: python tools/make_profiles.py gpurun_out/r02f r02"""
 import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02f")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+src = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r03f")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 sys.path.insert(0, ROOT)
 from bench import kernel_source_hash
 out = os.path.join(ROOT, "profiles")
@@ -39,10 +39,9 @@ with open(os.path.join(out, f"{tag}_bench_rocprof_summary.md"), "w") as f:
             tb += per_step
     f.write(f"\nforward operator = sample sort (ctx_count + 2 scans + ctx_scatter) + hashgrid_fwd_level_pair (fine levels) + "
             f"hashgrid_fwd_rows (coarse levels + row assembly) = {tf:.1f} us of kernel time; backward "
-            f"operator = transpose_grad + bin_count + 2 scans + bin_scatter + bin_consume + direct_accumulate + memset = "
-            f"{tb:.1f} us of kernel time per step. The backward's event time is shorter than its kernel-time sum because "
-            f"bin_count and the scans run on the library's side stream concurrently with transpose_grad and "
-            f"direct_accumulate (DESIGN.md 4.3).\n")
+            f"operator = zero_words + zero_unowned_rows + front16 (16-byte transpose + bucket counts) + bin_scan_buckets + "
+            f"zero_odd_buckets + bin_scatter + bin_consume = {tb:.1f} us of kernel time per step, all on the caller's stream "
+            f"(S1 has no LDS-resident level left at this batch size: level 0 travels as compact items; DESIGN.md 4.3).\n")
 
 def counter(dirname):
     f = max(glob.glob(os.path.join(src, dirname, "*/*counter_collection.csv")), key=os.path.getmtime)
@@ -72,7 +71,7 @@ json.dump({"kernel_source_hash": kernel_source_hash(),
                    "{fwd|bwd} -1 3 3` (workload S1: 3-D L16 F2 bw19, N=2^20; 3 calls, per-call averages). Counters are in "
                    "KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section), so read "
                    "bytes = 2*FETCH_SIZE*1024 (verified: the transposes read 128 MiB and report 64 MiB); WRITE_SIZE is "
-                   "exact. fillBufferAligned is the hipMemsetAsync of the gradient table.",
+                   "exact.",
            "operators": ops}, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 for k, v in ops.items():
     print(k, "HBM bytes per launch %.3f GB (read %.3f, write %.3f)" % (v["hbm_bytes_per_launch"] / 1e9, v["read_bytes_corrected"] / 1e9, v["write_bytes"] / 1e9))
@@ -123,3 +122,83 @@ with open(os.path.join(out, f"{tag}_fwd_counters.md"), "w") as f:
                 notes.append(f"VALU instructions per wave = {d['SQ_INSTS_VALU'] / d['SQ_WAVES']:.0f}, VMEM reads per wave = {d.get('SQ_INSTS_VMEM_RD', 0) / d['SQ_WAVES']:.1f}")
             f.write("\n" + "; ".join(notes) + "\n\n")
 print("wrote", f"{tag}_fwd_counters.md")
+
+
+# backward unit counters (round 3)
+with open(os.path.join(out, f"{tag}_bwd_counters.md"), "w") as f:
+    f.write(f"# Backward kernels on S1 (N = 2^20), unit counters per launch ({tag}, source hash {kernel_source_hash()})\n\n"
+            "`rocprofv3 --pmc <group> --kernel-trace -- python3 tools/fwd_only.py bwd -1 3 3`, one pass per counter group "
+            "(SQ / LDS / TCC), averages over 3 calls.\n\n")
+    merged = defaultdict(dict)
+    for grp in ("sq", "lds", "tcc"):
+        for k, d in ctr(f"ctr_bwd_{grp}").items():
+            if "shacira::" in k:
+                merged[k].update(d)
+    for k, d in merged.items():
+        f.write(f"### `{k}`\n\n| counter | per launch |\n|---|---|\n")
+        for c in sorted(d):
+            f.write(f"| {c} | {d[c]:,.0f} |\n")
+        notes = []
+        if d.get("SQ_WAVE_CYCLES"):
+            notes.append(f"waves parked in waits = SQ_WAIT_ANY / SQ_WAVE_CYCLES = {d.get('SQ_WAIT_ANY', 0) / d['SQ_WAVE_CYCLES']:.2f}")
+        if d.get("SQ_WAVES") and d.get("SQ_INSTS_VALU"):
+            notes.append(f"VALU instructions per wave = {d['SQ_INSTS_VALU'] / d['SQ_WAVES']:.0f}, LDS instructions per wave = {d.get('SQ_INSTS_LDS', 0) / d['SQ_WAVES']:.0f}")
+        if d.get("SQ_LDS_IDX_ACTIVE") and d.get("SQ_BUSY_CYCLES"):
+            notes.append(f"LDS bank-conflict share of LDS-active cycles = {d.get('SQ_LDS_BANK_CONFLICT', 0) / d['SQ_LDS_IDX_ACTIVE']:.2f}")
+        hit, miss = d.get("TCC_HIT_sum"), d.get("TCC_MISS_sum")
+        if hit is not None and miss is not None and hit + miss > 0:
+            notes.append(f"L2 hit rate = {hit / (hit + miss):.3f}")
+        f.write("\n" + "; ".join(notes) + "\n\n")
+print("wrote", f"{tag}_bwd_counters.md")
+
+# what the operators sit inside: eager step of the NeRF fit / image fit, kernel time vs wall time
+def step_md(w, title, fname, hot=("hashgrid_fwd", "untranspose_feats", "ctx_", "front16", "bin_", "zero_", "direct_accumulate", "transpose_grad")):
+    jp = os.path.join(src, f"step_{w}.json")
+    fs = glob.glob(os.path.join(src, f"step_{w}", "*/*kernel_stats.csv"))
+    if not os.path.exists(jp) or not fs:
+        return
+    try:
+        rec = json.loads([l for l in open(jp).read().splitlines() if l.startswith("{")][-1])
+    except (IndexError, ValueError):
+        return
+    rows = list(csv.DictReader(open(max(fs, key=os.path.getmtime))))
+    steps = rec["steps"]
+    tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e3 / steps
+    hot_us = sum(float(r["TotalDurationNs"]) for r in rows if any(h in r["Name"] for h in hot)) / 1e3 / steps
+    wall = rec["ms_per_step"] * 1e3
+    with open(os.path.join(out, fname), "w") as f:
+        f.write(f"# {title}\n\n`rocprofv3 --kernel-trace --stats -- python3 tools/step_breakdown.py {w} {steps}` ({tag}, source hash "
+                f"{kernel_source_hash()}).\n\n")
+        f.write(f"Wall time per step (the loop's own clock, under the profiler): **{wall:.0f} us**. GPU kernel time per step (every "
+                f"kernel of the trace, setup and validation included): **{tot:.0f} us**  -> the GPU is busy "
+                f"{min(tot / wall, 1.0) * 100:.0f} % of the step; the rest is host time between launches (Python, autograd, "
+                f"allocator, launch latency).\nHash-grid operators (forward + backward kernels of this library's hot path): "
+                f"**{hot_us:.0f} us** per step = {hot_us / wall * 100:.0f} % of the wall time, {hot_us / max(tot, 1e-9) * 100:.0f} % of the kernel time.\n\n")
+        f.write("| kernel | us per step | calls per step |\n|---|---|---|\n")
+        for r in rows[:28]:
+            f.write(f"| `{r['Name'][:100]}` | {float(r['TotalDurationNs']) / 1e3 / steps:.1f} | {int(r['Calls']) / steps:.1f} |\n")
+    print("wrote", fname, "wall", wall, "kernels", tot, "hot", hot_us)
+
+step_md("nerf", "NeRF-style render-and-fit (harness.fit_nerf), one eager training step", f"{tag}_nerf_step.md")
+step_md("image", "Config-B image fit (harness.fit_image, 512x768), one eager training step", f"{tag}_imagefit_step.md")
+step_md("image_graphed", "Config-B image fit, the step replayed from a HIP graph (GraphedImageFitter)", f"{tag}_imagefit_graphed_step.md")
+
+# MFMA utilisation of the decoder kernels (width 64 and 128)
+mf = ctr("ctr_mlp128")
+if mf:
+    with open(os.path.join(out, f"{tag}_mlp_mfma_util.md"), "w") as f:
+        f.write(f"# Decoder MLP kernels, matrix-core utilisation ({tag})\n\n`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES "
+                "SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace -- python3 tools/mlp128_check.py` (averages over all "
+                "launches of a kernel; batch sizes 65 536 / 409 600 / 2^20 mixed). MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / "
+                "(GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs) is not exact for mixed launches; the ratio to SQ_BUSY_CYCLES is "
+                "given as well.\n\n| kernel | MFMA busy cycles | SQ busy cycles | GRBM_GUI_ACTIVE | MFMA busy / (GUI/8 x 1024 SIMDs) |\n|---|---|---|---|---|\n")
+        for k, d in mf.items():
+            if "mlp" not in k:
+                continue
+            gui = d.get("GRBM_GUI_ACTIVE", 0.0)
+            util = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8 * 1024) if gui else float("nan")
+            f.write(f"| `{k[:90]}` | {d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):,.0f} | {d.get('SQ_BUSY_CYCLES', 0):,.0f} | {gui:,.0f} | {util:.2f} |\n")
+        p2 = os.path.join(src, "mlp128_check.txt")
+        if os.path.exists(p2):
+            f.write("\n```\n" + open(p2).read() + "```\n")
+    print("wrote", f"{tag}_mlp_mfma_util.md")

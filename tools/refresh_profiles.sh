@@ -1,20 +1,20 @@
 # Regenerates the raw material of profiles/ on the GPU box (run through gpurun): bash tools/refresh_profiles.sh [tag]
 # then, back in the repo: python tools/make_profiles.py gpurun_out/<tag>f <tag>
 set -x
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}f
 mkdir -p $OUT
-STAGES=${STAGES:-"bench checks stats pmc ctr"}    # subset to re-run, e.g. STAGES="bench ctr"
+STAGES=${STAGES:-"bench checks stats pmc ctr bctr steps mfma"}    # subset to re-run, e.g. STAGES="bench ctr"
 has() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
 if has bench; then
-( time python bench.py > $OUT/bench_line.json 2> $OUT/bench_err.txt ) 2> $OUT/bench_wall.txt
+( time timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_err.txt ) 2> $OUT/bench_wall.txt
 tail -c 600 $OUT/bench_line.json; cat $OUT/bench_wall.txt
 fi
 if has checks; then
-python tools/gpu_check.py > $OUT/parity_and_timing.txt 2>&1
-python tools/config_c.py > $OUT/config_c.txt 2>&1
-python tools/tiled_check.py > $OUT/tiled_check.txt 2>&1
+timeout 300 python tools/gpu_check.py > $OUT/parity_and_timing.txt 2>&1
+timeout 300 python tools/config_c.py > $OUT/config_c.txt 2>&1
+timeout 300 python tools/tiled_check.py > $OUT/tiled_check.txt 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp
 if has stats; then
@@ -36,5 +36,20 @@ timeout 120 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum --
 timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $OUT/ctr_${mode}_tcc -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py fwd -1 3 3 > /dev/null 2>&1
 done
 unset SHACIRA_OPTIONS
+fi
+if has bctr; then
+# backward kernels, unit counters (same groups; separate passes)
+timeout 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/ctr_bwd_sq -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py bwd -1 3 3 > /dev/null 2>&1
+timeout 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/ctr_bwd_lds -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py bwd -1 3 3 > /dev/null 2>&1
+timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $OUT/ctr_bwd_tcc -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py bwd -1 3 3 > /dev/null 2>&1
+fi
+if has steps; then
+# what the operators sit inside: one eager step of the NeRF fit / the image fit (kernel time vs wall time), and the graphed image fit
+for w in nerf image image_graphed; do
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_$w -- python3 $GRAFT_REPO_ROOT/tools/step_breakdown.py $w 300 > $OUT/step_$w.json 2>/dev/null
+done
+fi
+if has mfma; then
+timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/ctr_mlp128 -- python3 $GRAFT_REPO_ROOT/tools/mlp128_check.py > $OUT/mlp128_check.txt 2>&1
 fi
 ls $OUT
