@@ -95,6 +95,46 @@ template <int F> struct alignas(F == 2 ? 16 : 8) Item {
     float a[F];
 };
 
+// fp16 tables with F = 2 (the reference's NeRF mode: AMP on, grid.py:73, .cu:198-211): the gradient is stored as fp16 anyway,
+// so the item stream may carry half-precision payloads -- HALF the bytes of the pass that bounds the backward:
+//   pair item, 8 B:     key = rowA (13) | kx (4) | validA | validB | fx quantised to 13 bits;  a = half2(g0 w, g1 w)
+//                       rowB = kx ? rowA ^ (2^kx - 1) : rowA + 1   (hashed: x ^ (x + 1) = 2^kx - 1; dense: the next row)
+//   compact item, 16 B: key = local base row | valid;  fx, fy, fz as 16-bit fixed point;  g = half2(g0, g1)  (two 8-byte units)
+// Weight error <= 2^-14, payload rounding 2^-11 relative per term (the reference's own fp16 atomics round the running SUM to
+// 11 bits at every add); sums are still accumulated in the 64-bit fixed-point / fp64 LDS images.
+struct alignas(8) ItemH {
+    uint32_t key;
+    __half2 a;
+};
+struct alignas(16) ItemHC {
+    uint32_t key;
+    uint16_t fx, fy, fz, pad;
+    __half2 g;
+};
+template <int F, bool H> struct ItemSel { typedef Item<F> type; };
+template <> struct ItemSel<2, true> { typedef ItemH type; };
+
+__device__ __forceinline__ uint32_t pack_half_key(uint32_t key, float fx, bool dense) {
+    const uint32_t ra = key & 0x1FFFu, rb = (key >> 13) & 0x1FFFu;
+    const uint32_t kx = dense ? 0u : (32u - (uint32_t)__clz((int)(ra ^ rb)));
+    const uint32_t fq = (uint32_t)(fx * 8192.0f);   // fx in [0, 1)
+    return ra | (kx << 13) | (((key >> 26) & 3u) << 17) | ((fq > 8191u ? 8191u : fq) << 19);
+}
+__device__ __forceinline__ void unpack_half_key(uint32_t k, uint32_t &ra, uint32_t &rb, bool &va, bool &vb, float &fx) {
+    ra = k & 0x1FFFu;
+    const uint32_t kx = (k >> 13) & 15u;
+    rb = kx ? (ra ^ ((1u << kx) - 1u)) : ((ra + 1u) & 0x1FFFu);
+    va = (k >> 17) & 1u;
+    vb = (k >> 18) & 1u;
+    fx = ((float)(k >> 19) + 0.5f) * (1.0f / 8192.0f);
+}
+__device__ __forceinline__ void store_item_nt(ItemH *p, const ItemH &it) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 v;
+    __builtin_memcpy(&v, &it, 8);
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p));
+}
+
 // One consumer work unit, written by the bucket scan: everything a consume workgroup needs in ONE 32-byte load (it used to
 // chase unit -> bucket -> base / unit_first -> level through four dependent loads and a 15-step scalar search: ~8 us per
 // unit before the first item arrived).
@@ -662,21 +702,23 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
 // Gradients from the transposed image gT [L][NP][F], grid (tiles, binned levels). A (tile, bucket) run is reserved with one
 // returning atomic on the bucket's cursor (set to the bucket's base by the bucket scan): runs of different tiles land in
 // the bucket in arrival order -- the consumer's fixed-point sums do not depend on it.
-template <int DIM, int F>
+// H: half-precision item stream (fp16 tables, F = 2): 8-byte pair items, 16-byte compact items.
+template <int DIM, int F, bool H>
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt, BinPlan plan,
                                                                   const float *__restrict__ coords,
                                                                   const float *__restrict__ gT,
                                                                   unsigned long long *__restrict__ cursor,
                                                                   const uint32_t *__restrict__ cnt, uint32_t cps,
                                                                   uint32_t cnt_rows,
-                                                                  Item<F> *__restrict__ items, int64_t sample0,
-                                                                  int64_t N, int64_t gpitch) {
+                                                                  typename ItemSel<F, H>::type *__restrict__ items,
+                                                                  int64_t sample0, int64_t N, int64_t gpitch) {
+    typedef typename ItemSel<F, H>::type ItemT;
     constexpr int NP = 1 << (DIM - 1);
     constexpr int kTileD = TileOf<DIM>::value;
     constexpr int SPT = kTileD / kBinThreads;  // samples per thread
     constexpr int kStage = kTileD * NP;        // staged items per block
     extern __shared__ __align__(16) unsigned char s_raw[];
-    Item<F> *s_items = reinterpret_cast<Item<F> *>(s_raw);
+    ItemT *s_items = reinterpret_cast<ItemT *>(s_raw);
     uint8_t *s_bucket = reinterpret_cast<uint8_t *>(s_items + kStage);
     __shared__ uint32_t s_hist[kMaxLevelBuckets];
     __shared__ uint32_t s_start[kMaxLevelBuckets + 1];
@@ -790,6 +832,27 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         for (int q = 0; q < NP; ++q) {
             if (ps[u][q].key >> 26) {
                 const uint32_t pos = s_start[ps[u][q].bucket] + rank[u][q];
+                if constexpr (H) {
+                    if (compact) {   // one 16-byte item = two 8-byte units (pos is even: every count of the level is)
+                        ItemHC c;
+                        c.key = ps[u][q].key;
+                        c.fx = (uint16_t)(fx[u] * 65536.0f);
+                        c.fy = (uint16_t)(fyz[u][0] * 65536.0f);
+                        c.fz = (uint16_t)(fyz[u][1] * 65536.0f);
+                        c.pad = 0;
+                        c.g = __floats2half2_rn(g[u][0], g[u][1]);
+                        *reinterpret_cast<ItemHC *>(&s_items[pos]) = c;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                        s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
+                    } else {
+                        ItemH it;
+                        it.key = pack_half_key(ps[u][q].key, fx[u], dense);
+                        it.a = __floats2half2_rn(g[u][0] * ps[u][q].wrest, g[u][1] * ps[u][q].wrest);
+                        s_items[pos] = it;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                    }
+                    continue;
+                }
                 Item<F> it;
                 it.key = ps[u][q].key;
                 it.fx = fx[u];
@@ -797,13 +860,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                     if constexpr (F == 2) {   // two slots: {key, fx, fy, fz} {0, g0, g1, 0}
                         it.a[0] = fyz[u][0];
                         it.a[1] = fyz[u][1];
-                        s_items[pos] = it;
+                        *reinterpret_cast<Item<F> *>(&s_items[pos]) = it;
                         Item<F> it2;
                         it2.key = 0;
                         it2.fx = g[u][0];
                         it2.a[0] = g[u][1];
                         it2.a[1] = 0.0f;
-                        s_items[pos + 1] = it2;
+                        *reinterpret_cast<Item<F> *>(&s_items[pos + 1]) = it2;
                         s_bucket[pos] = (uint8_t)ps[u][q].bucket;
                         s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
                     } else if constexpr (F == 4) {   // two 24-byte slots: {key, fx, fy, fz, g0, g1} {0, g2, g3, -, -, -}
@@ -811,20 +874,20 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                         it.a[1] = fyz[u][1];
                         it.a[2] = g[u][0];
                         it.a[3] = g[u][1];
-                        s_items[pos] = it;
+                        *reinterpret_cast<Item<F> *>(&s_items[pos]) = it;
                         Item<F> it2;
                         it2.key = 0;
                         it2.fx = g[u][2];
                         it2.a[0] = g[u][3];
                         it2.a[1] = 0.0f; it2.a[2] = 0.0f; it2.a[3] = 0.0f;
-                        s_items[pos + 1] = it2;
+                        *reinterpret_cast<Item<F> *>(&s_items[pos + 1]) = it2;
                         s_bucket[pos] = (uint8_t)ps[u][q].bucket;
                         s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
                     }
                 } else {
 #pragma unroll
                     for (int j = 0; j < F; ++j) it.a[j] = g[u][j] * ps[u][q].wrest;
-                    s_items[pos] = it;
+                    *reinterpret_cast<Item<F> *>(&s_items[pos]) = it;
                     s_bucket[pos] = (uint8_t)ps[u][q].bucket;
                 }
             }
@@ -836,7 +899,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     for (uint32_t pos = threadIdx.x; pos < staged; pos += kBinThreads) {
         const uint32_t b = s_bucket[pos];
         // write-once / read-once stream: non-temporal stores (measured -7 % on the whole backward)
-        store_item_nt<F>(items + s_gbase[b] + (pos - s_start[b]), s_items[pos]);
+        store_item_nt(items + s_gbase[b] + (pos - s_start[b]), s_items[pos]);
     }
 }
 
@@ -963,9 +1026,9 @@ template <int F> __device__ __forceinline__ float pick(const float (&a)[F], int 
 
 // ------------------------------------------------------------------------------------------------- pass C
 // one work unit (a bucket, or a chunk of an over-full one) on the calling workgroup
-template <int F, bool FX>
+template <int F, bool FX, bool H>
 __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan &plan, const int32_t *__restrict__ first_idx,
-                                             const UnitDesc d, const Item<F> *__restrict__ items,
+                                             const UnitDesc d, const typename ItemSel<F, H>::type *__restrict__ items,
                                              float *__restrict__ grad_table, int force_atomic,
                                              const uint32_t *__restrict__ gmax, int headroom, double *s_acc) {
     const uint32_t gb = d.bucket, lvl = d.level;
@@ -983,50 +1046,86 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
 
     const uint64_t begin = d.begin, end = d.end;
+    const int rot = (int)(threadIdx.x & (F - 1));
+    // feature order rotated by lane: the F slots of a row are consecutive 8-byte words, so with every lane adding feature j
+    // in the same instruction only 1 / F of the LDS banks were addressed (half of the pass's LDS cycles were bank conflicts)
+    auto add_row = [&](uint32_t row, const float (&v)[F], float w) {
+#pragma unroll
+        for (int jj = 0; jj < F; ++jj) {
+            const int j = (jj + rot) & (F - 1);
+            const float c = pick<F>(v, j) * w;
+            if (FX && fx.fixed) atomicAdd(&s_fix[row * F + j], fx_encode(c, fx.scale));
+            else atomicAdd(&s_acc[row * F + j], (double)c);
+        }
+    };
+    auto add_pair = [&](uint32_t ra, uint32_t rb, bool va, bool vb, float fxv, const float (&a)[F]) {
+        if (va) add_row(ra, a, 1.0f - fxv);
+        if (vb) add_row(rb, a, fxv);
+    };
+    const uint32_t r2 = r1 * r1;
+    auto add_compact = [&](uint32_t base_row, float fxx, float fyy, float fzz, const float (&gg)[F]) {
+        const float gxx = 1.0f - fxx, gyy = 1.0f - fyy, gzz = 1.0f - fzz;
+        const float wxy[4] = {gxx * gyy, gxx * fyy, fxx * gyy, fxx * fyy};   // reference order: (x * y) * z
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t row = base_row + ((c >> 2) & 1) + ((c >> 1) & 1) * r1 + (c & 1) * r2;
+            if (row >= nrows) continue;   // cannot happen for in-range cells; keeps the image safe
+            add_row(row, gg, wxy[c >> 1] * ((c & 1) ? fzz : gzz));
+        }
+    };
     if constexpr (F == 2 || F == 4) {
         if (bl.compact) {
-            // one sample per two slots: F = 2 {local base row | valid, fx, fy, fz} {-, g0, g1, -}; F = 4 {.., fx, fy, fz, g0, g1}
-            // {-, g2, g3, ...}; all 8 corners land here
             constexpr int UC = 2;
-            const uint32_t r2 = r1 * r1;
-            const int rotc = (int)(threadIdx.x & (F - 1));
-            for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
-                Item<F> ia[UC], ib[UC];
+            if constexpr (H) {
+                // one sample per 16-byte record (two 8-byte units): {local base row | valid, fx, fy, fz (u16), half2 g}
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
+                    ItemHC rec[UC];
 #pragma unroll
-                for (int u = 0; u < UC; ++u) {
-                    const uint64_t p = p0 + 2ull * u * kConsumeThreads;
-                    if (p + 1 < end) {
-                        ia[u] = load_item_nt<F>(items + p);
-                        ib[u] = load_item_nt<F>(items + p + 1);
-                    } else {
-                        ia[u].key = 0;
+                    for (int u = 0; u < UC; ++u) {
+                        const uint64_t p = p0 + 2ull * u * kConsumeThreads;
+                        rec[u].key = 0;
+                        if (p + 1 < end) {
+                            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p));
+                            __builtin_memcpy(&rec[u], &v, 16);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UC; ++u) {
+                        if (!(rec[u].key & (1u << 26))) continue;
+                        const float2 gf = __half22float2(rec[u].g);
+                        const float gg[F] = {gf.x, gf.y};
+                        const float q = 1.0f / 65536.0f;
+                        add_compact(rec[u].key & 0x1FFFu, ((float)rec[u].fx + 0.5f) * q, ((float)rec[u].fy + 0.5f) * q,
+                                    ((float)rec[u].fz + 0.5f) * q, gg);
                     }
                 }
+            } else {
+                // one sample per two slots: F = 2 {local base row | valid, fx, fy, fz} {-, g0, g1, -}; F = 4 {.., fx, fy, fz,
+                // g0, g1} {-, g2, g3, ...}; all 8 corners land here
+                const Item<F> *itf = reinterpret_cast<const Item<F> *>(items);
+                for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
+                    Item<F> ia[UC], ib[UC];
 #pragma unroll
-                for (int u = 0; u < UC; ++u) {
-                    if (!(ia[u].key & (1u << 26))) continue;
-                    const uint32_t base_row = ia[u].key & 0x1FFFu;
-                    const float fxx = ia[u].fx, fyy = ia[u].a[0], fzz = ia[u].a[1];
-                    const float gxx = 1.0f - fxx, gyy = 1.0f - fyy, gzz = 1.0f - fzz;
-                    float gg[F];
-                    if constexpr (F == 2) {
-                        gg[0] = ib[u].fx; gg[1] = ib[u].a[0];
-                    } else {
-                        gg[0] = ia[u].a[2]; gg[1] = ia[u].a[3]; gg[2] = ib[u].fx; gg[3] = ib[u].a[0];
-                    }
-                    const float wxy[4] = {gxx * gyy, gxx * fyy, fxx * gyy, fxx * fyy};   // reference order: (x * y) * z
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const uint32_t row = base_row + ((c >> 2) & 1) + ((c >> 1) & 1) * r1 + (c & 1) * r2;
-                        const float w = wxy[c >> 1] * ((c & 1) ? fzz : gzz);
-                        if (row >= nrows) continue;   // cannot happen for in-range cells; keeps the image safe
-#pragma unroll
-                        for (int jj = 0; jj < F; ++jj) {
-                            const int j = (jj + rotc) & (F - 1);
-                            const float gj = pick<F>(gg, j);
-                            if (FX && fx.fixed) atomicAdd(&s_fix[row * F + j], fx_encode(gj * w, fx.scale));
-                            else atomicAdd(&s_acc[row * F + j], (double)(gj * w));
+                    for (int u = 0; u < UC; ++u) {
+                        const uint64_t p = p0 + 2ull * u * kConsumeThreads;
+                        if (p + 1 < end) {
+                            ia[u] = load_item_nt<F>(itf + p);
+                            ib[u] = load_item_nt<F>(itf + p + 1);
+                        } else {
+                            ia[u].key = 0;
                         }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UC; ++u) {
+                        if (!(ia[u].key & (1u << 26))) continue;
+                        float gg[F];
+                        if constexpr (F == 2) {
+                            gg[0] = ib[u].fx; gg[1] = ib[u].a[0];
+                        } else {
+                            gg[0] = ia[u].a[2]; gg[1] = ia[u].a[3]; gg[2] = ib[u].fx; gg[3] = ib[u].a[0];
+                        }
+                        add_compact(ia[u].key & 0x1FFFu, ia[u].fx, ia[u].a[0], ia[u].a[1], gg);
                     }
                 }
             }
@@ -1042,54 +1141,63 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
             return;
         }
     }
-    constexpr int UN = 8;  // items in flight per thread (4: -1 %, 16: +3 % with the fixed-point atomics)
-    const int rotf = (int)(threadIdx.x & (F - 1));
-    for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
-        Item<F> it[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const uint64_t p = p0 + (uint64_t)u * kConsumeThreads;
-            if (p < end) it[u] = load_item_nt<F>(items + p);
-            else it[u].key = 0;
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const uint32_t ra = it[u].key & 0x1FFFu, rb = (it[u].key >> 13) & 0x1FFFu;
-            const float gx = 1.0f - it[u].fx;
-            if (FX && fx.fixed) {
-                // feature order rotated by lane: the F slots of a row are consecutive 8-byte words, so with every lane adding
-                // feature j in the same instruction only 1 / F of the LDS banks were addressed (half of the pass's LDS
-                // cycles were bank conflicts)
-                if (it[u].key & (1u << 26)) {
-#pragma unroll
-                    for (int jj = 0; jj < F; ++jj) {
-                        const int j = (jj + rotf) & (F - 1);
-                        atomicAdd(&s_fix[ra * F + j], fx_encode(pick<F>(it[u].a, j) * gx, fx.scale));
-                    }
-                }
-                if (it[u].key & (1u << 27)) {
-#pragma unroll
-                    for (int jj = 0; jj < F; ++jj) {
-                        const int j = (jj + rotf) & (F - 1);
-                        atomicAdd(&s_fix[rb * F + j], fx_encode(pick<F>(it[u].a, j) * it[u].fx, fx.scale));
-                    }
-                }
-            } else {
-                if (it[u].key & (1u << 26)) {
-#pragma unroll
-                    for (int jj = 0; jj < F; ++jj) {
-                        const int j = (jj + rotf) & (F - 1);
-                        atomicAdd(&s_acc[ra * F + j], (double)(pick<F>(it[u].a, j) * gx));
-                    }
-                }
-                if (it[u].key & (1u << 27)) {
-#pragma unroll
-                    for (int jj = 0; jj < F; ++jj) {
-                        const int j = (jj + rotf) & (F - 1);
-                        atomicAdd(&s_acc[rb * F + j], (double)(pick<F>(it[u].a, j) * it[u].fx));
-                    }
-                }
+    constexpr int UN = 8;  // 16-byte loads in flight per thread (4: -1 %, 16: +3 % with the fixed-point atomics)
+    if constexpr (H) {
+        // 8-byte items read two at a time (16-byte loads from even unit indices); a unit's odd first / last item goes alone
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        auto consume8 = [&](uint32_t key, uint32_t payload) {
+            uint32_t ra, rb;
+            bool va, vb;
+            float fxv;
+            unpack_half_key(key, ra, rb, va, vb, fxv);
+            __half2 h;
+            __builtin_memcpy(&h, &payload, 4);
+            const float2 af = __half22float2(h);
+            const float a[F] = {af.x, af.y};
+            add_pair(ra, rb, va, vb, fxv, a);
+        };
+        uint64_t p = begin;
+        if ((p & 1ull) && p < end) {
+            if (threadIdx.x == 0) {
+                const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(items + p));
+                consume8(v[0], v[1]);
             }
+            ++p;
+        }
+        const uint64_t even_end = end & ~1ull;
+        for (uint64_t p0 = p + 2ull * threadIdx.x; p0 < even_end; p0 += 2ull * kConsumeThreads * UN) {
+            u32x4 v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const uint64_t q = p0 + 2ull * u * kConsumeThreads;
+                v[u] = u32x4{0u, 0u, 0u, 0u};   // key 0: no valid corner
+                if (q < even_end) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + q));
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                consume8(v[u][0], v[u][1]);
+                consume8(v[u][2], v[u][3]);
+            }
+        }
+        if ((end & 1ull) && end - 1 >= p && threadIdx.x == 64) {
+            const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(items + end - 1));
+            consume8(v[0], v[1]);
+        }
+    } else {
+        const Item<F> *itf = reinterpret_cast<const Item<F> *>(items);
+        for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
+            Item<F> it[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
+                if (pp < end) it[u] = load_item_nt<F>(itf + pp);
+                else it[u].key = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                add_pair(it[u].key & 0x1FFFu, (it[u].key >> 13) & 0x1FFFu, (it[u].key >> 26) & 1u, (it[u].key >> 27) & 1u,
+                         it[u].fx, it[u].a);
         }
     }
     lds_barrier();
@@ -1111,14 +1219,14 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
 // number of workgroups the chip holds, not the number of units). A unit of a small batch is ~10 us of work between a launch,
 // a 128 KiB image to zero and a flush whose stores s_endpgm would wait for: as separate workgroups (one per CU at a time)
 // nerf_lego.yaml's 1 800 units of 8 K items took 228 us; here the flush of unit k drains behind unit k + 1 (all barriers in
-// consume_unit are LDS-only). `work_counter` NULL: one unit per workgroup (launches over a bucket range: option bwd_groups).
-template <int F, bool FX>
+// consume_unit are LDS-only). `work_counter` NULL: one unit per workgroup (small batches).
+template <int F, bool FX, bool H>
 __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable lt, BinPlan plan,
                                                                       const int32_t *__restrict__ first_idx,
                                                                       const uint64_t *__restrict__ base,
                                                                       const uint32_t *__restrict__ unit_first,
                                                                       const UnitDesc *__restrict__ unit_desc,
-                                                                      const Item<F> *__restrict__ items,
+                                                                      const typename ItemSel<F, H>::type *__restrict__ items,
                                                                       float *__restrict__ grad_table,
                                                                       int force_atomic,
                                                                       const uint32_t *__restrict__ gmax,
@@ -1130,7 +1238,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     if (work_counter == nullptr) {
         const uint32_t unit = blockIdx.x + unit0;
         if (unit >= unit_end) return;
-        consume_unit<F, FX>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
+        consume_unit<F, FX, H>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
         return;
     }
     for (;;) {
@@ -1138,7 +1246,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         lds_barrier();
         const uint32_t unit = s_unit + unit0;
         if (unit >= unit_end) return;
-        consume_unit<F, FX>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
+        consume_unit<F, FX, H>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
         lds_barrier();   // the image and s_unit are free again; the flush stores keep draining
     }
 }
@@ -1441,8 +1549,14 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
 }
 
 // sub-batch so that the item array stays below the cap (default 1.5 GiB, option "bin_batch_mib")
-static int64_t bin_batch_samples(int dim, const LevelTable &lt, int64_t n) {
-    const size_t item = 8 + 4 * (size_t)lt.feature_dim;
+// bytes of one item unit: 8 + 4 F (fp32 payloads), 8 with the half-precision stream (fp16 tables, F = 2)
+static inline bool half_items(int dtype, const LevelTable &lt) { return dtype == SHACIRA_F16 && lt.feature_dim == 2; }
+static inline size_t item_unit_bytes(int dtype, const LevelTable &lt) {
+    return half_items(dtype, lt) ? 8 : 8 + 4 * (size_t)lt.feature_dim;
+}
+
+static int64_t bin_batch_samples(int dim, int dtype, const LevelTable &lt, int64_t n) {
+    const size_t item = item_unit_bytes(dtype, lt);
     BinPlan plan;
     make_plan(dim, lt, kTile, plan, choose_acc_kib(dim, lt, n), one_image_compact_rule(n));
     const size_t per_sample = (size_t)(plan.nbl ? plan.nbl : 1) * (1u << (dim - 1)) * item;
@@ -1471,9 +1585,9 @@ static inline int64_t level_pitch(int64_t n) { return (n + 1) & ~(int64_t)1; }
 
 static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, void *ws) {
     BinPlan plan;
-    const int64_t nb = bin_batch_samples(dim, lt, n);
+    const int64_t nb = bin_batch_samples(dim, dtype, lt, n);
     make_plan(dim, lt, nb, plan, choose_acc_kib(dim, lt, n), one_image_compact_rule(n));
-    const size_t item = 8 + 4 * (size_t)lt.feature_dim;
+    const size_t item = item_unit_bytes(dtype, lt);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     // gT and gmax first: their offsets must not depend on the level range of the call (REUSE_STAGED calls share them)
@@ -1589,7 +1703,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     const int acc_kib = choose_acc_kib(DIM, lt, n);
     const bool oic = one_image_compact_rule(n);
     make_plan(DIM, lt, n, whole, acc_kib, oic);
-    const int64_t nb = bin_batch_samples(DIM, lt, n);
+    const int64_t nb = bin_batch_samples(DIM, dtype, lt, n);
     const bool multi = nb < n;
     const bool stage_all = (lt.stage_flags & SHACIRA_BWD_STAGE_ALL_LEVELS) != 0;
     const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
@@ -1721,7 +1835,9 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     if (fork) SHACIRA_CHECK(hipEventRecord(ss->join, ss->stream));
     if (whole.nbl == 0) return hipSuccess;   // (fork implies binned levels)
     constexpr int NPAIR = 1 << (DIM - 1);
-    const size_t stage = (size_t)TileOf<DIM>::value * NPAIR * (sizeof(Item<F>) + 1);
+    // half-precision item stream: fp16 tables with F = 2 (8-byte units)
+    const bool half = half_items(dtype, lt);
+    const size_t stage = (size_t)TileOf<DIM>::value * NPAIR * ((half ? sizeof(ItemH) : sizeof(Item<F>)) + 1);
     bool first_batch = true;
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
@@ -1746,11 +1862,18 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                                w.unit_first, lt, plan);
             SHACIRA_CHECK_LAUNCH();
         }
-        hipLaunchKernelGGL((bin_scatter_kernel<DIM, F>),
-                           dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads), stage, s, lt,
-                           plan, coords, w.gT, w.cursor, w.cnt, fused_now ? (uint32_t)(TileOf<DIM>::value / ts16) : 1u,
-                           fused_now ? (uint32_t)((n + ts16 - 1) / ts16) : plan.num_tiles,
-                           reinterpret_cast<Item<F> *>(w.items), s0, hi, NP);
+        const uint32_t cps = fused_now ? (uint32_t)(TileOf<DIM>::value / ts16) : 1u;
+        const uint32_t cnt_rows = fused_now ? (uint32_t)((n + ts16 - 1) / ts16) : plan.num_tiles;
+        if constexpr (F == 2) {
+            if (half)
+                hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
+                                   stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                                   reinterpret_cast<ItemH *>(w.items), s0, hi, NP);
+        }
+        if (!half)
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
+                               stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                               reinterpret_cast<Item<F> *>(w.items), s0, hi, NP);
         SHACIRA_CHECK_LAUNCH();
         if (fork) SHACIRA_CHECK(hipStreamWaitEvent(s, ss->join, 0));   // table zeroed, direct levels in
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NPAIR;
@@ -1761,15 +1884,27 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         // is 5 us faster, so small batches keep it)
         uint32_t *wc = (opt().bwd_persistent != 0 && n >= (1 << 17)) ? w.work_counter : nullptr;
         if (wc != nullptr && grid_units > 512u) grid_units = 512u;
-        if (use_fx)   // a unit streams <= chunk items
-            hipLaunchKernelGGL((bin_consume_kernel<F, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,
+        const int headroom = use_fx ? fx_headroom((uint64_t)plan.chunk + 1) : -1;   // a unit streams <= chunk items
+        const uint32_t *gm = use_fx ? w.gmax : nullptr;
+        const int fa = multi ? 1 : 0;
+        if constexpr (F == 2) {
+            if (half && use_fx)
+                hipLaunchKernelGGL((bin_consume_kernel<F, true, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s,
+                                   lt, plan, first_idx, w.base, w.unit_first, w.unit_desc,
+                                   reinterpret_cast<const ItemH *>(w.items), acc, fa, gm, headroom, wc);
+            else if (half)
+                hipLaunchKernelGGL((bin_consume_kernel<F, false, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s,
+                                   lt, plan, first_idx, w.base, w.unit_first, w.unit_desc,
+                                   reinterpret_cast<const ItemH *>(w.items), acc, fa, gm, headroom, wc);
+        }
+        if (!half && use_fx)
+            hipLaunchKernelGGL((bin_consume_kernel<F, true, false>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,
                                plan, first_idx, w.base, w.unit_first, w.unit_desc,
-                               reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, w.gmax,
-                               fx_headroom((uint64_t)plan.chunk + 1), wc);
-        else
-            hipLaunchKernelGGL((bin_consume_kernel<F, false>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,
+                               reinterpret_cast<const Item<F> *>(w.items), acc, fa, gm, headroom, wc);
+        else if (!half)
+            hipLaunchKernelGGL((bin_consume_kernel<F, false, false>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,
                                plan, first_idx, w.base, w.unit_first, w.unit_desc,
-                               reinterpret_cast<const Item<F> *>(w.items), acc, multi ? 1 : 0, nullptr, -1, wc);
+                               reinterpret_cast<const Item<F> *>(w.items), acc, fa, gm, headroom, wc);
         SHACIRA_CHECK_LAUNCH();
     }
     return hipSuccess;
@@ -1807,14 +1942,16 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, __half, false, false>), 16384 * sizeof(double));
         SHACIRA_DIRECT_ATTR(2, 2) SHACIRA_DIRECT_ATTR(2, 4) SHACIRA_DIRECT_ATTR(3, 2) SHACIRA_DIRECT_ATTR(3, 4)
 #undef SHACIRA_DIRECT_ATTR
-        set(reinterpret_cast<const void *>(&bin_consume_kernel<2, true>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&bin_consume_kernel<4, true>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&bin_consume_kernel<2, false>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&bin_consume_kernel<4, false>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<4>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<2, true, false>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<4, true, false>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<2, false, false>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<4, false, false>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<2, true, true>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<2, false, true>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, false>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, false>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, false>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, false>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
         return attr_err;
     });
     if (attr_err != hipSuccess) return attr_err;
