@@ -111,8 +111,17 @@ struct alignas(16) ItemHC {
     uint16_t fx, fy, fz, pad;
     __half2 g;
 };
+// F = 4 (nerf_lego.yaml under AMP): 16-byte pair items {key, fx (fp32: exact weights), half2 a01, half2 a23} instead of
+// 24 bytes moved as 8-byte pieces; compact items = two 16-byte units {key, fx, fy, fz} {half2 g01, half2 g23, -, -} (32
+// instead of 48 bytes). Keys as in the fp32 stream.
+struct alignas(16) ItemH4 {
+    uint32_t key;
+    float fx;
+    uint32_t p2, p3;   // two half2 as raw bits (pair item: a01, a23; compact unit 0: fy, fz as fp32 bits)
+};
 template <int F, bool H> struct ItemSel { typedef Item<F> type; };
 template <> struct ItemSel<2, true> { typedef ItemH type; };
+template <> struct ItemSel<4, true> { typedef ItemH4 type; };
 
 __device__ __forceinline__ uint32_t pack_half_key(uint32_t key, float fx, bool dense) {
     const uint32_t ra = key & 0x1FFFu, rb = (key >> 13) & 0x1FFFu;
@@ -127,6 +136,21 @@ __device__ __forceinline__ void unpack_half_key(uint32_t k, uint32_t &ra, uint32
     va = (k >> 17) & 1u;
     vb = (k >> 18) & 1u;
     fx = ((float)(k >> 19) + 0.5f) * (1.0f / 8192.0f);
+}
+// (raw 16-bit halves on purpose: __builtin_bit_cast between uint32_t and __half2 miscompiled here -- both halves came out
+// as the low one)
+__device__ __forceinline__ uint32_t float2_to_half2_bits(float a, float b) {
+    return (uint32_t)__half_as_ushort(__float2half_rn(a)) | ((uint32_t)__half_as_ushort(__float2half_rn(b)) << 16);
+}
+__device__ __forceinline__ float2 half2_bits_to_float2(uint32_t bits) {
+    return make_float2(__half2float(__ushort_as_half((unsigned short)(bits & 0xFFFFu))),
+                       __half2float(__ushort_as_half((unsigned short)(bits >> 16))));
+}
+__device__ __forceinline__ void store_item_nt(ItemH4 *p, const ItemH4 &it) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;
+    __builtin_memcpy(&v, &it, 16);
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
 }
 __device__ __forceinline__ void store_item_nt(ItemH *p, const ItemH &it) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -832,7 +856,32 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         for (int q = 0; q < NP; ++q) {
             if (ps[u][q].key >> 26) {
                 const uint32_t pos = s_start[ps[u][q].bucket] + rank[u][q];
-                if constexpr (H) {
+                if constexpr (H && F == 4) {
+                    ItemH4 it;
+                    it.key = ps[u][q].key;
+                    it.fx = fx[u];
+                    if (compact) {   // two 16-byte units: {key, fx, fy, fz} {g01, g23, -, -}
+                        it.p2 = __float_as_uint(fyz[u][0]);
+                        it.p3 = __float_as_uint(fyz[u][1]);
+                        s_items[pos] = it;
+                        ItemH4 it2;
+                        it2.key = 0;
+                        it2.fx = 0.0f;
+                        it2.p2 = float2_to_half2_bits(g[u][0], g[u][1]);
+                        it2.p3 = float2_to_half2_bits(g[u][2], g[u][3]);
+                        s_items[pos + 1] = it2;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                        s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
+                    } else {
+                        const float w = ps[u][q].wrest;
+                        it.p2 = float2_to_half2_bits(g[u][0] * w, g[u][1] * w);
+                        it.p3 = float2_to_half2_bits(g[u][2] * w, g[u][3] * w);
+                        s_items[pos] = it;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                    }
+                    continue;
+                }
+                if constexpr (H && F == 2) {
                     if (compact) {   // one 16-byte item = two 8-byte units (pos is even: every count of the level is)
                         ItemHC c;
                         c.key = ps[u][q].key;
@@ -1076,7 +1125,32 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
     if constexpr (F == 2 || F == 4) {
         if (bl.compact) {
             constexpr int UC = 2;
-            if constexpr (H) {
+            if constexpr (H && F == 4) {
+                // one sample per two 16-byte units: {local base row | valid, fx, fy, fz (fp32)} {half2 g01, half2 g23, -, -}
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
+                    u32x4 va[UC], vb2[UC];
+#pragma unroll
+                    for (int u = 0; u < UC; ++u) {
+                        const uint64_t p = p0 + 2ull * u * kConsumeThreads;
+                        va[u] = u32x4{0u, 0u, 0u, 0u};
+                        vb2[u] = va[u];
+                        if (p + 1 < end) {
+                            va[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p));
+                            vb2[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p + 1));
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UC; ++u) {
+                        if (!(va[u][0] & (1u << 26))) continue;
+                        const float2 g01 = half2_bits_to_float2(vb2[u][2]);
+                        const float2 g23 = half2_bits_to_float2(vb2[u][3]);
+                        const float gg[F] = {g01.x, g01.y, g23.x, g23.y};
+                        add_compact(va[u][0] & 0x1FFFu, __uint_as_float(va[u][1]), __uint_as_float(va[u][2]),
+                                    __uint_as_float(va[u][3]), gg);
+                    }
+                }
+            } else if constexpr (H) {
                 // one sample per 16-byte record (two 8-byte units): {local base row | valid, fx, fy, fz (u16), half2 g}
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
@@ -1142,7 +1216,26 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
         }
     }
     constexpr int UN = 8;  // 16-byte loads in flight per thread (4: -1 %, 16: +3 % with the fixed-point atomics)
-    if constexpr (H) {
+    if constexpr (H && F == 4) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
+            u32x4 v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
+                v[u] = u32x4{0u, 0u, 0u, 0u};
+                if (pp < end) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + pp));
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const float2 a01 = half2_bits_to_float2(v[u][2]);
+                const float2 a23 = half2_bits_to_float2(v[u][3]);
+                const float a[F] = {a01.x, a01.y, a23.x, a23.y};
+                add_pair(v[u][0] & 0x1FFFu, (v[u][0] >> 13) & 0x1FFFu, (v[u][0] >> 26) & 1u, (v[u][0] >> 27) & 1u,
+                         __uint_as_float(v[u][1]), a);
+            }
+        }
+    } else if constexpr (H) {
         // 8-byte items read two at a time (16-byte loads from even unit indices); a unit's odd first / last item goes alone
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -1550,9 +1643,12 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
 
 // sub-batch so that the item array stays below the cap (default 1.5 GiB, option "bin_batch_mib")
 // bytes of one item unit: 8 + 4 F (fp32 payloads), 8 with the half-precision stream (fp16 tables, F = 2)
-static inline bool half_items(int dtype, const LevelTable &lt) { return dtype == SHACIRA_F16 && lt.feature_dim == 2; }
+static inline bool half_items(int dtype, const LevelTable &lt) {
+    return dtype == SHACIRA_F16 && (lt.feature_dim == 2 || lt.feature_dim == 4);
+}
 static inline size_t item_unit_bytes(int dtype, const LevelTable &lt) {
-    return half_items(dtype, lt) ? 8 : 8 + 4 * (size_t)lt.feature_dim;
+    if (half_items(dtype, lt)) return lt.feature_dim == 2 ? 8 : 16;
+    return 8 + 4 * (size_t)lt.feature_dim;
 }
 
 static int64_t bin_batch_samples(int dim, int dtype, const LevelTable &lt, int64_t n) {
@@ -1837,7 +1933,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     constexpr int NPAIR = 1 << (DIM - 1);
     // half-precision item stream: fp16 tables with F = 2 (8-byte units)
     const bool half = half_items(dtype, lt);
-    const size_t stage = (size_t)TileOf<DIM>::value * NPAIR * ((half ? sizeof(ItemH) : sizeof(Item<F>)) + 1);
+    const size_t stage = (size_t)TileOf<DIM>::value * NPAIR * ((half ? sizeof(typename ItemSel<F, true>::type) : sizeof(Item<F>)) + 1);
     bool first_batch = true;
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
@@ -1864,13 +1960,11 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         }
         const uint32_t cps = fused_now ? (uint32_t)(TileOf<DIM>::value / ts16) : 1u;
         const uint32_t cnt_rows = fused_now ? (uint32_t)((n + ts16 - 1) / ts16) : plan.num_tiles;
-        if constexpr (F == 2) {
-            if (half)
-                hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
-                                   stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
-                                   reinterpret_cast<ItemH *>(w.items), s0, hi, NP);
-        }
-        if (!half)
+        if (half)
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
+                               stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                               reinterpret_cast<typename ItemSel<F, true>::type *>(w.items), s0, hi, NP);
+        else
             hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
                                stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
                                reinterpret_cast<Item<F> *>(w.items), s0, hi, NP);
@@ -1887,17 +1981,15 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const int headroom = use_fx ? fx_headroom((uint64_t)plan.chunk + 1) : -1;   // a unit streams <= chunk items
         const uint32_t *gm = use_fx ? w.gmax : nullptr;
         const int fa = multi ? 1 : 0;
-        if constexpr (F == 2) {
-            if (half && use_fx)
-                hipLaunchKernelGGL((bin_consume_kernel<F, true, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s,
-                                   lt, plan, first_idx, w.base, w.unit_first, w.unit_desc,
-                                   reinterpret_cast<const ItemH *>(w.items), acc, fa, gm, headroom, wc);
-            else if (half)
-                hipLaunchKernelGGL((bin_consume_kernel<F, false, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s,
-                                   lt, plan, first_idx, w.base, w.unit_first, w.unit_desc,
-                                   reinterpret_cast<const ItemH *>(w.items), acc, fa, gm, headroom, wc);
-        }
-        if (!half && use_fx)
+        if (half && use_fx)
+            hipLaunchKernelGGL((bin_consume_kernel<F, true, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s,
+                               lt, plan, first_idx, w.base, w.unit_first, w.unit_desc,
+                               reinterpret_cast<const typename ItemSel<F, true>::type *>(w.items), acc, fa, gm, headroom, wc);
+        else if (half)
+            hipLaunchKernelGGL((bin_consume_kernel<F, false, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s,
+                               lt, plan, first_idx, w.base, w.unit_first, w.unit_desc,
+                               reinterpret_cast<const typename ItemSel<F, true>::type *>(w.items), acc, fa, gm, headroom, wc);
+        else if (use_fx)
             hipLaunchKernelGGL((bin_consume_kernel<F, true, false>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,
                                plan, first_idx, w.base, w.unit_first, w.unit_desc,
                                reinterpret_cast<const Item<F> *>(w.items), acc, fa, gm, headroom, wc);
@@ -1948,6 +2040,10 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, false, false>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2, true, true>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2, false, true>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<4, true, true>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<4, false, true>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, true>), (size_t)TileOf<2>::value * 2 * (sizeof(ItemH4) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, true>), (size_t)kTile * 4 * (sizeof(ItemH4) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, false>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<2>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, false>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<4>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, false>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));

@@ -314,6 +314,25 @@ def test_half_precision_tables(dev, n):
     np.testing.assert_allclose(grad.float().cpu().numpy(), ref_g, rtol=2e-3, atol=2e-3 * np.abs(ref_g).max())
 
 
+@pytest.mark.parametrize("dim,n", [(3, 20_000), (3, (1 << 17) + 11), (2, 50_001)])
+def test_half_precision_tables_with_four_features(dev, dim, n):
+    """fp16 tables with F = 4 (nerf_lego.yaml under AMP): the half-precision item stream (16-byte pair items, 32-byte
+    compact items) on dense-compact, dense-pair and hashed levels, fp64 and fixed-point images; same bar as the F = 2 test."""
+    res, bw, F = (geo(16, 512, 24), 19, 4) if dim == 3 else ([300, 700, 1100, 2000], 19, 4)
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, F=F, seed=77)
+    go16 = go.astype(np.float16).astype(np.float32)
+    ops = _ops()
+    tc, tg, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(go).to(dev).half(), torch.from_numpy(first).to(dev)
+    grad = ops.hashgrid_backward(dim, tc, tg, T, torch.float16, tf, res, bw, F)
+    assert grad.dtype == torch.float16
+    ref_g = oc.backward(coords, go16, (T, F), first, res, bw)
+    got = grad.float().cpu().numpy()
+    for l in range(len(res)):
+        lo, hi = int(first[l]), int(first[l]) + sizes[l]
+        np.testing.assert_allclose(got[lo:hi], ref_g[lo:hi], rtol=2e-3, atol=2e-3 * np.abs(ref_g[lo:hi]).max(),
+                                   err_msg=f"level {l} res {res[l]}")
+
+
 def test_full_size_properties(dev):
     """BASELINE headline size (N = 2^20, config D): size-independent properties instead of the (slow) oracle."""
     ops = _ops()

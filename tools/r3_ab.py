@@ -33,6 +33,7 @@ W = {"S1": (3, 19, 1 << 20, 2048, 16, 2), "S2": (2, 19, 1 << 20, 2048, 16, 2), "
      "B": (2, 11, 393216, 512, 16, 2), "LEGO": (3, 19, 1 << 18, 512, 24, 4), "S1h": (3, 19, 1 << 19, 2048, 16, 2),
      "S1q": (3, 19, 1 << 18, 2048, 16, 2)}
 name = sys.argv[1]
+DT = torch.float16 if os.environ.get("R3_DTYPE") == "f16" else torch.float32
 dim, bw, N, mx, L, F = W[name]
 res = geo(16, mx, L)
 sizes = [min(2 ** bw, r ** dim) for r in res]
@@ -48,13 +49,15 @@ else:
 coords[0] = 1.0
 coords[1] = -1.0
 coords = coords.cuda()
-go = torch.randn(N, L * F, generator=g).cuda()
-table = (torch.randn(T, F, generator=g) * 0.01).cuda()
+go = torch.randn(N, L * F, generator=g).cuda().to(DT)
+table = (torch.randn(T, F, generator=g) * 0.01).cuda().to(DT)
 fwd_op = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
 n_or = min(N, 1 << 15)
 cs, gs = coords[:n_or].contiguous(), go[:n_or].contiguous()
-ref_g = oc.backward(cs.cpu().numpy(), gs.cpu().numpy(), (T, F), first_np, res, bw)
-ref_f = oc.forward(cs.cpu().numpy(), table.cpu().numpy(), first_np, res, bw)
+ref_g = oc.backward(cs.cpu().numpy(), gs.float().cpu().numpy(), (T, F), first_np, res, bw)
+ref_f = oc.forward(cs.cpu().numpy(), table.float().cpu().numpy(), first_np, res, bw)
+if DT == torch.float16:
+    ref_f = ref_f.astype(np.float16)
 full_ref = None
 lib = _lib.lib()
 for optset in sys.argv[2:]:
@@ -64,11 +67,11 @@ for optset in sys.argv[2:]:
         assert lib.shacira_set_option(k.encode(), int(v)) == 0, k
     try:
         f = lambda: fwd_op(coords, table, first, res, bw)
-        b = lambda: hip_ops.hashgrid_backward(dim, coords, go, T, torch.float32, first, res, bw, F)
+        b = lambda: hip_ops.hashgrid_backward(dim, coords, go, T, DT, first, res, bw, F)
         tf, tb = timed(f), timed(b)
         # interleaved like the bench step
         both = timed(lambda: (f(), b()))
-        gr = hip_ops.hashgrid_backward(dim, cs, gs, T, torch.float32, first, res, bw, F).cpu().numpy()
+        gr = hip_ops.hashgrid_backward(dim, cs, gs, T, DT, first, res, bw, F).float().cpu().numpy()
         err = 0.0
         for l in range(L):
             lo, hi = first_np[l], first_np[l] + sizes[l]
@@ -76,7 +79,7 @@ for optset in sys.argv[2:]:
         full = b()
         if full_ref is None:
             full_ref = full.clone()
-        dfull = float((full - full_ref).abs().max() / full_ref.abs().max())
+        dfull = float((full.float() - full_ref.float()).abs().max() / full_ref.float().abs().max())
         ff = fwd_op(cs, table, first, res, bw).cpu().numpy()
         fwd_ok = np.array_equal(ff, ref_f)
         print(f"{name} [{optset}] fwd {tf:.4f} bwd {tb:.4f} pair {both:.4f} ms | bwd slice err {err:.1e} full-vs-first {dfull:.1e} "
