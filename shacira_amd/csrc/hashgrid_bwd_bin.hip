@@ -6,20 +6,25 @@
 // feature, hashgrid_interpolate_cuda.cu:212-221) therefore runs ~30x under the HBM roof here. This file replaces
 // it by "partition, then accumulate on chip":
 //
-//   pass T  transpose   grad_output [N, L*F] -> gT [L][N][F]            (coalesced both ways through LDS)
-//   pass A  count       per (level, tile of samples): how many items fall into each bucket  -> cnt[tile][bucket]
-//   pass S  scan        exclusive scans: per bucket over tiles, then over buckets; builds the consumer work list
-//   pass B  bin         recompute the corners, stage the tile's items in LDS sorted by bucket, write each bucket's
-//                       run to its exact slot in HBM with coalesced 16-byte stores
-//   pass C  consume     one workgroup per (bucket, chunk): accumulate the items into an LDS-resident fp64 image of
-//                       the bucket's rows (ds_add_f64), then write the rows out (plain coalesced stores when the
-//                       bucket has a single chunk, coalesced float atomics otherwise)
+//   pass F  front       grad_output [N, L*F] -> gT [L][NP][F] with 16-byte accesses both ways, FUSED with the bucket
+//                       counting of the same samples (front16_kernel): cnt[tile][bucket] rows + per-bucket totals
+//   pass S  scan        one workgroup: exclusive scan of the totals -> first item of every bucket, the cursors the
+//                       scatter pass reserves its runs from, and the consumer work list
+//   pass B  bin         recompute the corners, stage the tile's items in LDS sorted by bucket, reserve each (tile, bucket)
+//                       run with one returning atomic on the bucket's cursor, write it with coalesced 16-byte stores
+//   pass C  consume     persistent workgroups fetch (bucket, chunk) units: accumulate the items into an LDS-resident
+//                       64-bit fixed-point (or fp64) image of the bucket's rows, then write the rows out (plain coalesced
+//                       stores when the bucket has a single unit, coalesced float atomics otherwise)
+//   pass D  direct      levels whose rows fit one LDS image and that do not travel as compact items: no items at all
+//   (pass T / pass A: the 8-byte transpose and the standalone counting pass remain for rows that are not whole 16-byte
+//    vectors, sub-batches and level-range calls on staged gradients)
 //
 // A *bucket* is a range of <= BR consecutive rows of one level (BR*F*8 B = 128 KiB of LDS). An *item* is one
 // x-pair of corners (x, x+1) at fixed (y[,z]) offsets: both rows always share a bucket (hashed levels: the rows
 // differ only in the low bits x ^ (x+1); dense levels: buckets hold whole x-lines), so an item is 8 + 4F bytes:
 //   { key = rowA | rowB << 13 | validA << 26 | validB << 27,  fx,  a_j = grad_j * w_rest }   (rows bucket-local)
-// and the consumer adds a_j*(1-fx) to rowA and a_j*fx to rowB. The sum is kept in fp64 and rounded once.
+// and the consumer adds a_j*(1-fx) to rowA and a_j*fx to rowB. The sum is kept in 64 bits and rounded once. fp16 tables
+// carry half-precision payloads (8- / 16-byte items, ItemH / ItemH4 below).
 //
 // Results differ from the reference only by summation order / two fp32 roundings per term (the reference's own
 // atomicAdd order is unspecified); tests hold them to 1e-5 relative against the fp64-accumulating oracle.
