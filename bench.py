@@ -51,7 +51,7 @@ SECONDARY = ["S2_kodak_2d_L16_F2_bw19_N2^20", "B_kodak_2d_L16_F2_bw11_N393216", 
              "nerf_lego_yaml_3d_L24_F4_bw19_N409600"]
 
 
-def quick_measure(name, device, iters=10):
+def quick_measure(name, device, iters=20):
     """fwd / bwd operator times of another BASELINE config (same protocol, fewer iterations); not the headline."""
     from shacira_amd import hip_ops
     dim, res, bw, F, n = WORKLOADS[name]
@@ -69,21 +69,22 @@ def quick_measure(name, device, iters=10):
         coords = (torch.rand(n, dim, generator=g) * 2 - 1).to(device)
     go = torch.randn(n, L * F, generator=g).to(device)
     fwd = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     for _ in range(3):
         fwd(coords, table, first, res, bw)
         hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F)
     torch.cuda.synchronize()
-    tf = tb = 0.0
-    for _ in range(iters):
+    # the headline loop's protocol: steps issued back to back (no host synchronisation inside the region, so that small
+    # batches are not charged the Python wrapper's ~20 us per call while the GPU sits idle), HIP events around each operator
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
+    for ev in evs:
         ev[0].record()
         fwd(coords, table, first, res, bw)
         ev[1].record()
         hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F)
         ev[2].record()
-        torch.cuda.synchronize()
-        tf += ev[0].elapsed_time(ev[1]) / iters
-        tb += ev[1].elapsed_time(ev[2]) / iters
+    torch.cuda.synchronize()
+    tf = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in evs]))
+    tb = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in evs]))
     bf, bb = algorithmic_bytes_per_sample(dim, L, F)
     gbs = (bf + bb) * n / ((tf + tb) * 1e-3) / 1e9
     return {"samples_per_s": n / ((tf + tb) * 1e-3), "ms_forward": tf, "ms_backward": tb, "samples": n,
