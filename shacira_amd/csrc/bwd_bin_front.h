@@ -1,0 +1,465 @@
+// bwd_bin_front.h -- the front of the binned backward: transpose (+ fused bucket counting), standalone counting, bucket scan, table zeroing
+// Part of the translation unit hashgrid_bwd_bin.hip (included there, in this order: bwd_bin_types.h, bwd_bin_front.h,
+// bwd_bin_passes.h); see that file's header for the pipeline.
+#pragma once
+
+#include "bwd_bin_types.h"
+
+namespace shacira {
+
+// ------------------------------------------------------------------------------------------------- pass T
+// grad_output [N, L*F] (T) -> gT [L][NP][F] fp32 (NP = N rounded up to even), through LDS, F scalars per lane per access.
+// Block: 256 samples. Generic fallback: rows that are not whole 16-byte vectors (odd level counts), unaligned input.
+template <typename T, int F, bool GMAX>
+__global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict__ go, float *__restrict__ gT,
+                                                             int64_t N, int64_t NP, int L, int lb, int le,
+                                                             uint32_t *__restrict__ gmax) {
+    __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
+    if (GMAX && threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
+    struct alignas(sizeof(T) * F) PieceIn { T v[F]; };
+    struct alignas(sizeof(float) * F) PieceOut { float v[F]; };
+    extern __shared__ __align__(16) unsigned char s_raw_g[];
+    PieceOut *s_tile = reinterpret_cast<PieceOut *>(s_raw_g);  // [256][L + 1]
+    const int pitch = L + 1;
+    const int64_t s0 = (int64_t)blockIdx.x * 256;
+    const int ns = (int)((N - s0 < 256) ? (N - s0) : 256);
+    const PieceIn *in = reinterpret_cast<const PieceIn *>(go) + s0 * L;
+    const int total = ns * L;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int sm = e / L, l = e - sm * L;
+        const PieceIn p = in[e];
+        PieceOut q;
+#pragma unroll
+        for (int j = 0; j < F; ++j) q.v[j] = Scalar<T>::load(&p.v[j]);
+        s_tile[sm * pitch + l] = q;
+    }
+    __syncthreads();
+    PieceOut *out = reinterpret_cast<PieceOut *>(gT);
+    for (int l = lb; l < le; ++l) {
+        uint32_t m = 0;
+        if ((int)threadIdx.x < ns) {
+            const PieceOut q = s_tile[threadIdx.x * pitch + l];
+            if constexpr (GMAX) {
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    const uint32_t b = __float_as_uint(fabsf(q.v[j]));
+                    m = b > m ? b : m;
+                }
+            }
+            float *dst = reinterpret_cast<float *>(out + (int64_t)l * NP + s0 + threadIdx.x);
+            if constexpr (F == 2) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 v = {q.v[0], q.v[1]};
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x2 *>(dst));
+            } else {
+#pragma unroll
+                for (int j = 0; j < F; ++j) __builtin_nontemporal_store(q.v[j], dst + j);
+            }
+        }
+        if constexpr (GMAX) {   // wave max -> one LDS atomic per wave and level
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = __shfl_xor(m, off, 64);
+                m = o > m ? o : m;
+            }
+            if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_max[l], m);
+        }
+    }
+    if constexpr (GMAX) {
+        __syncthreads();
+        if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x])
+            atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
+    }
+}
+
+// 16-byte form of pass T, fused with pass A (round 3). The 8-byte kernel above ran at 2.5 TB/s, half the chip's copy rate
+// (the guide prices 8-byte accesses at 0.54-0.70x the 16-byte rate), and the bucket counting ran as a separate kernel on a
+// side stream that slowed it down further (105 us together on S1). Here a workgroup of 512 threads walks `rounds` tiles of
+// TS samples: it issues every 16-byte load of a tile's gradient rows (K = 16 / (sizeof(T) * F) level pieces of one sample
+// per lane), COUNTs the buckets of that tile's samples while the rows are in flight (corner hashing: pure ALU + LDS
+// atomics; COUNT = true), parks the rows LEVEL-major in LDS and writes them out as 16-byte non-temporal vectors of
+// M = 16 / (4 F) consecutive samples of one level. The staging image gT is [L][NP][F] with the level pitch NP = N rounded
+// up to even, so that every vector is 16-byte aligned for any batch size. Bucket counts leave as ONE global atomic per
+// (workgroup, non-empty bucket) into totals[] -- the per-(tile, bucket) matrix and its scan are gone: the scatter pass
+// reserves its runs with returning atomics on per-bucket cursors instead.
+constexpr int kFrontThreads = 512;
+template <int DIM, typename T, int F, bool GMAX, bool COUNT>
+__global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, BinPlan plan, const T *__restrict__ go,
+                                                                float *__restrict__ gT, const float *__restrict__ coords,
+                                                                uint32_t *__restrict__ totals, uint32_t *__restrict__ cnt,
+                                                                int64_t N, int64_t NP, int lb, int le, int ts_log2,
+                                                                int rounds, uint32_t *__restrict__ gmax) {
+    constexpr int K = 16 / (int)(sizeof(T) * F);   // level pieces per 16-byte input vector
+    constexpr int HE = SHACIRA_MAX_LODS * kMaxLevelBuckets / kFrontThreads;   // histogram words per thread (<= 8)
+    constexpr int M = 16 / (4 * F);                // samples per 16-byte output vector
+    constexpr int M_LOG2 = (M == 2) ? 1 : 0;
+    constexpr int UL = 8;                          // 16-byte loads in flight per thread and round
+    static_assert(K >= 1 && (M == 1 || M == 2), "16-byte transpose: F = 2 or 4");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    struct alignas(sizeof(float) * F) PieceOut { float v[F]; };
+    __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
+    extern __shared__ __align__(16) unsigned char s_raw_g[];
+    const int L = lt.num_lods;
+    const int TS = 1 << ts_log2;                   // samples per tile: a power of two in [128, 512]
+    const int pitch = TS + 2;                      // even: 16-byte LDS reads stay aligned; 2-way conflicts on the writes only
+    PieceOut *s_tile = reinterpret_cast<PieceOut *>(s_raw_g);                                    // [L][TS + 2]
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_raw_g + (size_t)L * pitch * sizeof(PieceOut));   // [nbl][128]
+    if (GMAX && threadIdx.x < SHACIRA_MAX_LODS) s_max[threadIdx.x] = 0;
+    if constexpr (COUNT)
+        for (uint32_t k = threadIdx.x; k < plan.nbl * (uint32_t)kMaxLevelBuckets; k += kFrontThreads) s_hist[k] = 0;
+    __syncthreads();
+    const int VPR = L / K;                         // input vectors per row
+    const int nvec_log2 = ts_log2 - M_LOG2;        // output vectors per level and tile (a multiple of 64)
+    // input vector e = tid + u * 512 of a tile belongs to sample e / VPR, level group e % VPR: divided once here, then
+    // stepped (no integer division inside the rounds -- the kernel is bound by its vector ALU work, not by memory)
+    const int q512 = kFrontThreads / VPR, r512 = kFrontThreads % VPR;
+    const int sm_first = (int)threadIdx.x / VPR, v_first = (int)threadIdx.x % VPR;
+    // counting: thread = (sample of the tile, level slot); tiles smaller than the workgroup split a sample's levels over
+    // 512 / TS threads. A wave's threads share the slot (TS >= 128): readfirstlane keeps the level loop uniform.
+    const int cslots = kFrontThreads >> ts_log2, csm = (int)threadIdx.x & (TS - 1);
+    const int cslot = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> ts_log2);
+    const int64_t tile0 = (int64_t)blockIdx.x * rounds;
+    const int64_t tiles = (N + TS - 1) >> ts_log2;
+    // the histogram is per ROUND: after each tile a thread moves its words (k = tid + j * 512 <-> (level k / 128, bucket
+    // k % 128)) to the tile's row of cnt[tile][bucket] -- what lets the scatter pass reserve its runs before it has ranked
+    // anything -- and keeps the workgroup's sums in registers for the totals
+    int hcol[HE];
+    uint32_t hsum[HE];
+    if constexpr (COUNT) {
+#pragma unroll
+        for (int j = 0; j < HE; ++j) {
+            const uint32_t k = threadIdx.x + j * kFrontThreads, li = k / kMaxLevelBuckets, b = k % kMaxLevelBuckets;
+            hcol[j] = (li < plan.nbl && b < plan.lv[plan.blevel[li < plan.nbl ? li : 0]].nb) ? (int)(plan.bstart[li] + b) : -1;
+            hsum[j] = 0;
+        }
+    }
+    for (int r = 0; r < rounds && tile0 + r < tiles; ++r) {
+        const int64_t s0 = (tile0 + r) << ts_log2;
+        const int ns = (int)((N - s0 < TS) ? (N - s0) : TS);
+        const int total = ns * VPR;
+        // the sample's coordinates FIRST (vmcnt counts in order: the counting then waits for them only), then the row
+        // vectors; all loads unconditional with clamped indices (a branch around a load makes the compiler wait with
+        // vmcnt(0) in front of the counting, which would serialise it with the row loads)
+        float cc[DIM];
+        if constexpr (COUNT) {
+            const int64_t ci = s0 + (csm < ns ? csm : ns - 1);
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) cc[a] = coords[ci * DIM + a];
+        }
+        const u32x4 *in = reinterpret_cast<const u32x4 *>(go) + s0 * VPR;
+        u32x4 raw[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const int e = (int)threadIdx.x + u * kFrontThreads;
+            raw[u] = __builtin_nontemporal_load(in + (e < total ? e : total - 1));   // idle lanes: one merged request
+        }
+        if constexpr (COUNT) {
+            if (csm < ns) {
+                double t[DIM];
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) t[a] = axis_unit(cc[a]);
+#pragma unroll 2
+                for (uint32_t li = (uint32_t)cslot; li < plan.nbl; li += (uint32_t)cslots)
+                    count_level<DIM>(t, plan.cl[li], lt.mask, s_hist + li * kMaxLevelBuckets);
+            }
+        }
+        // rows -> LEVEL-major LDS image
+        auto park1 = [&](const u32x4 &rv, int sm, int v) {
+            T tv[K * F];
+            __builtin_memcpy(tv, &rv, 16);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                PieceOut q;
+#pragma unroll
+                for (int j = 0; j < F; ++j) q.v[j] = Scalar<T>::load(&tv[k * F + j]);
+                s_tile[(v * K + k) * pitch + sm] = q;
+            }
+        };
+        int sm = sm_first, v = v_first;
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            if ((int)threadIdx.x + u * kFrontThreads < total) park1(raw[u], sm, v);
+            sm += q512;
+            v += r512;
+            if (v >= VPR) { v -= VPR; ++sm; }
+        }
+        for (int e = (int)threadIdx.x + kFrontThreads * UL; e < total; e += kFrontThreads) {   // rows wider than 8 vectors
+            park1(__builtin_nontemporal_load(in + e), sm, v);
+            sm += q512;
+            v += r512;
+            if (v >= VPR) { v -= VPR; ++sm; }
+        }
+        lds_barrier();
+        if constexpr (COUNT) {
+            uint32_t *row = cnt + (size_t)(tile0 + r) * plan.total_buckets;
+#pragma unroll
+            for (int j = 0; j < HE; ++j) {
+                if (hcol[j] >= 0) {
+                    const uint32_t h = s_hist[threadIdx.x + j * kFrontThreads];
+                    s_hist[threadIdx.x + j * kFrontThreads] = 0;
+                    row[hcol[j]] = h;
+                    hsum[j] += h;
+                }
+            }
+        }
+        // LDS image -> gT: (level, vector) pairs over all threads; a wave stays inside one level per trip
+        const int work = (le - lb) << nvec_log2;
+        for (int idx = threadIdx.x; idx < work; idx += kFrontThreads) {
+            const int l = lb + (idx >> nvec_log2), smo = (idx & ((1 << nvec_log2) - 1)) << M_LOG2;
+            uint32_t m = 0;
+            if (smo < ns) {
+                const f32x4 val = *reinterpret_cast<const f32x4 *>(&s_tile[l * pitch + smo]);
+                float *dst = gT + ((int64_t)l * NP + s0 + smo) * F;
+                if (smo + M <= ns) {
+                    __builtin_nontemporal_store(val, reinterpret_cast<f32x4 *>(dst));
+                    if constexpr (GMAX) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t b = __float_as_uint(fabsf(val[j]));
+                            m = b > m ? b : m;
+                        }
+                    }
+                } else {   // last sample of an odd tail (M == 2)
+#pragma unroll
+                    for (int j = 0; j < F; ++j) {
+                        dst[j] = val[j];
+                        if constexpr (GMAX) {
+                            const uint32_t b = __float_as_uint(fabsf(val[j]));
+                            m = b > m ? b : m;
+                        }
+                    }
+                }
+            }
+            if constexpr (GMAX) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint32_t o = __shfl_xor(m, off, 64);
+                    m = o > m ? o : m;
+                }
+                if ((threadIdx.x & 63) == 0 && m) atomicMax(&s_max[l], m);
+            }
+        }
+        lds_barrier();   // s_tile is refilled by the next round (the stores keep draining)
+    }
+    __syncthreads();
+    if constexpr (COUNT) {
+        // lanes = consecutive buckets: contiguous atomics into one of kTotalShards copies of the totals (512 workgroups adding to the same word serialise at the memory side: 18 us of the 30 this kernel took
+        // on 65 536 samples); the bucket scan adds the copies up
+        uint32_t *mine = totals + (size_t)(blockIdx.x % kTotalShards) * kMaxBuckets;
+#pragma unroll
+        for (int j = 0; j < HE; ++j)
+            if (hcol[j] >= 0 && hsum[j]) atomicAdd(&mine[hcol[j]], hsum[j]);
+    }
+    if constexpr (GMAX) {
+        if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x])
+            atomicMax(&gmax[threadIdx.x], s_max[threadIdx.x]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- pass S
+// single block: bucket bases (exclusive scan of totals) and the consumer work list
+//   base[b]         first item of bucket b in the item array (base[nb] = total)
+//   unit_first[b]   first work unit of bucket b; unit_first[nb] = number of units
+//   unit_desc[u]    item range, bucket and level of work unit u
+__global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *__restrict__ totals,
+                                                                uint64_t *__restrict__ base,
+                                                                uint32_t *__restrict__ unit_first,
+                                                                UnitDesc *__restrict__ unit_desc, uint32_t nb,
+                                                                BinPlan plan,
+                                                                uint32_t *__restrict__ work_counter,
+                                                                unsigned long long *__restrict__ cursor) {
+    __shared__ uint64_t s_items[kMaxBuckets + 2];
+    __shared__ uint32_t s_units[kMaxBuckets + 2];
+    __shared__ uint64_t s_wave_items[16];
+    __shared__ uint32_t s_wave_units[16];
+    // each thread owns buckets 2t, 2t+1 (kMaxBuckets = 2 * 1024)
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) work_counter[0] = 0;   // the persistent consume pass fetches its units from here
+    uint64_t c[2];
+    uint32_t u[2], lv_of[2], ck[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t b = 2 * t + k;
+        c[k] = 0u;
+        if (b < nb)
+            for (int sh = 0; sh < kTotalShards; ++sh) c[k] += totals[(size_t)sh * kMaxBuckets + b];
+        uint32_t lq = 0;
+        for (uint32_t q = 1; q < plan.nbl; ++q)
+            if (plan.bstart[q] <= b) lq = q;
+        lv_of[k] = plan.blevel[lq];
+        ck[k] = plan.lv[lv_of[k]].chunk;
+        u[k] = (uint32_t)((c[k] + ck[k] - 1) / ck[k]);
+    }
+    uint64_t ci = c[0] + c[1];
+    uint32_t ui = u[0] + u[1];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t nc = __shfl_up(ci, off, 64);
+        const uint32_t nu = __shfl_up(ui, off, 64);
+        if (lane >= (uint32_t)off) { ci += nc; ui += nu; }
+    }
+    if (lane == 63) { s_wave_items[wave] = ci; s_wave_units[wave] = ui; }
+    __syncthreads();
+    uint64_t wc = 0;
+    uint32_t wu = 0;
+    for (uint32_t w = 0; w < wave; ++w) { wc += s_wave_items[w]; wu += s_wave_units[w]; }
+    const uint64_t ex_items = wc + ci - (c[0] + c[1]);
+    const uint32_t ex_units = wu + ui - (u[0] + u[1]);
+    s_items[2 * t] = ex_items;
+    s_items[2 * t + 1] = ex_items + c[0];
+    s_units[2 * t] = ex_units;
+    s_units[2 * t + 1] = ex_units + u[0];
+    if (t == 1023) {  // grand totals for nb == kMaxBuckets
+        s_items[kMaxBuckets] = ex_items + c[0] + c[1];
+        s_units[kMaxBuckets] = ex_units + u[0] + u[1];
+    }
+    __syncthreads();
+    for (uint32_t b = t; b <= nb; b += 1024) {
+        base[b] = s_items[b];          // entries >= nb hold the grand totals (zero counts beyond nb)
+        cursor[b] = s_items[b];        // the scatter pass reserves its runs from here (returning atomics)
+        unit_first[b] = s_units[b];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t b = 2 * t + k;
+        if (b < nb) {
+            const uint32_t lvl = lv_of[k];
+            for (uint32_t q = 0; q < u[k]; ++q) {
+                UnitDesc d;
+                d.begin = s_items[b] + (uint64_t)q * ck[k];
+                const uint64_t bucket_end = s_items[b] + c[k];
+                d.end = (d.begin + ck[k] < bucket_end) ? (d.begin + ck[k]) : bucket_end;
+                d.bucket = b;
+                d.level = lvl;
+                d.single = u[k] == 1 ? 1u : 0u;
+                d.pad = 0;
+                unit_desc[s_units[b] + q] = d;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- pass A
+// Standalone counting pass (calls that do not transpose: sub-batches, level-range calls on staged gradients, rows the
+// 16-byte front kernel cannot read). One workgroup per TILE counting every binned level: the coordinates are loaded once;
+// counts leave as one global atomic per (workgroup, non-empty bucket) into totals[].
+template <int DIM>
+__global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTable lt, BinPlan plan,
+                                                                       const float *__restrict__ coords,
+                                                                       uint32_t *__restrict__ totals,
+                                                                       uint32_t *__restrict__ cnt, int64_t sample0,
+                                                                       int64_t N) {
+    __shared__ uint32_t s_hist[SHACIRA_MAX_LODS][kMaxLevelBuckets];
+    constexpr int kTileD = TileOf<DIM>::value;
+    constexpr int SPT = kTileD / kBinThreads;
+    const uint32_t tile = blockIdx.x;
+    // gridDim.y workgroups share a tile's levels (bi = blockIdx.y, blockIdx.y + gridDim.y, ...): small batches keep the chip
+    // busy with one level each, large ones load the coordinates once for all levels
+    for (uint32_t e = threadIdx.x; e < plan.nbl * kMaxLevelBuckets; e += kBinThreads) (&s_hist[0][0])[e] = 0;
+    double t[SPT][DIM];
+    bool live[SPT];
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+        const int64_t i = sample0 + (int64_t)tile * kTileD + threadIdx.x + u * kBinThreads;
+        live[u] = i < N;
+        load_unit_coords<DIM>(coords, i, N, t[u]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t bi = blockIdx.y; bi < plan.nbl; bi += gridDim.y) {
+        const uint32_t lvl = plan.blevel[bi];
+        const BinLevel bl = plan.lv[lvl];
+        const int32_t res = lt.res[lvl];
+        const float hi = lt.hi[lvl];
+        const bool dense = lt.dense[lvl] != 0;
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            if (!live[u]) continue;
+            if constexpr (DIM == 3) {
+                if (bl.compact) {
+                    int32_t pz;
+                    float fz, gz;
+                    axis_transform(t[u][2], res, hi, pz, fz, gz);
+                    atomicAdd(&s_hist[bi][(uint32_t)pz / bl.slab], 2u);
+                    continue;
+                }
+            }
+            uint32_t bk[1 << (DIM - 1)];
+            bool ok[1 << (DIM - 1)];
+            enumerate_buckets<DIM>(t[u], res, hi, dense, lt.mask, bl, bk, ok);
+#pragma unroll
+            for (int q = 0; q < (1 << (DIM - 1)); ++q)
+                if (ok[q]) atomicAdd(&s_hist[bi][bk[q]], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t bi = blockIdx.y; bi < plan.nbl; bi += gridDim.y) {
+        const BinLevel bl = plan.lv[plan.blevel[bi]];
+        for (uint32_t b = threadIdx.x; b < bl.nb; b += kBinThreads)
+        {
+            cnt[(size_t)tile * plan.total_buckets + bl.bucket0 + b] = s_hist[bi][b];
+            if (s_hist[bi][b])
+                atomicAdd(&totals[(size_t)((blockIdx.x + blockIdx.y) % kTotalShards) * kMaxBuckets + bl.bucket0 + b], s_hist[bi][b]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- table zeroing
+// at::zeros_like of the reference, minus what the consume pass overwrites anyway: the rows of a HASHED binned level are
+// covered by its buckets, and a bucket with exactly one work unit writes all its rows with plain stores. So only the
+// other rows are zeroed up front (S1: 6.6 of 48.8 MB; the table-sized memset was 13 of config D's 93 us and 40 MB of the
+// write-bound traffic of every call) and the buckets that turn out to have 0 or several units are zeroed once the bucket
+// scan knows them. grid (x, num_lods): segment l = rows [first_idx[l], first_idx[l + 1]) (segment 0 starts at row 0).
+__global__ __launch_bounds__(256) void zero_unowned_rows_kernel(float *__restrict__ acc,
+                                                                const int32_t *__restrict__ first_idx, LevelTable lt,
+                                                                BinPlan plan) {
+    const int l = blockIdx.y, F = lt.feature_dim;
+    const int64_t level0 = first_idx[l];
+    const int64_t start = (l == 0) ? 0 : level0;
+    const int64_t end = (l + 1 < lt.num_lods) ? (int64_t)first_idx[l + 1] : lt.table_rows;
+    const BinLevel bl = plan.lv[l];
+    const bool covered = bl.nb > 0 && bl.dgroup < 0 && lt.dense[l] == 0;   // hashed + binned: rows [level0, level0 + used)
+    // two plain ranges around the covered rows: [start, hole_lo) and [hole_hi, end)
+    const int64_t hole_lo = covered ? level0 : end;
+    int64_t hole_hi = covered ? level0 + (int64_t)bl.used : end;
+    if (hole_hi > end) hole_hi = end;
+    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (int64_t e = start * F + t0; e < hole_lo * F; e += stride) acc[e] = 0.0f;
+    for (int64_t e = hole_hi * F + t0; e < end * F; e += stride) acc[e] = 0.0f;
+}
+
+// control words of a call (bucket totals, per-level max |grad_output|): a kernel of our own rather than hipMemsetAsync -- a
+// memset node captured into a HIP graph after an eager call on ANOTHER stream was seen not to take effect on replay
+// (round 3: stale totals -> wrong bucket bases)
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__restrict__ p, uint32_t n) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0u;
+}
+
+// after the bucket scan: hashed buckets with 0 units (never written) or several (they add atomically) are zeroed now.
+// grid (kMaxLevelBuckets, nbl)
+__global__ __launch_bounds__(256) void zero_odd_buckets_kernel(float *__restrict__ acc, const int32_t *__restrict__ first_idx,
+                                                               const uint32_t *__restrict__ unit_first, LevelTable lt,
+                                                               BinPlan plan) {
+    const uint32_t lvl = plan.blevel[blockIdx.y];
+    const BinLevel bl = plan.lv[lvl];
+    const uint32_t b = blockIdx.x;
+    if (b >= bl.nb || lt.dense[lvl] != 0) return;
+    const uint32_t gb = bl.bucket0 + b;
+    if (unit_first[gb + 1] - unit_first[gb] == 1u) return;
+    const uint32_t row0 = b * bl.rows_pb;
+    const uint32_t nrows = (bl.used - row0 < bl.rows_pb) ? (bl.used - row0) : bl.rows_pb;
+    float *dst = acc + ((int64_t)first_idx[lvl] + row0) * lt.feature_dim;
+    for (uint32_t e = threadIdx.x; e < nrows * (uint32_t)lt.feature_dim; e += 256) dst[e] = 0.0f;
+}
+
+// a[j] for a lane-dependent j without a scratch array (select chain)
+template <int F> __device__ __forceinline__ float pick(const float (&a)[F], int j) {
+    float v = a[0];
+#pragma unroll
+    for (int k = 1; k < F; ++k) v = (j == k) ? a[k] : v;
+    return v;
+}
+
+
+}  // namespace shacira

@@ -1,0 +1,600 @@
+// bwd_bin_passes.h -- the item passes of the binned backward: scatter (pass B), consume (pass C), direct levels (pass D)
+// Part of the translation unit hashgrid_bwd_bin.hip (included there, in this order: bwd_bin_types.h, bwd_bin_front.h,
+// bwd_bin_passes.h); see that file's header for the pipeline.
+#pragma once
+
+#include "bwd_bin_types.h"
+
+namespace shacira {
+
+// ------------------------------------------------------------------------------------------------- pass B
+// Gradients from the transposed image gT [L][NP][F], grid (tiles, binned levels). A (tile, bucket) run is reserved with one
+// returning atomic on the bucket's cursor (set to the bucket's base by the bucket scan): runs of different tiles land in
+// the bucket in arrival order -- the consumer's fixed-point sums do not depend on it.
+// H: half-precision item stream (fp16 tables, F = 2): 8-byte pair items, 16-byte compact items.
+template <int DIM, int F, bool H>
+__global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt, BinPlan plan,
+                                                                  const float *__restrict__ coords,
+                                                                  const float *__restrict__ gT,
+                                                                  unsigned long long *__restrict__ cursor,
+                                                                  const uint32_t *__restrict__ cnt, uint32_t cps,
+                                                                  uint32_t cnt_rows,
+                                                                  typename ItemSel<F, H>::type *__restrict__ items,
+                                                                  int64_t sample0, int64_t N, int64_t gpitch) {
+    typedef typename ItemSel<F, H>::type ItemT;
+    constexpr int NP = 1 << (DIM - 1);
+    constexpr int kTileD = TileOf<DIM>::value;
+    constexpr int SPT = kTileD / kBinThreads;  // samples per thread
+    constexpr int kStage = kTileD * NP;        // staged items per block
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    ItemT *s_items = reinterpret_cast<ItemT *>(s_raw);
+    uint8_t *s_bucket = reinterpret_cast<uint8_t *>(s_items + kStage);
+    __shared__ uint32_t s_hist[kMaxLevelBuckets];
+    __shared__ uint32_t s_start[kMaxLevelBuckets + 1];
+    __shared__ uint64_t s_gbase[kMaxLevelBuckets];
+
+    // (tile-fastest numbering; level-fastest -- a tile's levels back to back -- measured 3 % slower, round 3)
+    const uint32_t tile = blockIdx.x, bi = blockIdx.y;
+    const uint32_t lvl = plan.blevel[bi];
+    const BinLevel bl = plan.lv[lvl];
+    if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t res = lt.res[lvl];
+    const float hi = lt.hi[lvl];
+    const bool dense = lt.dense[lvl] != 0;
+
+    PairSlot ps[SPT][NP];
+    uint32_t rank[SPT][NP];
+    float fx[SPT];
+    float g[SPT][F];
+    float fyz[SPT][2];   // compact levels: y / z fractions travel with the item
+    const bool compact = (DIM == 3) && bl.compact != 0;
+    // every global load of the workgroup up front, unconditional (indices clamped into the batch): coordinates and
+    // gradients of the thread's samples, then -- waves 1 and 2 -- the tile's bucket counts (rows of cnt[tile][bucket]
+    // written by the counting pass) and straight away the returning atomic that reserves the bucket's run: it is the
+    // YOUNGEST memory operation of the wave, so nothing below waits for it until the run offsets are needed (after the
+    // staging phase); issued after the ranking instead, its round trip cost 23 us on S1
+    float craw[SPT][DIM], graw[SPT][F];
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+        int64_t i = sample0 + (int64_t)tile * kTileD + threadIdx.x + u * kBinThreads;
+        i = i < N ? i : N - 1;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) craw[u][a] = coords[i * DIM + a];
+        const float *gp = gT + ((int64_t)lvl * gpitch + i) * F;
+        if constexpr (F == 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(gp);
+            graw[u][0] = v.x; graw[u][1] = v.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < F; ++j) graw[u][j] = gp[j];
+        }
+    }
+    const bool reserver = threadIdx.x >= 64 && threadIdx.x - 64 < bl.nb;
+    unsigned long long run_base = 0ull;
+    if (reserver) {
+        const uint32_t gb = bl.bucket0 + threadIdx.x - 64;
+        const uint32_t *row = cnt + (size_t)tile * cps * plan.total_buckets + gb;
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < cps && tile * cps + k < cnt_rows; ++k) c += row[(size_t)k * plan.total_buckets];
+        if (c) run_base = atomicAdd(&cursor[gb], (unsigned long long)c);
+    }
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+        const int k = threadIdx.x + u * kBinThreads;
+        const int64_t i = sample0 + (int64_t)tile * kTileD + k;
+        const bool live = i < N;
+        double t[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(craw[u][a]);
+#pragma unroll
+        for (int j = 0; j < F; ++j) g[u][j] = graw[u][j];
+        if (compact) {
+            if constexpr (DIM == 3) {
+                // slot key = local row of the base corner inside the bucket's image (slab + halo planes) | valid bit
+                int32_t pp[3];
+                float ff[3], gg[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) axis_transform(t[a], res, hi, pp[a], ff[a], gg[a]);
+                const uint32_t r = (uint32_t)res, b = (uint32_t)pp[2] / bl.slab;
+                const uint32_t local = ((uint32_t)pp[2] - b * bl.slab) * r * r + (uint32_t)pp[1] * r + (uint32_t)pp[0];
+                fx[u] = ff[0];
+                fyz[u][0] = ff[1];
+                fyz[u][1] = ff[2];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    ps[u][q].bucket = b;
+                    ps[u][q].key = 0;
+                    ps[u][q].wrest = 0.0f;
+                }
+                ps[u][0].key = local | (1u << 26);
+            }
+        } else {
+            enumerate_pairs<DIM>(t, res, hi, dense, lt.mask, bl, plan.BR, fx[u], ps[u]);
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (!live) ps[u][q].key = 0;
+            rank[u][q] = (ps[u][q].key >> 26) ? atomicAdd(&s_hist[ps[u][q].bucket], compact ? 2u : 1u) : 0u;
+        }
+    }
+    lds_barrier();   // (not __syncthreads(): its vmcnt(0) would wait for the reservation)
+    if (threadIdx.x < 64) {  // wave 0: exclusive scan of the <= 128 bucket counts, two per lane
+        const uint32_t lane = threadIdx.x;
+        const uint32_t c0 = (2 * lane < bl.nb) ? s_hist[2 * lane] : 0u;
+        const uint32_t c1 = (2 * lane + 1 < bl.nb) ? s_hist[2 * lane + 1] : 0u;
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t nbr = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += nbr;
+        }
+        const uint32_t excl = incl - (c0 + c1);
+        if (2 * lane < bl.nb) s_start[2 * lane] = excl;
+        if (2 * lane + 1 < bl.nb) s_start[2 * lane + 1] = excl + c0;
+        if (lane == 63) s_start[bl.nb] = incl;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (ps[u][q].key >> 26) {
+                const uint32_t pos = s_start[ps[u][q].bucket] + rank[u][q];
+                if constexpr (H && F == 4) {
+                    ItemH4 it;
+                    it.key = ps[u][q].key;
+                    it.fx = fx[u];
+                    if (compact) {   // two 16-byte units: {key, fx, fy, fz} {g01, g23, -, -}
+                        it.p2 = __float_as_uint(fyz[u][0]);
+                        it.p3 = __float_as_uint(fyz[u][1]);
+                        s_items[pos] = it;
+                        ItemH4 it2;
+                        it2.key = 0;
+                        it2.fx = 0.0f;
+                        it2.p2 = float2_to_half2_bits(g[u][0], g[u][1]);
+                        it2.p3 = float2_to_half2_bits(g[u][2], g[u][3]);
+                        s_items[pos + 1] = it2;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                        s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
+                    } else {
+                        const float w = ps[u][q].wrest;
+                        it.p2 = float2_to_half2_bits(g[u][0] * w, g[u][1] * w);
+                        it.p3 = float2_to_half2_bits(g[u][2] * w, g[u][3] * w);
+                        s_items[pos] = it;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                    }
+                    continue;
+                }
+                if constexpr (H && F == 2) {
+                    if (compact) {   // one 16-byte item = two 8-byte units (pos is even: every count of the level is)
+                        ItemHC c;
+                        c.key = ps[u][q].key;
+                        c.fx = (uint16_t)(fx[u] * 65536.0f);
+                        c.fy = (uint16_t)(fyz[u][0] * 65536.0f);
+                        c.fz = (uint16_t)(fyz[u][1] * 65536.0f);
+                        c.pad = 0;
+                        c.g = __floats2half2_rn(g[u][0], g[u][1]);
+                        *reinterpret_cast<ItemHC *>(&s_items[pos]) = c;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                        s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
+                    } else {
+                        ItemH it;
+                        it.key = pack_half_key(ps[u][q].key, fx[u], dense);
+                        it.a = __floats2half2_rn(g[u][0] * ps[u][q].wrest, g[u][1] * ps[u][q].wrest);
+                        s_items[pos] = it;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                    }
+                    continue;
+                }
+                Item<F> it;
+                it.key = ps[u][q].key;
+                it.fx = fx[u];
+                if (compact) {
+                    if constexpr (F == 2) {   // two slots: {key, fx, fy, fz} {0, g0, g1, 0}
+                        it.a[0] = fyz[u][0];
+                        it.a[1] = fyz[u][1];
+                        *reinterpret_cast<Item<F> *>(&s_items[pos]) = it;
+                        Item<F> it2;
+                        it2.key = 0;
+                        it2.fx = g[u][0];
+                        it2.a[0] = g[u][1];
+                        it2.a[1] = 0.0f;
+                        *reinterpret_cast<Item<F> *>(&s_items[pos + 1]) = it2;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                        s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
+                    } else if constexpr (F == 4) {   // two 24-byte slots: {key, fx, fy, fz, g0, g1} {0, g2, g3, -, -, -}
+                        it.a[0] = fyz[u][0];
+                        it.a[1] = fyz[u][1];
+                        it.a[2] = g[u][0];
+                        it.a[3] = g[u][1];
+                        *reinterpret_cast<Item<F> *>(&s_items[pos]) = it;
+                        Item<F> it2;
+                        it2.key = 0;
+                        it2.fx = g[u][2];
+                        it2.a[0] = g[u][3];
+                        it2.a[1] = 0.0f; it2.a[2] = 0.0f; it2.a[3] = 0.0f;
+                        *reinterpret_cast<Item<F> *>(&s_items[pos + 1]) = it2;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                        s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < F; ++j) it.a[j] = g[u][j] * ps[u][q].wrest;
+                    *reinterpret_cast<Item<F> *>(&s_items[pos]) = it;
+                    s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                }
+            }
+        }
+    }
+    if (reserver) s_gbase[threadIdx.x - 64] = run_base;
+    __syncthreads();
+    const uint32_t staged = s_start[bl.nb];
+    for (uint32_t pos = threadIdx.x; pos < staged; pos += kBinThreads) {
+        const uint32_t b = s_bucket[pos];
+        // write-once / read-once stream: non-temporal stores (measured -7 % on the whole backward)
+        store_item_nt(items + s_gbase[b] + (pos - s_start[b]), s_items[pos]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- pass C
+// one work unit (a bucket, or a chunk of an over-full one) on the calling workgroup
+template <int F, bool FX, bool H>
+__device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan &plan, const int32_t *__restrict__ first_idx,
+                                             const UnitDesc d, const typename ItemSel<F, H>::type *__restrict__ items,
+                                             float *__restrict__ grad_table, int force_atomic,
+                                             const uint32_t *__restrict__ gmax, int headroom, double *s_acc) {
+    const uint32_t gb = d.bucket, lvl = d.level;
+    const BinLevel bl = plan.lv[lvl];
+    const uint32_t b = gb - bl.bucket0;
+    const uint32_t r1 = (uint32_t)lt.res[lvl];
+    // compact levels: the image starts at the bucket's first base plane and includes one halo plane
+    const uint32_t row0 = bl.compact ? b * bl.slab * r1 * r1 : b * bl.rows_pb;
+    const uint32_t nrows = (bl.used - row0 < bl.rows_pb) ? (bl.used - row0) : bl.rows_pb;
+
+    for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) s_acc[e] = 0.0;   // all-zero bits either way
+    lds_barrier();
+    FxScale fx{1.0, 1.0, false};
+    if constexpr (FX) fx = fx_scale_of(gmax[lvl], headroom);
+    unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
+
+    const uint64_t begin = d.begin, end = d.end;
+    const int rot = (int)(threadIdx.x & (F - 1));
+    // feature order rotated by lane: the F slots of a row are consecutive 8-byte words, so with every lane adding feature j
+    // in the same instruction only 1 / F of the LDS banks were addressed (half of the pass's LDS cycles were bank conflicts)
+    auto add_row = [&](uint32_t row, const float (&v)[F], float w) {
+#pragma unroll
+        for (int jj = 0; jj < F; ++jj) {
+            const int j = (jj + rot) & (F - 1);
+            const float c = pick<F>(v, j) * w;
+            if (FX && fx.fixed) atomicAdd(&s_fix[row * F + j], fx_encode(c, fx.scale));
+            else atomicAdd(&s_acc[row * F + j], (double)c);
+        }
+    };
+    auto add_pair = [&](uint32_t ra, uint32_t rb, bool va, bool vb, float fxv, const float (&a)[F]) {
+        if (va) add_row(ra, a, 1.0f - fxv);
+        if (vb) add_row(rb, a, fxv);
+    };
+    const uint32_t r2 = r1 * r1;
+    auto add_compact = [&](uint32_t base_row, float fxx, float fyy, float fzz, const float (&gg)[F]) {
+        const float gxx = 1.0f - fxx, gyy = 1.0f - fyy, gzz = 1.0f - fzz;
+        const float wxy[4] = {gxx * gyy, gxx * fyy, fxx * gyy, fxx * fyy};   // reference order: (x * y) * z
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t row = base_row + ((c >> 2) & 1) + ((c >> 1) & 1) * r1 + (c & 1) * r2;
+            if (row >= nrows) continue;   // cannot happen for in-range cells; keeps the image safe
+            add_row(row, gg, wxy[c >> 1] * ((c & 1) ? fzz : gzz));
+        }
+    };
+    if constexpr (F == 2 || F == 4) {
+        if (bl.compact) {
+            constexpr int UC = 2;
+            if constexpr (H && F == 4) {
+                // one sample per two 16-byte units: {local base row | valid, fx, fy, fz (fp32)} {half2 g01, half2 g23, -, -}
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
+                    u32x4 va[UC], vb2[UC];
+#pragma unroll
+                    for (int u = 0; u < UC; ++u) {
+                        const uint64_t p = p0 + 2ull * u * kConsumeThreads;
+                        va[u] = u32x4{0u, 0u, 0u, 0u};
+                        vb2[u] = va[u];
+                        if (p + 1 < end) {
+                            va[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p));
+                            vb2[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p + 1));
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UC; ++u) {
+                        if (!(va[u][0] & (1u << 26))) continue;
+                        const float2 g01 = half2_bits_to_float2(vb2[u][2]);
+                        const float2 g23 = half2_bits_to_float2(vb2[u][3]);
+                        const float gg[F] = {g01.x, g01.y, g23.x, g23.y};
+                        add_compact(va[u][0] & 0x1FFFu, __uint_as_float(va[u][1]), __uint_as_float(va[u][2]),
+                                    __uint_as_float(va[u][3]), gg);
+                    }
+                }
+            } else if constexpr (H) {
+                // one sample per 16-byte record (two 8-byte units): {local base row | valid, fx, fy, fz (u16), half2 g}
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
+                    ItemHC rec[UC];
+#pragma unroll
+                    for (int u = 0; u < UC; ++u) {
+                        const uint64_t p = p0 + 2ull * u * kConsumeThreads;
+                        rec[u].key = 0;
+                        if (p + 1 < end) {
+                            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p));
+                            __builtin_memcpy(&rec[u], &v, 16);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UC; ++u) {
+                        if (!(rec[u].key & (1u << 26))) continue;
+                        const float2 gf = __half22float2(rec[u].g);
+                        const float gg[F] = {gf.x, gf.y};
+                        const float q = 1.0f / 65536.0f;
+                        add_compact(rec[u].key & 0x1FFFu, ((float)rec[u].fx + 0.5f) * q, ((float)rec[u].fy + 0.5f) * q,
+                                    ((float)rec[u].fz + 0.5f) * q, gg);
+                    }
+                }
+            } else {
+                // one sample per two slots: F = 2 {local base row | valid, fx, fy, fz} {-, g0, g1, -}; F = 4 {.., fx, fy, fz,
+                // g0, g1} {-, g2, g3, ...}; all 8 corners land here
+                const Item<F> *itf = reinterpret_cast<const Item<F> *>(items);
+                for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
+                    Item<F> ia[UC], ib[UC];
+#pragma unroll
+                    for (int u = 0; u < UC; ++u) {
+                        const uint64_t p = p0 + 2ull * u * kConsumeThreads;
+                        if (p + 1 < end) {
+                            ia[u] = load_item_nt<F>(itf + p);
+                            ib[u] = load_item_nt<F>(itf + p + 1);
+                        } else {
+                            ia[u].key = 0;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UC; ++u) {
+                        if (!(ia[u].key & (1u << 26))) continue;
+                        float gg[F];
+                        if constexpr (F == 2) {
+                            gg[0] = ib[u].fx; gg[1] = ib[u].a[0];
+                        } else {
+                            gg[0] = ia[u].a[2]; gg[1] = ia[u].a[3]; gg[2] = ib[u].fx; gg[3] = ib[u].a[0];
+                        }
+                        add_compact(ia[u].key & 0x1FFFu, ia[u].fx, ia[u].a[0], ia[u].a[1], gg);
+                    }
+                }
+            }
+            lds_barrier();
+            // neighbouring buckets share their boundary plane: everything is added atomically (the table is zeroed)
+            const int64_t grow0c = (int64_t)first_idx[lvl] + row0;
+            for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) {
+                const int64_t grow = grow0c + e / F;
+                if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
+                const float v = (FX && fx.fixed) ? fx_decode(s_fix[e], fx.inv) : (float)s_acc[e];
+                if (v != 0.0f) unsafeAtomicAdd(grad_table + grow * F + (e % F), v);
+            }
+            return;
+        }
+    }
+    constexpr int UN = 8;  // 16-byte loads in flight per thread (4: -1 %, 16: +3 % with the fixed-point atomics)
+    if constexpr (H && F == 4) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
+            u32x4 v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
+                v[u] = u32x4{0u, 0u, 0u, 0u};
+                if (pp < end) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + pp));
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const float2 a01 = half2_bits_to_float2(v[u][2]);
+                const float2 a23 = half2_bits_to_float2(v[u][3]);
+                const float a[F] = {a01.x, a01.y, a23.x, a23.y};
+                add_pair(v[u][0] & 0x1FFFu, (v[u][0] >> 13) & 0x1FFFu, (v[u][0] >> 26) & 1u, (v[u][0] >> 27) & 1u,
+                         __uint_as_float(v[u][1]), a);
+            }
+        }
+    } else if constexpr (H) {
+        // 8-byte items read two at a time (16-byte loads from even unit indices); a unit's odd first / last item goes alone
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        auto consume8 = [&](uint32_t key, uint32_t payload) {
+            uint32_t ra, rb;
+            bool va, vb;
+            float fxv;
+            unpack_half_key(key, ra, rb, va, vb, fxv);
+            __half2 h;
+            __builtin_memcpy(&h, &payload, 4);
+            const float2 af = __half22float2(h);
+            const float a[F] = {af.x, af.y};
+            add_pair(ra, rb, va, vb, fxv, a);
+        };
+        uint64_t p = begin;
+        if ((p & 1ull) && p < end) {
+            if (threadIdx.x == 0) {
+                const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(items + p));
+                consume8(v[0], v[1]);
+            }
+            ++p;
+        }
+        const uint64_t even_end = end & ~1ull;
+        for (uint64_t p0 = p + 2ull * threadIdx.x; p0 < even_end; p0 += 2ull * kConsumeThreads * UN) {
+            u32x4 v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const uint64_t q = p0 + 2ull * u * kConsumeThreads;
+                v[u] = u32x4{0u, 0u, 0u, 0u};   // key 0: no valid corner
+                if (q < even_end) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + q));
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                consume8(v[u][0], v[u][1]);
+                consume8(v[u][2], v[u][3]);
+            }
+        }
+        if ((end & 1ull) && end - 1 >= p && threadIdx.x == 64) {
+            const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(items + end - 1));
+            consume8(v[0], v[1]);
+        }
+    } else {
+        const Item<F> *itf = reinterpret_cast<const Item<F> *>(items);
+        for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
+            Item<F> it[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
+                if (pp < end) it[u] = load_item_nt<F>(itf + pp);
+                else it[u].key = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                add_pair(it[u].key & 0x1FFFu, (it[u].key >> 13) & 0x1FFFu, (it[u].key >> 26) & 1u, (it[u].key >> 27) & 1u,
+                         it[u].fx, it[u].a);
+        }
+    }
+    lds_barrier();
+
+    const bool single = d.single != 0 && !force_atomic;
+    const int64_t grow0 = (int64_t)first_idx[lvl] + row0;
+    for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) {
+        const int64_t grow = grow0 + e / F;
+        if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
+        const float v = (FX && fx.fixed) ? fx_decode(s_fix[e], fx.inv) : (float)s_acc[e];
+        float *dst = grad_table + grow * F + (e % F);
+        if (single) *dst = v;
+        else if (v != 0.0f) unsafeAtomicAdd(dst, v);
+    }
+}
+
+
+// Persistent form: `work_counter` non-NULL -> every workgroup keeps fetching units from it until they run out (grid = the
+// number of workgroups the chip holds, not the number of units). A unit of a small batch is ~10 us of work between a launch,
+// a 128 KiB image to zero and a flush whose stores s_endpgm would wait for: as separate workgroups (one per CU at a time)
+// nerf_lego.yaml's 1 800 units of 8 K items took 228 us; here the flush of unit k drains behind unit k + 1 (all barriers in
+// consume_unit are LDS-only). `work_counter` NULL: one unit per workgroup (small batches).
+template <int F, bool FX, bool H>
+__global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable lt, BinPlan plan,
+                                                                      const int32_t *__restrict__ first_idx,
+                                                                      const uint64_t *__restrict__ base,
+                                                                      const uint32_t *__restrict__ unit_first,
+                                                                      const UnitDesc *__restrict__ unit_desc,
+                                                                      const typename ItemSel<F, H>::type *__restrict__ items,
+                                                                      float *__restrict__ grad_table,
+                                                                      int force_atomic,
+                                                                      const uint32_t *__restrict__ gmax,
+                                                                      int headroom,
+                                                                      uint32_t *__restrict__ work_counter) {
+    extern __shared__ double s_acc[];  // [rows_pb][F]: fp64, or 64-bit fixed point (same size)
+    __shared__ uint32_t s_unit;
+    const uint32_t unit0 = 0u, unit_end = unit_first[plan.total_buckets];
+    if (work_counter == nullptr) {
+        const uint32_t unit = blockIdx.x + unit0;
+        if (unit >= unit_end) return;
+        consume_unit<F, FX, H>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
+        return;
+    }
+    for (;;) {
+        if (threadIdx.x == 0) s_unit = atomicAdd(work_counter, 1u);
+        lds_barrier();
+        const uint32_t unit = s_unit + unit0;
+        if (unit >= unit_end) return;
+        consume_unit<F, FX, H>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
+        lds_barrier();   // the image and s_unit are free again; the flush stores keep draining
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- direct levels
+// Levels whose whole (used) row range fits one LDS image need no partitioning at all: a workgroup keeps a private
+// fp64 image of a GROUP of such levels, walks its share of the samples adding every corner with ds_add_f64, and
+// adds the image to the (zeroed) gradient table with coalesced float atomics at the end.
+// GT = float: gradients come from the transposed image gT [L][N][F]; otherwise (T = table scalar) straight from
+// grad_output [N, L*F] -- used when no level needs binning, which makes the transposing pass unnecessary.
+template <int DIM, int F, typename GT, bool TRANSPOSED, bool FX>
+__global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(LevelTable lt, BinPlan plan,
+                                                                            const int32_t *__restrict__ first_idx,
+                                                                            const float *__restrict__ coords,
+                                                                            const GT *__restrict__ gT,
+                                                                            float *__restrict__ grad_table,
+                                                                            int64_t N, int64_t gpitch,
+                                                                            const uint32_t *__restrict__ gmax,
+                                                                            int headroom) {
+    constexpr int NC = 1 << DIM;
+    extern __shared__ double s_acc[];
+    __shared__ double s_scale[SHACIRA_MAX_LODS], s_inv[SHACIRA_MAX_LODS];
+    __shared__ int s_all_fixed;
+    const uint32_t grp = blockIdx.y;
+    const uint32_t rows = plan.grows[grp];
+    const uint32_t mask = plan.gmask[grp];
+    if (threadIdx.x == 0) s_all_fixed = 1;
+    for (uint32_t e = threadIdx.x; e < rows * F; e += kConsumeThreads) s_acc[e] = 0.0;
+    __syncthreads();
+    if constexpr (FX) {
+        if ((int)threadIdx.x < lt.num_lods && ((mask >> threadIdx.x) & 1u)) {
+            const FxScale f = fx_scale_of(gmax[threadIdx.x], headroom);
+            s_scale[threadIdx.x] = f.scale;
+            s_inv[threadIdx.x] = f.inv;
+            if (!f.fixed) s_all_fixed = 0;     // one non-finite level: the whole group accumulates in fp64
+        }
+        __syncthreads();
+    }
+    const bool fixed = FX && s_all_fixed != 0;
+    unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
+    const int64_t stride = (int64_t)gridDim.x * kConsumeThreads;
+    const int rotd = (int)(threadIdx.x & (F - 1));
+    for (int64_t i = (int64_t)blockIdx.x * kConsumeThreads + threadIdx.x; i < N; i += stride) {
+        double t[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
+        for (int l = 0; l < lt.num_lods; ++l) {
+            if (!((mask >> l) & 1u)) continue;
+            const BinLevel bl = plan.lv[l];
+            Corners<DIM> c;
+            compute_corners<DIM>(t, lt.res[l], lt.hi[l], lt.dense[l] != 0, lt.mask, c);
+            const GT *gp = TRANSPOSED ? gT + ((int64_t)l * gpitch + i) * F : gT + (i * lt.num_lods + l) * F;
+            float g[F];
+#pragma unroll
+            for (int j = 0; j < F; ++j) g[j] = Scalar<GT>::load(gp + j);
+            const double scale = FX ? s_scale[l] : 1.0;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if (c.row[k] < bl.used) {
+                    const size_t slot = (size_t)(bl.drow0 + c.row[k]) * F;
+                    if (fixed) {
+#pragma unroll
+                        for (int jj = 0; jj < F; ++jj) {   // feature order rotated by lane (LDS bank spreading)
+                            const int j = (jj + rotd) & (F - 1);
+                            atomicAdd(s_fix + slot + j, fx_encode(pick<F>(g, j) * c.w[k], scale));
+                        }
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < F; ++jj) {
+                            const int j = (jj + rotd) & (F - 1);
+                            atomicAdd(s_acc + slot + j, (double)(pick<F>(g, j) * c.w[k]));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int l = 0; l < lt.num_lods; ++l) {
+        if (!((mask >> l) & 1u)) continue;
+        const BinLevel bl = plan.lv[l];
+        const int64_t grow0 = (int64_t)first_idx[l];
+        for (uint32_t e = threadIdx.x; e < bl.used * F; e += kConsumeThreads) {
+            const int64_t grow = grow0 + e / F;
+            if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
+            const float v = fixed ? fx_decode(s_fix[(size_t)bl.drow0 * F + e], s_inv[l])
+                                  : (float)s_acc[(size_t)bl.drow0 * F + e];
+            if (v != 0.0f) unsafeAtomicAdd(grad_table + grow * F + (e % F), v);
+        }
+    }
+}
+
+
+}  // namespace shacira

@@ -1,0 +1,371 @@
+// bwd_bin_types.h -- plan / item / unit types, corner and bucket enumeration, fixed-point helpers of the binned backward
+// Part of the translation unit hashgrid_bwd_bin.hip (included there, in this order: bwd_bin_types.h, bwd_bin_front.h,
+// bwd_bin_passes.h); see that file's header for the pipeline.
+#pragma once
+
+#include "internal.h"
+
+namespace shacira {
+
+#ifndef SHACIRA_KTILE
+#define SHACIRA_KTILE 1024
+#endif
+#ifndef SHACIRA_KBIN
+#define SHACIRA_KBIN 512
+#endif
+constexpr int kTile = SHACIRA_KTILE;       // samples per (level, tile) block in passes A and B, 3-D
+// 2-D samples have half as many x-pairs: tiles of twice as many samples fill the same LDS staging buffer and halve the number
+// of scatter workgroups (each pays the same latencies and barriers whatever it carries: 16 us per level either way before)
+template <int DIM> struct TileOf { static constexpr int value = (DIM == 2) ? 2 * kTile : kTile; };
+static inline int tile_samples(int dim) { return dim == 2 ? 2 * kTile : kTile; }
+constexpr int kBinThreads = SHACIRA_KBIN;  // threads of passes A and B
+constexpr int kConsumeThreads = 1024;
+constexpr int kMaxBuckets = 2048;     // over all levels
+constexpr int kMaxLevelBuckets = 128; // per level (LDS histogram size)
+constexpr int kTotalShards = 16;      // bucket totals are accumulated in this many copies (same-address atomic contention)
+
+struct BinLevel {
+    uint32_t nb;        // buckets in this level
+    uint32_t bucket0;   // global index of its first bucket
+    uint32_t rows_pb;   // rows per bucket (hashed: BR; dense: G*res)
+    uint32_t G;         // dense: x-lines per bucket
+    uint64_t magicG;    // ceil(2^40 / G): line / G == (line * magicG) >> 40 for line < 2^20
+    uint32_t used;      // rows of the level the kernels can touch: dense res^d, hashed 2^bw
+    uint32_t shift;     // hashed: log2(BR)
+    int32_t dgroup;     // >= 0: "direct" level (fits one LDS image): index of its group; -1: binned level
+    uint32_t drow0;     // direct: first row of the level inside its group's LDS image
+    uint32_t compact;   // 1: dense 3-D level binned by z-slab with ONE two-slot item per sample (all 8 corners): 32 B (F = 2), 48 B (F = 4)
+    uint32_t slab;      // compact: base-cell planes per bucket (its image holds slab + 1 planes)
+    uint32_t chunk;     // items per consumer work unit of this level
+};
+
+// What the counting needs to know about binned level q, dense in q (one unchained scalar load per level: reading the fields
+// through blevel[q] -> lv[lvl] / lt.res[lvl] chained four scalar-load round trips per level and made the fused front kernel
+// latency bound).
+struct CountLevel {
+    int32_t res;
+    float hi;
+    uint32_t kind;      // 0 hashed, 1 compact (z slab), 2 dense x-lines
+    uint32_t shift;     // hashed: log2(rows per bucket)
+    uint32_t m_lo, m_hi; // compact: m_lo = ceil(2^18 / slab) (pz / slab == (pz * m_lo) >> 18, checked by make_plan); dense: magicG
+};
+
+struct BinPlan {
+    BinLevel lv[SHACIRA_MAX_LODS];
+    CountLevel cl[SHACIRA_MAX_LODS];
+    uint32_t total_buckets;
+    uint32_t BR;
+    uint32_t num_tiles;
+    uint32_t pairs;     // items per (sample, level) = 2^(dim-1)
+    uint32_t chunk;     // items per consumer work unit
+    uint32_t chunk_min; // smallest unit size of the plan (sizes the unit list)
+    uint32_t nbl;       // number of binned levels
+    uint32_t blevel[SHACIRA_MAX_LODS];  // their level indices (grid.y of passes A/B); 32-bit = scalar loads
+    uint32_t bstart[SHACIRA_MAX_LODS];  // first global bucket of binned level q (= lv[blevel[q]].bucket0)
+    uint32_t ngroups;   // groups of direct levels
+    uint32_t gmask[SHACIRA_MAX_LODS];   // levels of each group (bit l)
+    uint32_t grows[SHACIRA_MAX_LODS];   // rows of each group's LDS image
+};
+
+template <int F> struct alignas(F == 2 ? 16 : 8) Item {
+    uint32_t key;
+    float fx;
+    float a[F];
+};
+
+// fp16 tables with F = 2 (the reference's NeRF mode: AMP on, grid.py:73, .cu:198-211): the gradient is stored as fp16 anyway,
+// so the item stream may carry half-precision payloads -- HALF the bytes of the pass that bounds the backward:
+//   pair item, 8 B:     key = rowA (13) | kx (4) | validA | validB | fx quantised to 13 bits;  a = half2(g0 w, g1 w)
+//                       rowB = kx ? rowA ^ (2^kx - 1) : rowA + 1   (hashed: x ^ (x + 1) = 2^kx - 1; dense: the next row)
+//   compact item, 16 B: key = local base row | valid;  fx, fy, fz as 16-bit fixed point;  g = half2(g0, g1)  (two 8-byte units)
+// Weight error <= 2^-14, payload rounding 2^-11 relative per term (the reference's own fp16 atomics round the running SUM to
+// 11 bits at every add); sums are still accumulated in the 64-bit fixed-point / fp64 LDS images.
+struct alignas(8) ItemH {
+    uint32_t key;
+    __half2 a;
+};
+struct alignas(16) ItemHC {
+    uint32_t key;
+    uint16_t fx, fy, fz, pad;
+    __half2 g;
+};
+// F = 4 (nerf_lego.yaml under AMP): 16-byte pair items {key, fx (fp32: exact weights), half2 a01, half2 a23} instead of
+// 24 bytes moved as 8-byte pieces; compact items = two 16-byte units {key, fx, fy, fz} {half2 g01, half2 g23, -, -} (32
+// instead of 48 bytes). Keys as in the fp32 stream.
+struct alignas(16) ItemH4 {
+    uint32_t key;
+    float fx;
+    uint32_t p2, p3;   // two half2 as raw bits (pair item: a01, a23; compact unit 0: fy, fz as fp32 bits)
+};
+template <int F, bool H> struct ItemSel { typedef Item<F> type; };
+template <> struct ItemSel<2, true> { typedef ItemH type; };
+template <> struct ItemSel<4, true> { typedef ItemH4 type; };
+
+__device__ __forceinline__ uint32_t pack_half_key(uint32_t key, float fx, bool dense) {
+    const uint32_t ra = key & 0x1FFFu, rb = (key >> 13) & 0x1FFFu;
+    const uint32_t kx = dense ? 0u : (32u - (uint32_t)__clz((int)(ra ^ rb)));
+    const uint32_t fq = (uint32_t)(fx * 8192.0f);   // fx in [0, 1)
+    return ra | (kx << 13) | (((key >> 26) & 3u) << 17) | ((fq > 8191u ? 8191u : fq) << 19);
+}
+__device__ __forceinline__ void unpack_half_key(uint32_t k, uint32_t &ra, uint32_t &rb, bool &va, bool &vb, float &fx) {
+    ra = k & 0x1FFFu;
+    const uint32_t kx = (k >> 13) & 15u;
+    rb = kx ? (ra ^ ((1u << kx) - 1u)) : ((ra + 1u) & 0x1FFFu);
+    va = (k >> 17) & 1u;
+    vb = (k >> 18) & 1u;
+    fx = ((float)(k >> 19) + 0.5f) * (1.0f / 8192.0f);
+}
+// (raw 16-bit halves on purpose: __builtin_bit_cast between uint32_t and __half2 miscompiled here -- both halves came out
+// as the low one)
+__device__ __forceinline__ uint32_t float2_to_half2_bits(float a, float b) {
+    return (uint32_t)__half_as_ushort(__float2half_rn(a)) | ((uint32_t)__half_as_ushort(__float2half_rn(b)) << 16);
+}
+__device__ __forceinline__ float2 half2_bits_to_float2(uint32_t bits) {
+    return make_float2(__half2float(__ushort_as_half((unsigned short)(bits & 0xFFFFu))),
+                       __half2float(__ushort_as_half((unsigned short)(bits >> 16))));
+}
+__device__ __forceinline__ void store_item_nt(ItemH4 *p, const ItemH4 &it) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;
+    __builtin_memcpy(&v, &it, 16);
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+}
+__device__ __forceinline__ void store_item_nt(ItemH *p, const ItemH &it) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 v;
+    __builtin_memcpy(&v, &it, 8);
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p));
+}
+
+// One consumer work unit, written by the bucket scan: everything a consume workgroup needs in ONE 32-byte load (it used to
+// chase unit -> bucket -> base / unit_first -> level through four dependent loads and a 15-step scalar search: ~8 us per
+// unit before the first item arrived).
+struct alignas(16) UnitDesc {
+    uint64_t begin, end;   // item range
+    uint32_t bucket;       // global bucket index
+    uint32_t level;
+    uint32_t single;       // 1: the bucket's only unit (rows are written with plain stores)
+    uint32_t pad;
+};
+
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also drains the wave's global loads AND stores
+// (s_waitcnt vmcnt(0)), which serialises a block's write-out with its next phase.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Items are written once and read once: stream them past the caches (non-temporal).
+template <int F> __device__ __forceinline__ void store_item_nt(Item<F> *p, const Item<F> &it) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (sizeof(Item<F>) == 16) {
+        u32x4 v;
+        __builtin_memcpy(&v, &it, 16);
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+    } else {   // 24-byte items (F = 4, 8-byte aligned): three 8-byte stores instead of six dwords
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        static_assert(sizeof(Item<F>) % 8 == 0, "item size");
+        u32x2 *q = reinterpret_cast<u32x2 *>(p);
+        u32x2 d[sizeof(Item<F>) / 8];
+        __builtin_memcpy(d, &it, sizeof(Item<F>));
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(Item<F>) / 8); ++k) __builtin_nontemporal_store(d[k], q + k);
+    }
+}
+
+template <int F> __device__ __forceinline__ Item<F> load_item_nt(const Item<F> *p) {
+    Item<F> it;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (sizeof(Item<F>) == 16) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        __builtin_memcpy(&it, &v, 16);
+    } else {   // 24-byte items: three 8-byte loads
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 *q = reinterpret_cast<const u32x2 *>(p);
+        u32x2 d[sizeof(Item<F>) / 8];
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(Item<F>) / 8); ++k) d[k] = __builtin_nontemporal_load(q + k);
+        __builtin_memcpy(&it, d, sizeof(Item<F>));
+    }
+    return it;
+}
+
+// One x-pair of corners of a (sample, level), in bucket coordinates.
+struct PairSlot {
+    uint32_t bucket;  // level-local bucket index
+    uint32_t key;     // rowA | rowB << 13 | validA << 26 | validB << 27   (0 valid bits -> nothing to add)
+    float wrest;      // product of the non-x weights
+};
+
+// Enumerates the 2^(DIM-1) x-pairs of one (sample, level). fx/gx are the x-axis weights (corner x+1 / corner x).
+template <int DIM>
+__device__ __forceinline__ void enumerate_pairs(const double (&t)[DIM], int32_t res, float hi, bool dense,
+                                                uint32_t mask, const BinLevel &bl, uint32_t BR, float &fx,
+                                                PairSlot (&out)[1 << (DIM - 1)]) {
+    int32_t p[DIM];
+    float f[DIM], g[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) axis_transform(t[a], res, hi, p[a], f[a], g[a]);
+    fx = f[0];
+    const uint32_t ux = (uint32_t)p[0];
+    const uint32_t r = (uint32_t)res;
+    constexpr int NP = 1 << (DIM - 1);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        // q bit (DIM-2) -> y offset, bit 0 -> z offset (3-D); q -> y offset (2-D): same order as the corner bits
+        const int dy = (DIM == 3) ? ((q >> 1) & 1) : (q & 1);
+        const int dz = (DIM == 3) ? (q & 1) : 0;
+        float w = dy ? f[1] : g[1];
+        if constexpr (DIM == 3) w = w * (dz ? f[2] : g[2]);
+        out[q].wrest = w;
+        const uint32_t uy = (uint32_t)p[1] + dy;
+        uint32_t uz = 0;
+        if constexpr (DIM == 3) uz = (uint32_t)p[2] + dz;
+        if (dense) {
+            // corners with a coordinate == res lie outside the level (weight 0 in the reference): dropped
+            bool ok = uy < r;
+            uint32_t line = uy;
+            if constexpr (DIM == 3) {
+                ok = ok && uz < r;
+                line += uz * r;
+            }
+            const uint32_t b = (uint32_t)(((uint64_t)line * bl.magicG) >> 40);
+            const uint32_t ra = (line - b * bl.G) * r + ux;
+            const uint32_t va = ok ? 1u : 0u;
+            const uint32_t vb = (ok && (ux + 1u) < r) ? 1u : 0u;
+            out[q].bucket = ok ? b : 0u;
+            out[q].key = (ra & 0x1FFFu) | (((ra + 1u) & 0x1FFFu) << 13) | (va << 26) | (vb << 27);
+        } else {
+            uint32_t h = uy * kPrimeY;
+            if constexpr (DIM == 3) h ^= uz * kPrimeZ;
+            const uint32_t rowA = (ux ^ h) & mask;
+            const uint32_t rowB = ((ux + 1u) ^ h) & mask;
+            out[q].bucket = rowA >> bl.shift;
+            out[q].key = (rowA & (BR - 1u)) | ((rowB & (BR - 1u)) << 13) | (3u << 26);
+        }
+    }
+}
+
+// Buckets of the 2^(DIM-1) x-pairs of one (sample, level) WITHOUT the x axis: a pair's bucket and validity depend on its
+// (y[, z]) line only (hashed: x < 2^shift never reaches the bucket bits; dense: buckets hold whole x-lines, and a pair is
+// dropped only when its line lies outside the level). Same result as enumerate_pairs(...).bucket / (key >> 26 != 0) at a
+// third of the arithmetic: this is what the counting passes run.
+template <int DIM>
+__device__ __forceinline__ void enumerate_buckets(const double (&t)[DIM], int32_t res, float hi, bool dense, uint32_t mask,
+                                                  const BinLevel &bl, uint32_t (&bucket)[1 << (DIM - 1)],
+                                                  bool (&valid)[1 << (DIM - 1)]) {
+    int32_t p[DIM];
+    float f, g;
+#pragma unroll
+    for (int a = 1; a < DIM; ++a) axis_transform(t[a], res, hi, p[a], f, g);
+    const uint32_t r = (uint32_t)res;
+    constexpr int NP = 1 << (DIM - 1);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int dy = (DIM == 3) ? ((q >> 1) & 1) : (q & 1);
+        const int dz = (DIM == 3) ? (q & 1) : 0;
+        const uint32_t uy = (uint32_t)p[1] + dy;
+        uint32_t uz = 0;
+        if constexpr (DIM == 3) uz = (uint32_t)p[2] + dz;
+        if (dense) {
+            bool ok = uy < r;
+            uint32_t line = uy;
+            if constexpr (DIM == 3) {
+                ok = ok && uz < r;
+                line += uz * r;
+            }
+            valid[q] = ok;
+            bucket[q] = ok ? (uint32_t)(((uint64_t)line * bl.magicG) >> 40) : 0u;
+        } else {
+            uint32_t h = uy * kPrimeY;
+            if constexpr (DIM == 3) h ^= uz * kPrimeZ;
+            valid[q] = true;
+            bucket[q] = (h & mask) >> bl.shift;
+        }
+    }
+}
+
+// position along one axis only (axis_transform without the fractions)
+__device__ __forceinline__ uint32_t axis_pos(double t, int32_t res, float hi) {
+    float x = (float)((double)res * t);
+    x = fmaxf(0.0f, fminf(hi, x));
+    return (uint32_t)(int32_t)floorf(x);
+}
+
+// bucket counts of one (sample, binned level) into the level's LDS histogram -- the same buckets / validity as
+// enumerate_pairs (hashed, dense) and the compact scatter path, from the dense per-level record
+template <int DIM>
+__device__ __forceinline__ void count_level(const double (&t)[DIM], const CountLevel cl, uint32_t mask, uint32_t *hist) {
+    if (cl.kind == 1u) {
+        if constexpr (DIM == 3) {
+            const uint32_t pz = axis_pos(t[2], cl.res, cl.hi);
+            const uint32_t b = cl.m_lo ? (__umul24(pz, cl.m_lo) >> 18) : pz / cl.m_hi;
+            atomicAdd(hist + b, 2u);
+        }
+    } else if (cl.kind == 0u) {
+        const uint32_t hy0 = axis_pos(t[1], cl.res, cl.hi) * kPrimeY, hy1 = hy0 + kPrimeY;
+        if constexpr (DIM == 3) {
+            const uint32_t hz0 = axis_pos(t[2], cl.res, cl.hi) * kPrimeZ, hz1 = hz0 + kPrimeZ;
+            atomicAdd(hist + (((hy0 ^ hz0) & mask) >> cl.shift), 1u);
+            atomicAdd(hist + (((hy0 ^ hz1) & mask) >> cl.shift), 1u);
+            atomicAdd(hist + (((hy1 ^ hz0) & mask) >> cl.shift), 1u);
+            atomicAdd(hist + (((hy1 ^ hz1) & mask) >> cl.shift), 1u);
+        } else {
+            atomicAdd(hist + ((hy0 & mask) >> cl.shift), 1u);
+            atomicAdd(hist + ((hy1 & mask) >> cl.shift), 1u);
+        }
+    } else {
+        const uint64_t magic = ((uint64_t)cl.m_hi << 32) | cl.m_lo;
+        const uint32_t r = (uint32_t)cl.res;
+        const uint32_t py = axis_pos(t[1], cl.res, cl.hi);
+        uint32_t pz = 0;
+        if constexpr (DIM == 3) pz = axis_pos(t[2], cl.res, cl.hi);
+#pragma unroll
+        for (int q = 0; q < (1 << (DIM - 1)); ++q) {
+            const uint32_t uy = py + ((DIM == 3) ? ((q >> 1) & 1) : (q & 1));
+            bool ok = uy < r;
+            uint32_t line = uy;
+            if constexpr (DIM == 3) {
+                const uint32_t uz = pz + (q & 1);
+                ok = ok && uz < r;
+                line += uz * r;
+            }
+            if (ok) atomicAdd(hist + (uint32_t)(((uint64_t)line * magic) >> 40), 1u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fixed point
+// LDS integer atomics run 1.6x faster than ds_add_f64 (2.1-2.5 vs 1.3-1.4 T op/s, profiles/r01_microbench2), so the
+// accumulator images hold 64-bit fixed-point numbers. Scale per level: gmax[l] = max |grad_output| over the level's
+// columns (bit pattern of the float, gathered by pass T for free; integer max on the bits orders
+// finite < inf < NaN). Every contribution is |g * weight| <= gmax < 2^e, so with scale 2^(headroom - e) a contribution
+// stays below 2^headroom and n_max of them below 2^62: headroom = min(50, 62 - ceil(log2(n_max))). Conversion is one
+// fp64 fma with the 1.5 * 2^52 constant (the integer appears in the low mantissa bits) -- exact to the scale's LSB, i.e.
+// 2^-headroom relative to gmax (>= 41 bits here vs 24 of the reference's fp32 atomics) and order-independent.
+// A level whose gmax is inf / NaN falls back to the fp64 image so that non-finite gradients propagate as before.
+struct FxScale {
+    double scale, inv;   // 2^k, 2^-k
+    bool fixed;          // false: accumulate in fp64 (non-finite gradients)
+};
+__device__ __forceinline__ FxScale fx_scale_of(uint32_t gmax_bits, int headroom) {
+    FxScale f;
+    f.fixed = gmax_bits < 0x7F800000u;
+    int e = (int)((gmax_bits >> 23) & 0xFFu) - 126;   // |g| < 2^e for normal floats; denormals / zero: e = -126
+    if (e < -126) e = -126;
+    const int k = headroom - e;
+    f.scale = __longlong_as_double((long long)(1023 + k) << 52);
+    f.inv = __longlong_as_double((long long)(1023 - k) << 52);
+    return f;
+}
+__device__ __forceinline__ unsigned long long fx_encode(float c, double scale) {
+    const double magic = 6755399441055744.0;   // 1.5 * 2^52
+    return (unsigned long long)(__double_as_longlong(fma((double)c, scale, magic)) - __double_as_longlong(magic));
+}
+__device__ __forceinline__ float fx_decode(unsigned long long v, double inv) { return (float)((double)(long long)v * inv); }
+static inline int fx_headroom(uint64_t n_max) {
+    int bits = 0;
+    while (((uint64_t)1 << bits) < n_max) ++bits;
+    const int h = 62 - bits;
+    return h > 50 ? 50 : (h < 24 ? 24 : h);
+}
+
+
+}  // namespace shacira

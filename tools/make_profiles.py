@@ -7,8 +7,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r03f")
 tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 sys.path.insert(0, ROOT)
-from bench import kernel_source_hash
+from bench import kernel_source_hash as _local_hash
 out = os.path.join(ROOT, "profiles")
+_hp = os.path.join(src, "source_hash.txt")
+_measured = open(_hp).read().strip() if os.path.exists(_hp) else None
+if _measured and _measured != _local_hash():
+    print(f"WARNING: the raw data was measured on kernel sources {_measured}, the tree is now {_local_hash()}")
+
+
+def kernel_source_hash():
+    """the hash of the sources the raw data was MEASURED on (written on the GPU box), else of the local tree"""
+    return _measured or _local_hash()
+
 
 line = json.load(open(os.path.join(src, "bench_line.json")))
 json.dump(line, open(os.path.join(out, f"{tag}_bench_line.json"), "w"), indent=1)

@@ -5,6 +5,7 @@ TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}f
 mkdir -p $OUT
+python -c "from bench import kernel_source_hash; print(kernel_source_hash())" > $OUT/source_hash.txt   # the sources measured
 STAGES=${STAGES:-"bench checks stats pmc ctr bctr steps mfma"}    # subset to re-run, e.g. STAGES="bench ctr"
 has() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
 if has bench; then
