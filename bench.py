@@ -395,7 +395,17 @@ def main():
                 "config": "B: 2-D LatentGrid L16 F2 ld1 bw11 res16..512, quant+entropy on, 512x768 procedural image, "
                           "Adam (kodak.yaml learning rates)", "bpp": fit["bpp"], "bpp_file": fit["bpp_file"],
                 "file_bytes": fit["file_bytes"], "rgb_loss": fit["rgb_loss"],
-                "seconds": time.perf_counter() - tp, "n_gpus": world}
+                "seconds": time.perf_counter() - tp, "ms_per_step": fit["ms_per_step"], "n_gpus": world,
+                "mode": "eager step (Python issues ~60 launches per step: the GPU is busy ~16 % of it, "
+                        "profiles/r03_imagefit_step.md)"}
+        if world == 1:
+            # the same fit with the step captured once into a HIP graph and replayed (GraphedImageFitter: device-side
+            # entropy noise and Adam step count): what a user who cares about wall time runs
+            tg = time.perf_counter()
+            gfit = harness.fit_image(device, steps=args.psnr_steps, graphed=True)
+            torch.cuda.synchronize()
+            psnr["graph_replay"] = {"value": gfit["psnr"], "bpp": gfit["bpp"], "ms_per_step": gfit["ms_per_step"],
+                                    "seconds": time.perf_counter() - tg}
 
     # second PSNR figure (rank 0 only, outside the timed region): the reference's per-step NeRF pipeline -- ray marching
     # on the occupancy grid, hash-grid lookup, MFMA decoders, volume integration, L1, fused Adam -- on a closed-form scene

@@ -175,11 +175,19 @@ def step_md(w, title, fname, hot=("hashgrid_fwd", "untranspose_feats", "ctx_", "
     steps = rec["steps"]
     tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e3 / steps
     hot_us = sum(float(r["TotalDurationNs"]) for r in rows if any(h in r["Name"] for h in hot)) / 1e3 / steps
-    wall = rec["ms_per_step"] * 1e3
+    prof_wall = rec["ms_per_step"] * 1e3
+    wall, plain = prof_wall, False
+    pp = os.path.join(src, f"step_{w}_plain.json")     # the same loop without the profiler attached
+    if os.path.exists(pp):
+        try:
+            wall = json.loads([l for l in open(pp).read().splitlines() if l.startswith("{")][-1])["ms_per_step"] * 1e3
+            plain = True
+        except (IndexError, ValueError, KeyError):
+            pass
     with open(os.path.join(out, fname), "w") as f:
         f.write(f"# {title}\n\n`rocprofv3 --kernel-trace --stats -- python3 tools/step_breakdown.py {w} {steps}` ({tag}, source hash "
                 f"{kernel_source_hash()}).\n\n")
-        f.write(f"Wall time per step (the loop's own clock, under the profiler): **{wall:.0f} us**. GPU kernel time per step (every "
+        f.write(f"Wall time per step (the loop's own clock, " + (f"a run WITHOUT the profiler; {prof_wall:.0f} us under it" if plain else "under the profiler, which inflates it") + f"): **{wall:.0f} us**. GPU kernel time per step (every "
                 f"kernel of the trace, setup and validation included): **{tot:.0f} us**  -> the GPU is busy "
                 f"{min(tot / wall, 1.0) * 100:.0f} % of the step; the rest is host time between launches (Python, autograd, "
                 f"allocator, launch latency).\nHash-grid operators (forward + backward kernels of this library's hot path): "
