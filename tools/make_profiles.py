@@ -172,7 +172,7 @@ def step_md(w, title, fname, hot=("hashgrid_fwd", "untranspose_feats", "ctx_", "
     except (IndexError, ValueError):
         return
     rows = list(csv.DictReader(open(max(fs, key=os.path.getmtime))))
-    steps = rec["steps"]
+    steps = rec.get("steps_traced", rec["steps"])
     tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e3 / steps
     hot_us = sum(float(r["TotalDurationNs"]) for r in rows if any(h in r["Name"] for h in hot)) / 1e3 / steps
     prof_wall = rec["ms_per_step"] * 1e3
@@ -185,7 +185,7 @@ def step_md(w, title, fname, hot=("hashgrid_fwd", "untranspose_feats", "ctx_", "
         except (IndexError, ValueError, KeyError):
             pass
     with open(os.path.join(out, fname), "w") as f:
-        f.write(f"# {title}\n\n`rocprofv3 --kernel-trace --stats -- python3 tools/step_breakdown.py {w} {steps}` ({tag}, source hash "
+        f.write(f"# {title}\n\n`rocprofv3 --kernel-trace --stats -- python3 tools/step_breakdown.py {w} {rec['steps']}` ({tag}, source hash "
                 f"{kernel_source_hash()}).\n\n")
         f.write(f"Wall time per step (the loop's own clock, " + (f"a run WITHOUT the profiler; {prof_wall:.0f} us under it" if plain else "under the profiler, which inflates it") + f"): **{wall:.0f} us**. GPU kernel time per step (every "
                 f"kernel of the trace, setup and validation included): **{tot:.0f} us**  -> the GPU is busy "

@@ -47,8 +47,8 @@ fi
 if has steps; then
 # what the operators sit inside: one eager step of the NeRF fit / the image fit (kernel time vs wall time), and the graphed image fit
 for w in nerf image image_graphed; do
-timeout 300 python3 $GRAFT_REPO_ROOT/tools/step_breakdown.py $w 300 > $OUT/step_${w}_plain.json 2>/dev/null   # the unprofiled wall time
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_$w -- python3 $GRAFT_REPO_ROOT/tools/step_breakdown.py $w 300 > $OUT/step_$w.json 2>/dev/null
+timeout 300 python3 $GRAFT_REPO_ROOT/tools/step_breakdown.py $w 1000 > $OUT/step_${w}_plain.json 2>/dev/null   # the unprofiled wall time
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_$w -- python3 $GRAFT_REPO_ROOT/tools/step_breakdown.py $w 1000 > $OUT/step_$w.json 2>/dev/null
 done
 fi
 if has mfma; then

@@ -8,10 +8,17 @@ from shacira_amd import harness
 what = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 dev = torch.device("cuda:0")
-if what == "nerf":
-    r = harness.fit_nerf(dev, steps=steps)
-elif what == "image":
-    r = harness.fit_image(dev, steps=steps)
-else:
-    r = harness.fit_image(dev, steps=steps, graphed=True)
-print(json.dumps({"what": what, "steps": steps, "ms_per_step": r["ms_per_step"], "psnr": r["psnr"]}))
+WARM = 30      # a short fit first: module loading, allocator growth and autotuning stay out of the timed loop
+
+
+def fit(n):
+    if what == "nerf":
+        return harness.fit_nerf(dev, steps=n)
+    return harness.fit_image(dev, steps=n, graphed=(what == "image_graphed"))
+
+
+fit(WARM)
+torch.cuda.synchronize()
+r = fit(steps)
+# "steps_traced": what a kernel trace of this process has to be divided by (warm-up fit included)
+print(json.dumps({"what": what, "steps": steps, "steps_traced": steps + WARM, "ms_per_step": r["ms_per_step"], "psnr": r["psnr"]}))

@@ -15,7 +15,11 @@ first = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.
 T = sum(sizes)
 g = torch.Generator().manual_seed(0)
 table = (torch.randn(T, F, generator=g) * 0.01).cuda()
-coords = (torch.rand(N, dim, generator=g) * 2 - 1).cuda()
+if os.environ.get("RAYS"):     # config D's batch: ray points, N / 16 rays x 16 samples
+    from shacira_amd import harness
+    coords = harness.ray_points(N // 16, 16, g).contiguous().cuda()
+else:
+    coords = (torch.rand(N, dim, generator=g) * 2 - 1).cuda()
 go = torch.randn(N, 32, generator=g).cuda()
 for _ in range(int(os.environ.get("ITERS", 10))):
     hip_ops._hashgrid_forward(dim, coords, table, first, res, bw)
