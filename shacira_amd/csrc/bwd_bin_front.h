@@ -268,7 +268,8 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
                                                                 UnitDesc *__restrict__ unit_desc, uint32_t nb,
                                                                 BinPlan plan,
                                                                 uint32_t *__restrict__ work_counter,
-                                                                unsigned long long *__restrict__ cursor) {
+                                                                unsigned long long *__restrict__ cursor,
+                                                                const uint32_t *__restrict__ gmax) {
     __shared__ uint64_t s_items[kMaxBuckets + 2];
     __shared__ uint32_t s_units[kMaxBuckets + 2];
     __shared__ uint64_t s_wave_items[16];
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
         const uint32_t b = 2 * t + k;
         if (b < nb) {
             const uint32_t lvl = lv_of[k];
+            const uint32_t gm = (gmax != nullptr && u[k] > 0) ? gmax[lvl] : 0u;
             for (uint32_t q = 0; q < u[k]; ++q) {
                 UnitDesc d;
                 d.begin = s_items[b] + (uint64_t)q * ck[k];
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
                 d.bucket = b;
                 d.level = lvl;
                 d.single = u[k] == 1 ? 1u : 0u;
-                d.pad = 0;
+                d.gmax_bits = gm;
                 unit_desc[s_units[b] + q] = d;
             }
         }
@@ -411,9 +413,16 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
 // other rows are zeroed up front (S1: 6.6 of 48.8 MB; the table-sized memset was 13 of config D's 93 us and 40 MB of the
 // write-bound traffic of every call) and the buckets that turn out to have 0 or several units are zeroed once the bucket
 // scan knows them. grid (x, num_lods): segment l = rows [first_idx[l], first_idx[l + 1]) (segment 0 starts at row 0).
+// Slice blockIdx.y == num_lods (when launched with one extra slice) zeroes the call's control words instead: one launch
+// fewer on the small-batch path.
 __global__ __launch_bounds__(256) void zero_unowned_rows_kernel(float *__restrict__ acc,
                                                                 const int32_t *__restrict__ first_idx, LevelTable lt,
-                                                                BinPlan plan) {
+                                                                BinPlan plan, uint32_t *__restrict__ words,
+                                                                uint32_t nwords) {
+    if ((int)blockIdx.y == lt.num_lods) {
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nwords; i += gridDim.x * 256) words[i] = 0u;
+        return;
+    }
     const int l = blockIdx.y, F = lt.feature_dim;
     const int64_t level0 = first_idx[l];
     const int64_t start = (l == 0) ? 0 : level0;
@@ -434,23 +443,6 @@ __global__ __launch_bounds__(256) void zero_unowned_rows_kernel(float *__restric
 // (round 3: stale totals -> wrong bucket bases)
 __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__restrict__ p, uint32_t n) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0u;
-}
-
-// after the bucket scan: hashed buckets with 0 units (never written) or several (they add atomically) are zeroed now.
-// grid (kMaxLevelBuckets, nbl)
-__global__ __launch_bounds__(256) void zero_odd_buckets_kernel(float *__restrict__ acc, const int32_t *__restrict__ first_idx,
-                                                               const uint32_t *__restrict__ unit_first, LevelTable lt,
-                                                               BinPlan plan) {
-    const uint32_t lvl = plan.blevel[blockIdx.y];
-    const BinLevel bl = plan.lv[lvl];
-    const uint32_t b = blockIdx.x;
-    if (b >= bl.nb || lt.dense[lvl] != 0) return;
-    const uint32_t gb = bl.bucket0 + b;
-    if (unit_first[gb + 1] - unit_first[gb] == 1u) return;
-    const uint32_t row0 = b * bl.rows_pb;
-    const uint32_t nrows = (bl.used - row0 < bl.rows_pb) ? (bl.used - row0) : bl.rows_pb;
-    float *dst = acc + ((int64_t)first_idx[lvl] + row0) * lt.feature_dim;
-    for (uint32_t e = threadIdx.x; e < nrows * (uint32_t)lt.feature_dim; e += 256) dst[e] = 0.0f;
 }
 
 // a[j] for a lane-dependent j without a scratch array (select chain)

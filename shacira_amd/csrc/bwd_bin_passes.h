@@ -20,7 +20,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                                                                   const uint32_t *__restrict__ cnt, uint32_t cps,
                                                                   uint32_t cnt_rows,
                                                                   typename ItemSel<F, H>::type *__restrict__ items,
-                                                                  int64_t sample0, int64_t N, int64_t gpitch) {
+                                                                  int64_t sample0, int64_t N, int64_t gpitch,
+                                                                  float *__restrict__ zero_acc,
+                                                                  const int32_t *__restrict__ first_idx,
+                                                                  const uint32_t *__restrict__ unit_first) {
     typedef typename ItemSel<F, H>::type ItemT;
     constexpr int NP = 1 << (DIM - 1);
     constexpr int kTileD = TileOf<DIM>::value;
@@ -235,15 +238,32 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         // write-once / read-once stream: non-temporal stores (measured -7 % on the whole backward)
         store_item_nt(items + s_gbase[b] + (pos - s_start[b]), s_items[pos]);
     }
+    // selective table zeroing, second half (zero_unowned_rows_kernel did the rows no bucket covers): a hashed bucket with
+    // exactly one work unit is overwritten by the consume pass; one with none is never written and one with several is
+    // added to atomically -- those are zeroed here, by the workgroups of the level's first tiles, behind their own item
+    // stores (the consume pass runs after this kernel either way).
+    if (zero_acc != nullptr && !dense) {
+        for (uint32_t b = tile; b < bl.nb; b += gridDim.x) {
+            const uint32_t gb = bl.bucket0 + b;
+            if (unit_first[gb + 1] - unit_first[gb] == 1u) continue;
+            const uint32_t row0 = b * bl.rows_pb;
+            const uint32_t nrows = (bl.used - row0 < bl.rows_pb) ? (bl.used - row0) : bl.rows_pb;
+            float *dst = zero_acc + ((int64_t)first_idx[lvl] + row0) * F;
+            for (uint32_t e = threadIdx.x; e < nrows * (uint32_t)F; e += kBinThreads) dst[e] = 0.0f;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------- pass C
-// one work unit (a bucket, or a chunk of an over-full one) on the calling workgroup
-template <int F, bool FX, bool H>
+// One work unit (a bucket, or a chunk of an over-full one) on the calling workgroup. Every item format streams the same way
+// (`stream` below): the first round of 16-byte loads goes out BEFORE the image is zeroed, so the zeroing and its barrier sit
+// inside the loads' latency instead of in front of it; `hook()` runs once after the first round has been added (the
+// persistent kernel fetches its next unit's descriptor there). The fixed-point scale comes with the descriptor.
+template <int F, bool FX, bool H, class Hook>
 __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan &plan, const int32_t *__restrict__ first_idx,
                                              const UnitDesc d, const typename ItemSel<F, H>::type *__restrict__ items,
-                                             float *__restrict__ grad_table, int force_atomic,
-                                             const uint32_t *__restrict__ gmax, int headroom, double *s_acc) {
+                                             float *__restrict__ grad_table, int force_atomic, int headroom, double *s_acc,
+                                             Hook &&hook) {
     const uint32_t gb = d.bucket, lvl = d.level;
     const BinLevel bl = plan.lv[lvl];
     const uint32_t b = gb - bl.bucket0;
@@ -252,13 +272,27 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
     const uint32_t row0 = bl.compact ? b * bl.slab * r1 * r1 : b * bl.rows_pb;
     const uint32_t nrows = (bl.used - row0 < bl.rows_pb) ? (bl.used - row0) : bl.rows_pb;
 
-    for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) s_acc[e] = 0.0;   // all-zero bits either way
-    lds_barrier();
     FxScale fx{1.0, 1.0, false};
-    if constexpr (FX) fx = fx_scale_of(gmax[lvl], headroom);
+    if constexpr (FX) fx = fx_scale_of(d.gmax_bits, headroom);
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
-
+    auto zero_image = [&]() {
+        for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) s_acc[e] = 0.0;   // all-zero bits either way
+        lds_barrier();
+    };
     const uint64_t begin = d.begin, end = d.end;
+    // load(p0): the thread's round of items starting at p0 (elements past the unit's end come back with no valid corner);
+    // proc(): add the round to the image
+    auto stream = [&](uint64_t first, uint64_t lim, uint64_t stride, auto &&load, auto &&proc) {
+        uint64_t p0 = first;
+        load(p0);
+        zero_image();
+        proc();
+        hook();
+        for (p0 += stride; p0 < lim; p0 += stride) {
+            load(p0);
+            proc();
+        }
+    };
     const int rot = (int)(threadIdx.x & (F - 1));
     // feature order rotated by lane: the F slots of a row are consecutive 8-byte words, so with every lane adding feature j
     // in the same instruction only 1 / F of the LDS banks were addressed (half of the pass's LDS cycles were bank conflicts)
@@ -286,86 +320,96 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
             add_row(row, gg, wxy[c >> 1] * ((c & 1) ? fzz : gzz));
         }
     };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     if constexpr (F == 2 || F == 4) {
         if (bl.compact) {
             constexpr int UC = 2;
+            const uint64_t first = begin + 2ull * threadIdx.x, stride = 2ull * kConsumeThreads * UC;
             if constexpr (H && F == 4) {
                 // one sample per two 16-byte units: {local base row | valid, fx, fy, fz (fp32)} {half2 g01, half2 g23, -, -}
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
-                    u32x4 va[UC], vb2[UC];
+                u32x4 va[UC], vb2[UC];
+                stream(first, end, stride,
+                       [&](uint64_t p0) {
 #pragma unroll
-                    for (int u = 0; u < UC; ++u) {
-                        const uint64_t p = p0 + 2ull * u * kConsumeThreads;
-                        va[u] = u32x4{0u, 0u, 0u, 0u};
-                        vb2[u] = va[u];
-                        if (p + 1 < end) {
-                            va[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p));
-                            vb2[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p + 1));
-                        }
-                    }
+                           for (int u = 0; u < UC; ++u) {
+                               const uint64_t p = p0 + 2ull * u * kConsumeThreads;
+                               va[u] = u32x4{0u, 0u, 0u, 0u};
+                               vb2[u] = va[u];
+                               if (p + 1 < end) {
+                                   va[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p));
+                                   vb2[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p + 1));
+                               }
+                           }
+                       },
+                       [&]() {
 #pragma unroll
-                    for (int u = 0; u < UC; ++u) {
-                        if (!(va[u][0] & (1u << 26))) continue;
-                        const float2 g01 = half2_bits_to_float2(vb2[u][2]);
-                        const float2 g23 = half2_bits_to_float2(vb2[u][3]);
-                        const float gg[F] = {g01.x, g01.y, g23.x, g23.y};
-                        add_compact(va[u][0] & 0x1FFFu, __uint_as_float(va[u][1]), __uint_as_float(va[u][2]),
-                                    __uint_as_float(va[u][3]), gg);
-                    }
-                }
+                           for (int u = 0; u < UC; ++u) {
+                               if (!(va[u][0] & (1u << 26))) continue;
+                               const float2 g01 = half2_bits_to_float2(vb2[u][2]);
+                               const float2 g23 = half2_bits_to_float2(vb2[u][3]);
+                               const float gg[F] = {g01.x, g01.y, g23.x, g23.y};
+                               add_compact(va[u][0] & 0x1FFFu, __uint_as_float(va[u][1]), __uint_as_float(va[u][2]),
+                                           __uint_as_float(va[u][3]), gg);
+                           }
+                       });
             } else if constexpr (H) {
                 // one sample per 16-byte record (two 8-byte units): {local base row | valid, fx, fy, fz (u16), half2 g}
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
-                    ItemHC rec[UC];
+                ItemHC rec[UC];
+                stream(first, end, stride,
+                       [&](uint64_t p0) {
 #pragma unroll
-                    for (int u = 0; u < UC; ++u) {
-                        const uint64_t p = p0 + 2ull * u * kConsumeThreads;
-                        rec[u].key = 0;
-                        if (p + 1 < end) {
-                            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p));
-                            __builtin_memcpy(&rec[u], &v, 16);
-                        }
-                    }
+                           for (int u = 0; u < UC; ++u) {
+                               const uint64_t p = p0 + 2ull * u * kConsumeThreads;
+                               rec[u].key = 0;
+                               if (p + 1 < end) {
+                                   const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + p));
+                                   __builtin_memcpy(&rec[u], &v, 16);
+                               }
+                           }
+                       },
+                       [&]() {
 #pragma unroll
-                    for (int u = 0; u < UC; ++u) {
-                        if (!(rec[u].key & (1u << 26))) continue;
-                        const float2 gf = __half22float2(rec[u].g);
-                        const float gg[F] = {gf.x, gf.y};
-                        const float q = 1.0f / 65536.0f;
-                        add_compact(rec[u].key & 0x1FFFu, ((float)rec[u].fx + 0.5f) * q, ((float)rec[u].fy + 0.5f) * q,
-                                    ((float)rec[u].fz + 0.5f) * q, gg);
-                    }
-                }
+                           for (int u = 0; u < UC; ++u) {
+                               if (!(rec[u].key & (1u << 26))) continue;
+                               const float2 gf = __half22float2(rec[u].g);
+                               const float gg[F] = {gf.x, gf.y};
+                               const float q = 1.0f / 65536.0f;
+                               add_compact(rec[u].key & 0x1FFFu, ((float)rec[u].fx + 0.5f) * q, ((float)rec[u].fy + 0.5f) * q,
+                                           ((float)rec[u].fz + 0.5f) * q, gg);
+                           }
+                       });
             } else {
                 // one sample per two slots: F = 2 {local base row | valid, fx, fy, fz} {-, g0, g1, -}; F = 4 {.., fx, fy, fz,
                 // g0, g1} {-, g2, g3, ...}; all 8 corners land here
                 const Item<F> *itf = reinterpret_cast<const Item<F> *>(items);
-                for (uint64_t p0 = begin + 2ull * threadIdx.x; p0 < end; p0 += 2ull * kConsumeThreads * UC) {
-                    Item<F> ia[UC], ib[UC];
+                Item<F> ia[UC], ib[UC];
+                stream(first, end, stride,
+                       [&](uint64_t p0) {
 #pragma unroll
-                    for (int u = 0; u < UC; ++u) {
-                        const uint64_t p = p0 + 2ull * u * kConsumeThreads;
-                        if (p + 1 < end) {
-                            ia[u] = load_item_nt<F>(itf + p);
-                            ib[u] = load_item_nt<F>(itf + p + 1);
-                        } else {
-                            ia[u].key = 0;
-                        }
-                    }
+                           for (int u = 0; u < UC; ++u) {
+                               const uint64_t p = p0 + 2ull * u * kConsumeThreads;
+                               if (p + 1 < end) {
+                                   ia[u] = load_item_nt<F>(itf + p);
+                                   ib[u] = load_item_nt<F>(itf + p + 1);
+                               } else {
+                                   ia[u].key = 0;
+                               }
+                           }
+                       },
+                       [&]() {
 #pragma unroll
-                    for (int u = 0; u < UC; ++u) {
-                        if (!(ia[u].key & (1u << 26))) continue;
-                        float gg[F];
-                        if constexpr (F == 2) {
-                            gg[0] = ib[u].fx; gg[1] = ib[u].a[0];
-                        } else {
-                            gg[0] = ia[u].a[2]; gg[1] = ia[u].a[3]; gg[2] = ib[u].fx; gg[3] = ib[u].a[0];
-                        }
-                        add_compact(ia[u].key & 0x1FFFu, ia[u].fx, ia[u].a[0], ia[u].a[1], gg);
-                    }
-                }
+                           for (int u = 0; u < UC; ++u) {
+                               if (!(ia[u].key & (1u << 26))) continue;
+                               float gg[F];
+                               if constexpr (F == 2) {
+                                   gg[0] = ib[u].fx; gg[1] = ib[u].a[0];
+                               } else {
+                                   gg[0] = ia[u].a[2]; gg[1] = ia[u].a[3]; gg[2] = ib[u].fx; gg[3] = ib[u].a[0];
+                               }
+                               add_compact(ia[u].key & 0x1FFFu, ia[u].fx, ia[u].a[0], ia[u].a[1], gg);
+                           }
+                       });
             }
             lds_barrier();
             // neighbouring buckets share their boundary plane: everything is added atomically (the table is zeroed)
@@ -381,28 +425,28 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
     }
     constexpr int UN = 8;  // 16-byte loads in flight per thread (4: -1 %, 16: +3 % with the fixed-point atomics)
     if constexpr (H && F == 4) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
-            u32x4 v[UN];
+        u32x4 v[UN];
+        stream(begin + threadIdx.x, end, (uint64_t)kConsumeThreads * UN,
+               [&](uint64_t p0) {
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
-                v[u] = u32x4{0u, 0u, 0u, 0u};
-                if (pp < end) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + pp));
-            }
+                   for (int u = 0; u < UN; ++u) {
+                       const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
+                       v[u] = u32x4{0u, 0u, 0u, 0u};
+                       if (pp < end) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + pp));
+                   }
+               },
+               [&]() {
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const float2 a01 = half2_bits_to_float2(v[u][2]);
-                const float2 a23 = half2_bits_to_float2(v[u][3]);
-                const float a[F] = {a01.x, a01.y, a23.x, a23.y};
-                add_pair(v[u][0] & 0x1FFFu, (v[u][0] >> 13) & 0x1FFFu, (v[u][0] >> 26) & 1u, (v[u][0] >> 27) & 1u,
-                         __uint_as_float(v[u][1]), a);
-            }
-        }
+                   for (int u = 0; u < UN; ++u) {
+                       const float2 a01 = half2_bits_to_float2(v[u][2]);
+                       const float2 a23 = half2_bits_to_float2(v[u][3]);
+                       const float a[F] = {a01.x, a01.y, a23.x, a23.y};
+                       add_pair(v[u][0] & 0x1FFFu, (v[u][0] >> 13) & 0x1FFFu, (v[u][0] >> 26) & 1u, (v[u][0] >> 27) & 1u,
+                                __uint_as_float(v[u][1]), a);
+                   }
+               });
     } else if constexpr (H) {
         // 8-byte items read two at a time (16-byte loads from even unit indices); a unit's odd first / last item goes alone
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         auto consume8 = [&](uint32_t key, uint32_t payload) {
             uint32_t ra, rb;
             bool va, vb;
@@ -415,47 +459,52 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
             add_pair(ra, rb, va, vb, fxv, a);
         };
         uint64_t p = begin;
-        if ((p & 1ull) && p < end) {
-            if (threadIdx.x == 0) {
-                const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(items + p));
-                consume8(v[0], v[1]);
-            }
-            ++p;
-        }
+        const bool head = (p & 1ull) && p < end;
+        if (head) ++p;
         const uint64_t even_end = end & ~1ull;
-        for (uint64_t p0 = p + 2ull * threadIdx.x; p0 < even_end; p0 += 2ull * kConsumeThreads * UN) {
-            u32x4 v[UN];
+        u32x4 v[UN];
+        stream(p + 2ull * threadIdx.x, even_end, 2ull * kConsumeThreads * UN,
+               [&](uint64_t p0) {
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const uint64_t q = p0 + 2ull * u * kConsumeThreads;
-                v[u] = u32x4{0u, 0u, 0u, 0u};   // key 0: no valid corner
-                if (q < even_end) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + q));
-            }
+                   for (int u = 0; u < UN; ++u) {
+                       const uint64_t q = p0 + 2ull * u * kConsumeThreads;
+                       v[u] = u32x4{0u, 0u, 0u, 0u};   // key 0: no valid corner
+                       if (q < even_end) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + q));
+                   }
+               },
+               [&]() {
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                consume8(v[u][0], v[u][1]);
-                consume8(v[u][2], v[u][3]);
-            }
+                   for (int u = 0; u < UN; ++u) {
+                       consume8(v[u][0], v[u][1]);
+                       consume8(v[u][2], v[u][3]);
+                   }
+               });
+        if (head && threadIdx.x == 0) {
+            const u32x2 v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(items + begin));
+            consume8(v1[0], v1[1]);
         }
         if ((end & 1ull) && end - 1 >= p && threadIdx.x == 64) {
-            const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(items + end - 1));
-            consume8(v[0], v[1]);
+            const u32x2 v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(items + end - 1));
+            consume8(v1[0], v1[1]);
         }
     } else {
         const Item<F> *itf = reinterpret_cast<const Item<F> *>(items);
-        for (uint64_t p0 = begin + threadIdx.x; p0 < end; p0 += (uint64_t)kConsumeThreads * UN) {
-            Item<F> it[UN];
+        Item<F> it[UN];
+        stream(begin + threadIdx.x, end, (uint64_t)kConsumeThreads * UN,
+               [&](uint64_t p0) {
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
-                if (pp < end) it[u] = load_item_nt<F>(itf + pp);
-                else it[u].key = 0;
-            }
+                   for (int u = 0; u < UN; ++u) {
+                       const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
+                       if (pp < end) it[u] = load_item_nt<F>(itf + pp);
+                       else it[u].key = 0;
+                   }
+               },
+               [&]() {
 #pragma unroll
-            for (int u = 0; u < UN; ++u)
-                add_pair(it[u].key & 0x1FFFu, (it[u].key >> 13) & 0x1FFFu, (it[u].key >> 26) & 1u, (it[u].key >> 27) & 1u,
-                         it[u].fx, it[u].a);
-        }
+                   for (int u = 0; u < UN; ++u)
+                       add_pair(it[u].key & 0x1FFFu, (it[u].key >> 13) & 0x1FFFu, (it[u].key >> 26) & 1u,
+                                (it[u].key >> 27) & 1u, it[u].fx, it[u].a);
+               });
     }
     lds_barrier();
 
@@ -471,40 +520,57 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
     }
 }
 
-
 // Persistent form: `work_counter` non-NULL -> every workgroup keeps fetching units from it until they run out (grid = the
 // number of workgroups the chip holds, not the number of units). A unit of a small batch is ~10 us of work between a launch,
 // a 128 KiB image to zero and a flush whose stores s_endpgm would wait for: as separate workgroups (one per CU at a time)
 // nerf_lego.yaml's 1 800 units of 8 K items took 228 us; here the flush of unit k drains behind unit k + 1 (all barriers in
-// consume_unit are LDS-only). `work_counter` NULL: one unit per workgroup (small batches).
+// consume_unit are LDS-only). The fetch is pipelined one unit ahead: thread 0 draws the NEXT unit's number when a unit
+// starts and loads its descriptor once the first round of items is in (consume_unit's hook), so that neither the returning
+// atomic nor the descriptor load stands between two units. `work_counter` NULL: one unit per workgroup (small batches).
 template <int F, bool FX, bool H>
 __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable lt, BinPlan plan,
                                                                       const int32_t *__restrict__ first_idx,
-                                                                      const uint64_t *__restrict__ base,
                                                                       const uint32_t *__restrict__ unit_first,
                                                                       const UnitDesc *__restrict__ unit_desc,
                                                                       const typename ItemSel<F, H>::type *__restrict__ items,
                                                                       float *__restrict__ grad_table,
-                                                                      int force_atomic,
-                                                                      const uint32_t *__restrict__ gmax,
-                                                                      int headroom,
+                                                                      int force_atomic, int headroom,
                                                                       uint32_t *__restrict__ work_counter) {
     extern __shared__ double s_acc[];  // [rows_pb][F]: fp64, or 64-bit fixed point (same size)
+    __shared__ UnitDesc s_desc;
     __shared__ uint32_t s_unit;
-    const uint32_t unit0 = 0u, unit_end = unit_first[plan.total_buckets];
     if (work_counter == nullptr) {
-        const uint32_t unit = blockIdx.x + unit0;
-        if (unit >= unit_end) return;
-        consume_unit<F, FX, H>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
+        // (the descriptor array is sized for the grid: the load needs no bound check and goes out with the unit count's)
+        const UnitDesc d = unit_desc[blockIdx.x];
+        const uint32_t unit_end = unit_first[plan.total_buckets];
+        if (blockIdx.x >= unit_end) return;
+        consume_unit<F, FX, H>(lt, plan, first_idx, d, items, grad_table, force_atomic, headroom, s_acc, []() {});
         return;
     }
+    const uint32_t unit_end = unit_first[plan.total_buckets];
+    if (unit_end == 0u) return;
+    uint32_t nxt = 0;          // thread 0: the unit after the current one
+    UnitDesc dn;               // thread 0: its descriptor
+    if (threadIdx.x == 0) {
+        const uint32_t u = atomicAdd(work_counter, 1u);
+        s_unit = u;
+        s_desc = unit_desc[u < unit_end ? u : unit_end - 1u];
+    }
+    lds_barrier();
     for (;;) {
-        if (threadIdx.x == 0) s_unit = atomicAdd(work_counter, 1u);
-        lds_barrier();
-        const uint32_t unit = s_unit + unit0;
+        const uint32_t unit = s_unit;
         if (unit >= unit_end) return;
-        consume_unit<F, FX, H>(lt, plan, first_idx, unit_desc[unit], items, grad_table, force_atomic, gmax, headroom, s_acc);
-        lds_barrier();   // the image and s_unit are free again; the flush stores keep draining
+        const UnitDesc d = s_desc;
+        if (threadIdx.x == 0) nxt = atomicAdd(work_counter, 1u);
+        consume_unit<F, FX, H>(lt, plan, first_idx, d, items, grad_table, force_atomic, headroom, s_acc, [&]() {
+            if (threadIdx.x == 0) dn = unit_desc[nxt < unit_end ? nxt : unit_end - 1u];
+        });
+        // (every thread read s_unit / s_desc before the barriers inside consume_unit: thread 0 may overwrite them now)
+        if (threadIdx.x == 0) {
+            s_unit = nxt;
+            s_desc = dn;
+        }
+        lds_barrier();   // the next unit is known and the image is free again; the flush stores keep draining
     }
 }
 

@@ -145,7 +145,7 @@ struct alignas(16) UnitDesc {
     uint32_t bucket;       // global bucket index
     uint32_t level;
     uint32_t single;       // 1: the bucket's only unit (rows are written with plain stores)
-    uint32_t pad;
+    uint32_t gmax_bits;    // bit pattern of the level's max |grad_output| (fixed-point scale; 0 when the call keeps fp64)
 };
 
 // Workgroup barrier that orders LDS traffic only. __syncthreads() also drains the wave's global loads AND stores

@@ -438,17 +438,22 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         SHACIRA_CHECK(hipStreamWaitEvent(ss->stream, ss->fork, 0));
         zs = ss->stream;
     }
+    // bucket totals (and, when this call transposes, the per-level max |grad_output| right behind them) start at zero
+    const bool need_words = whole.nbl > 0 || (!staged && use_fx);
+    const uint32_t words = (uint32_t)kTotalShards * kMaxBuckets + ((!staged && use_fx) ? SHACIRA_MAX_LODS : 0);
+    bool words_done = false;
     if (zero_table) {   // at::zeros_like of the reference
         if (!selective) {
             SHACIRA_CHECK(zero_fill_async(acc, (int64_t)lt.table_rows * lt.feature_dim, zs));
         } else {
-            hipLaunchKernelGGL(zero_unowned_rows_kernel, dim3(256, (uint32_t)L), dim3(256), 0, zs, acc, first_idx, lt, whole);
+            // (same stream: the control words ride along as one extra slice of this launch)
+            words_done = need_words && zs == s;
+            hipLaunchKernelGGL(zero_unowned_rows_kernel, dim3(256, (uint32_t)L + (words_done ? 1u : 0u)), dim3(256), 0, zs, acc,
+                               first_idx, lt, whole, w.totals, words);
             SHACIRA_CHECK_LAUNCH();
         }
     }
-    // bucket totals (and, when this call transposes, the per-level max |grad_output| right behind them) start at zero
-    if (whole.nbl > 0 || (!staged && use_fx)) {
-        const uint32_t words = (uint32_t)kTotalShards * kMaxBuckets + ((!staged && use_fx) ? SHACIRA_MAX_LODS : 0);
+    if (need_words && !words_done) {
         hipLaunchKernelGGL(zero_words_kernel, dim3(32), dim3(256), 0, s, w.totals, words);
         SHACIRA_CHECK_LAUNCH();
     }
@@ -555,23 +560,21 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         }
         first_batch = false;
         hipLaunchKernelGGL(bin_scan_buckets_kernel, dim3(1), dim3(1024), 0, s, w.totals, w.base, w.unit_first, w.unit_desc,
-                           plan.total_buckets, plan, w.work_counter, w.cursor);
+                           plan.total_buckets, plan, w.work_counter, w.cursor, use_fx ? w.gmax : nullptr);
         SHACIRA_CHECK_LAUNCH();
-        if (selective) {   // hashed buckets with 0 or several units are zeroed now (the others are overwritten)
-            hipLaunchKernelGGL(zero_odd_buckets_kernel, dim3(kMaxLevelBuckets, plan.nbl), dim3(256), 0, s, acc, first_idx,
-                               w.unit_first, lt, plan);
-            SHACIRA_CHECK_LAUNCH();
-        }
+        // (selective zeroing: hashed buckets with 0 or several units are zeroed by the scatter pass's tail)
+        float *zacc = selective ? acc : nullptr;
         const uint32_t cps = fused_now ? (uint32_t)(TileOf<DIM>::value / ts16) : 1u;
         const uint32_t cnt_rows = fused_now ? (uint32_t)((n + ts16 - 1) / ts16) : plan.num_tiles;
         if (half)
             hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
                                stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
-                               reinterpret_cast<typename ItemSel<F, true>::type *>(w.items), s0, hi, NP);
+                               reinterpret_cast<typename ItemSel<F, true>::type *>(w.items), s0, hi, NP, zacc, first_idx,
+                               w.unit_first);
         else
             hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
                                stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
-                               reinterpret_cast<Item<F> *>(w.items), s0, hi, NP);
+                               reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
         SHACIRA_CHECK_LAUNCH();
         if (fork) SHACIRA_CHECK(hipStreamWaitEvent(s, ss->join, 0));   // table zeroed, direct levels in
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NPAIR;
@@ -583,24 +586,23 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         uint32_t *wc = (opt().bwd_persistent != 0 && n >= (1 << 17)) ? w.work_counter : nullptr;
         if (wc != nullptr && grid_units > 512u) grid_units = 512u;
         const int headroom = use_fx ? fx_headroom((uint64_t)plan.chunk + 1) : -1;   // a unit streams <= chunk items
-        const uint32_t *gm = use_fx ? w.gmax : nullptr;
         const int fa = multi ? 1 : 0;
         if (half && use_fx)
             hipLaunchKernelGGL((bin_consume_kernel<F, true, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s,
-                               lt, plan, first_idx, w.base, w.unit_first, w.unit_desc,
-                               reinterpret_cast<const typename ItemSel<F, true>::type *>(w.items), acc, fa, gm, headroom, wc);
+                               lt, plan, first_idx, w.unit_first, w.unit_desc,
+                               reinterpret_cast<const typename ItemSel<F, true>::type *>(w.items), acc, fa, headroom, wc);
         else if (half)
             hipLaunchKernelGGL((bin_consume_kernel<F, false, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s,
-                               lt, plan, first_idx, w.base, w.unit_first, w.unit_desc,
-                               reinterpret_cast<const typename ItemSel<F, true>::type *>(w.items), acc, fa, gm, headroom, wc);
+                               lt, plan, first_idx, w.unit_first, w.unit_desc,
+                               reinterpret_cast<const typename ItemSel<F, true>::type *>(w.items), acc, fa, headroom, wc);
         else if (use_fx)
             hipLaunchKernelGGL((bin_consume_kernel<F, true, false>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,
-                               plan, first_idx, w.base, w.unit_first, w.unit_desc,
-                               reinterpret_cast<const Item<F> *>(w.items), acc, fa, gm, headroom, wc);
+                               plan, first_idx, w.unit_first, w.unit_desc,
+                               reinterpret_cast<const Item<F> *>(w.items), acc, fa, headroom, wc);
         else if (!half)
             hipLaunchKernelGGL((bin_consume_kernel<F, false, false>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,
-                               plan, first_idx, w.base, w.unit_first, w.unit_desc,
-                               reinterpret_cast<const Item<F> *>(w.items), acc, fa, gm, headroom, wc);
+                               plan, first_idx, w.unit_first, w.unit_desc,
+                               reinterpret_cast<const Item<F> *>(w.items), acc, fa, headroom, wc);
         SHACIRA_CHECK_LAUNCH();
     }
     return hipSuccess;
