@@ -378,14 +378,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
 #pragma unroll
         for (int u = 0; u < SPT; ++u) {
             if (!live[u]) continue;
-            if constexpr (DIM == 3) {
-                if (bl.compact) {
-                    int32_t pz;
-                    float fz, gz;
-                    axis_transform(t[u][2], res, hi, pz, fz, gz);
-                    atomicAdd(&s_hist[bi][(uint32_t)pz / bl.slab], 2u);
-                    continue;
+            if (bl.compact) {
+                if constexpr (DIM == 3) {
+                    atomicAdd(&s_hist[bi][axis_pos(t[u][2], res, hi) / bl.slab], 2u);
+                } else {
+                    atomicAdd(&s_hist[bi][compact2d_line(axis_pos(t[u][1], res, hi), (uint32_t)res) / bl.slab], 1u);
                 }
+                continue;
             }
             uint32_t bk[1 << (DIM - 1)];
             bool ok[1 << (DIM - 1)];

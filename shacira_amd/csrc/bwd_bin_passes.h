@@ -51,7 +51,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     float fx[SPT];
     float g[SPT][F];
     float fyz[SPT][2];   // compact levels: y / z fractions travel with the item
-    const bool compact = (DIM == 3) && bl.compact != 0;
+    const bool compact = bl.compact != 0;   // (2-D: fp32 item stream only -- the plan never marks a level otherwise)
+    constexpr uint32_t kCompactSlots = (DIM == 3) ? 2u : 1u;
     // every global load of the workgroup up front, unconditional (indices clamped into the batch): coordinates and
     // gradients of the thread's samples, then -- waves 1 and 2 -- the tile's bucket counts (rows of cnt[tile][bucket]
     // written by the counting pass) and straight away the returning atomic that reserves the bucket's run: it is the
@@ -111,6 +112,23 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                     ps[u][q].wrest = 0.0f;
                 }
                 ps[u][0].key = local | (1u << 26);
+            } else {
+                // 2-D: local row of the base corner inside the bucket's image (slab of lines + one halo line)
+                int32_t pp[2];
+                float ff[2], gg[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) axis_transform(t[a], res, hi, pp[a], ff[a], gg[a]);
+                const uint32_t r = (uint32_t)res, b = compact2d_line((uint32_t)pp[1], r) / bl.slab;
+                const uint32_t local = ((uint32_t)pp[1] - b * bl.slab) * r + (uint32_t)pp[0];
+                fx[u] = ff[0];
+                fyz[u][0] = ff[1];
+                fyz[u][1] = 0.0f;
+                ps[u][0].bucket = b;
+                ps[u][0].key = local | (1u << 26);
+                ps[u][0].wrest = 0.0f;
+                ps[u][1].bucket = b;
+                ps[u][1].key = 0;
+                ps[u][1].wrest = 0.0f;
             }
         } else {
             enumerate_pairs<DIM>(t, res, hi, dense, lt.mask, bl, plan.BR, fx[u], ps[u]);
@@ -118,7 +136,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             if (!live) ps[u][q].key = 0;
-            rank[u][q] = (ps[u][q].key >> 26) ? atomicAdd(&s_hist[ps[u][q].bucket], compact ? 2u : 1u) : 0u;
+            rank[u][q] = (ps[u][q].key >> 26) ? atomicAdd(&s_hist[ps[u][q].bucket], compact ? kCompactSlots : 1u) : 0u;
         }
     }
     lds_barrier();   // (not __syncthreads(): its vmcnt(0) would wait for the reservation)
@@ -193,6 +211,19 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                 Item<F> it;
                 it.key = ps[u][q].key;
                 it.fx = fx[u];
+                if constexpr (DIM == 2 && !H) {
+                    if (compact) {   // one slot: {local | valid | fx, fy (25-bit fixed point), g[F]}
+                        uint32_t w0, w1;
+                        pack_compact2d(ps[u][q].key, fx[u], fyz[u][0], w0, w1);
+                        it.key = w0;
+                        it.fx = __uint_as_float(w1);
+#pragma unroll
+                        for (int j = 0; j < F; ++j) it.a[j] = g[u][j];
+                        *reinterpret_cast<Item<F> *>(&s_items[pos]) = it;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                        continue;
+                    }
+                }
                 if (compact) {
                     if constexpr (F == 2) {   // two slots: {key, fx, fy, fz} {0, g0, g1, 0}
                         it.a[0] = fyz[u][0];
@@ -269,7 +300,8 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
     const uint32_t b = gb - bl.bucket0;
     const uint32_t r1 = (uint32_t)lt.res[lvl];
     // compact levels: the image starts at the bucket's first base plane and includes one halo plane
-    const uint32_t row0 = bl.compact ? b * bl.slab * r1 * r1 : b * bl.rows_pb;
+    const bool two_d = plan.pairs == 2u;
+    const uint32_t row0 = bl.compact ? b * bl.slab * (two_d ? r1 : r1 * r1) : b * bl.rows_pb;
     const uint32_t nrows = (bl.used - row0 < bl.rows_pb) ? (bl.used - row0) : bl.rows_pb;
 
     FxScale fx{1.0, 1.0, false};
@@ -322,6 +354,57 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    if constexpr ((F == 2 || F == 4) && !H) {
+        if (bl.compact && two_d) {
+            // 2-D: one sample per item {local base row | valid | fx, fy (25-bit fixed point), g[F]}; 4 corners
+            const Item<F> *itf = reinterpret_cast<const Item<F> *>(items);
+            constexpr int UD = 8;
+            Item<F> it[UD];
+            stream(begin + threadIdx.x, end, (uint64_t)kConsumeThreads * UD,
+                   [&](uint64_t p0) {
+#pragma unroll
+                       for (int u = 0; u < UD; ++u) {
+                           const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
+                           if (pp < end) it[u] = load_item_nt<F>(itf + pp);
+                           else it[u].key = 0;
+                       }
+                   },
+                   [&]() {
+#pragma unroll
+                       for (int u = 0; u < UD; ++u) {
+                           if (!(it[u].key & (1u << 13))) continue;
+                           uint32_t local, qx, qy;
+                           unpack_compact2d(it[u].key, __float_as_uint(it[u].fx), local, qx, qy);
+                           const float q = 1.0f / 33554432.0f;
+                           const float fxx = (float)qx * q, fyy = (float)qy * q;
+                           const float gxx = 1.0f - fxx, gyy = 1.0f - fyy;
+                           // a zero fraction = a corner of weight 0 (it lies outside the level when the coordinate was clamped
+                           // onto the last line / column): skipped, like the pair items' validity bits
+                           if (local + r1 + 1u < nrows) {
+                               add_row(local, it[u].a, gxx * gyy);
+                               if (qx) add_row(local + 1u, it[u].a, fxx * gyy);
+                               if (qy) {
+                                   add_row(local + r1, it[u].a, gxx * fyy);
+                                   if (qx) add_row(local + r1 + 1u, it[u].a, fxx * fyy);
+                               }
+                           } else {   // the level's last line: only rows inside the image
+                               if (local < nrows) add_row(local, it[u].a, gxx * gyy);
+                               if (qx && local + 1u < nrows) add_row(local + 1u, it[u].a, fxx * gyy);
+                               if (qy && local + r1 < nrows) add_row(local + r1, it[u].a, gxx * fyy);
+                           }
+                       }
+                   });
+            lds_barrier();
+            const int64_t grow0d = (int64_t)first_idx[lvl] + row0;
+            for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) {
+                const int64_t grow = grow0d + e / F;
+                if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
+                const float v = (FX && fx.fixed) ? fx_decode(s_fix[e], fx.inv) : (float)s_acc[e];
+                if (v != 0.0f) unsafeAtomicAdd(grad_table + grow * F + (e % F), v);
+            }
+            return;
+        }
+    }
     if constexpr (F == 2 || F == 4) {
         if (bl.compact) {
             constexpr int UC = 2;
@@ -596,7 +679,14 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
     const uint32_t grp = blockIdx.y;
     const uint32_t rows = plan.grows[grp];
     const uint32_t mask = plan.gmask[grp];
-    if (threadIdx.x == 0) s_all_fixed = 1;
+    __shared__ int s_lv[SHACIRA_MAX_LODS], s_nl;   // the group's levels
+    if (threadIdx.x == 0) {
+        s_all_fixed = 1;
+        int n = 0;
+        for (int l = 0; l < lt.num_lods; ++l)
+            if ((mask >> l) & 1u) s_lv[n++] = l;
+        s_nl = n;
+    }
     for (uint32_t e = threadIdx.x; e < rows * F; e += kConsumeThreads) s_acc[e] = 0.0;
     __syncthreads();
     if constexpr (FX) {
@@ -612,35 +702,60 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
     const int64_t stride = (int64_t)gridDim.x * kConsumeThreads;
     const int rotd = (int)(threadIdx.x & (F - 1));
-    for (int64_t i = (int64_t)blockIdx.x * kConsumeThreads + threadIdx.x; i < N; i += stride) {
+    // The walk is a chain of memory latencies at 16 waves per CU (one 128 KiB image per CU), so every load goes out as early
+    // as it can: the NEXT sample's coordinates while this one is added, and the gradients of kLv levels of the group at a
+    // time, unconditionally (the group's level list sits in LDS; slots past its end repeat the last level and are skipped).
+    constexpr int kLv = 4;
+    const int nl = s_nl;
+    int64_t i = (int64_t)blockIdx.x * kConsumeThreads + threadIdx.x;
+    float cn[DIM];
+    {
+        const int64_t ic = i < N ? i : N - 1;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) cn[a] = coords[ic * DIM + a];
+    }
+    for (; i < N; i += stride) {
         double t[DIM];
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
-        for (int l = 0; l < lt.num_lods; ++l) {
-            if (!((mask >> l) & 1u)) continue;
-            const BinLevel bl = plan.lv[l];
-            Corners<DIM> c;
-            compute_corners<DIM>(t, lt.res[l], lt.hi[l], lt.dense[l] != 0, lt.mask, c);
-            const GT *gp = TRANSPOSED ? gT + ((int64_t)l * gpitch + i) * F : gT + (i * lt.num_lods + l) * F;
-            float g[F];
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(cn[a]);
+        {
+            const int64_t in = (i + stride < N) ? i + stride : N - 1;
 #pragma unroll
-            for (int j = 0; j < F; ++j) g[j] = Scalar<GT>::load(gp + j);
-            const double scale = FX ? s_scale[l] : 1.0;
+            for (int a = 0; a < DIM; ++a) cn[a] = coords[in * DIM + a];
+        }
+        for (int q0 = 0; q0 < nl; q0 += kLv) {
+            float g[kLv][F];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                if (c.row[k] < bl.used) {
-                    const size_t slot = (size_t)(bl.drow0 + c.row[k]) * F;
-                    if (fixed) {
+            for (int k = 0; k < kLv; ++k) {
+                const int l = s_lv[(q0 + k < nl) ? q0 + k : nl - 1];
+                const GT *gp = TRANSPOSED ? gT + ((int64_t)l * gpitch + i) * F : gT + (i * lt.num_lods + l) * F;
 #pragma unroll
-                        for (int jj = 0; jj < F; ++jj) {   // feature order rotated by lane (LDS bank spreading)
-                            const int j = (jj + rotd) & (F - 1);
-                            atomicAdd(s_fix + slot + j, fx_encode(pick<F>(g, j) * c.w[k], scale));
-                        }
-                    } else {
+                for (int j = 0; j < F; ++j) g[k][j] = Scalar<GT>::load(gp + j);
+            }
 #pragma unroll
-                        for (int jj = 0; jj < F; ++jj) {
-                            const int j = (jj + rotd) & (F - 1);
-                            atomicAdd(s_acc + slot + j, (double)(pick<F>(g, j) * c.w[k]));
+            for (int k = 0; k < kLv; ++k) {
+                if (q0 + k >= nl) continue;
+                const int l = s_lv[q0 + k];
+                const BinLevel bl = plan.lv[l];
+                Corners<DIM> c;
+                compute_corners<DIM>(t, lt.res[l], lt.hi[l], lt.dense[l] != 0, lt.mask, c);
+                const double scale = FX ? s_scale[l] : 1.0;
+#pragma unroll
+                for (int kc = 0; kc < NC; ++kc) {
+                    if (c.row[kc] < bl.used) {
+                        const size_t slot = (size_t)(bl.drow0 + c.row[kc]) * F;
+                        if (fixed) {
+#pragma unroll
+                            for (int jj = 0; jj < F; ++jj) {   // feature order rotated by lane (LDS bank spreading)
+                                const int j = (jj + rotd) & (F - 1);
+                                atomicAdd(s_fix + slot + j, fx_encode(pick<F>(g[k], j) * c.w[kc], scale));
+                            }
+                        } else {
+#pragma unroll
+                            for (int jj = 0; jj < F; ++jj) {
+                                const int j = (jj + rotd) & (F - 1);
+                                atomicAdd(s_acc + slot + j, (double)(pick<F>(g[k], j) * c.w[kc]));
+                            }
                         }
                     }
                 }

@@ -282,6 +282,23 @@ __device__ __forceinline__ void enumerate_buckets(const double (&t)[DIM], int32_
     }
 }
 
+// 2-D compact levels: the line that picks a sample's bucket. Base cells sit on lines [0, res - 2]; a coordinate clamped onto
+// the last line (y == hi == res - 1 exactly, possible from res = 513 on) stays in the last slab: its y + 1 corner has weight 0.
+__device__ __forceinline__ uint32_t compact2d_line(uint32_t py, uint32_t res) { return py < res - 2u ? py : res - 2u; }
+
+// 2-D compact item, first 8 bytes: local base row (13 bits) | valid (bit 13) | fx and fy as 25-bit fixed point (exact for
+// fractions >= 0.25, 2^-25 absolute below: the reference's own `1 - fx` rounds at 2^-25)
+__device__ __forceinline__ void pack_compact2d(uint32_t local, float fx, float fy, uint32_t &w0, uint32_t &w1) {
+    const uint32_t qx = (uint32_t)(fx * 33554432.0f), qy = (uint32_t)(fy * 33554432.0f);   // < 2^25: fractions are < 1
+    w0 = (local & 0x1FFFu) | (1u << 13) | ((qx >> 7) << 14);
+    w1 = ((qx & 127u) << 25) | qy;
+}
+__device__ __forceinline__ void unpack_compact2d(uint32_t w0, uint32_t w1, uint32_t &local, uint32_t &qx, uint32_t &qy) {
+    local = w0 & 0x1FFFu;
+    qx = ((w0 >> 14) << 7) | (w1 >> 25);
+    qy = w1 & 0x1FFFFFFu;
+}
+
 // position along one axis only (axis_transform without the fractions)
 __device__ __forceinline__ uint32_t axis_pos(double t, int32_t res, float hi) {
     float x = (float)((double)res * t);
@@ -298,6 +315,10 @@ __device__ __forceinline__ void count_level(const double (&t)[DIM], const CountL
             const uint32_t pz = axis_pos(t[2], cl.res, cl.hi);
             const uint32_t b = cl.m_lo ? (__umul24(pz, cl.m_lo) >> 18) : pz / cl.m_hi;
             atomicAdd(hist + b, 2u);
+        } else {   // 2-D compact: one 16-byte item per sample, bucket = slab of base lines (compact2d_line)
+            const uint32_t py = compact2d_line(axis_pos(t[1], cl.res, cl.hi), (uint32_t)cl.res);
+            const uint32_t b = cl.m_lo ? (__umul24(py, cl.m_lo) >> 18) : py / cl.m_hi;
+            atomicAdd(hist + b, 1u);
         }
     } else if (cl.kind == 0u) {
         const uint32_t hy0 = axis_pos(t[1], cl.res, cl.hi) * kPrimeY, hy1 = hy0 + kPrimeY;

@@ -42,11 +42,13 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // `one_image_compact`: a dense 3-D level that fits ONE image travels as compact items too (one bucket whose units flush
 // atomically) instead of the direct pass in front of the scatter pass; decided per CALL from the total batch (below), so
 // that every plan of a call classifies the levels alike
-static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib, bool one_image_compact);
+static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
+                      bool one_image_compact);
+static inline bool half_items(int dtype, const LevelTable &lt);
 static inline bool one_image_compact_rule(int64_t n_total) { return n_total >= ((int64_t)1 << 17); }
 
 // can the table be partitioned with an LDS accumulator image of `acc_kib` KiB per consumer workgroup?
-static bool bin_feasible(int dim, const LevelTable &lt, int acc_kib) {
+static bool bin_feasible(int dim, int dtype, const LevelTable &lt, int acc_kib) {
     const int F = lt.feature_dim;
     if (F != 2 && F != 4) return false;
     const uint32_t BR = (uint32_t)acc_kib * 128u / (uint32_t)F;  // rows of the fp64 image
@@ -62,7 +64,7 @@ static bool bin_feasible(int dim, const LevelTable &lt, int acc_kib) {
         }
     }
     BinPlan plan;
-    make_plan(dim, lt, kTile, plan, acc_kib, false);
+    make_plan(dim, dtype, lt, kTile, plan, acc_kib, false);
     if (plan.total_buckets + (uint32_t)lt.num_lods > (uint32_t)kMaxBuckets) return false;   // (+ one-image compact levels)
     for (int l = 0; l < lt.num_lods; ++l)
         if (plan.lv[l].nb > (uint32_t)kMaxLevelBuckets) return false;
@@ -72,26 +74,28 @@ static bool bin_feasible(int dim, const LevelTable &lt, int acc_kib) {
 // Image size per call, from the TOTAL batch (one choice per call so that every plan of the call classifies the levels
 // alike). Option "bin_acc_kib": 64 / 128 force it, 0 (default) = measured rule: 64 KiB images (two consumer workgroups
 // per CU overlap their zero / stream / flush phases) win up to 2^19 3-D samples, 128 KiB (half as many buckets) beyond.
-static int choose_acc_kib(int dim, const LevelTable &lt, int64_t n) {
+static int choose_acc_kib(int dim, int dtype, const LevelTable &lt, int64_t n) {
     const int kib = opt().bin_acc_kib;
     if (kib != 0) return kib;
     const int64_t pairs = (int64_t)1 << (dim - 1);
-    if (n * pairs > ((int64_t)1 << 21) || !bin_feasible(dim, lt, 64)) return 128;
+    if (n * pairs > ((int64_t)1 << 21) || !bin_feasible(dim, dtype, lt, 64)) return 128;
     // tables whose levels are all "direct" (config B: every level fits an LDS image) want the big image: fewer level
     // groups, hence fewer walks over the samples (measured 82 vs 124 us on the 393 216-pixel batch)
     BinPlan big;
-    make_plan(dim, lt, kTile, big, 128, false);
+    make_plan(dim, dtype, lt, kTile, big, 128, false);
     return big.nbl == 0 ? 128 : 64;
 }
 
 bool bin_supported(int dim, const LevelTable &lt) {
     const int kib = opt().bin_acc_kib;
-    return bin_feasible(dim, lt, kib ? kib : 128);
+    // (fp32 plan: its 2-D compact levels need a few more buckets than the half-precision stream's pair items)
+    return bin_feasible(dim, SHACIRA_F32, lt, kib ? kib : 128);
 }
 
-static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib, bool one_image_compact) {
+static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
+                      bool one_image_compact) {
     if (one_image_compact) {   // tables whose levels are ALL direct stay that way (no transposing pass at all)
-        make_plan(dim, lt, n_batch, plan, acc_kib, false);
+        make_plan(dim, dtype, lt, n_batch, plan, acc_kib, false);
         if (plan.nbl == 0) return;
     }
     const int F = lt.feature_dim;
@@ -130,16 +134,21 @@ static void make_plan(int dim, const LevelTable &lt, int64_t n_batch, BinPlan &p
             // Compact mode (3-D, F = 2): when an image holds at least two z-planes of the level, bucket = slab of base
             // cells in z and the image = that slab plus one halo plane, so all 8 corners of a sample land in ONE
             // bucket and the sample travels as one 32-byte item instead of four 16-byte pair items.
-            const uint64_t planes = (dim == 3 && (F == 2 || F == 4) && opt().bwd_compact != 0) ? BR / (res * res) : 0;
+            // 2-D (fp32 item stream): the same with slabs of LINES -- all 4 corners in one bucket, one 8 + 4 F byte item per
+            // sample (fractions as 25-bit fixed point) instead of two pair items
+            const bool cm = (F == 2 || F == 4) && opt().bwd_compact != 0 && (dim == 3 || !half_items(dtype, lt));
+            const uint64_t plane_rows = (dim == 3) ? res * res : res;
+            const uint64_t planes = cm ? BR / plane_rows : 0;
             // (exp2: a level that fits ONE image may also travel as compact items -- one bucket, its units flush atomically --
-            // instead of the direct pass that walks the whole batch in front of the scatter pass)
-            if (planes >= 2 && res >= 3 && (bl.used > BR || one_image_compact)) {
+            // instead of the direct pass that walks the whole batch in front of the scatter pass; 3-D only: on the 2-D bw-19
+            // table it turns six more levels into items, 0.314 -> 0.352 ms at 2^20 samples)
+            if (planes >= 2 && res >= 3 && (bl.used > BR || (one_image_compact && dim == 3))) {
                 const uint32_t slab = (uint32_t)planes - 1;
-                const uint32_t nbz = ((uint32_t)res - 2u) / slab + 1u;      // base cells: z in [0, res - 2]
+                const uint32_t nbz = ((uint32_t)res - 2u) / slab + 1u;      // base cells: z (2-D: y) in [0, res - 2]
                 if (nbz <= (uint32_t)kMaxLevelBuckets) {
                     bl.compact = 1;
                     bl.slab = slab;
-                    bl.rows_pb = (slab + 1u) * (uint32_t)(res * res);
+                    bl.rows_pb = (slab + 1u) * (uint32_t)plane_rows;
                     bl.nb = nbz;
                 }
             }
@@ -258,7 +267,7 @@ static inline size_t item_unit_bytes(int dtype, const LevelTable &lt) {
 static int64_t bin_batch_samples(int dim, int dtype, const LevelTable &lt, int64_t n) {
     const size_t item = item_unit_bytes(dtype, lt);
     BinPlan plan;
-    make_plan(dim, lt, kTile, plan, choose_acc_kib(dim, lt, n), one_image_compact_rule(n));
+    make_plan(dim, dtype, lt, kTile, plan, choose_acc_kib(dim, dtype, lt, n), one_image_compact_rule(n));
     const size_t per_sample = (size_t)(plan.nbl ? plan.nbl : 1) * (1u << (dim - 1)) * item;
     int64_t cap = (int64_t)(((size_t)opt().bin_batch_mib << 20) / per_sample);
     cap = cap / tile_samples(dim) * tile_samples(dim);
@@ -286,7 +295,7 @@ static inline int64_t level_pitch(int64_t n) { return (n + 1) & ~(int64_t)1; }
 static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, void *ws) {
     BinPlan plan;
     const int64_t nb = bin_batch_samples(dim, dtype, lt, n);
-    make_plan(dim, lt, nb, plan, choose_acc_kib(dim, lt, n), one_image_compact_rule(n));
+    make_plan(dim, dtype, lt, nb, plan, choose_acc_kib(dim, dtype, lt, n), one_image_compact_rule(n));
     const size_t item = item_unit_bytes(dtype, lt);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -400,9 +409,9 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     const int L = lt.num_lods;
     const int64_t NP = level_pitch(n);
     BinPlan whole;
-    const int acc_kib = choose_acc_kib(DIM, lt, n);
+    const int acc_kib = choose_acc_kib(DIM, dtype, lt, n);
     const bool oic = one_image_compact_rule(n);
-    make_plan(DIM, lt, n, whole, acc_kib, oic);
+    make_plan(DIM, dtype, lt, n, whole, acc_kib, oic);
     const int64_t nb = bin_batch_samples(DIM, dtype, lt, n);
     const bool multi = nb < n;
     const bool stage_all = (lt.stage_flags & SHACIRA_BWD_STAGE_ALL_LEVELS) != 0;
@@ -547,7 +556,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
         BinPlan plan;
-        make_plan(DIM, lt, hi - s0, plan, acc_kib, oic);
+        make_plan(DIM, dtype, lt, hi - s0, plan, acc_kib, oic);
         if (!first_batch) {
             hipLaunchKernelGGL(zero_words_kernel, dim3(32), dim3(256), 0, s, w.totals, (uint32_t)kTotalShards * kMaxBuckets);
             SHACIRA_CHECK_LAUNCH();

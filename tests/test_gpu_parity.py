@@ -912,6 +912,36 @@ def test_compact_dense_items_nerf_lego_table(dev, n, F):
         _lib.set_option("bwd_compact", 1)
 
 
+@pytest.mark.parametrize("F", [2, 4])
+@pytest.mark.parametrize("n", [40_000, (1 << 17) + 7, (1 << 19) + 1])
+def test_compact_dense_items_2d_table(dev, n, F):
+    """2-D table with dense levels larger than one accumulator image (res 16..2048, bw 19: 12 dense levels up to 563^2
+    rows): those levels travel as ONE item per sample (8 + 4 F bytes: local base row, fx / fy as 25-bit fixed point, the
+    gradient) in buckets of whole lines with a halo line, instead of two pair items (option bwd_compact). Coordinates
+    clamped onto the last line / column (+1 exactly; res >= 513 makes hi == res - 1) are part of the batch. Same gradient
+    as the pair-item path and as the oracle, small batch (64 KiB images), large (128 KiB, fixed point)."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, bw = 2, 19
+    res = geo(16, 2048, 16)
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, F=F, seed=43)
+    coords[8:40, 1] = 1.0                      # a run of samples on the last line
+    coords[40:60, 0] = 1.0                     # and on the last column
+    coords[60:70] = np.float32(-1.0)
+    tc, tg, tf = (torch.from_numpy(a).to(dev) for a in (coords, go, first))
+    ref = oc.backward(coords, go, (T, F), first, res, bw)
+    try:
+        for compact in (1, 0):
+            _lib.set_option("bwd_compact", compact)
+            got = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, F).cpu().numpy()
+            for l in range(len(res)):
+                lo, hi = int(first[l]), int(first[l]) + sizes[l]
+                np.testing.assert_allclose(got[lo:hi], ref[lo:hi], rtol=RTOL, atol=RTOL * np.abs(ref[lo:hi]).max(),
+                                           err_msg=f"level {l} res {res[l]} compact={compact}")
+    finally:
+        _lib.set_option("bwd_compact", 1)
+
+
 def test_shipped_kodak_yaml_shape_through_latent_grid(dev):
     """kodak.yaml as shipped (app/image/configs/kodak.yaml:29-33: 24 levels, feature_dim 1 -> the repeat-to-2 trick of
     latent_grid.py:361-370, bw 11, res 16..512, latent_dim 1) at the full image batch of 393 216 pixels, through
