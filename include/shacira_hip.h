@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SHACIRA_ABI_VERSION 7
+#define SHACIRA_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define SHACIRA_API __attribute__((visibility("default")))
@@ -254,6 +254,41 @@ SHACIRA_API int shacira_latent_decode_sga_backward(int64_t num_rows, int latent_
                                        float clamp_weights, const float *grad_decoded, float *grad_latent,
                                        float *grad_matrix, float *grad_colscale, float *grad_shift, void *workspace,
                                        size_t workspace_bytes, void *stream);
+
+/*
+ * Latent decoder WITH hidden layers / activations -- LatentDecoder with num_layers_dec > 0 and / or activation,
+ * final_activation != 'none' (wisp/models/latent_decoders/basic_latent_decoder.py:97-198: the layer stack :139-147, forward
+ * :182-198, DecoderLayer.forward :86-91, SineScaled(30.0) wisp/models/activations): a per-row MLP over the table,
+ *     decoded = clamp(final_act(L_n(act(... act(L_1(q(latent) / div)) ...)))),     L_k(x) = x @ W_k + b_k,
+ * q = round (straight-through) or, with uniforms != NULL, the SGA sample of the operators above. One pass each way.
+ *   num_layers   hidden layers + 1, 1 .. SHACIRA_LATENT_MLP_MAX_LAYERS
+ *   widths_host  HOST int32 [num_layers + 1]: latent_dim, hidden widths ..., feature_dim; each 1 .. SHACIRA_LATENT_MLP_MAX_WIDTH
+ *   params       device fp32, packed per layer: W_k [widths[k], widths[k+1]] row-major (the layer's effective matrix: `scale`
+ *                for 'sq', `dft * scale` for 'dft*'), then b_k [widths[k+1]] (`shift`; zeros when the layer has none)
+ *   activation / final_activation   SHACIRA_ACT_* (the reference's act_dict keys)
+ *   backward: grad_latent [num_rows, latent_dim] (NULL = skip), grad_params packed like params (the caller chains it to
+ *   scale / shift); workspace of shacira_latent_mlp_backward_workspace_bytes() bytes (fp64 block partials: the table
+ *   reductions are bitwise reproducible).
+ * Returns SHACIRA_EINVAL for shapes outside the limits (the caller keeps its own per-layer evaluation for those).
+ */
+#define SHACIRA_LATENT_MLP_MAX_LAYERS 4
+#define SHACIRA_LATENT_MLP_MAX_WIDTH 16
+#define SHACIRA_ACT_NONE 0
+#define SHACIRA_ACT_SIGMOID 1
+#define SHACIRA_ACT_TANH 2
+#define SHACIRA_ACT_RELU 3
+#define SHACIRA_ACT_SINE30 4
+SHACIRA_API int shacira_latent_mlp_supported(int num_layers, const int32_t *widths_host);
+SHACIRA_API size_t shacira_latent_mlp_backward_workspace_bytes(int num_layers, const int32_t *widths_host);
+SHACIRA_API int shacira_latent_mlp_forward(int64_t num_rows, int num_layers, const int32_t *widths_host, const float *latent,
+                               const float *uniforms, float temperature, int diff_sampling, const float *div,
+                               const float *params, int activation, int final_activation, float clamp_weights,
+                               float *decoded, void *stream);
+SHACIRA_API int shacira_latent_mlp_backward(int64_t num_rows, int num_layers, const int32_t *widths_host, const float *latent,
+                                const float *uniforms, float temperature, int diff_sampling, const float *div,
+                                const float *params, int activation, int final_activation, float clamp_weights,
+                                const float *grad_decoded, float *grad_latent, float *grad_params, void *workspace,
+                                size_t workspace_bytes, void *stream);
 
 /*
  * Per-level latent decoders -- HierarchicalLatentDecoder (wisp/models/latent_decoders/hierarchical_latent_decoder.py:3-36,

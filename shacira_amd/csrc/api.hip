@@ -219,6 +219,59 @@ int shacira_latent_decode_backward(int64_t num_rows, int latent_dim, int feature
     return (int)latent_decode_dispatch(true, latent_dim, feature_dim, a, (hipStream_t)stream);
 }
 
+int shacira_latent_mlp_supported(int num_layers, const int32_t *widths_host) {
+    return latent_mlp_supported(num_layers, widths_host) ? 1 : 0;
+}
+
+size_t shacira_latent_mlp_backward_workspace_bytes(int num_layers, const int32_t *widths_host) {
+    return latent_mlp_workspace_bytes(num_layers, widths_host);
+}
+
+static int latent_mlp_call(bool bwd, int64_t num_rows, int num_layers, const int32_t *widths_host, const float *latent,
+                           const float *uniforms, float temperature, int diff_sampling, const float *div,
+                           const float *params, int activation, int final_activation, float clamp_weights, float *decoded,
+                           const float *grad_decoded, float *grad_latent, float *grad_params, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+    options_snapshot();
+    if (num_rows < 0 || !latent_mlp_supported(num_layers, widths_host)) return SHACIRA_EINVAL;
+    if (activation < SHACIRA_ACT_NONE || activation > SHACIRA_ACT_SINE30 || final_activation < SHACIRA_ACT_NONE ||
+        final_activation > SHACIRA_ACT_SINE30)
+        return SHACIRA_EINVAL;
+    if (!div || !params) return SHACIRA_EINVAL;
+    if (num_rows > 0 && (!latent || (bwd ? !grad_decoded : !decoded))) return SHACIRA_EINVAL;
+    if (uniforms && !(temperature > 0.0f)) return SHACIRA_EINVAL;
+    if (bwd) {
+        if (!grad_params) return SHACIRA_EINVAL;
+        if (!workspace || workspace_bytes < latent_mlp_workspace_bytes(num_layers, widths_host)) return SHACIRA_EWORKSPACE;
+    }
+    LatentMlpArgs a{};
+    a.num_layers = num_layers; a.widths = widths_host; a.latent = latent; a.uniforms = uniforms; a.div = div;
+    a.params = params; a.temperature = temperature; a.diff_sampling = diff_sampling; a.act = activation;
+    a.final_act = final_activation; a.clampw = clamp_weights; a.decoded = decoded; a.grad_decoded = grad_decoded;
+    a.grad_latent = grad_latent; a.grad_params = grad_params; a.partials = static_cast<double *>(workspace);
+    a.rows = num_rows;
+    return (int)latent_mlp_dispatch(bwd, a, (hipStream_t)stream);
+}
+
+int shacira_latent_mlp_forward(int64_t num_rows, int num_layers, const int32_t *widths_host, const float *latent,
+                               const float *uniforms, float temperature, int diff_sampling, const float *div,
+                               const float *params, int activation, int final_activation, float clamp_weights,
+                               float *decoded, void *stream) {
+    return latent_mlp_call(false, num_rows, num_layers, widths_host, latent, uniforms, temperature, diff_sampling, div, params,
+                           activation, final_activation, clamp_weights, decoded, nullptr, nullptr, nullptr, nullptr, 0,
+                           stream);
+}
+
+int shacira_latent_mlp_backward(int64_t num_rows, int num_layers, const int32_t *widths_host, const float *latent,
+                                const float *uniforms, float temperature, int diff_sampling, const float *div,
+                                const float *params, int activation, int final_activation, float clamp_weights,
+                                const float *grad_decoded, float *grad_latent, float *grad_params, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    return latent_mlp_call(true, num_rows, num_layers, widths_host, latent, uniforms, temperature, diff_sampling, div, params,
+                           activation, final_activation, clamp_weights, nullptr, grad_decoded, grad_latent, grad_params,
+                           workspace, workspace_bytes, stream);
+}
+
 int shacira_latent_decode_sga_forward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,
                                       const float *uniforms, float temperature, int diff_sampling, const float *div,
                                       const float *matrix, const float *colscale, const float *shift,

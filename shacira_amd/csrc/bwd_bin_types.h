@@ -16,8 +16,11 @@ namespace shacira {
 constexpr int kTile = SHACIRA_KTILE;       // samples per (level, tile) block in passes A and B, 3-D
 // 2-D samples have half as many x-pairs: tiles of twice as many samples fill the same LDS staging buffer and halve the number
 // of scatter workgroups (each pays the same latencies and barriers whatever it carries: 16 us per level either way before)
-template <int DIM> struct TileOf { static constexpr int value = (DIM == 2) ? 2 * kTile : kTile; };
-static inline int tile_samples(int dim) { return dim == 2 ? 2 * kTile : kTile; }
+#ifndef SHACIRA_TILE2D_MUL
+#define SHACIRA_TILE2D_MUL 2
+#endif
+template <int DIM> struct TileOf { static constexpr int value = (DIM == 2) ? SHACIRA_TILE2D_MUL * kTile : kTile; };
+static inline int tile_samples(int dim) { return dim == 2 ? SHACIRA_TILE2D_MUL * kTile : kTile; }
 constexpr int kBinThreads = SHACIRA_KBIN;  // threads of passes A and B
 constexpr int kConsumeThreads = 1024;
 constexpr int kMaxBuckets = 2048;     // over all levels

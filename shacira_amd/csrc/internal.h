@@ -71,6 +71,24 @@ struct EntropyArgs {
     double *partials;
     int64_t rows;
 };
+// latent_mlp.hip
+struct LatentMlpArgs {
+    int num_layers;
+    const int32_t *widths;   // host
+    const float *latent, *uniforms, *div, *params;
+    float temperature;
+    int diff_sampling, act, final_act;
+    float clampw;
+    float *decoded;
+    const float *grad_decoded;
+    float *grad_latent, *grad_params;
+    double *partials;
+    int64_t rows;
+};
+bool latent_mlp_supported(int num_layers, const int32_t *widths);
+size_t latent_mlp_workspace_bytes(int num_layers, const int32_t *widths);
+hipError_t latent_mlp_dispatch(bool bwd, const LatentMlpArgs &a, hipStream_t s);
+
 size_t latent_workspace_bytes();
 bool latent_decode_supported(int ld, int f);
 hipError_t latent_decode_dispatch(bool bwd, int ld, int f, const DecodeArgs &a, hipStream_t s);

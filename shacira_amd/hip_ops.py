@@ -260,6 +260,69 @@ def latent_decode_sga_backward(latent, uniforms, temperature, diff_sampling, div
     return g_lat, g_mat, g_cs, g_sh
 
 
+LATENT_ACTIVATIONS = {"none": 0, "sigmoid": 1, "tanh": 2, "relu": 3, "sine": 4}   # SHACIRA_ACT_*
+
+
+def _widths_array(widths):
+    return (ctypes.c_int32 * len(widths))(*[int(w) for w in widths])
+
+
+def latent_mlp_supported(widths):
+    """Hidden-layer latent decoder (shacira_latent_mlp_*): ``widths`` = (latent_dim, hidden..., feature_dim)."""
+    return len(widths) >= 2 and bool(_lib.lib().shacira_latent_mlp_supported(len(widths) - 1, _widths_array(widths)))
+
+
+def _check_mlp_operands(latent, uniforms, div, params, widths):
+    _need_gpu(latent, uniforms, div, params)
+    T, ld = latent.shape
+    if ld != widths[0] or div.numel() != ld:
+        raise RuntimeError("latent / div do not match widths[0]")
+    want = sum(a * b + b for a, b in zip(widths[:-1], widths[1:]))
+    if params.numel() != want or params.dtype != torch.float32 or not params.is_contiguous():
+        raise RuntimeError(f"params must be a contiguous fp32 vector of {want} elements (W_k then b_k per layer)")
+    if uniforms is not None and (tuple(uniforms.shape) != (T, ld, 2) or uniforms.dtype != torch.float32
+                                 or not uniforms.is_contiguous()):
+        raise RuntimeError("uniforms must be a contiguous fp32 [rows, latent_dim, 2] tensor")
+    return T
+
+
+def latent_mlp_forward(latent, uniforms, temperature, diff_sampling, div, params, widths, activation, final_activation,
+                       clamp_weights):
+    """decoded [T, widths[-1]] = clamp(final_act(MLP(q(latent) / div))): one kernel (reference basic_latent_decoder.py:182-198
+    with hidden layers). ``params``: per layer the effective matrix [in, out] row-major, then the shift [out]."""
+    T = _check_mlp_operands(latent, uniforms, div, params, widths)
+    out = torch.empty((T, widths[-1]), dtype=torch.float32, device=latent.device)
+    with torch.cuda.device(latent.device):
+        rc = _lib.lib().shacira_latent_mlp_forward(
+            T, len(widths) - 1, _widths_array(widths), _ptr(latent), _ptr(uniforms), float(temperature),
+            int(bool(diff_sampling)), _ptr(div), _ptr(params), LATENT_ACTIVATIONS[activation],
+            LATENT_ACTIVATIONS[final_activation], float(clamp_weights), _ptr(out), _stream(latent))
+    _lib.check(rc, "latent_mlp_forward")
+    return out
+
+
+def latent_mlp_backward(latent, uniforms, temperature, diff_sampling, div, params, widths, activation, final_activation,
+                        clamp_weights, grad_decoded):
+    """-> (grad_latent [T, ld], grad_params packed like ``params``)."""
+    T = _check_mlp_operands(latent, uniforms, div, params, widths)
+    _need_gpu(grad_decoded)
+    if tuple(grad_decoded.shape) != (T, widths[-1]) or grad_decoded.dtype != torch.float32 or not grad_decoded.is_contiguous():
+        raise RuntimeError("grad_decoded must be a contiguous fp32 [rows, feature_dim] tensor")
+    dev = latent.device
+    g_lat = torch.empty_like(latent)
+    g_par = torch.empty_like(params)
+    wa = _widths_array(widths)
+    with torch.cuda.device(dev):
+        n = _lib.lib().shacira_latent_mlp_backward_workspace_bytes(len(widths) - 1, wa)
+        ws = torch.empty((n,), dtype=torch.uint8, device=dev)
+        rc = _lib.lib().shacira_latent_mlp_backward(
+            T, len(widths) - 1, wa, _ptr(latent), _ptr(uniforms), float(temperature), int(bool(diff_sampling)), _ptr(div),
+            _ptr(params), LATENT_ACTIVATIONS[activation], LATENT_ACTIVATIONS[final_activation], float(clamp_weights),
+            _ptr(grad_decoded), _ptr(g_lat), _ptr(g_par), _ptr(ws), ws.numel(), _stream(latent))
+    _lib.check(rc, "latent_mlp_backward")
+    return g_lat, g_par
+
+
 def _offsets_array(offsets):
     return (ctypes.c_int64 * len(offsets))(*[int(o) for o in offsets])
 

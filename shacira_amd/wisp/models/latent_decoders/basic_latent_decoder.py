@@ -8,7 +8,10 @@ Execution:
     (after the SGA warm-up, at validation, whenever SGA is off) and ``_FusedLatentDecodeSGA`` for the SGA path (the
     two uniforms per latent come from ``torch.rand`` on the device: the single draw the reference's
     RelaxedOneHotCategorical makes, so a seeded run consumes the generator exactly like the reference);
-  * hidden layers and non-identity activations stay torch ops, as do tensors that live on the host.
+  * hidden layers and / or activations (``num_layers_dec > 0``, ``activation`` / ``final_activation`` != 'none'), table on
+    the GPU, widths up to 16 and up to 4 layers: the per-row MLP kernel ``decode_layer._FusedLatentMLP`` (one kernel
+    forward, one + a finishing kernel backward; the layers' effective matrices are packed by three tiny torch ops);
+  * wider / deeper decoders and tensors that live on the host stay torch ops.
 """
 import torch
 import torch.nn as nn
@@ -16,7 +19,8 @@ from torch import Tensor
 from torch.nn.modules.utils import _ntuple
 
 from .... import hip_ops
-from .decode_layer import DecoderLayer, _FusedLatentDecode, _FusedLatentDecodeSGA, get_dft_matrix  # noqa: F401
+from .decode_layer import (DecoderLayer, _FusedLatentDecode, _FusedLatentDecodeSGA, _FusedLatentMLP,  # noqa: F401
+                           get_dft_matrix)
 from .quantizers import StraightThrough, StraightThroughFloor, epsilon, sga_sample  # noqa: F401
 
 
@@ -45,6 +49,7 @@ class LatentDecoder(nn.Module):
         self.num_layers_dec, self.use_shift, self.clamp_weights = num_layers_dec, use_shift, clamp_weights
         self.use_sga, self.diff_sampling, self.temperature = use_sga, diff_sampling, 1.0
         self._identity_acts = activation == "none" and final_activation == "none"
+        self._act_names = (activation, final_activation)
         # per-channel normaliser, maintained by the trainer (max-abs or std of the latents); never trained
         self.div = nn.Parameter(torch.ones(latent_dim), requires_grad=False)
         self.act = _ACTIVATIONS[activation]()
@@ -61,6 +66,7 @@ class LatentDecoder(nn.Module):
             if k < num_layers_dec:
                 stack.append(self.act)
         self.layers = nn.Sequential(*stack)
+        self._widths = tuple(widths)
         self.reset_parameters("normal", ldec_std)
 
     # -- reference helper surface ---------------------------------------------------------------------------
@@ -102,6 +108,20 @@ class LatentDecoder(nn.Module):
                 and self.num_layers_dec == 0 and self._identity_acts
                 and hip_ops.latent_decode_supported(self.latent_dim, self.channels))
 
+    def _mlp_fusable(self, weight: Tensor) -> bool:
+        """Hidden layers and / or activations: the per-row MLP kernel (widths up to 16, up to 4 layers)."""
+        return (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2
+                and hip_ops.latent_mlp_supported(self._widths))
+
+    def _packed_layers(self) -> Tensor:
+        """Per layer: effective matrix [in, out] row-major, then the shift (zeros without one), as one fp32 vector."""
+        parts = []
+        for layer in self._decoder_layers():
+            parts.append(layer.effective_matrix().reshape(-1))
+            parts.append(layer.shift.reshape(-1) if layer.shift is not None
+                         else torch.zeros(layer.out_features, dtype=layer.scale.dtype, device=layer.scale.device))
+        return torch.cat(parts)
+
     def forward(self, weight: Tensor) -> Tensor:
         if self._fusable(weight):
             matrix, colscale, shift = self._decoder_layers()[0].fused_operands()
@@ -110,9 +130,15 @@ class LatentDecoder(nn.Module):
                 return _FusedLatentDecodeSGA.apply(weight, uniforms, float(self.temperature), bool(self.diff_sampling),
                                                    self.div, matrix, colscale, shift, float(self.clamp_weights))
             return _FusedLatentDecode.apply(weight, self.div, matrix, colscale, shift, float(self.clamp_weights))
+        if self._mlp_fusable(weight):
+            uniforms = None
+            if self.use_sga:
+                uniforms = torch.rand(weight.shape + (2,), dtype=weight.dtype, device=weight.device)
+            return _FusedLatentMLP.apply(weight, uniforms, float(self.temperature), bool(self.diff_sampling), self.div,
+                                         self._packed_layers(), self._widths, self._act_names[0], self._act_names[1],
+                                         float(self.clamp_weights))
         if weight.is_cuda:
-            hip_ops.warn_unfused("LatentDecoder.forward", "hidden decoder layers / activations, or an unsupported "
-                                 f"(latent_dim, feature_dim) = ({self.latent_dim}, {self.channels})")
+            hip_ops.warn_unfused("LatentDecoder.forward", f"decoder widths {self._widths} outside the fused kernels' limits")
         if self.use_sga:
             weight = sga_sample(weight, self.temperature, self.diff_sampling)
         else:

@@ -71,6 +71,32 @@ class _FusedLatentDecodeSGA(torch.autograd.Function):
                 g_sh.reshape(shift.shape) if (shift is not None and ctx.needs_input_grad[7]) else None, None)
 
 
+class _FusedLatentMLP(torch.autograd.Function):
+    """quantise (round or SGA) -> /div -> decoder layers with activations -> final activation -> clamp: the hidden-layer
+    decoder of basic_latent_decoder.py:139-147,182-198 as one HIP kernel each way (shacira_latent_mlp_*). ``params`` packs,
+    per layer, the effective matrix [in, out] and the shift [out]; its gradient flows on to ``scale`` / ``shift`` through the
+    packing ops of ``LatentDecoder._packed_layers``."""
+
+    @staticmethod
+    def forward(ctx, latent, uniforms, temperature, diff_sampling, div, params, widths, activation, final_activation,
+                clamp_weights):
+        latent, params = latent.contiguous(), params.contiguous()
+        ctx.save_for_backward(latent, uniforms, div, params)
+        ctx.opts = (float(temperature), bool(diff_sampling), tuple(widths), activation, final_activation,
+                    float(clamp_weights))
+        return hip_ops.latent_mlp_forward(latent, uniforms, temperature, diff_sampling, div, params, tuple(widths), activation,
+                                          final_activation, clamp_weights)
+
+    @staticmethod
+    def backward(ctx, grad_decoded):
+        latent, uniforms, div, params = ctx.saved_tensors
+        temperature, diff_sampling, widths, activation, final_activation, clamp_weights = ctx.opts
+        g_lat, g_par = hip_ops.latent_mlp_backward(latent, uniforms, temperature, diff_sampling, div, params, widths,
+                                                   activation, final_activation, clamp_weights, grad_decoded.contiguous())
+        return (g_lat if ctx.needs_input_grad[0] else None, None, None, None, None,
+                g_par if ctx.needs_input_grad[5] else None, None, None, None, None)
+
+
 class DecoderLayer(Module):
     """One affine decode layer: 'sq' learns the full [in, out] matrix; 'dft*' fixes a DCT basis and learns a
     per-output scale. ``shift`` exists only with ``bias=True``."""
@@ -104,6 +130,10 @@ class DecoderLayer(Module):
     def clamp(self, val: float = 0.5) -> None:
         with torch.no_grad():
             self.scale.clamp_(-val, val)
+
+    def effective_matrix(self):
+        """[in, out] matrix the layer multiplies by: ``scale``, or the fixed basis times the per-output scale."""
+        return self.dft * self.scale if "dft" in self.ldecode_matrix else self.scale
 
     def fused_operands(self):
         """(matrix, colscale, shift) in the C-ABI's convention."""

@@ -9,6 +9,8 @@ What is pinned by the real reference code (executed, not restated):
   latent_decoder_sga.npz  LatentDecoder.forward/backward on the SGA path (use_sga, diff_sampling on/off), with the
                       uniforms the reference's RelaxedOneHotCategorical drew                            basic_latent_decoder.py:183-191
                       (written by `python tests/golden/make_golden.py sga`, leaves the other files untouched)
+  latent_decoder_mlp.npz  LatentDecoder with hidden layers / activations (num_layers_dec, activation, final_activation),
+                      rounding and SGA paths   basic_latent_decoder.py:139-147,182-198       (python make_golden.py mlp)
   hierarchical_decoder.npz  HierarchicalLatentDecoder.forward/backward over row ranges, incl. an empty level and the
                       (sic) last offset of latent_grid.py:182 (`python tests/golden/make_golden.py hier`)   hierarchical_latent_decoder.py:3-36
   bit_estimator.npz   BitEstimator CDF + gradients for num_layers 1..4                               bit_estimator.py:9-65
@@ -468,6 +470,74 @@ def make_hier():
     print("hierarchical decoder golden vectors written")
 
 
+def make_mlp():
+    """LatentDecoder of the reference with HIDDEN layers / activations (num_layers_dec > 0, activation, final_activation;
+    basic_latent_decoder.py:139-147,182-198), executed: rounding path and SGA path (uniforms recovered by re-seeding)."""
+    _install_shims()
+    import importlib
+    core_mod = importlib.import_module("wisp.core.wisp_module")
+    sys.modules["wisp.core"].WispModule = core_mod.WispModule
+    ldec = importlib.import_module("wisp.models.latent_decoders")
+    out, cases = {}, []
+    g = torch.Generator().manual_seed(2468)
+    rows = 700                                   # three 256-row tiles, the last one ragged
+    for ci, (ld, fd, mat, shift, nl, hid, act, fact, clampw, sga, diff, temp) in enumerate([
+            (1, 2, "sq", True, 1, 8, "relu", "none", 0.0, False, False, 1.0),
+            (2, 2, "sq", True, 2, (8, 4), "tanh", "none", 0.0, False, False, 1.0),
+            (2, 4, "dft", True, 1, 4, "sigmoid", "tanh", 0.0, False, False, 1.0),
+            (3, 2, "sq", False, 3, 16, "sine", "none", 0.0, False, False, 1.0),
+            (4, 4, "sq", True, 1, 0, "relu", "sigmoid", 0.6, False, False, 1.0),       # hidden_dim_dec 0 -> feature_dim
+            (2, 2, "sq", True, 0, 0, "none", "tanh", 0.0, False, False, 1.0),          # no hidden layer, final activation only
+            (2, 2, "sq", True, 2, 8, "relu", "none", 0.0, True, True, 0.4),
+            (1, 2, "dft", True, 1, 8, "tanh", "none", 0.0, True, False, 0.7)]):
+        torch.manual_seed(300 + ci)
+        dec = ldec.LatentDecoder(latent_dim=ld, feature_dim=fd, norm="none", ldecode_matrix=mat, use_shift=shift,
+                                 num_layers_dec=nl, hidden_dim_dec=hid, activation=act, final_activation=fact,
+                                 clamp_weights=clampw, ldec_std=0.4, use_sga=sga, diff_sampling=diff)
+        dec.temperature = temp
+        layers = [m for m in dec.layers.children() if isinstance(m, ldec.DecoderLayer)]
+        with torch.no_grad():
+            dec.div.fill_(1.7)
+            if ld > 1:
+                dec.div[1] = 0.9
+            if act == "sine":                    # keep 30 * z in a range where fp32 sin() is well conditioned
+                for m in layers:
+                    m.scale.mul_(0.1)
+            if shift:
+                for m in layers:
+                    m.shift.copy_(torch.randn(m.shift.shape, generator=g) * 0.05)
+        lat = ((torch.rand(rows, ld, generator=g) - 0.5) * 7.0)
+        lat[0] = 0.5; lat[1] = -0.5; lat[2] = 1.5; lat[3] = 2.0
+        lat.requires_grad_(True)
+        seed = 950 + ci
+        torch.manual_seed(seed)
+        y = dec(lat)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        pre = f"c{ci}_"
+        if sga:
+            torch.manual_seed(seed)
+            out[pre + "uniforms"] = torch.rand(rows, ld, 2).numpy()
+        out[pre + "latent"] = lat.detach().numpy()
+        out[pre + "div"] = dec.div.detach().numpy()
+        for k, m in enumerate(layers):
+            out[pre + f"scale{k}"] = m.scale.detach().numpy()
+            out[pre + f"grad_scale{k}"] = m.scale.grad.numpy()
+            if shift:
+                out[pre + f"shift{k}"] = m.shift.detach().numpy()
+                out[pre + f"grad_shift{k}"] = m.shift.grad.numpy()
+        out[pre + "out"] = y.detach().numpy()
+        out[pre + "grad_out"] = gy.numpy()
+        out[pre + "grad_latent"] = lat.grad.numpy()
+        cases.append(dict(latent_dim=ld, feature_dim=fd, ldecode_matrix=mat, use_shift=shift, num_layers_dec=nl,
+                          hidden_dim_dec=hid, activation=act, final_activation=fact, clamp_weights=clampw, use_sga=sga,
+                          diff_sampling=diff, temperature=temp, num_layers=len(layers),
+                          state_keys=sorted(dec.state_dict().keys())))
+    out["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "latent_decoder_mlp.npz"), **out)
+    print("hidden-layer decoder golden vectors written")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; goldens can only be regenerated in the dev container")
@@ -475,5 +545,7 @@ if __name__ == "__main__":
         make_sga()
     elif len(sys.argv) > 1 and sys.argv[1] == "hier":
         make_hier()
+    elif len(sys.argv) > 1 and sys.argv[1] == "mlp":
+        make_mlp()
     else:
         main()

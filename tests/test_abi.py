@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(handle, name), name
-    assert _lib.lib().shacira_abi_version() == 7
+    assert _lib.lib().shacira_abi_version() == 8
 
 
 def test_argument_validation_codes():
@@ -67,3 +67,23 @@ def test_argument_validation_codes():
         _lib.check(_lib.EODD)
     with pytest.raises(RuntimeError):
         _lib.check(_lib.EINVAL, "x")
+
+
+def test_latent_mlp_entry_points_validate_their_arguments():
+    """shacira_latent_mlp_*: shape limits and NULL operands are refused before anything is launched (no GPU needed)."""
+    import ctypes
+    lib = _lib.lib()
+    arr = lambda *w: (ctypes.c_int32 * len(w))(*w)
+    assert lib.shacira_latent_mlp_supported(2, arr(2, 8, 2)) == 1
+    assert lib.shacira_latent_mlp_supported(4, arr(1, 16, 16, 16, 4)) == 1
+    assert lib.shacira_latent_mlp_supported(5, arr(1, 2, 2, 2, 2, 2)) == 0          # too deep
+    assert lib.shacira_latent_mlp_supported(1, arr(2, 17)) == 0                      # too wide
+    assert lib.shacira_latent_mlp_supported(1, arr(0, 2)) == 0
+    assert lib.shacira_latent_mlp_backward_workspace_bytes(2, arr(2, 8, 2)) == 512 * (2 * 8 + 8 + 8 * 2 + 2) * 8
+    einval = -1
+    rc = lib.shacira_latent_mlp_forward(10, 5, arr(1, 2, 2, 2, 2, 2), None, None, 1.0, 0, None, None, 0, 0, 0.0, None, None)
+    assert rc != 0
+    rc = lib.shacira_latent_mlp_forward(10, 1, arr(2, 2), None, None, 1.0, 0, None, None, 0, 0, 0.0, None, None)
+    assert rc != 0                                                                   # NULL div / params
+    rc = lib.shacira_latent_mlp_forward(10, 1, arr(2, 2), None, None, 1.0, 0, None, None, 9, 0, 0.0, None, None)
+    assert rc != 0                                                                   # unknown activation

@@ -392,6 +392,78 @@ def test_latent_decode_against_reference_vectors(dev, golden):
             np.testing.assert_allclose(gs.reshape(1, -1).cpu().numpy(), g[p + "grad_shift"], rtol=RTOL, atol=1e-5)
 
 
+def test_latent_decoder_with_hidden_layers_against_reference_vectors(dev, golden, monkeypatch):
+    """LatentDecoder with hidden layers / activations (num_layers_dec > 0, activation, final_activation; rounding and SGA)
+    on the GPU: the per-row MLP kernel (shacira_latent_mlp_*) against vectors of the executed reference module, through
+    the module (so the packing of scale / dft / shift and the chaining of their gradients are covered), with a spy that the
+    fused operator is what ran."""
+    from test_host_mirror import build_mlp_decoder_case
+    ops = _ops()
+    g = golden("latent_decoder_mlp.npz")
+    calls = {"fwd": 0, "bwd": 0}
+    f0, b0 = ops.latent_mlp_forward, ops.latent_mlp_backward
+    monkeypatch.setattr(ops, "latent_mlp_forward", lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), f0(*a, **k))[1])
+    monkeypatch.setattr(ops, "latent_mlp_backward", lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), b0(*a, **k))[1])
+    cases = npz_json(g["cases_json"])
+    for ci, case in enumerate(cases):
+        p = f"c{ci}_"
+        dec, layers = build_mlp_decoder_case(g, ci, case, device=dev)
+        lat = torch.from_numpy(g[p + "latent"]).to(dev).requires_grad_(True)
+        if case["use_sga"]:
+            uni = torch.from_numpy(g[p + "uniforms"]).to(dev)
+            with monkeypatch.context() as m:
+                m.setattr(torch, "rand", lambda *a, **k: uni.clone())
+                y = dec(lat)
+        else:
+            y = dec(lat)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g[p + "out"], rtol=2e-5, atol=2e-6, err_msg=f"case {ci}")
+        y.backward(torch.from_numpy(g[p + "grad_out"]).to(dev))
+        np.testing.assert_allclose(lat.grad.cpu().numpy(), g[p + "grad_latent"], rtol=1e-4, atol=2e-5, err_msg=f"case {ci}")
+        for k, layer in enumerate(layers):
+            ref = g[p + f"grad_scale{k}"]
+            np.testing.assert_allclose(layer.scale.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max() + 1e-7,
+                                       err_msg=f"case {ci} layer {k} scale")
+            if case["use_shift"]:
+                ref = g[p + f"grad_shift{k}"]
+                np.testing.assert_allclose(layer.shift.grad.cpu().numpy(), ref, rtol=1e-4,
+                                           atol=1e-4 * np.abs(ref).max() + 1e-7, err_msg=f"case {ci} layer {k} shift")
+    assert calls["fwd"] == len(cases) and calls["bwd"] == len(cases)
+
+
+def test_latent_mlp_large_table_is_reproducible_and_matches_torch(dev):
+    """A table-sized call (6.1 M rows = config D's table, widths 2-16-16-2, tanh): the fused kernel against the same
+    decoder evaluated with torch ops in fp64, twice (the table reductions are bitwise reproducible)."""
+    from shacira_amd.wisp.models.latent_decoders import LatentDecoder
+    torch.manual_seed(5)
+    T = 6_098_925
+    dec = LatentDecoder(2, 2, "none", "sq", True, num_layers_dec=2, hidden_dim_dec=16, activation="tanh", ldec_std=0.3).to(dev)
+    with torch.no_grad():
+        dec.div.copy_(torch.tensor([1.3, 0.8]))
+    lat = ((torch.rand(T, 2, device=dev) - 0.5) * 8).requires_grad_(True)
+    gy = torch.randn(T, 2, device=dev)
+    y = dec(lat)
+    y.backward(gy)
+    got = [y.detach().clone(), lat.grad.clone()] + [p.grad.clone() for p in dec.parameters() if p.requires_grad]
+    lat.grad = None
+    dec.zero_grad(set_to_none=True)
+    y2 = dec(lat)
+    y2.backward(gy)
+    again = [y2.detach(), lat.grad] + [p.grad for p in dec.parameters() if p.requires_grad]
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
+    # fp64 torch evaluation of the same decoder
+    ref = LatentDecoder(2, 2, "none", "sq", True, num_layers_dec=2, hidden_dim_dec=16, activation="tanh").double().to(dev)
+    ref.load_state_dict({k: v.double() for k, v in dec.state_dict().items()})
+    lat64 = lat.detach().double().requires_grad_(True)
+    z = torch.round(lat64).detach() + (lat64 - lat64.detach())                # straight-through rounding
+    yr = ref.final_activation(ref.layers(z / ref.div))
+    yr.backward(gy.double())
+    np.testing.assert_allclose(got[0].cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got[1].cpu().numpy(), lat64.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    for a, pr in zip(got[2:], [p for p in ref.parameters() if p.requires_grad]):
+        scale = float(pr.grad.abs().max())
+        np.testing.assert_allclose(a.cpu().numpy(), pr.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+
+
 @pytest.mark.parametrize("ld,F", [(1, 2), (2, 2), (1, 4), (4, 4), (3, 2), (8, 8)])
 def test_latent_decode_large_against_oracle(dev, ld, F):
     ops = _ops()

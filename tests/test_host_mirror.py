@@ -299,6 +299,54 @@ def test_latent_decoder_module(golden):
     assert float(dec.layers[0].scale.abs().max()) <= 0.01
 
 
+def build_mlp_decoder_case(g, ci, case, device="cpu"):
+    """LatentDecoder with hidden layers / activations loaded with case ``ci`` of latent_decoder_mlp.npz (vectors of the
+    executed reference module). Returns (decoder, its DecoderLayers)."""
+    from shacira_amd.wisp.models.latent_decoders.decode_layer import DecoderLayer
+    p = f"c{ci}_"
+    hid = case["hidden_dim_dec"]
+    dec = LatentDecoder(latent_dim=case["latent_dim"], feature_dim=case["feature_dim"], norm="none",
+                        ldecode_matrix=case["ldecode_matrix"], use_shift=case["use_shift"],
+                        num_layers_dec=case["num_layers_dec"], hidden_dim_dec=tuple(hid) if isinstance(hid, list) else hid,
+                        activation=case["activation"], final_activation=case["final_activation"],
+                        clamp_weights=case["clamp_weights"], ldec_std=0.4, use_sga=case["use_sga"],
+                        diff_sampling=case["diff_sampling"])
+    dec.temperature = case["temperature"]
+    assert sorted(dec.state_dict().keys()) == case["state_keys"]
+    layers = [m for m in dec.layers.children() if isinstance(m, DecoderLayer)]
+    assert len(layers) == case["num_layers"]
+    with torch.no_grad():
+        dec.div.copy_(torch.from_numpy(g[p + "div"]))
+        for k, m in enumerate(layers):
+            m.scale.copy_(torch.from_numpy(g[p + f"scale{k}"]))
+            if case["use_shift"]:
+                m.shift.copy_(torch.from_numpy(g[p + f"shift{k}"]))
+    return dec.to(device), layers
+
+
+def test_latent_decoder_with_hidden_layers_module(golden, monkeypatch):
+    """The mirror's own evaluation (torch ops: CPU tensors never reach the fused kernel) of decoders with hidden layers and
+    activations against the executed reference -- pins the module semantics the fused GPU kernel is then held to."""
+    import shacira_amd.wisp.models.latent_decoders.quantizers as quant
+    g = golden("latent_decoder_mlp.npz")
+    for ci, case in enumerate(npz_json(g["cases_json"])):
+        p = f"c{ci}_"
+        dec, layers = build_mlp_decoder_case(g, ci, case)
+        lat = torch.from_numpy(g[p + "latent"]).requires_grad_(True)
+        if case["use_sga"]:      # the sampler draws ONE torch.rand([rows, ld, 2]): feed it the recorded uniforms
+            uni = torch.from_numpy(g[p + "uniforms"])
+            monkeypatch.setattr(torch, "rand", lambda *a, **k: uni.clone())
+        y = dec(lat)
+        monkeypatch.undo()
+        np.testing.assert_allclose(y.detach().numpy(), g[p + "out"], rtol=2e-5, atol=2e-6, err_msg=f"case {ci}")
+        y.backward(torch.from_numpy(g[p + "grad_out"]))
+        np.testing.assert_allclose(lat.grad.numpy(), g[p + "grad_latent"], rtol=1e-4, atol=2e-5, err_msg=f"case {ci}")
+        for k, m in enumerate(layers):
+            ref = g[p + f"grad_scale{k}"]
+            np.testing.assert_allclose(m.scale.grad.numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max() + 1e-7,
+                                       err_msg=f"case {ci} layer {k}")
+
+
 @pytest.mark.parametrize("nl", [1, 2, 3, 4])
 def test_bit_estimator_module(golden, nl):
     g = golden("bit_estimator.npz")
