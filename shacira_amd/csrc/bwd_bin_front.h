@@ -285,12 +285,16 @@ __global__ __launch_bounds__(1024) void bin_scan_buckets_kernel(const uint32_t *
         c[k] = 0u;
         if (b < nb)
             for (int sh = 0; sh < kTotalShards; ++sh) c[k] += totals[(size_t)sh * kMaxBuckets + b];
-        uint32_t lq = 0;
-        for (uint32_t q = 1; q < plan.nbl; ++q)
-            if (plan.bstart[q] <= b) lq = q;
-        lv_of[k] = plan.blevel[lq];
-        ck[k] = plan.lv[lv_of[k]].chunk;
-        u[k] = (uint32_t)((c[k] + ck[k] - 1) / ck[k]);
+        // the bucket's level: a fixed-length scan with uniform indices (scalar loads of the whole arrays in one go; a
+        // `q < plan.nbl` loop bound and the lane-dependent blevel[lq] / lv[..].chunk lookups were three dependent memory
+        // round trips in a one-workgroup kernel that sits on every backward's critical path)
+        uint32_t lvl = plan.blevel[0];
+#pragma unroll
+        for (uint32_t q = 1; q < SHACIRA_MAX_LODS; ++q)
+            if (q < plan.nbl && plan.bstart[q] <= b) lvl = plan.blevel[q];
+        lv_of[k] = lvl;
+        ck[k] = plan.chunk;   // (one unit size for every level of a plan)
+        u[k] = (c[k] >> 32) ? (uint32_t)((c[k] + ck[k] - 1) / ck[k]) : (c[k] ? ((uint32_t)c[k] - 1u) / ck[k] + 1u : 0u);
     }
     uint64_t ci = c[0] + c[1];
     uint32_t ui = u[0] + u[1];

@@ -625,7 +625,7 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         hipError_t attr_err = hipSuccess;
         // dynamic LDS actually requested (static LDS of the kernels comes on top and must fit in 160 KiB too)
         auto set = [&attr_err](const void *fn, size_t bytes) {
-            if (bytes <= 64 * 1024) return;
+            if (bytes <= 64 * 1024 || bytes > 160 * 1024) return;   // (beyond the CU's LDS: such a launch fails by itself)
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (e != hipSuccess) attr_err = e;
         };
