@@ -49,9 +49,11 @@ if has steps; then
 for w in nerf image image_graphed; do
 timeout 300 python3 $GRAFT_REPO_ROOT/tools/step_breakdown.py $w 1000 > $OUT/step_${w}_plain.json 2>/dev/null   # the unprofiled wall time
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_$w -- python3 $GRAFT_REPO_ROOT/tools/step_breakdown.py $w 1000 > $OUT/step_$w.json 2>/dev/null
+find $OUT/step_$w -name "*kernel_trace.csv" -delete    # 10^5 rows each: only the stats summary is used (gpurun_out merges <= 64 MiB)
 done
 fi
 if has mfma; then
 timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/ctr_mlp128 -- python3 $GRAFT_REPO_ROOT/tools/mlp128_check.py > $OUT/mlp128_check.txt 2>&1
 fi
+du -sh $OUT
 ls $OUT
