@@ -396,8 +396,8 @@ def main():
                           "Adam (kodak.yaml learning rates)", "bpp": fit["bpp"], "bpp_file": fit["bpp_file"],
                 "file_bytes": fit["file_bytes"], "rgb_loss": fit["rgb_loss"],
                 "seconds": time.perf_counter() - tp, "ms_per_step": fit["ms_per_step"], "n_gpus": world,
-                "mode": "eager step (Python issues ~60 launches per step: the GPU is busy ~16 % of it, "
-                        "profiles/r03_imagefit_step.md)"}
+                "mode": "eager step, cold (Python issues ~60 launches per step; warmed up it takes ~1 ms with the GPU busy "
+                        "a third of it: profiles/r03_imagefit_step.md)"}
         if world == 1:
             # the same fit with the step captured once into a HIP graph and replayed (GraphedImageFitter: device-side
             # entropy noise and Adam step count): what a user who cares about wall time runs
