@@ -45,6 +45,14 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
                       bool one_image_compact);
 static inline bool half_items(int dtype, const LevelTable &lt);
+#ifndef SHACIRA_FX_MIN
+#define SHACIRA_FX_MIN (1 << 17)       // fixed-point images from this batch size (below: fp64 images)
+#endif
+#ifndef SHACIRA_PERSIST_MIN
+#define SHACIRA_PERSIST_MIN (1 << 16)  // persistent consume workgroups from this batch size (measured: -2.5 % at 65 536
+                                       // samples, equal at 32 768, +2 % at 16 384: below, the hardware's own dispatch of the
+                                       // ~1 400 tiny workgroups is as good)
+#endif
 static inline bool one_image_compact_rule(int64_t n_total) { return n_total >= ((int64_t)1 << 17); }
 
 // can the table be partitioned with an LDS accumulator image of `acc_kib` KiB per consumer workgroup?
@@ -420,7 +428,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     const bool need_T = whole.nbl > 0 || stage_all || staged;
     // fixed-point images pay off once the accumulation itself dominates; small batches are bound by fixed costs and
     // keep the fp64 image (and skip the gmax bookkeeping): measured 100 vs 107 us at 65 536 samples
-    const bool use_fx = need_T && n >= (1 << 17);
+    const bool use_fx = need_T && n >= SHACIRA_FX_MIN;
     // the 16-byte front kernel needs rows of whole 16-byte vectors and a 16-byte aligned input
     const size_t esz = dtype == SHACIRA_F32 ? 4 : 2;
     const int kvec = (int)(16 / (esz * F));
@@ -590,9 +598,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         uint32_t grid_units = (uint32_t)(max_items / plan.chunk_min) + plan.total_buckets + 1;
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         // persistent: as many workgroups as the chip holds fetch units from the work counter (measured: S1 backward
-        // 0.611 -> 0.595 ms, 2-D 0.375 -> 0.369; at 65 536 samples the hardware's own dispatch of 1 400 tiny workgroups
-        // is 5 us faster, so small batches keep it)
-        uint32_t *wc = (opt().bwd_persistent != 0 && n >= (1 << 17)) ? w.work_counter : nullptr;
+        // 0.611 -> 0.595 ms, 2-D 0.375 -> 0.369; with the fetch pipelined one unit ahead also at 65 536 samples)
+        uint32_t *wc = (opt().bwd_persistent != 0 && n >= SHACIRA_PERSIST_MIN) ? w.work_counter : nullptr;
         if (wc != nullptr && grid_units > 512u) grid_units = 512u;
         const int headroom = use_fx ? fx_headroom((uint64_t)plan.chunk + 1) : -1;   // a unit streams <= chunk items
         const int fa = multi ? 1 : 0;
