@@ -689,12 +689,70 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
     }
     for (uint32_t e = threadIdx.x; e < rows * F; e += kConsumeThreads) s_acc[e] = 0.0;
     __syncthreads();
+    __shared__ float s_limit[SHACIRA_MAX_LODS];   // largest |gradient| the level's fixed-point scale is good for
     if constexpr (FX) {
-        if ((int)threadIdx.x < lt.num_lods && ((mask >> threadIdx.x) & 1u)) {
-            const FxScale f = fx_scale_of(gmax[threadIdx.x], headroom);
-            s_scale[threadIdx.x] = f.scale;
-            s_inv[threadIdx.x] = f.inv;
-            if (!f.fixed) s_all_fixed = 0;     // one non-finite level: the whole group accumulates in fp64
+        if (gmax != nullptr) {
+            if ((int)threadIdx.x < lt.num_lods && ((mask >> threadIdx.x) & 1u)) {
+                const FxScale f = fx_scale_of(gmax[threadIdx.x], headroom);
+                s_scale[threadIdx.x] = f.scale;
+                s_inv[threadIdx.x] = f.inv;
+                s_limit[threadIdx.x] = __uint_as_float(0x7F800000u);   // the true maximum: every finite value fits
+                if (!f.fixed) s_all_fixed = 0;     // one non-finite level: the whole group accumulates in fp64
+            }
+        } else {
+            // No max |gradient| from a transposing pass (all-direct tables, small batches): the workgroup takes a PILOT
+            // maximum per level over 1 024 of its own samples (one per thread, spread over its whole walk), and scales for
+            // 2^12 times that. A contribution beyond the limit -- or non-finite -- goes straight to the table with a float
+            // atomic (the image is flushed that way too), so the limit only has to be right for almost all of them; a level
+            // whose pilot saw nothing but zeros keeps the fp64 image (with its group).
+            __shared__ uint32_t s_pm[SHACIRA_MAX_LODS];
+            if ((int)threadIdx.x < SHACIRA_MAX_LODS) s_pm[threadIdx.x] = 0u;
+            __syncthreads();
+            const int64_t stride0 = (int64_t)gridDim.x * kConsumeThreads;
+            const int64_t base = (int64_t)blockIdx.x * kConsumeThreads + threadIdx.x;
+            const int64_t iters = (N + stride0 - 1) / stride0;
+            int64_t ip = base + (int64_t)(threadIdx.x % (uint32_t)(iters > 0 ? iters : 1)) * stride0;
+            if (ip >= N) ip = base;
+            const int nlp = s_nl;
+            const int64_t ipc = ip < N ? ip : N - 1;
+            for (int q0 = 0; q0 < nlp; q0 += 4) {     // four levels' loads in flight
+                float gp4[4][F];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int l = s_lv[(q0 + k < nlp) ? q0 + k : nlp - 1];
+                    const GT *gp = TRANSPOSED ? gT + ((int64_t)l * gpitch + ipc) * F : gT + (ipc * lt.num_lods + l) * F;
+#pragma unroll
+                    for (int j = 0; j < F; ++j) gp4[k][j] = Scalar<GT>::load(gp + j);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float m = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < F; ++j) {
+                        const float v = fabsf(gp4[k][j]);
+                        if (ip < N && v < __uint_as_float(0x7F800000u) && v > m) m = v;    // finite values only
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                    if (q0 + k < nlp && (threadIdx.x & 63) == 0 && m > 0.0f)
+                        atomicMax(&s_pm[s_lv[q0 + k]], __float_as_uint(m));
+                }
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < lt.num_lods && ((mask >> threadIdx.x) & 1u)) {
+                const uint32_t bits = s_pm[threadIdx.x];
+                if (bits == 0u) {
+                    s_all_fixed = 0;
+                } else {
+                    uint32_t ef = ((bits >> 23) & 0xFFu) + 13u;     // limit = 2^(exponent + 13 - 127) >= 2^12 x pilot max
+                    if (ef > 254u) ef = 254u;
+                    const uint32_t lim_bits = ef << 23;
+                    const FxScale f = fx_scale_of(lim_bits, headroom);   // every accepted |contribution| <= limit < 2^(ef - 126)
+                    s_scale[threadIdx.x] = f.scale;
+                    s_inv[threadIdx.x] = f.inv;
+                    s_limit[threadIdx.x] = __uint_as_float(lim_bits);
+                }
+            }
         }
         __syncthreads();
     }
@@ -740,15 +798,31 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
                 Corners<DIM> c;
                 compute_corners<DIM>(t, lt.res[l], lt.hi[l], lt.dense[l] != 0, lt.mask, c);
                 const double scale = FX ? s_scale[l] : 1.0;
+                const float lim = FX ? s_limit[l] : 0.0f;
+                bool in_range = true;
+#pragma unroll
+                for (int j = 0; j < F; ++j) in_range = in_range && (fabsf(g[k][j]) <= lim);
 #pragma unroll
                 for (int kc = 0; kc < NC; ++kc) {
                     if (c.row[kc] < bl.used) {
                         const size_t slot = (size_t)(bl.drow0 + c.row[kc]) * F;
-                        if (fixed) {
+                        if (fixed && in_range) {
 #pragma unroll
                             for (int jj = 0; jj < F; ++jj) {   // feature order rotated by lane (LDS bank spreading)
                                 const int j = (jj + rotd) & (F - 1);
                                 atomicAdd(s_fix + slot + j, fx_encode(pick<F>(g[k], j) * c.w[kc], scale));
+                            }
+                        } else if (fixed) {
+                            // a gradient beyond the pilot's limit, or non-finite (rare): that feature goes straight to the table
+#pragma unroll
+                            for (int j = 0; j < F; ++j) {
+                                if (fabsf(g[k][j]) <= lim) {
+                                    atomicAdd(s_fix + slot + j, fx_encode(g[k][j] * c.w[kc], scale));
+                                } else {
+                                    const int64_t grow = (int64_t)first_idx[l] + c.row[kc];
+                                    if ((uint64_t)grow < (uint64_t)lt.table_rows)
+                                        unsafeAtomicAdd(grad_table + grow * F + j, g[k][j] * c.w[kc]);
+                                }
                             }
                         } else {
 #pragma unroll

@@ -521,9 +521,9 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         SHACIRA_CHECK(hipEventRecord(ss->staged, s));
         SHACIRA_CHECK(hipStreamWaitEvent(ss->stream, ss->staged, 0));
     }
-    // When nothing is transposed (every level is direct: the image configs) gmax would cost an extra read of grad_output
-    // (tried: a streaming abs-max kernel); measured on config B it costs more than the faster atomics return (0.103 vs
-    // 0.082 ms for the whole backward), so those calls keep the fp64 image.
+    // When nothing is transposed (every level is direct: the image configs) there is no gmax, and a pass of its own over
+    // grad_output costs more than the faster atomics return (tried: a streaming abs-max kernel, 0.103 vs 0.082 ms on config
+    // B): the direct kernel's workgroups take a pilot maximum over their own samples instead (direct_accumulate_kernel).
     // direct levels: one pass over the whole batch, no items (they add into the zeroed table)
     if (whole.ngroups > 0) {
         const BinPlan &plan = whole;
@@ -536,22 +536,23 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         if (bpg < 1) bpg = 1;
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         const dim3 grid(bpg, plan.ngroups);
-        // a row receives at most (samples walked by one workgroup) x (corners) contributions
-        const int headroom = (use_fx && need_T) ? fx_headroom(((uint64_t)n / bpg + kConsumeThreads) * (1u << DIM)) : -1;
-        if (need_T && use_fx)
+        // a row receives at most (samples walked by one workgroup) x (corners) contributions. Fixed-point images always:
+        // scaled by the transposing pass's max |gradient| per level when there is one (gmax), else by the workgroup's own
+        // pilot maximum (all-direct tables, small batches: direct_accumulate_kernel; config C backward 0.84 -> 0.63 ms,
+        // B 0.056 -> 0.047, kodak.yaml-shaped 0.104 -> 0.082 against the fp64 images)
+        const int headroom = fx_headroom(((uint64_t)n / bpg + kConsumeThreads) * (1u << DIM));
+        const uint32_t *gm = (need_T && use_fx) ? w.gmax : nullptr;
+        if (need_T)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, true>), grid, dim3(kConsumeThreads),
-                               acc_bytes, zs, lt, plan, first_idx, coords, w.gT, acc, n, NP, w.gmax, headroom);
-        else if (need_T)
-            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, false>), grid, dim3(kConsumeThreads),
-                               acc_bytes, zs, lt, plan, first_idx, coords, w.gT, acc, n, NP, nullptr, headroom);
+                               acc_bytes, zs, lt, plan, first_idx, coords, w.gT, acc, n, NP, gm, headroom);
         else if (dtype == SHACIRA_F32)
-            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, false, false>), grid, dim3(kConsumeThreads),
+            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, false, true>), grid, dim3(kConsumeThreads),
                                acc_bytes, zs, lt, plan, first_idx, coords, static_cast<const float *>(grad_out), acc, n,
-                               NP, nullptr, headroom);
+                               NP, gm, headroom);
         else
-            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, __half, false, false>), grid, dim3(kConsumeThreads),
+            hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, __half, false, true>), grid, dim3(kConsumeThreads),
                                acc_bytes, zs, lt, plan, first_idx, coords, static_cast<const __half *>(grad_out), acc, n,
-                               NP, nullptr, headroom);
+                               NP, gm, headroom);
         SHACIRA_CHECK_LAUNCH();
     }
     if (fork) SHACIRA_CHECK(hipEventRecord(ss->join, ss->stream));
@@ -651,9 +652,8 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
 #undef SHACIRA_T_ATTR
 #define SHACIRA_DIRECT_ATTR(D, FF)                                                                              \
         set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, float, true, true>), 16384 * sizeof(double));   \
-        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, float, true, false>), 16384 * sizeof(double));  \
-        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, float, false, false>), 16384 * sizeof(double)); \
-        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, __half, false, false>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, float, false, true>), 16384 * sizeof(double));  \
+        set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, __half, false, true>), 16384 * sizeof(double));
         SHACIRA_DIRECT_ATTR(2, 2) SHACIRA_DIRECT_ATTR(2, 4) SHACIRA_DIRECT_ATTR(3, 2) SHACIRA_DIRECT_ATTR(3, 4)
 #undef SHACIRA_DIRECT_ATTR
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2, true, false>), 16384 * sizeof(double));

@@ -933,6 +933,38 @@ def test_non_finite_and_extreme_gradients(dev, name):
             np.testing.assert_allclose(got_b[lo:hi], ref_ok[lo:hi], rtol=RTOL, atol=RTOL * np.abs(ref_ok[lo:hi]).max())
 
 
+@pytest.mark.parametrize("case", ["spikes", "sparse", "one_level_silent"])
+@pytest.mark.parametrize("name,n", [("B", 140_000), ("B", 3_000), ("Bp", 90_000)])
+def test_direct_levels_with_a_pilot_scale(dev, name, n, case):
+    """All-direct tables have no max |gradient| from a transposing pass: each workgroup of the direct-level kernel scales its
+    fixed-point image by a pilot maximum over 1 024 of its own samples (x 2^13). Gradients far beyond that limit go straight
+    to the table with float atomics, a level whose pilot saw only zeros keeps the fp64 image: spikes of 1e9 x the typical
+    magnitude, gradients that are zero except for a handful of samples, and one level without any gradient."""
+    ops = _ops()
+    dim, res, bw = CONFIGS[name]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, seed=71)
+    rng = np.random.default_rng(5)
+    L = len(res)
+    if case == "spikes":
+        go *= np.float32(1e-3)
+        rows = rng.choice(n, size=40, replace=False)
+        go[rows] *= np.float32(1e9)
+    elif case == "sparse":
+        keep = rng.choice(n, size=min(100, n), replace=False)
+        mask = np.zeros((n, 1), np.float32)
+        mask[keep] = 1.0
+        go *= mask
+    else:
+        go[:, 2 * (L // 2): 2 * (L // 2) + 2] = 0.0
+    tc, tg, tf = (torch.from_numpy(a).to(dev) for a in (coords, go, first))
+    got = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2).cpu().numpy()
+    ref = oc.backward(coords, go, (T, 2), first, res, bw)
+    _assert_grad_close(got, ref, first, sizes)
+    if case == "one_level_silent":
+        lo, hi = int(first[L // 2]), int(first[L // 2]) + sizes[L // 2]
+        assert not got[lo:hi].any()
+
+
 def test_level_ranges_share_the_fixed_point_scales(dev):
     """N >= 2^17: the backward accumulates in fixed point scaled by max |grad| per level, recorded by the transpose of
     the FIRST call of a level-range series (STAGE_ALL_LEVELS) and reused by the later calls (REUSE_STAGED)."""
