@@ -90,8 +90,16 @@ def quick_measure(name, device, iters=20):
     tb = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in evs]))
     bf, bb = algorithmic_bytes_per_sample(dim, L, F)
     gbs = (bf + bb) * n / ((tf + tb) * 1e-3) / 1e9
+    # SURVEY 8(d)'s accounting charges every corner's 8 bytes as HBM bytes; a table that sits in the caches (the Kodak tables
+    # are 0.2-0.3 MB) is read from L1 / LDS, so its fraction says how far the kernels are from "every algorithmic byte at HBM
+    # speed", not from the HBM limit (it can exceed 1). The sample streams alone (coordinates + feature rows out, coordinates +
+    # gradient rows in) are what such a table really moves through HBM:
+    esz = 4
+    stream = (2 * dim * 4 + 2 * L * F * esz) * n / ((tf + tb) * 1e-3) / 1e9
+    table_mb = T * F * esz / 1e6
     return {"samples_per_s": n / ((tf + tb) * 1e-3), "ms_forward": tf, "ms_backward": tb, "samples": n,
-            "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS}
+            "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS, "table_MB": table_mb,
+            "sample_streams_GBps": stream}
 
 
 def kernel_source_hash():
