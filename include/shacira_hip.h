@@ -434,11 +434,14 @@ SHACIRA_API int shacira_stream_probe(int kind, const void *src, void *dst, size_
  * entered and uses that for the whole call (its workspace-size check included), so changing an option from another thread
  * never makes a running call inconsistent -- it applies to calls entered later. Unknown names / values -> SHACIRA_EINVAL.
  *   "fwd_variant": -1 (default) = measured rule; 0 = one gather per corner, the reference's kernel shape (any even F);
- *               3 = lane pairs, sample-major; 6 = one level per XCD + level-major staging; 8 = cell-sorted forward.
+ *               3 = lane pairs, sample-major; 6 = one level per XCD + level-major staging; 8 = cell-sorted forward;
+ *               9 = tables whose levels fit LDS images (groups of levels resident in LDS; refused silently, i.e. the rule
+ *               applies, when a level does not fit).
  *   "bwd_variant": -1 (default) = by batch size; 0 = scattered atomics (the reference's design); 1 = binned.
  *   "bin_batch_mib": cap (MiB) of the backward's item array; larger batches are processed in sub-batches.
  *   "bin_acc_kib": LDS accumulator image per consumer workgroup: 64, 128, or 0 = chosen from the batch size (default).
- *   "bwd_compact": 1 (default) = dense 3-D levels travel as one two-slot item per sample (z-slab buckets), 0 = pair items.
+ *   "bwd_compact": 1 (default) = dense levels travel as one item per sample (3-D: z-slab buckets, two slots; 2-D: line-slab
+ *               buckets, one slot), 0 = pair items.
  *   "mlp_variant": -1 (default) = decoder MLPs on the fp32 matrix cores wherever instantiated, 0 = VALU kernels.
  *   "tiled": -1 (default) = the cell-sorted forward (hashgrid_tiled.hip) for batches where it measured faster (tables
  *            > 8 MB; 3-D: from 2^18 samples for F = 2, 80 K for F = 4; 2-D: from 192 K), 0 = never, 1 = whenever the shape

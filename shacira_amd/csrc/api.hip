@@ -17,7 +17,7 @@ struct OptionSlot {
     std::atomic<int> value;
 };
 static OptionSlot g_slots[] = {
-    {"fwd_variant", &Options::fwd_variant, -1, 8, {-1}},
+    {"fwd_variant", &Options::fwd_variant, -1, 9, {-1}},
     {"bwd_variant", &Options::bwd_variant, -1, 1, {-1}},
     {"mlp_variant", &Options::mlp_variant, -1, 1, {-1}},
     {"bwd_compact", &Options::bwd_compact, 0, 1, {1}},
@@ -36,7 +36,7 @@ void options_snapshot() {
 }
 static bool option_value_ok(const OptionSlot &sl, int v) {
     if (v < sl.lo || v > sl.hi) return false;
-    if (!std::strcmp(sl.name, "fwd_variant")) return v == -1 || v == 0 || v == 3 || v == 6 || v == 8;
+    if (!std::strcmp(sl.name, "fwd_variant")) return v == -1 || v == 0 || v == 3 || v == 6 || v == 8 || v == 9;
     if (!std::strcmp(sl.name, "bin_acc_kib")) return v == 0 || v == 64 || v == 128;
     return true;
 }

@@ -135,6 +135,7 @@ static hipError_t bwd_atomic_f(const LevelTable &lt, const int32_t *first_idx, c
 
 // hashgrid_bwd_bin.hip
 bool bin_supported(int dim, const LevelTable &lt);
+bool bin_all_direct(int dim, const LevelTable &lt);
 size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n);
 float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace);
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
@@ -145,7 +146,9 @@ static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
     const int v = opt().bwd_variant;
     if (v == 0 || !bin_supported(dim, lt)) return false;
     if (v == 1) return true;
-    return n >= 8192;
+    // tables whose levels all fit LDS images need no partitioning pass at all: one kernel, ahead of the scattered atomics
+    // from ~2 K samples (Kodak table: 21.7 vs 49.8 us at 4 096 samples, 21.4 vs 18.6 us at 1 024)
+    return n >= (bin_all_direct(dim, lt) ? 2048 : 8192);
 }
 
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {

@@ -94,6 +94,16 @@ static int choose_acc_kib(int dim, int dtype, const LevelTable &lt, int64_t n) {
     return big.nbl == 0 ? 128 : 64;
 }
 
+bool bin_supported(int dim, const LevelTable &lt);
+
+// every level fits an LDS image (no level is binned): the backward is the direct-level kernel alone
+bool bin_all_direct(int dim, const LevelTable &lt) {
+    if (!bin_supported(dim, lt)) return false;
+    BinPlan plan;
+    make_plan(dim, SHACIRA_F32, lt, kTile, plan, 128, false);
+    return plan.nbl == 0 && plan.ngroups > 0;
+}
+
 bool bin_supported(int dim, const LevelTable &lt) {
     const int kib = opt().bin_acc_kib;
     // (fp32 plan: its 2-D compact levels need a few more buckets than the half-precision stream's pair items)

@@ -12,6 +12,8 @@
 //   variant 3  lane pair = sample (x / x+1 corners merge into one request), sample-major   [default: 2-D, small N]
 //   variant 6  one level per XCD at a time + lane pairing, level-major staging + transposing copy [default: 3-D, N >= 16 K]
 //   variant 8  cell-sorted forward (hashgrid_tiled.hip) over this file's rows / level-pair kernels [default: large batches]
+//   variant 9  small tables (every level fits an LDS image: the Kodak tables): groups of consecutive levels held in LDS,
+//              lane = (sample, level) like variant 0 -> corner reads are ds_read, outputs coalesce    [default: such tables, large N]
 // (option "fwd_variant"; -1 = the measured rule. Variants 1, 2, 4, 5, 7 of rounds 1-2 lost and were removed: git 4a7dfa7)
 // HBM-bound: algorithmic bytes per sample = 4*DIM + L*2^DIM*F*s + L*F*s.
 #include <mutex>
@@ -21,6 +23,7 @@
 namespace shacira {
 
 static bool use_staged(int dim, const LevelTable &lt, int64_t n);
+static bool use_lds_tables(int dim, int esz, const LevelTable &lt, int64_t n);
 
 template <typename T, int F> struct RowVec;  // one table row as a single vector access
 template <> struct RowVec<float, 2> { using type = float2; };
@@ -117,6 +120,178 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(LevelTable lt, const 
                 }
                 Scalar<T>::store(feats + (i * L + lvl) * Fr + j, acc);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 9 (round 3): LDS-resident tables. The image configs' tables are a few hundred KB (configs B / C: 26 704 rows =
+// 0.2 MB; kodak.yaml: 0.3 MB): too large for the 32 KiB L1, so every corner gather of variants 0 / 3 is an L2 -> L1 line
+// transfer (2 clk per 128-byte line for 8-16 useful bytes) -- the forward of the 24-image batch ran at the line rate, not at
+// any byte rate. Here a workgroup copies a GROUP of G consecutive levels (<= 128 KiB of rows) into LDS once and then walks
+// its share of the samples: corner reads are ds_read_b64 / b128. A sample is served by P = G / LPC adjacent lanes, lane p
+// owning the LPC levels that make the p-th 16-byte piece of the group's part of the output row (its level parameters stay
+// in registers for the whole walk): a wave's store instruction writes whole contiguous runs (P = 4: 16 samples x 64 bytes)
+// instead of 64 pieces in 64 lines. grid = (workgroups per group, groups). Arithmetic is variant 0's (same corner order,
+// same fmaf chain): bit-identical.
+constexpr int kLdsFwdThreads = 1024;
+constexpr int kLdsFwdMaxGroups = 8;
+constexpr size_t kLdsFwdBytes = 128 * 1024;
+
+struct LdsFwdPlan {
+    int32_t ngroups;
+    int32_t G;                                     // levels per group (a power of two times LPC; the last group may hold fewer)
+    int32_t P;                                     // lanes per sample = 16-byte pieces per group = G / LPC (power of two)
+    uint32_t loff[SHACIRA_MAX_LODS];               // first row of the level inside its group's LDS image
+    uint32_t grows[kLdsFwdMaxGroups];              // rows of the group
+};
+
+static uint64_t level_rows(int dim, const LevelTable &lt, int l) {
+    if (!lt.dense[l]) return (uint64_t)lt.mask + 1u;
+    uint64_t rows = 1;
+    for (int a = 0; a < dim; ++a) rows *= (uint64_t)lt.res[l];
+    return rows;
+}
+
+// The largest G = LPC * 2^k (<= 32 levels) whose blocks of G consecutive levels each fit one image, in at most 8 groups.
+// Dense levels must have res <= 256: below that the clamp keeps every corner inside its level (hi < res - 1), so the kernel
+// reads LDS rows without a bound check.
+static bool make_lds_fwd_plan(int dim, const LevelTable &lt, size_t esz, LdsFwdPlan &p) {
+    const size_t row_bytes = (size_t)lt.feature_dim * esz;
+    if (row_bytes > 16 || (16 % row_bytes) != 0) return false;
+    const int lpc = (int)(16 / row_bytes);
+    const uint64_t cap = kLdsFwdBytes / row_bytes;
+    for (int l = 0; l < lt.num_lods; ++l)
+        if (lt.dense[l] && lt.res[l] > 256) return false;
+    for (int G = lpc * 8; G >= lpc; G /= 2) {
+        const int ng = (lt.num_lods + G - 1) / G;
+        if (ng > kLdsFwdMaxGroups) break;
+        bool ok = true;
+        for (int g = 0; g < ng && ok; ++g) {
+            uint64_t used = 0;
+            for (int l = g * G; l < (g + 1) * G && l < lt.num_lods; ++l) {
+                p.loff[l] = (uint32_t)used;
+                used += level_rows(dim, lt, l);
+            }
+            ok = used <= cap;
+            p.grows[g] = (uint32_t)used;
+        }
+        if (ok) {
+            p.ngroups = ng;
+            p.G = G;
+            p.P = G / lpc;
+            return true;
+        }
+    }
+    return false;
+}
+
+template <int DIM, typename T, int F>
+__global__ __launch_bounds__(kLdsFwdThreads) void hashgrid_fwd_lds_kernel(LevelTable lt, LdsFwdPlan plan,
+                                                                          const int32_t *__restrict__ first_idx,
+                                                                          const float *__restrict__ coords,
+                                                                          const T *__restrict__ table, T *__restrict__ feats,
+                                                                          int64_t n) {
+    constexpr int NC = 1 << DIM;
+    constexpr int LPC = 16 / (F * (int)sizeof(T));     // levels per 16-byte piece of an output row (1, 2 or 4)
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    T *s_tab = reinterpret_cast<T *>(s_raw);
+    const int g = blockIdx.y;
+    const int lb = g * plan.G;
+    const int le = (lb + plan.G < lt.num_lods) ? lb + plan.G : lt.num_lods;
+    const int L = lt.num_lods;
+    // the group's rows: consecutive levels are consecutive in the table, so this is ONE contiguous copy (16-byte global loads
+    // from the first aligned element on; the LDS side is written element-wise, its offset need not be 16-byte aligned)
+    {
+        const int64_t row0 = first_idx[lb];
+        int64_t rows = plan.grows[g];
+        if (row0 + rows > lt.table_rows) rows = lt.table_rows - row0;     // (a table shorter than its last level: zeros behind)
+        if (rows < 0) rows = 0;
+        const T *src = table + row0 * F;
+        const int64_t elems = rows * F, total = (int64_t)plan.grows[g] * F;
+        constexpr int VE = 16 / (int)sizeof(T);
+        const int64_t head = (int64_t)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u)) & 15u) / sizeof(T));
+        const int64_t h = head < elems ? head : elems;
+        for (int64_t e = threadIdx.x; e < h; e += kLdsFwdThreads) s_tab[e] = src[e];
+        const int64_t nvec = (elems - h) / VE;
+        for (int64_t v = threadIdx.x; v < nvec; v += kLdsFwdThreads) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(src + h + v * VE);
+            T tmp[VE];
+            __builtin_memcpy(tmp, &q, 16);
+#pragma unroll
+            for (int k = 0; k < VE; ++k) s_tab[h + v * VE + k] = tmp[k];
+        }
+        for (int64_t e = h + nvec * VE + threadIdx.x; e < elems; e += kLdsFwdThreads) s_tab[e] = src[e];
+        for (int64_t e = elems + threadIdx.x; e < total; e += kLdsFwdThreads) Scalar<T>::store(&s_tab[e], 0.0f);
+    }
+    // this lane's piece of the group and the parameters of its LPC levels (constant for the whole walk)
+    const uint32_t P = (uint32_t)plan.P;
+    const uint32_t piece = threadIdx.x & (P - 1u);
+    int32_t res[LPC];
+    float hi[LPC];
+    bool dense[LPC], have[LPC];
+    uint32_t off[LPC];
+    bool all = true;
+#pragma unroll
+    for (int u = 0; u < LPC; ++u) {
+        const int l = lb + (int)piece * LPC + u;
+        have[u] = l < le;
+        all = all && have[u];
+        const int lc = have[u] ? l : lb;
+        res[u] = lt.res[lc];
+        hi[u] = lt.hi[lc];
+        dense[u] = lt.dense[lc] != 0;
+        off[u] = plan.loff[lc];
+    }
+    __syncthreads();
+
+    const uint32_t spw = kLdsFwdThreads / P;                       // samples per workgroup and iteration
+    const int64_t stride = (int64_t)gridDim.x * spw;
+    int64_t i = (int64_t)blockIdx.x * spw + threadIdx.x / P;
+    float cn[DIM];
+    {
+        const int64_t ic = i < n ? i : n - 1;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) cn[a] = coords[ic * DIM + a];
+    }
+    for (; i < n; i += stride) {
+        double t[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(cn[a]);
+        {   // next sample's coordinates while this one is interpolated
+            const int64_t in = (i + stride < n) ? i + stride : n - 1;
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) cn[a] = coords[in * DIM + a];
+        }
+        float acc[LPC][F];
+#pragma unroll
+        for (int u = 0; u < LPC; ++u) {
+            Corners<DIM> c;
+            compute_corners<DIM>(t, res[u], hi[u], dense[u], lt.mask, c);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                float v[F];
+                // (no bound check: hashed rows are masked, dense levels have res <= 256 -- the planner's condition)
+                load_row<T, F>(s_tab + (size_t)(off[u] + c.row[k]) * F, v);
+#pragma unroll
+                for (int j = 0; j < F; ++j) acc[u][j] = (k == 0) ? v[j] * c.w[0] : fmaf(v[j], c.w[k], acc[u][j]);
+            }
+        }
+        T *out = feats + ((int64_t)i * L + lb + (int64_t)piece * LPC) * F;
+        if (all) {
+            T pc[LPC * F];
+#pragma unroll
+            for (int u = 0; u < LPC; ++u) {
+#pragma unroll
+                for (int j = 0; j < F; ++j) Scalar<T>::store(&pc[u * F + j], acc[u][j]);
+            }
+            uint4 pv;
+            __builtin_memcpy(&pv, pc, 16);
+            *reinterpret_cast<uint4 *>(out) = pv;
+        } else {
+#pragma unroll
+            for (int u = 0; u < LPC; ++u)
+                if (have[u]) store_row<T, F>(out + (size_t)u * F, acc[u]);
         }
     }
 }
@@ -564,6 +739,28 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
                              void *feats, void *workspace, int64_t num_coords, hipStream_t stream) {
     const int variant = opt().fwd_variant;
     if constexpr (F > 0) {
+        // (its 16-byte output pieces need output rows of whole 16-byte units and an aligned base)
+        if (use_lds_tables(DIM, (int)sizeof(T), lt, num_coords) && ((size_t)lt.num_lods * F * sizeof(T)) % 16 == 0 &&
+            (reinterpret_cast<uintptr_t>(feats) & 15u) == 0) {
+            LdsFwdPlan plan;
+            make_lds_fwd_plan(DIM, lt, sizeof(T), plan);
+            static PerDeviceOnce once;  // per instantiation and device: 128 KiB of dynamic LDS
+            hipError_t e = once.run([]() -> hipError_t {
+                return hipFuncSetAttribute(reinterpret_cast<const void *>(&hashgrid_fwd_lds_kernel<DIM, T, F>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsFwdBytes);
+            });
+            if (e != hipSuccess) return e;
+            // one resident workgroup per CU (the image fills its LDS): 256 in total, never more than the items ask for
+            uint32_t bpg = 256u / (uint32_t)plan.ngroups;
+            const uint64_t spw = (uint64_t)kLdsFwdThreads / (uint64_t)plan.P;
+            const uint64_t need = ((uint64_t)num_coords + spw - 1) / spw;
+            if (bpg > need) bpg = (uint32_t)need;
+            if (bpg < 1) bpg = 1;
+            hipLaunchKernelGGL((hashgrid_fwd_lds_kernel<DIM, T, F>), dim3(bpg, (uint32_t)plan.ngroups), dim3(kLdsFwdThreads),
+                               kLdsFwdBytes, stream, lt, plan, first_idx, coords, static_cast<const T *>(table),
+                               static_cast<T *>(feats), num_coords);
+            return hipGetLastError();
+        }
         if (use_staged(DIM, lt, num_coords) && workspace) {
             // variant 6: level-per-XCD schedule with lane pairing, features staged level-major (coalesced stores),
             // then one transposing copy into the caller's [N, L*F] layout
@@ -622,6 +819,18 @@ static hipError_t dispatch_f(const LevelTable &lt, const int32_t *first_idx, con
         case 4: return launch_fwd<DIM, T, 4>(lt, first_idx, coords, table, feats, ws, n, s);
         default: return launch_fwd<DIM, T, 0>(lt, first_idx, coords, table, feats, ws, n, s);
     }
+}
+
+// variant 9: every level fits an LDS image (and the levels make at most 8 groups). Measured on the Kodak tables: 0.0194 vs
+// 0.0335 ms at 393 216 samples, 0.47 vs 0.85 ms at 9.4 M, still ahead at 4 096 (13.7 vs 16.3 us, both launch-bound)
+static bool use_lds_tables(int dim, int esz, const LevelTable &lt, int64_t n) {
+    const int v = opt().fwd_variant;
+    if (lt.feature_dim != 2 && lt.feature_dim != 4) return false;
+    if (v >= 0 && v != 9) return false;
+    if (n < 1 || n >= ((int64_t)1 << 31)) return false;
+    LdsFwdPlan p;
+    if (!make_lds_fwd_plan(dim, lt, (size_t)esz, p)) return false;
+    return v == 9 || n >= 4096;
 }
 
 // level-major staging buffer [L][N][F] of the table's scalar type (variant 6)
@@ -736,6 +945,7 @@ hipError_t hashgrid_debug_corners(int dim, const LevelTable &lt, const float *co
 size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
     if (tiled_supported(dim, dtype, lt, n)) return tiled_forward_workspace(dim, dtype, lt, n);
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return 0;
+    if (use_lds_tables(dim, dtype == SHACIRA_F32 ? 4 : 2, lt, n)) return 0;   // variant 9 stages nothing
     size_t b = ((size_t)n * lt.num_lods * lt.feature_dim * (dtype == SHACIRA_F32 ? 4 : 2) + 255) / 256 * 256;
     return b;
 }

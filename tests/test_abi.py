@@ -58,10 +58,10 @@ def test_argument_validation_codes():
     # pruned in ABI 7 (round 3): the lost code paths' switches are gone, and forward variants 1, 2, 4, 5, 7 are refused
     for name in (b"bwd_rows", b"bwd_groups", b"bwd_direct_side", b"bwd_fuse"):
         assert L.shacira_set_option(name, 1) == _lib.EINVAL
-    for v in (1, 2, 4, 5, 7, 9):
+    for v in (1, 2, 4, 5, 7, 10):
         assert L.shacira_set_option(b"fwd_variant", v) == _lib.EINVAL
     assert L.shacira_set_option(b"bin_acc_kib", 96) == _lib.EINVAL
-    for v in (0, 3, 6, 8, -1):
+    for v in (0, 3, 6, 8, 9, -1):
         assert L.shacira_set_option(b"fwd_variant", v) == 0 and L.shacira_get_option(b"fwd_variant") == v
     with pytest.raises(Exception, match="multiple of 2"):
         _lib.check(_lib.EODD)

@@ -74,7 +74,7 @@ def _assert_grad_close(got, ref, first, sizes, rtol=RTOL):
 
 
 @pytest.mark.parametrize("name", ["A", "B", "Bp", "D"])
-@pytest.mark.parametrize("variant", [(-1, -1), (0, 0), (3, 1), (6, 1), (8, 1)])
+@pytest.mark.parametrize("variant", [(-1, -1), (0, 0), (3, 1), (6, 1), (8, 1), (9, -1)])
 def test_forward_bit_exact_backward_within_tolerance(dev, name, variant):
     from shacira_amd import _lib
     dim, res, bw = CONFIGS[name]
@@ -1246,6 +1246,33 @@ def test_tiled_forward_other_shapes(dev, dim, F, dtype):
     finally:
         _lib.set_option("fwd_variant", -1)
         _lib.set_option("tiled_lc_fwd", -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", ["B", "kodak_yaml", "small3d", "F4"])
+def test_forward_with_lds_resident_tables(dev, shape, dtype):
+    """Tables whose levels fit LDS images (the Kodak tables of configs B / C, kodak.yaml's 24 levels, a small 3-D table,
+    F = 4): from 2^17 samples the forward keeps groups of consecutive levels in LDS (fwd_variant 9 by the automatic rule).
+    Bit-identical to the oracle, at a batch that takes the rule and, forced, at a ragged small one; edge coordinates
+    (+-1, NaN, out of range) included by _problem."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw, F = {"B": (2, geo(16, 512, 16), 11, 2), "kodak_yaml": (2, geo(16, 512, 24), 11, 2),
+                       "small3d": (3, geo(4, 64, 10), 12, 2), "F4": (2, geo(8, 256, 12), 10, 4)}[shape]
+    for n, force in (((1 << 17) + 77, False), (5_003, True)):
+        sizes, first, T, coords, table, go = _problem(dim, res, bw, n, F=F, seed=81)
+        stored = table.astype(np.float16).astype(np.float32) if dtype == torch.float16 else table
+        tc, tt, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(table).to(dev).to(dtype), torch.from_numpy(first).to(dev)
+        fwd = ops.hashgrid_interpolate_cuda if dim == 3 else ops.hashgrid_interpolate2d_cuda
+        ref = oc.forward(coords, stored, first, res, bw)
+        want = ref.astype(np.float16) if dtype == torch.float16 else ref
+        if force:
+            _lib.set_option("fwd_variant", 9)
+        try:
+            got = fwd(tc, tt, tf, res, bw).cpu().numpy()
+        finally:
+            _lib.set_option("fwd_variant", -1)
+        assert np.array_equal(got, want), (shape, n, str(dtype))
 
 
 @pytest.mark.parametrize("seed", range(24))
