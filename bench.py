@@ -49,28 +49,36 @@ WORKLOADS = {
     "kodak_yaml_2d_L24_F1rep2_bw11_N393216": (2, geo(16, 512, 24), 11, 2, 393216),
     "nerf_lego_yaml_3d_L24_F4_bw19_N409600": (3, geo(16, 512, 24), 19, 4, 409600),
 }
+# the same shapes with an fp16 table and fp16 gradients: the reference's NeRF runs under AMP (wisp/ops/grid.py:73 casts the
+# operator's inputs to half), so this is the precision its trainer actually calls the kernels with
+HALF_VARIANTS = {"nerf_lego_yaml_3d_L24_F4_bw19_N409600_fp16": "nerf_lego_yaml_3d_L24_F4_bw19_N409600",
+                 "S1_nerf_hash_3d_L16_F2_bw19_N2^20_fp16": "S1_nerf_hash_3d_L16_F2_bw19_N2^20"}
 SECONDARY = ["S2_kodak_2d_L16_F2_bw19_N2^20", "B_kodak_2d_L16_F2_bw11_N393216", "C_kodak24_2d_L16_F2_bw11_N9437184",
              "D_nerf_lego_3d_L16_F2_bw19_N65536", "kodak_yaml_2d_L24_F1rep2_bw11_N393216",
-             "nerf_lego_yaml_3d_L24_F4_bw19_N409600"]
+             "nerf_lego_yaml_3d_L24_F4_bw19_N409600", "nerf_lego_yaml_3d_L24_F4_bw19_N409600_fp16",
+             "S1_nerf_hash_3d_L16_F2_bw19_N2^20_fp16"]
 
 
 def quick_measure(name, device, iters=20):
     """fwd / bwd operator times of another BASELINE config (same protocol, fewer iterations); not the headline."""
     from shacira_amd import hip_ops
-    dim, res, bw, F, n = WORKLOADS[name]
+    half = name in HALF_VARIANTS
+    dim, res, bw, F, n = WORKLOADS[HALF_VARIANTS.get(name, name)]
     L = len(res)
     sizes = [min(2 ** bw, r ** dim) for r in res]
     first = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)).to(device)
     T = int(sum(sizes))
     g = torch.Generator().manual_seed(7)
     table = (torch.randn(T, F, generator=g) * 0.01).to(device)
+    if half:
+        table = table.half()
     if name.startswith("D_"):
         # SURVEY S3: NeRF-like ray points -- 4096 rays from the radius-3 sphere, 16 stratified samples inside the cube
         from shacira_amd import harness
         coords = harness.ray_points(n // 16, 16, g).contiguous().to(device)
     else:
         coords = (torch.rand(n, dim, generator=g) * 2 - 1).to(device)
-    go = torch.randn(n, L * F, generator=g).to(device)
+    go = torch.randn(n, L * F, generator=g).to(device).to(table.dtype)
     fwd = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
     for _ in range(3):
         fwd(coords, table, first, res, bw)
@@ -88,18 +96,18 @@ def quick_measure(name, device, iters=20):
     torch.cuda.synchronize()
     tf = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in evs]))
     tb = float(np.mean([ev[1].elapsed_time(ev[2]) for ev in evs]))
-    bf, bb = algorithmic_bytes_per_sample(dim, L, F)
+    bf, bb = algorithmic_bytes_per_sample(dim, L, F, 2 if half else 4)
     gbs = (bf + bb) * n / ((tf + tb) * 1e-3) / 1e9
     # SURVEY 8(d)'s accounting charges every corner's 8 bytes as HBM bytes; a table that sits in the caches (the Kodak tables
     # are 0.2-0.3 MB) is read from L1 / LDS, so its fraction says how far the kernels are from "every algorithmic byte at HBM
     # speed", not from the HBM limit (it can exceed 1). The sample streams alone (coordinates + feature rows out, coordinates +
     # gradient rows in) are what such a table really moves through HBM:
-    esz = 4
+    esz = 2 if half else 4
     stream = (2 * dim * 4 + 2 * L * F * esz) * n / ((tf + tb) * 1e-3) / 1e9
     table_mb = T * F * esz / 1e6
     return {"samples_per_s": n / ((tf + tb) * 1e-3), "ms_forward": tf, "ms_backward": tb, "samples": n,
             "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS, "table_MB": table_mb,
-            "sample_streams_GBps": stream}
+            "sample_streams_GBps": stream, "dtype": "f16" if half else "f32"}
 
 
 def kernel_source_hash():
