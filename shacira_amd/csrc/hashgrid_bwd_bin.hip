@@ -80,13 +80,18 @@ static bool bin_feasible(int dim, int dtype, const LevelTable &lt, int acc_kib) 
 }
 
 // Image size per call, from the TOTAL batch (one choice per call so that every plan of the call classifies the levels
-// alike). Option "bin_acc_kib": 64 / 128 force it, 0 (default) = measured rule: 64 KiB images (two consumer workgroups
-// per CU overlap their zero / stream / flush phases) win up to 2^19 3-D samples, 128 KiB (half as many buckets) beyond.
+// alike). Option "bin_acc_kib": 64 / 128 force it, 0 (default) = measured rule: 64 KiB images for small batches (below 2^17
+// samples in 3-D, up to 2^20 in 2-D), 128 KiB (half as many buckets) beyond.
 static int choose_acc_kib(int dim, int dtype, const LevelTable &lt, int64_t n) {
     const int kib = opt().bin_acc_kib;
     if (kib != 0) return kib;
     const int64_t pairs = (int64_t)1 << (dim - 1);
-    if (n * pairs > ((int64_t)1 << 21) || !bin_feasible(dim, dtype, lt, 64)) return 128;
+    // (3-D, re-measured after the consume pass learned to fetch one unit ahead: 128 KiB wins from 2^17 samples -- 0.124 vs
+    // 0.130 ms at 2^17, 0.180 vs 0.196 at 2^18, 0.315 vs 0.333 at 2^19 -- the fixed-point consume kernel needs 66 VGPRs, so
+    // two 64 KiB workgroups do not share a CU anyway; 65 536 samples, fp64 images: 64 KiB 0.0925 vs 0.0960. 2-D: 64 KiB up to
+    // 2^20 samples, 0.125 vs 0.134 ms at 2^18)
+    const bool large = dim == 3 ? n >= ((int64_t)1 << 17) : n * pairs > ((int64_t)1 << 21);
+    if (large || !bin_feasible(dim, dtype, lt, 64)) return 128;
     // tables whose levels are all "direct" (config B: every level fits an LDS image) want the big image: fewer level
     // groups, hence fewer walks over the samples (measured 82 vs 124 us on the 393 216-pixel batch)
     BinPlan big;
