@@ -148,7 +148,8 @@ static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
     if (v == 1) return true;
     // tables whose levels all fit LDS images need no partitioning pass at all: one kernel, ahead of the scattered atomics
     // from ~2 K samples (Kodak table: 21.7 vs 49.8 us at 4 096 samples, 21.4 vs 18.6 us at 1 024)
-    return n >= (bin_all_direct(dim, lt) ? 2048 : 8192);
+    // (config D's 48.8 MB table: binned 62 us at 4 096 - 8 192 samples against 66 / 122 us for the atomics; 64 vs 40 us at 2 048)
+    return n >= (bin_all_direct(dim, lt) ? 2048 : 4096);
 }
 
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
