@@ -7,20 +7,6 @@
 
 namespace shacira {
 
-#ifdef SHACIRA_SCATTER_TIMING
-__device__ unsigned long long g_scatter_t[8];
-#define SCT(k)                                                                     \
-    do {                                                                           \
-        if (threadIdx.x == 0) {                                                    \
-            const unsigned long long now_ = wall_clock64();                        \
-            atomicAdd(&g_scatter_t[k], now_ - sct_last);                           \
-            sct_last = now_;                                                       \
-        }                                                                          \
-    } while (0)
-#else
-#define SCT(k) do { } while (0)
-#endif
-
 // ------------------------------------------------------------------------------------------------- pass B
 // Gradients from the transposed image gT [L][NP][F], grid (tiles, binned levels). A (tile, bucket) run is reserved with one
 // returning atomic on the bucket's cursor (set to the bucket's base by the bucket scan): runs of different tiles land in
@@ -50,10 +36,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     __shared__ uint32_t s_start[kMaxLevelBuckets + 1];
     __shared__ uint64_t s_gbase[kMaxLevelBuckets];
 
-#ifdef SHACIRA_SCATTER_TIMING
-    unsigned long long sct_last = wall_clock64();
-    if (threadIdx.x == 0) atomicAdd(&g_scatter_t[7], 1ull);
-#endif
     // (tile-fastest numbering; level-fastest -- a tile's levels back to back -- measured 3 % slower, round 3)
     const uint32_t tile = blockIdx.x, bi = blockIdx.y;
     const uint32_t lvl = plan.blevel[bi];
@@ -157,9 +139,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
             rank[u][q] = (ps[u][q].key >> 26) ? atomicAdd(&s_hist[ps[u][q].bucket], compact ? kCompactSlots : 1u) : 0u;
         }
     }
-    SCT(0);
     lds_barrier();   // (not __syncthreads(): its vmcnt(0) would wait for the reservation)
-    SCT(1);
     if (threadIdx.x < 64) {  // wave 0: exclusive scan of the <= 128 bucket counts, two per lane
         const uint32_t lane = threadIdx.x;
         const uint32_t c0 = (2 * lane < bl.nb) ? s_hist[2 * lane] : 0u;
@@ -176,7 +156,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         if (lane == 63) s_start[bl.nb] = incl;
     }
     lds_barrier();
-    SCT(2);
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
 #pragma unroll
@@ -283,20 +262,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         }
     }
     if (reserver) s_gbase[threadIdx.x - 64] = run_base;
-    SCT(3);
     __syncthreads();
-    SCT(4);
     const uint32_t staged = s_start[bl.nb];
     for (uint32_t pos = threadIdx.x; pos < staged; pos += kBinThreads) {
         const uint32_t b = s_bucket[pos];
         // write-once / read-once stream: non-temporal stores (measured -7 % on the whole backward)
         store_item_nt(items + s_gbase[b] + (pos - s_start[b]), s_items[pos]);
     }
-    SCT(5);
-#ifdef SHACIRA_SCATTER_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    SCT(6);
-#endif
     // selective table zeroing, second half (zero_unowned_rows_kernel did the rows no bucket covers): a hashed bucket with
     // exactly one work unit is overwritten by the consume pass; one with none is never written and one with several is
     // added to atomically -- those are zeroed here, by the workgroups of the level's first tiles, behind their own item

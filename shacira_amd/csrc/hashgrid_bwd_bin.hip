@@ -101,17 +101,6 @@ static int choose_acc_kib(int dim, int dtype, const LevelTable &lt, int64_t n) {
     return big.nbl == 0 ? 128 : 64;
 }
 
-#ifdef SHACIRA_SCATTER_TIMING
-extern "C" __attribute__((visibility("default"))) int shacira_debug_scatter_times(unsigned long long *out, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scatter_t), sizeof(unsigned long long) * 8);
-    if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_scatter_t), z, sizeof(z));
-    }
-    return (int)e;
-}
-#endif
-
 bool bin_supported(int dim, const LevelTable &lt);
 
 // every level fits an LDS image (no level is binned): the backward is the direct-level kernel alone
