@@ -15,7 +15,7 @@
 
 namespace shacira {
 
-constexpr int kMaxPartialBlocks = 1024;
+constexpr int kMaxPartialBlocks = 2048;   // 8 workgroups of 256 threads per CU
 constexpr int kThreads = 256;
 constexpr int kMaxRed = 96;  // largest reduction width of any kernel below
 
@@ -683,7 +683,17 @@ template <int LD> struct CdfConsts {
     }
 };
 
-__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+// 1 / (1 + exp(-x)) with the hardware reciprocal (1 ulp) instead of the IEEE division sequence; exp stays the accurate one
+// (a probability is the DIFFERENCE of two of these: their absolute error is what the tails' gradients see)
+__device__ __forceinline__ float sigmoidf_ref(float x) { return __frcp_rn(1.0f + expf(-x)); }
+
+// tanh(u) = 1 - 2 / (exp(2u) + 1): one exp + one reciprocal instead of libm's ~120-instruction tanhf (the entropy backward was
+// VALU-bound at 1 300 instructions per table row and 246 VGPRs). Absolute error ~1e-7; it enters the CDF through
+// x = u + tanh(u) * tanh(a) and a sigmoid of slope <= 1/4, i.e. below the fp32 rounding of the CDF value itself.
+__device__ __forceinline__ float tanhf_fast(float u) {
+    const float e = __expf(2.0f * u);               // (hardware exp2: its error reaches tanh scaled by <= 1/2) inf -> 1, 0 -> -1
+    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+}
 
 // CDF with the chain's intermediates kept for the backward (NL = num_layers; layers used: first NL-1 of f1..f3, then f4)
 template <int LD> struct CdfTrace {
@@ -692,14 +702,15 @@ template <int LD> struct CdfTrace {
     float s;       // sigmoid output
 };
 
-template <int LD>
-__device__ __forceinline__ float cdf_eval(const CdfConsts<LD> &p, int nl, int c, float x, CdfTrace<LD> &tr) {
+template <int LD, int NL>
+__device__ __forceinline__ float cdf_eval(const CdfConsts<LD> &p, int c, float x, CdfTrace<LD> &tr) {
+    constexpr int nl = NL;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (k < nl - 1) {
             tr.xin[k] = x;
             const float u = x * p.sp[k][c] + p.b[k][c];
-            const float th = tanhf(u);
+            const float th = tanhf_fast(u);
             tr.th[k] = th;
             x = u + th * p.ta[k][c];
         }
@@ -710,9 +721,10 @@ __device__ __forceinline__ float cdf_eval(const CdfConsts<LD> &p, int nl, int c,
 }
 
 // back-propagates g = dL/d(cdf output); accumulates parameter grads into acc[(k*3+slot)*LD + c]; returns dL/dx
-template <int LD>
-__device__ __forceinline__ float cdf_backward(const CdfConsts<LD> &p, const float *__restrict__ prm, int nl, int c,
+template <int LD, int NL>
+__device__ __forceinline__ float cdf_backward(const CdfConsts<LD> &p, const float *__restrict__ prm, int c,
                                               const CdfTrace<LD> &tr, float g, float (&acc)[12 * LD]) {
+    constexpr int nl = NL;
     float du = g * tr.s * (1.0f - tr.s);
     acc[(3 * 3 + 0) * LD + c] += du * tr.xin[3] * p.sgh[3][c];
     acc[(3 * 3 + 1) * LD + c] += du;
@@ -733,12 +745,12 @@ __device__ __forceinline__ float cdf_backward(const CdfConsts<LD> &p, const floa
     return dx;
 }
 
-constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kInvLn2 = 1.4426950408889634f;
 
-template <int LD>
+template <int LD, int NL>
 __global__ __launch_bounds__(kThreads) void entropy_fwd_kernel(const float *__restrict__ latent,
                                                                const float *__restrict__ noise,
-                                                               const float *__restrict__ prm, int nl,
+                                                               const float *__restrict__ prm,
                                                                double *__restrict__ partials, int64_t rows) {
     CdfConsts<LD> p;
     p.load(prm);
@@ -750,8 +762,8 @@ __global__ __launch_bounds__(kThreads) void entropy_fwd_kernel(const float *__re
             const float v = latent[r * LD + c];
             const float w = noise ? (v + noise[r * LD + c]) : rintf(v);
             CdfTrace<LD> tp, tn;
-            const float prob = cdf_eval<LD>(p, nl, c, w + 0.5f, tp) - cdf_eval<LD>(p, nl, c, w - 0.5f, tn);
-            float bits = -1.0f * logf(prob + 1e-10f) / kLn2;
+            const float prob = cdf_eval<LD, NL>(p, c, w + 0.5f, tp) - cdf_eval<LD, NL>(p, c, w - 0.5f, tn);
+            float bits = -__log2f(prob + 1e-10f);      // hardware log2, 1 ulp
             bits = fminf(fmaxf(bits, 0.0f), 50.0f);
             acc[0] += bits;
         }
@@ -759,10 +771,10 @@ __global__ __launch_bounds__(kThreads) void entropy_fwd_kernel(const float *__re
     block_reduce_store<1>(acc, partials);
 }
 
-template <int LD>
+template <int LD, int NL>
 __global__ __launch_bounds__(kThreads) void entropy_bwd_kernel(const float *__restrict__ latent,
                                                                const float *__restrict__ noise,
-                                                               const float *__restrict__ prm, int nl,
+                                                               const float *__restrict__ prm,
                                                                const float *__restrict__ grad_total,
                                                                float *__restrict__ grad_latent,
                                                                double *__restrict__ partials, int64_t rows) {
@@ -779,32 +791,32 @@ __global__ __launch_bounds__(kThreads) void entropy_bwd_kernel(const float *__re
             const float v = latent[r * LD + c];
             const float w = noise ? (v + noise[r * LD + c]) : rintf(v);
             CdfTrace<LD> tp, tn;
-            const float prob = cdf_eval<LD>(p, nl, c, w + 0.5f, tp) - cdf_eval<LD>(p, nl, c, w - 0.5f, tn);
+            const float prob = cdf_eval<LD, NL>(p, c, w + 0.5f, tp) - cdf_eval<LD, NL>(p, c, w - 0.5f, tn);
             const float q = prob + 1e-10f;
-            const float bits = -1.0f * logf(q) / kLn2;
+            const float bits = -__log2f(q);
             // clamp(., 0, 50) passes the gradient on the closed interval; parameter grads are scaled by gt at the end
-            const float gp = (bits >= 0.0f && bits <= 50.0f) ? (-1.0f / (q * kLn2)) : 0.0f;
-            const float dxp = cdf_backward<LD>(p, prm, nl, c, tp, gp, acc);
-            const float dxn = cdf_backward<LD>(p, prm, nl, c, tn, -gp, acc);
+            const float gp = (bits >= 0.0f && bits <= 50.0f) ? -kInvLn2 * __frcp_rn(q) : 0.0f;
+            const float dxp = cdf_backward<LD, NL>(p, prm, c, tp, gp, acc);
+            const float dxn = cdf_backward<LD, NL>(p, prm, c, tn, -gp, acc);
             if (grad_latent) grad_latent[r * LD + c] = noise ? gt * (dxp + dxn) : 0.0f;  // round(): zero gradient
         }
     }
     block_reduce_store<12 * LD>(acc, partials);
 }
 
-template <int LD> static hipError_t entropy_launch(bool bwd, const EntropyArgs &a, hipStream_t s) {
+template <int LD, int NL> static hipError_t entropy_launch_nl(bool bwd, const EntropyArgs &a, hipStream_t s) {
     const int blocks = grid_for(a.rows);
     if (!bwd) {
-        hipLaunchKernelGGL((entropy_fwd_kernel<LD>), dim3(blocks), dim3(kThreads), 0, s, a.latent, a.noise, a.params,
-                           a.num_layers, a.partials, a.rows);
+        hipLaunchKernelGGL((entropy_fwd_kernel<LD, NL>), dim3(blocks), dim3(kThreads), 0, s, a.latent, a.noise, a.params,
+                           a.partials, a.rows);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(256), 0, s, a.partials, blocks, 1,
                            (const float *)nullptr, a.total_bits, 1, (float *)nullptr, 0, (float *)nullptr, 0);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((entropy_bwd_kernel<LD>), dim3(blocks), dim3(kThreads), 0, s, a.latent, a.noise, a.params,
-                       a.num_layers, a.grad_total, a.grad_latent, a.partials, a.rows);
+    hipLaunchKernelGGL((entropy_bwd_kernel<LD, NL>), dim3(blocks), dim3(kThreads), 0, s, a.latent, a.noise, a.params,
+                       a.grad_total, a.grad_latent, a.partials, a.rows);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.grad_params) {
@@ -813,6 +825,17 @@ template <int LD> static hipError_t entropy_launch(bool bwd, const EntropyArgs &
         e = hipGetLastError();
     }
     return e;
+}
+
+// the number of Bitparm layers is a template parameter: the unused layers' code (and registers) are gone at compile time
+template <int LD> static hipError_t entropy_launch(bool bwd, const EntropyArgs &a, hipStream_t s) {
+    switch (a.num_layers) {
+        case 1: return entropy_launch_nl<LD, 1>(bwd, a, s);
+        case 2: return entropy_launch_nl<LD, 2>(bwd, a, s);
+        case 3: return entropy_launch_nl<LD, 3>(bwd, a, s);
+        case 4: return entropy_launch_nl<LD, 4>(bwd, a, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 bool entropy_supported(int ld) { return ld == 1 || ld == 2 || ld == 3 || ld == 4 || ld == 8; }
