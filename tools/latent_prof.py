@@ -14,3 +14,8 @@ for _ in range(10):
     t = be.total_bits(lat, noise); t.backward()
     y = dec(lat); y.backward(gy)
 torch.cuda.synchronize()
+dec.use_sga = True
+dec.temperature = 0.5
+for _ in range(10):
+    y = dec(lat); y.backward(gy)
+torch.cuda.synchronize()
