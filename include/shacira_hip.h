@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SHACIRA_ABI_VERSION 8
+#define SHACIRA_ABI_VERSION 9
 
 #if defined(__GNUC__)
 #define SHACIRA_API __attribute__((visibility("default")))
@@ -43,6 +43,11 @@ extern "C" {
 /* table / feature scalar types (AT_DISPATCH_FLOATING_TYPES_AND_HALF in hashgrid_interpolate_cuda.cu:125) */
 #define SHACIRA_F32 0
 #define SHACIRA_F16 1
+/* double tables (the third type of the reference's dispatch macro, .cu:125,290). Forward: every table value narrowed to
+ * float, fp32 interpolation, result widened (.cu:96-107) -- the reference-shaped kernel only. Backward: (float)(grad * weight)
+ * accumulated with atomicAdd(double). NOTE the reference's own double backward is broken: .cu:212-221 adds a float through
+ * `(float*)(grad_codebook + ...)`, i.e. into the LOW WORD of each double; this library computes the intended gradient. */
+#define SHACIRA_F64 2
 
 #define SHACIRA_MAX_LODS 32
 

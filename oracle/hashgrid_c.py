@@ -34,7 +34,7 @@ def lib():
         L.shacira_oracle_hashgrid_fwd.restype = None
         L.shacira_oracle_hashgrid_fwd.argtypes = [ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   p, p, i64, p, p, p, p, p]
-        for name in ("shacira_oracle_hashgrid_bwd", "shacira_oracle_hashgrid_bwd_f32"):
+        for name in ("shacira_oracle_hashgrid_bwd", "shacira_oracle_hashgrid_bwd_f32", "shacira_oracle_hashgrid_bwd_f64"):
             fn = getattr(L, name)
             fn.restype = None
             fn.argtypes = [ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, p, p, i64, p, p, p]
@@ -104,4 +104,27 @@ def backward(coords, grad_out, table_shape, first_idx, resolutions, bitwidth, ac
         out = np.zeros((T, F), np.float32)
         fn = lib().shacira_oracle_hashgrid_bwd_f32
     fn(dim, N, L, F, int(bitwidth), _ptr(res), _ptr(fi), T, _ptr(coords), _ptr(grad_out), _ptr(out))
+    return out
+
+
+def forward_f64(coords, table64, first_idx, resolutions, bitwidth):
+    """scalar_t = double (the third type of the reference's dispatch, hashgrid_interpolate_cuda.cu:125): every table value is
+    narrowed with static_cast<float>, the interpolation runs in fp32 and the result is widened (.cu:96-107)."""
+    return forward(coords, np.asarray(table64, dtype=np.float64).astype(np.float32), first_idx, resolutions,
+                   bitwidth).astype(np.float64)
+
+
+def backward_f64(coords, grad_out64, table_shape, first_idx, resolutions, bitwidth):
+    """grad_table [T, F] float64 for a double table: float products of double gradients (.cu:215-217), summed in double --
+    the INTENDED result; the reference's own kernel adds them into the low words of the doubles (see hashgrid_oracle.c)."""
+    T, F = table_shape
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    res = np.ascontiguousarray(resolutions, dtype=np.int32)
+    fi = np.ascontiguousarray(first_idx, dtype=np.int32)
+    N, dim = coords.shape
+    L = len(res)
+    grad_out64 = np.ascontiguousarray(grad_out64, dtype=np.float64).reshape(N, L * F)
+    out = np.zeros((T, F), np.float64)
+    lib().shacira_oracle_hashgrid_bwd_f64(dim, N, L, F, int(bitwidth), _ptr(res), _ptr(fi), T, _ptr(coords),
+                                          _ptr(grad_out64), _ptr(out))
     return out

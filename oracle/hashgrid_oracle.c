@@ -161,6 +161,33 @@ ORACLE_API void shacira_oracle_hashgrid_bwd(int dim, int64_t N, int L, int F, in
     }
 }
 
+/* scalar_t = double (AT_DISPATCH_FLOATING_TYPES_AND_HALF, .cu:290): `float grad = grad_output[..] * coeffs[k]` (.cu:215-217)
+ * forms the product in double (double * float) and narrows it to float. The reference then adds that float through
+ * `(float*)(grad_codebook + ...)`, i.e. into the LOW WORD of each double -- a bug of the reference; this restates the
+ * intended sum (double accumulation of the float products, sample order). */
+ORACLE_API void shacira_oracle_hashgrid_bwd_f64(int dim, int64_t N, int L, int F, int bw, const int32_t *res,
+                                                const int32_t *first_idx, int64_t T, const float *coords,
+                                                const double *grad_out, double *grad_table64) {
+    const int nc = 1 << dim;
+    const int32_t cs = (int32_t)pow(2.0, (double)bw);
+    for (int64_t i = 0; i < N; ++i) {
+        for (int l = 0; l < L; ++l) {
+            int32_t idx[8];
+            float w[8];
+            corners(dim, coords + i * dim, res[l], cs, idx, w);
+            for (int j = 0; j < F; ++j) {
+                double g = grad_out[i * (int64_t)L * F + (int64_t)l * F + j];
+                for (int k = 0; k < nc; ++k) {
+                    int64_t row = (int64_t)first_idx[l] + idx[k];
+                    if (row < 0 || row >= T) continue;
+                    float prod = (float)(g * (double)w[k]);
+                    grad_table64[row * F + j] += (double)prod;
+                }
+            }
+        }
+    }
+}
+
 /* Same as above but accumulates in fp32 in sample order: one admissible atomicAdd ordering. */
 ORACLE_API void shacira_oracle_hashgrid_bwd_f32(int dim, int64_t N, int L, int F, int bw, const int32_t *res,
                                                 const int32_t *first_idx, int64_t T, const float *coords,

@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SHACIRA_HIP_LIB") or os.path.join(_HERE, "lib", "libshacira_hip.so")   # env: A/B builds (tools/)
 
-F32, F16 = 0, 1
+F32, F16, F64 = 0, 1, 2
 EINVAL, EDTYPE, EODD, EWORKSPACE = -1, -2, -3, -4
 BWD_STAGE_ALL_LEVELS, BWD_REUSE_STAGED = 1, 2
 
@@ -111,8 +111,13 @@ def check(code, what=""):
     raise RuntimeError(f"{what}: {msg} (code {code})" if what else f"{msg} (code {code})")
 
 
+options_epoch = 0   # bumped by set_option: cached workspace sizes (hip_ops) depend on the tunables
+
+
 def set_option(name, value):
+    global options_epoch
     check(lib().shacira_set_option(name.encode(), int(value)), "shacira_set_option")
+    options_epoch += 1
 
 
 def get_option(name):

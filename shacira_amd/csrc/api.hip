@@ -124,7 +124,7 @@ int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feat
     LevelTable lt;
     int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
     if (rc) return rc;
-    if (dtype != SHACIRA_F32 && dtype != SHACIRA_F16) return SHACIRA_EDTYPE;
+    if (dtype != SHACIRA_F32 && dtype != SHACIRA_F16 && dtype != SHACIRA_F64) return SHACIRA_EDTYPE;
     if (num_coords < 0) return SHACIRA_EINVAL;
     if (num_coords == 0) return 0;
     if (!codebook_first_idx || !coords || !codebook || !feats) return SHACIRA_EINVAL;
@@ -178,7 +178,7 @@ int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, int num_lods, 
     lt.level_begin = level_begin;
     lt.level_end = level_end;
     lt.stage_flags = flags & (SHACIRA_BWD_STAGE_ALL_LEVELS | SHACIRA_BWD_REUSE_STAGED);
-    if (dtype != SHACIRA_F32 && dtype != SHACIRA_F16) return SHACIRA_EDTYPE;
+    if (dtype != SHACIRA_F32 && dtype != SHACIRA_F16 && dtype != SHACIRA_F64) return SHACIRA_EDTYPE;
     if (num_coords < 0 || !grad_codebook) return SHACIRA_EINVAL;
     if (num_coords > 0 && (!codebook_first_idx || !coords || !grad_output)) return SHACIRA_EINVAL;
     const size_t need = hashgrid_backward_workspace(dim, dtype, lt, num_coords);

@@ -704,7 +704,10 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
             // maximum per level over 1 024 of its own samples (one per thread, spread over its whole walk), and scales for
             // 2^12 times that. A contribution beyond the limit -- or non-finite -- goes straight to the table with a float
             // atomic (the image is flushed that way too), so the limit only has to be right for almost all of them; a level
-            // whose pilot saw nothing but zeros keeps the fp64 image (with its group).
+            // whose pilot saw nothing but zeros keeps the fp64 image (with its group). Consequences to know: (1) the result is
+            // bitwise reproducible (order-independent fixed-point sums) only while no gradient exceeds a workgroup's limit --
+            // out-of-range contributions take float atomics in arrival order; (2) heavy-tailed or mostly-zero gradients (masked
+            // pixels, a loss spike outside the pilot) send a larger share down that slow path: correct (tested), but slower.
             __shared__ uint32_t s_pm[SHACIRA_MAX_LODS];
             if ((int)threadIdx.x < SHACIRA_MAX_LODS) s_pm[threadIdx.x] = 0u;
             __syncthreads();

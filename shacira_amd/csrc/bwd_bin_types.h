@@ -289,10 +289,14 @@ __device__ __forceinline__ void enumerate_buckets(const double (&t)[DIM], int32_
 // the last line (y == hi == res - 1 exactly, possible from res = 513 on) stays in the last slab: its y + 1 corner has weight 0.
 __device__ __forceinline__ uint32_t compact2d_line(uint32_t py, uint32_t res) { return py < res - 2u ? py : res - 2u; }
 
-// 2-D compact item, first 8 bytes: local base row (13 bits) | valid (bit 13) | fx and fy as 25-bit fixed point (exact for
-// fractions >= 0.25, 2^-25 absolute below: the reference's own `1 - fx` rounds at 2^-25)
+// 2-D compact item, first 8 bytes: local base row (13 bits) | valid (bit 13) | fx and fy as 25-bit fixed point, rounded to
+// nearest: exact for fractions >= 0.5 (their ulp is 2^-24) and wherever the position is >= 2 (fraction = a multiple of 2^-22),
+// within 2^-26 absolute otherwise -- below the 2^-25 rounding of the reference's own `1 - fx`. Not bit-identical to the
+// pair-item path, far inside the 1e-5 bar.
 __device__ __forceinline__ void pack_compact2d(uint32_t local, float fx, float fy, uint32_t &w0, uint32_t &w1) {
-    const uint32_t qx = (uint32_t)(fx * 33554432.0f), qy = (uint32_t)(fy * 33554432.0f);   // < 2^25: fractions are < 1
+    uint32_t qx = __float2uint_rn(fx * 33554432.0f), qy = __float2uint_rn(fy * 33554432.0f);   // fractions are < 1
+    qx = qx > 33554431u ? 33554431u : qx;    // (a fraction within 2^-26 of 1 rounds up to 2^25: clamped)
+    qy = qy > 33554431u ? 33554431u : qy;
     w0 = (local & 0x1FFFu) | (1u << 13) | ((qx >> 7) << 14);
     w1 = ((qx & 127u) << 25) | qy;
 }

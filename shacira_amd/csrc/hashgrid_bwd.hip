@@ -69,6 +69,59 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(LevelTable lt,
     }
 }
 
+// fp64 tables: contribution = (float)(grad * weight) with the product formed in double (`float grad = grad_output[..] *
+// coeffs[k]`, .cu:215-217, scalar_t = double), accumulated with atomicAdd(double). The reference then adds that float
+// through `(float*)(grad_codebook + ...)` -- into the low word of each double, a bug; this is the intended gradient.
+template <int DIM>
+__global__ __launch_bounds__(256) void hashgrid_bwd_atomic_f64_kernel(LevelTable lt, const int32_t *__restrict__ first_idx,
+                                                                      const float *__restrict__ coords,
+                                                                      const double *__restrict__ grad_out,
+                                                                      double *__restrict__ grad_table, int64_t sample0,
+                                                                      uint32_t num_items) {
+    constexpr int NC = 1 << DIM;
+    const uint32_t L = (uint32_t)lt.num_lods;
+    const int Fr = lt.feature_dim;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < num_items; w += stride) {
+        const uint32_t s = w / L;
+        const uint32_t lvl = w - s * L;
+        const int64_t i = sample0 + s;
+        double t[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
+        Corners<DIM> c;
+        compute_corners<DIM>(t, lt.res[lvl], lt.hi[lvl], lt.dense[lvl] != 0, lt.mask, c);
+        const int64_t base = (int64_t)first_idx[lvl];
+        const double *g = grad_out + (i * L + lvl) * Fr;
+        for (int j = 0; j < Fr; ++j) {
+            const double gj = g[j];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int64_t row = base + (int64_t)c.row[k];
+                if ((uint64_t)row < (uint64_t)lt.table_rows)
+                    unsafeAtomicAdd(grad_table + row * Fr + j, (double)(float)(gj * (double)c.w[k]));
+            }
+        }
+    }
+}
+
+template <int DIM>
+static hipError_t launch_bwd_atomic_f64(const LevelTable &lt, const int32_t *first_idx, const float *coords,
+                                        const void *grad_out, void *grad_table, int64_t num_coords, hipStream_t stream) {
+    const int64_t L = lt.num_lods;
+    const int64_t max_samples = ((int64_t)1 << 31) / L - 1;
+    for (int64_t s0 = 0; s0 < num_coords; s0 += max_samples) {
+        const int64_t ns = (num_coords - s0 < max_samples) ? (num_coords - s0) : max_samples;
+        const uint32_t items = (uint32_t)(ns * L);
+        hipLaunchKernelGGL(hashgrid_bwd_atomic_f64_kernel<DIM>, dim3((items + 255u) / 256u), dim3(256), 0, stream, lt,
+                           first_idx, coords, static_cast<const double *>(grad_out), static_cast<double *>(grad_table), s0,
+                           items);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float *__restrict__ src, __half *__restrict__ dst,
                                                          int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,6 +206,7 @@ static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
 }
 
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
+    if (dtype == SHACIRA_F64) return 0;   // atomicAdd(double) straight into the caller's table
     size_t need = (dtype == SHACIRA_F16) ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0;
     if (bin_supported(dim, lt) && n > 0) {
         const size_t b = bin_workspace_bytes(dim, dtype, lt, n);
@@ -166,6 +220,12 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
                                       size_t workspace_bytes, int64_t n, hipStream_t s) {
     (void)workspace_bytes;
     const int64_t numel = lt.table_rows * lt.feature_dim;
+    if (dtype == SHACIRA_F64) {   // the reference-shaped form only: zeros_like, then one atomicAdd(double) per corner and feature
+        hipError_t e64 = zero_fill_async(static_cast<float *>(grad_table), 2 * numel, s);
+        if (e64 != hipSuccess || n <= 0) return e64;
+        return dim == 3 ? launch_bwd_atomic_f64<3>(lt, first_idx, coords, grad_out, grad_table, n, s)
+                        : launch_bwd_atomic_f64<2>(lt, first_idx, coords, grad_out, grad_table, n, s);
+    }
     const bool bin = n > 0 && use_bin(dim, lt, n);
     // fp16 tables accumulate in an fp32 image: the tail of the bin workspace, or the whole workspace (atomic variant)
     float *acc = static_cast<float *>(grad_table);

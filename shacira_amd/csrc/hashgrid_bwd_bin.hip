@@ -358,6 +358,28 @@ struct BinWorkspace {
 
 static inline int64_t level_pitch(int64_t n) { return (n + 1) & ~(int64_t)1; }
 
+// every level of the table is "direct" (fits an LDS image) whatever level range a call names: such tables never need the
+// transposed gradients nor items (the image configs B / C / kodak.yaml: the direct kernel reads grad_output itself)
+static bool table_all_direct(int dim, int dtype, const LevelTable &lt, int64_t n) {
+    LevelTable full = lt;
+    full.level_begin = 0;
+    full.level_end = lt.num_lods;
+    BinPlan plan;
+    make_plan(dim, dtype, full, kTile, plan, choose_acc_kib(dim, dtype, full, n), one_image_compact_rule(n));
+    return plan.nbl == 0;
+}
+
+// 16-byte (item-unit) slots one sample can occupy over all binned levels of the plan: x-pair items 2^(dim-1) per level,
+// compact 3-D levels two slots, compact 2-D levels one
+static uint64_t slots_per_sample(const BinPlan &plan) {
+    uint64_t slots = 0;
+    for (uint32_t q = 0; q < plan.nbl; ++q) {
+        const BinLevel &bl = plan.lv[plan.blevel[q]];
+        slots += bl.compact ? (plan.pairs == 4u ? 2u : 1u) : plan.pairs;
+    }
+    return slots;
+}
+
 static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, void *ws) {
     BinPlan plan;
     const int64_t nb = bin_batch_samples(dim, dtype, lt, n);
@@ -365,10 +387,14 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     const size_t item = item_unit_bytes(dtype, lt);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    // gT and gmax first: their offsets must not depend on the level range of the call (REUSE_STAGED calls share them)
-    const size_t o_gT = take((size_t)level_pitch(n) * lt.num_lods * lt.feature_dim * sizeof(float));
+    // gT and gmax first: their offsets must not depend on the level range of the call (REUSE_STAGED calls share them).
+    // Sized by what the selected path uses (round 4): an all-direct table stages nothing -- config C's query returned 1.21 GB
+    // for a call that ran one kernel on grad_output -- and the item array holds the slots the plan's levels can emit
+    // (compact levels: 2 of the 4 pair slots), S1: 1.23 -> 1.05 GB.
+    const bool no_stage = table_all_direct(dim, dtype, lt, n);
+    const size_t o_gT = take(no_stage ? 0 : (size_t)level_pitch(n) * lt.num_lods * lt.feature_dim * sizeof(float));
     const size_t o_ctrl = take((size_t)(kTotalShards * kMaxBuckets + SHACIRA_MAX_LODS) * sizeof(uint32_t));   // totals | gmax: one memset
-    const size_t o_items = take((size_t)nb * plan.nbl * plan.pairs * item);
+    const size_t o_items = take((size_t)nb * slots_per_sample(plan) * item);
     const size_t o_base = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
     const size_t o_cur = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
     const size_t o_cnt = take((size_t)(nb / 128 + 8) * plan.total_buckets * sizeof(uint32_t));   // smallest counting tile: 128
@@ -482,8 +508,9 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     const bool multi = nb < n;
     const bool stage_all = (lt.stage_flags & SHACIRA_BWD_STAGE_ALL_LEVELS) != 0;
     const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
-    // only binned levels consume the transposed gradients (a later call on this workspace may, too: stage_all)
-    const bool need_T = whole.nbl > 0 || stage_all || staged;
+    // only binned levels consume the transposed gradients (a later call on this workspace may, too: stage_all) -- a table
+    // whose levels are all direct has none in any level range, so its calls never stage (and carve() reserves no gT)
+    const bool need_T = whole.nbl > 0 || ((stage_all || staged) && !table_all_direct(DIM, dtype, lt, n));
     // fixed-point images pay off once the accumulation itself dominates; small batches are bound by fixed costs and
     // keep the fp64 image (and skip the gmax bookkeeping): measured 100 vs 107 us at 65 536 samples
     const bool use_fx = need_T && n >= SHACIRA_FX_MIN;

@@ -72,6 +72,10 @@ template <> struct Scalar<float> {
     static __device__ __forceinline__ float load(const float *p) { return *p; }
     static __device__ __forceinline__ void store(float *p, float v) { *p = v; }
 };
+template <> struct Scalar<double> {   // fp64 tables: values narrowed to float at the load, results widened at the store (.cu:96-107)
+    static __device__ __forceinline__ float load(const double *p) { return (float)*p; }
+    static __device__ __forceinline__ void store(double *p, float v) { *p = (double)v; }
+};
 template <> struct Scalar<__half> {
     static __device__ __forceinline__ float load(const __half *p) { return __half2float(*p); }
     static __device__ __forceinline__ void store(__half *p, float v) { *p = __float2half_rn(v); }

@@ -200,29 +200,33 @@ __global__ __launch_bounds__(kLdsFwdThreads) void hashgrid_fwd_lds_kernel(LevelT
     const int lb = g * plan.G;
     const int le = (lb + plan.G < lt.num_lods) ? lb + plan.G : lt.num_lods;
     const int L = lt.num_lods;
-    // the group's rows: consecutive levels are consecutive in the table, so this is ONE contiguous copy (16-byte global loads
-    // from the first aligned element on; the LDS side is written element-wise, its offset need not be 16-byte aligned)
-    {
-        const int64_t row0 = first_idx[lb];
-        int64_t rows = plan.grows[g];
+    // the group's rows, level by level: level l starts at row codebook_first_idx[l] of the table (the header's contract: any
+    // layout with ascending starts, e.g. padded or aligned level starts of an external caller -- not only the packed layout
+    // the in-tree modules build) and lands at row plan.loff[l] of the image. 16-byte global loads from the first aligned
+    // element on; the LDS side is written element-wise, its offset need not be 16-byte aligned.
+    for (int l = lb; l < le; ++l) {
+        const int64_t row0 = first_idx[l];
+        const int64_t want = (int64_t)((l + 1 < le ? plan.loff[l + 1] : plan.grows[g]) - plan.loff[l]);
+        int64_t rows = want;
         if (row0 + rows > lt.table_rows) rows = lt.table_rows - row0;     // (a table shorter than its last level: zeros behind)
         if (rows < 0) rows = 0;
         const T *src = table + row0 * F;
-        const int64_t elems = rows * F, total = (int64_t)plan.grows[g] * F;
+        T *dst = s_tab + (size_t)plan.loff[l] * F;
+        const int64_t elems = rows * F, total = want * F;
         constexpr int VE = 16 / (int)sizeof(T);
         const int64_t head = (int64_t)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u)) & 15u) / sizeof(T));
         const int64_t h = head < elems ? head : elems;
-        for (int64_t e = threadIdx.x; e < h; e += kLdsFwdThreads) s_tab[e] = src[e];
+        for (int64_t e = threadIdx.x; e < h; e += kLdsFwdThreads) dst[e] = src[e];
         const int64_t nvec = (elems - h) / VE;
         for (int64_t v = threadIdx.x; v < nvec; v += kLdsFwdThreads) {
             const uint4 q = *reinterpret_cast<const uint4 *>(src + h + v * VE);
             T tmp[VE];
             __builtin_memcpy(tmp, &q, 16);
 #pragma unroll
-            for (int k = 0; k < VE; ++k) s_tab[h + v * VE + k] = tmp[k];
+            for (int k = 0; k < VE; ++k) dst[h + v * VE + k] = tmp[k];
         }
-        for (int64_t e = h + nvec * VE + threadIdx.x; e < elems; e += kLdsFwdThreads) s_tab[e] = src[e];
-        for (int64_t e = elems + threadIdx.x; e < total; e += kLdsFwdThreads) Scalar<T>::store(&s_tab[e], 0.0f);
+        for (int64_t e = h + nvec * VE + threadIdx.x; e < elems; e += kLdsFwdThreads) dst[e] = src[e];
+        for (int64_t e = elems + threadIdx.x; e < total; e += kLdsFwdThreads) Scalar<T>::store(&dst[e], 0.0f);
     }
     // this lane's piece of the group and the parameters of its LPC levels (constant for the whole walk)
     const uint32_t P = (uint32_t)plan.P;
@@ -942,7 +946,25 @@ hipError_t hashgrid_debug_corners(int dim, const LevelTable &lt, const float *co
     return hipGetLastError();
 }
 
+// fp64 tables: the reference-shaped kernel (one gather per corner, runtime feature_dim) with double loads / stores
+template <int DIM>
+static hipError_t launch_fwd_f64(const LevelTable &lt, const int32_t *first_idx, const float *coords, const void *table,
+                                 void *feats, int64_t num_coords, hipStream_t stream) {
+    const int64_t L = lt.num_lods;
+    const int64_t max_samples = ((int64_t)1 << 31) / L - 1;
+    for (int64_t s0 = 0; s0 < num_coords; s0 += max_samples) {
+        const int64_t ns = (num_coords - s0 < max_samples) ? (num_coords - s0) : max_samples;
+        const uint32_t items = (uint32_t)(ns * L);
+        hipLaunchKernelGGL((hashgrid_fwd_kernel<DIM, double, 0>), dim3((items + 255u) / 256u), dim3(256), 0, stream, lt,
+                           first_idx, coords, static_cast<const double *>(table), static_cast<double *>(feats), s0, items);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
+    if (dtype == SHACIRA_F64) return 0;
     if (tiled_supported(dim, dtype, lt, n)) return tiled_forward_workspace(dim, dtype, lt, n);
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return 0;
     if (use_lds_tables(dim, dtype == SHACIRA_F32 ? 4 : 2, lt, n)) return 0;   // variant 9 stages nothing
@@ -953,6 +975,9 @@ size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int6
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                      const float *coords, const void *table, void *feats, void *ws, int64_t n,
                                      hipStream_t s) {
+    if (dtype == SHACIRA_F64)
+        return dim == 3 ? launch_fwd_f64<3>(lt, first_idx, coords, table, feats, n, s)
+                        : launch_fwd_f64<2>(lt, first_idx, coords, table, feats, n, s);
     if (tiled_supported(dim, dtype, lt, n)) return tiled_forward(dim, dtype, lt, first_idx, coords, table, feats, ws, n, s);
     if (dim == 3) {
         return dtype == SHACIRA_F32 ? dispatch_f<3, float>(lt, first_idx, coords, table, feats, ws, n, s)

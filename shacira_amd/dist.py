@@ -185,12 +185,18 @@ class GradientReducer:
         if v.numel() % world:
             raise ValueError("rs_ag needs a buffer padded to a multiple of the world size (GradientReducer.padded_numel)")
         n = v.numel() // world
+        if async_op:
+            # the all-gather reads the shard the reduce-scatter fills: two async ops are ordered only on backends that keep
+            # one stream per process group (RCCL), not on gloo's worker threads, and the single shard buffer cannot be shared
+            # by two calls in flight -- so the asynchronous form gets a shard of its own and waits between the two phases
+            shard = torch.empty(n, dtype=v.dtype, device=v.device)
+            dist.reduce_scatter_tensor(shard, v, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+            return [dist.all_gather_into_tensor(v, shard, group=self.group, async_op=True)]
         if self._shard is None or self._shard.numel() != n or self._shard.device != v.device or self._shard.dtype != v.dtype:
             self._shard = torch.empty(n, dtype=v.dtype, device=v.device)
-        # reduce-scatter then all-gather: both on the same process group, so they are ordered on its stream
-        w1 = dist.reduce_scatter_tensor(self._shard, v, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-        w2 = dist.all_gather_into_tensor(v, self._shard, group=self.group, async_op=async_op)
-        return [w1, w2] if async_op else None
+        dist.reduce_scatter_tensor(self._shard, v, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_gather_into_tensor(v, self._shard, group=self.group)
+        return None
 
 
 def backward_in_groups(backward_levels, grad, groups, row_of, reducer):

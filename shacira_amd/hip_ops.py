@@ -7,12 +7,13 @@ Inputs must live on a HIP device; there is no CPU path (RuntimeError otherwise).
 """
 import ctypes
 import functools
+import threading
 
 import torch
 
 from . import _lib
 
-_DTYPES = {torch.float32: _lib.F32, torch.float16: _lib.F16}
+_DTYPES = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.float64: _lib.F64}
 
 
 def _stream(t):
@@ -55,11 +56,64 @@ def _check_coords(dim, coords):
                            f"{tuple(coords.shape)}")
 
 
+# ---- scratch memory: one grow-only buffer per (device, stream, host thread) -----------------------------------------------
+# The operators' workspaces (up to ~1 GB for a 2^20-sample backward) were a fresh torch.empty per call. Work one thread puts
+# on one stream is ordered, so its calls can share one buffer that only grows. Per host THREAD, because an operator is several
+# launches and ctypes drops the GIL: two threads on the same stream could interleave their launch sequences (the autograd
+# engine's backward thread therefore gets a buffer of its own). Exceptions: while the stream is being captured into a HIP
+# graph the buffer comes from the graph's own pool (a cached buffer could be replaced -- freed -- by a later, larger eager
+# call while the graph still replays into it), and a caller-supplied workspace wins.
+_scratch = {}
+
+
+def _workspace(device, nbytes):
+    if nbytes <= 0:
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _scratch.pop(key, None)          # release the old buffer before the larger one is allocated
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def release_workspaces():
+    """Drop the cached scratch buffers (they are returned to torch's caching allocator)."""
+    _scratch.clear()
+
+
+# workspace sizes are pure functions of the shape and the library's tunables: one C call per new shape, not per call
+@functools.lru_cache(maxsize=256)
+def _ws_bytes(kind, dim, N, L, F, bw, res, T, dt, epoch):
+    fn = _lib.lib().shacira_hashgrid_forward_workspace_bytes if kind == 0 else _lib.lib().shacira_hashgrid_backward_workspace_bytes
+    return int(fn(dim, N, L, F, bw, _res_array(res), T, dt))
+
+
+class _on_device:
+    """`with torch.cuda.device(d)` only when d is not already current (the context manager costs ~4 us a call)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        self.ctx = None if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
 def _dtype_code(t):
     try:
         return _DTYPES[t.dtype]
     except KeyError:
-        raise RuntimeError(f"shacira_amd: unsupported table dtype {t.dtype} (fp32 and fp16 are implemented)")
+        raise RuntimeError(f"shacira_amd: unsupported table dtype {t.dtype} (fp32, fp16 and fp64 are implemented)")
 
 
 def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth):
@@ -72,10 +126,9 @@ def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, cod
     feats = torch.empty((N, F * len(res)), dtype=codebook.dtype, device=codebook.device)
     dt = _dtype_code(codebook)
     L = _lib.lib()
-    with torch.cuda.device(codebook.device):
-        nbytes = L.shacira_hashgrid_forward_workspace_bytes(dim, N, len(res), F, int(codebook_bitwidth),
-                                                            _res_array(res), T, dt)
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=codebook.device) if nbytes else None
+    with _on_device(codebook.device):
+        nbytes = _ws_bytes(0, dim, N, len(res), F, int(codebook_bitwidth), res, T, dt, _lib.options_epoch)
+        ws = _workspace(codebook.device, nbytes)
         rc = L.shacira_hashgrid_forward(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
                                         _ptr(codebook_first_idx), T, _ptr(coords), _ptr(codebook), dt, _ptr(feats),
                                         _ptr(ws), nbytes, _stream(codebook))
@@ -96,7 +149,7 @@ def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codeboo
     res = tuple(int(r) for r in resolution)
     N, T, F = coords.shape[0], int(table_rows), int(feature_dim)
     if table_dtype not in _DTYPES:
-        raise RuntimeError(f"shacira_amd: unsupported table dtype {table_dtype} (fp32 and fp16 are implemented)")
+        raise RuntimeError(f"shacira_amd: unsupported table dtype {table_dtype} (fp32, fp16 and fp64 are implemented)")
     dt = _DTYPES[table_dtype]
     if grad_output.dtype != table_dtype:
         grad_output = grad_output.to(table_dtype)
@@ -111,15 +164,17 @@ def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codeboo
         grad_codebook = torch.empty((T, F), dtype=table_dtype, device=device)
     lb, le = (0, len(res)) if levels is None else (int(levels[0]), int(levels[1]))
     L = _lib.lib()
-    with torch.cuda.device(device):
-        nbytes = L.shacira_hashgrid_backward_workspace_bytes(dim, N, len(res), F, int(codebook_bitwidth),
-                                                             _res_array(res), T, dt)
+    with _on_device(device):
+        nbytes = _ws_bytes(1, dim, N, len(res), F, int(codebook_bitwidth), res, T, dt, _lib.options_epoch)
         if workspace is not None:
             if workspace.numel() * workspace.element_size() < nbytes:
                 raise RuntimeError("workspace too small")
             ws = workspace
-        else:
+        elif levels is not None and tuple(levels) != (0, len(res)):
+            # a level-range call WITHOUT a shared workspace stages nothing for later calls: scratch of its own
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
+        else:
+            ws = _workspace(device, nbytes)
         rc = L.shacira_hashgrid_backward_levels(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
                                                 _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
                                                 _ptr(grad_codebook), lb, le, int(flags), _ptr(ws), nbytes,
@@ -274,6 +329,11 @@ def latent_mlp_supported(widths):
 
 def _check_mlp_operands(latent, uniforms, div, params, widths):
     _need_gpu(latent, uniforms, div, params)
+    # the kernels read latent as float[rows * ld] and div as float[ld]: anything else would read garbage or out of bounds
+    if latent.dim() != 2 or latent.dtype != torch.float32 or not latent.is_contiguous():
+        raise RuntimeError("latent must be a contiguous fp32 [rows, latent_dim] tensor")
+    if div.dtype != torch.float32 or not div.is_contiguous():
+        raise RuntimeError("div must be a contiguous fp32 vector of latent_dim elements")
     T, ld = latent.shape
     if ld != widths[0] or div.numel() != ld:
         raise RuntimeError("latent / div do not match widths[0]")

@@ -110,7 +110,8 @@ class LatentDecoder(nn.Module):
 
     def _mlp_fusable(self, weight: Tensor) -> bool:
         """Hidden layers and / or activations: the per-row MLP kernel (widths up to 16, up to 4 layers)."""
-        return (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2
+        return (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2 and weight.is_contiguous()
+                and self.div.is_cuda and self.div.dtype == torch.float32     # (module.half() would make div fp16)
                 and hip_ops.latent_mlp_supported(self._widths))
 
     def _packed_layers(self) -> Tensor:

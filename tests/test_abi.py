@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(handle, name), name
-    assert _lib.lib().shacira_abi_version() == 8
+    assert _lib.lib().shacira_abi_version() == 9
 
 
 def test_argument_validation_codes():
@@ -87,3 +87,27 @@ def test_latent_mlp_entry_points_validate_their_arguments():
     assert rc != 0                                                                   # NULL div / params
     rc = lib.shacira_latent_mlp_forward(10, 1, arr(2, 2), None, None, 1.0, 0, None, None, 9, 0, 0.0, None, None)
     assert rc != 0                                                                   # unknown activation
+
+
+def test_backward_workspace_is_sized_by_the_selected_path():
+    """A table whose levels all fit LDS images (the Kodak tables of configs B / C, kodak.yaml) stages no transposed gradients
+    and writes no items: its backward workspace is control words only, whatever the batch (round 3 asked 1.21 GB for config C).
+    The NeRF table's workspace is the staged gradients + the item slots its levels can emit."""
+    from conftest import CONFIGS, geo, table_layout
+    L = _lib.lib()
+
+    def query(dim, res, bw, n, F=2, dtype=_lib.F32):
+        _, _, T = table_layout(res, bw, dim)
+        arr = (ctypes.c_int32 * len(res))(*res)
+        return L.shacira_hashgrid_backward_workspace_bytes(dim, n, len(res), F, bw, arr, T, dtype)
+
+    dim, res, bw = CONFIGS["B"]
+    assert query(dim, res, bw, 393_216) < (1 << 20)                 # config B
+    assert query(dim, res, bw, 24 * 393_216) < (1 << 20)            # config C: 9.4 M samples
+    assert query(2, geo(16, 512, 24), 11, 393_216) < (1 << 20)      # kodak.yaml's 24 levels
+    dim, res, bw = CONFIGS["D"]
+    n = 1 << 20
+    s1 = query(dim, res, bw, n)
+    staged = n * 16 * 2 * 4                                         # gT [L][N][F] fp32
+    slots = n * (5 * 2 + 11 * 4) * 16                               # 5 compact levels (2 slots), 11 hashed (4 pair items)
+    assert staged + slots <= s1 <= staged + slots + (32 << 20), s1  # S1: 1.07 GB (24 MB of count rows, unit list, control words)

@@ -1421,3 +1421,83 @@ def test_wrong_coordinate_shape_is_refused(dev):
         ops.hashgrid_backward(3, bad, torch.from_numpy(go).to(dev), T, torch.float32, tf, res, bw, 2)
     with pytest.raises(RuntimeError, match="coords"):
         ops.hashgrid_interpolate2d_cuda(torch.rand(1000, 3, device=dev), tt, tf, res, bw)
+
+
+@pytest.mark.parametrize("shape", ["B", "small3d", "D"])
+def test_padded_level_starts(dev, shape):
+    """The C-ABI promises only 'level l starts at row codebook_first_idx[l]' (include/shacira_hip.h): an external caller may
+    pad or align its level starts. Every forward variant (the LDS-resident one copies level by level since round 4) and both
+    backward forms must follow first_idx, not a packed layout of their own; rows between the levels stay zero in the gradient."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw, F = {"B": (2, geo(16, 512, 16), 11, 2), "small3d": (3, geo(4, 64, 10), 12, 2),
+                       "D": (3, geo(16, 2048, 16), 19, 2)}[shape]
+    n = 40_001
+    sizes, packed, _, coords, _, go = _problem(dim, res, bw, n, F=F, seed=91)
+    first, row = [], 5
+    for l, sz in enumerate(sizes):          # starts: 5 rows of slack in front, then every level padded to odd boundaries
+        first.append(row)
+        row += int(sz) + 3 + 2 * l
+    first = np.asarray(first, dtype=np.int32)
+    T = row + 7
+    rng = np.random.default_rng(92)
+    table = (rng.standard_normal((T, F)) * 0.01).astype(np.float32)
+    ref = oc.forward(coords, table, first, res, bw)
+    ref_g = oc.backward(coords, go, (T, F), first, res, bw)
+    tc, tt, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(table).to(dev), torch.from_numpy(first).to(dev)
+    tg = torch.from_numpy(go).to(dev)
+    fwd = ops.hashgrid_interpolate_cuda if dim == 3 else ops.hashgrid_interpolate2d_cuda
+    bwd = ops.hashgrid_interpolate_backward_cuda if dim == 3 else ops.hashgrid_interpolate2d_backward_cuda
+    variants = [-1, 0, 3, 6] + ([9] if shape != "D" else [8])
+    try:
+        for v in variants:
+            _lib.set_option("fwd_variant", v)
+            got = fwd(tc, tt, tf, res, bw).cpu().numpy()
+            assert np.array_equal(got, ref), (shape, "fwd_variant", v)
+        _lib.set_option("fwd_variant", -1)
+        used = np.zeros(T, dtype=bool)
+        for l, sz in enumerate(sizes):
+            used[first[l]:first[l] + int(sz)] = True
+        for bv in (0, 1):
+            _lib.set_option("bwd_variant", bv)
+            grad = bwd(tc, tg, tt, tf, res, bw, F, False).cpu().numpy()
+            _assert_grad_close(grad, ref_g, first, sizes)
+            assert not grad[~used].any(), (shape, "bwd_variant", bv, "padding rows must stay zero")
+    finally:
+        _lib.set_option("fwd_variant", -1)
+        _lib.set_option("bwd_variant", -1)
+
+
+@pytest.mark.parametrize("name", ["A", "B", "D"])
+def test_double_tables(dev, name):
+    """scalar_t = double, the third type of the reference's dispatch macro (hashgrid_interpolate_cuda.cu:125,290; 2-D :115,251).
+    Forward: table values narrowed to float, fp32 interpolation, result widened -- bit-identical to the oracle's double path.
+    Backward: float products of double gradients summed with atomicAdd(double) (the reference's own kernel type-puns the
+    double table to float* there: documented in include/shacira_hip.h); 1e-5 of each level's largest gradient as for fp32,
+    measured ~1e-16 (double sums differ from the oracle only by their order)."""
+    ops = _ops()
+    dim, res, bw = CONFIGS[name]
+    n = 20_011
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, seed=95)
+    rng = np.random.default_rng(96)
+    table64 = table.astype(np.float64) * (1.0 + 1e-9 * rng.standard_normal(table.shape))    # values fp32 cannot hold
+    go64 = go.astype(np.float64) * (1.0 + 1e-9 * rng.standard_normal(go.shape))
+    tc, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(first).to(dev)
+    tt, tg = torch.from_numpy(table64).to(dev), torch.from_numpy(go64).to(dev)
+    fwd = ops.hashgrid_interpolate_cuda if dim == 3 else ops.hashgrid_interpolate2d_cuda
+    bwd = ops.hashgrid_interpolate_backward_cuda if dim == 3 else ops.hashgrid_interpolate2d_backward_cuda
+    feats = fwd(tc, tt, tf, res, bw)
+    assert feats.dtype == torch.float64
+    assert np.array_equal(feats.cpu().numpy(), oc.forward_f64(coords, table64, first, res, bw))
+    grad = bwd(tc, tg, tt, tf, res, bw, 2, False)
+    assert grad.dtype == torch.float64 and tuple(grad.shape) == (T, 2)
+    ref = oc.backward_f64(coords, go64, (T, 2), first, res, bw)
+    _assert_grad_close(grad.cpu().numpy(), ref, first, sizes, rtol=1e-12)
+    # through the autograd Function, like a `.double()` HashGrid
+    from shacira_amd.wisp.ops import grid as G
+    cb = tt.clone().requires_grad_(True)
+    fn = G.hashgrid if dim == 3 else G.hashgrid2d
+    out = fn(tc, res, bw, 0, cb, torch.tensor(sizes, device=dev), tf)
+    assert out.dtype == torch.float64 and np.array_equal(out.detach().cpu().numpy(), feats.cpu().numpy())
+    out.backward(tg)
+    _assert_grad_close(cb.grad.cpu().numpy(), ref, first, sizes, rtol=1e-12)

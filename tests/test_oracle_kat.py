@@ -146,3 +146,27 @@ def test_empty_and_single():
     assert oc.forward(np.zeros((0, 2), np.float32), table, first, res, bw).shape == (0, 16)
     assert oc.backward(np.zeros((0, 2), np.float32), np.zeros((0, 16), np.float32), (T, 2), first, res, bw).sum() == 0
     assert oc.forward(np.zeros((1, 2), np.float32), table, first, res, bw).shape == (1, 16)
+
+
+def test_double_table_restatement():
+    """scalar_t = double (hashgrid_interpolate_cuda.cu:125,290): the forward narrows every table value to float and widens
+    the fp32 result (.cu:96-107); the backward's contribution is the float-narrowed product of a DOUBLE gradient and the
+    weight (.cu:215-217), so a gradient of 1 + 2^-30 (not a float) gives the same contributions as 1.0, and sums conserve."""
+    from oracle import hashgrid_c as oc
+    res, bw, dim = [5, 9, 17], 6, 2
+    sizes = [min(2 ** bw, r ** dim) for r in res]
+    first = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)
+    T = int(sum(sizes))
+    rng = np.random.default_rng(3)
+    coords = rng.uniform(-1, 1, (257, dim)).astype(np.float32)
+    table64 = rng.standard_normal((T, 2)) * (1.0 + 2.0 ** -40)
+    f64 = oc.forward_f64(coords, table64, first, res, bw)
+    assert f64.dtype == np.float64
+    assert np.array_equal(f64, oc.forward(coords, table64.astype(np.float32), first, res, bw).astype(np.float64))
+    ones = np.ones((257, len(res) * 2))
+    g_a = oc.backward_f64(coords, ones, (T, 2), first, res, bw)
+    g_b = oc.backward_f64(coords, ones * (1.0 + 2.0 ** -30), (T, 2), first, res, bw)
+    assert np.array_equal(g_a, g_b)                                   # products are narrowed to float
+    assert np.array_equal(g_a, oc.backward(coords, ones.astype(np.float32), (T, 2), first, res, bw))
+    for l in range(len(res)):                                         # partition of unity: every sample adds 1 per level, feature
+        assert abs(g_a[first[l]:first[l] + sizes[l]].sum() - 257 * 2) < 1e-3

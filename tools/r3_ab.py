@@ -64,7 +64,7 @@ for optset in sys.argv[2:]:
     opts = [] if optset == "-" else [kv.split("=") for kv in optset.split(",")]
     saved = [(k, lib.shacira_get_option(k.encode())) for k, _ in opts]
     for k, v in opts:
-        assert lib.shacira_set_option(k.encode(), int(v)) == 0, k
+        _lib.set_option(k, int(v))
     try:
         f = lambda: fwd_op(coords, table, first, res, bw)
         b = lambda: hip_ops.hashgrid_backward(dim, coords, go, T, DT, first, res, bw, F)
@@ -86,4 +86,4 @@ for optset in sys.argv[2:]:
               f"| fwd slice bit-exact {fwd_ok}", flush=True)
     finally:
         for k, v in saved:
-            lib.shacira_set_option(k.encode(), v)
+            _lib.set_option(k, v)
