@@ -43,6 +43,8 @@ WORKLOADS = {
     "B_kodak_2d_L16_F2_bw11_N393216": (2, geo(16, 512, 16), 11, 2, 393216),
     "C_kodak24_2d_L16_F2_bw11_N9437184": (2, geo(16, 512, 16), 11, 2, 24 * 393216),
     "D_nerf_lego_3d_L16_F2_bw19_N65536": (3, geo(16, 2048, 16), 19, 2, 65536),
+    # config E's per-GPU shard: the same 4096-ray batch split over 8 GPUs = 512 rays x 16 samples per rank
+    "E_shard_3d_L16_F2_bw19_N8192": (3, geo(16, 2048, 16), 19, 2, 8192),
     # the reference's SHIPPED configurations (not BASELINE's 16-level F = 2 metric shape): kodak.yaml's table as the operator
     # sees it (24 levels, feature_dim 1 repeated to F = 2, bw 11) and nerf_lego.yaml's (24 levels, F = 4, bw 19; 4096 rays x
     # 100 steps)
@@ -54,7 +56,7 @@ WORKLOADS = {
 HALF_VARIANTS = {"nerf_lego_yaml_3d_L24_F4_bw19_N409600_fp16": "nerf_lego_yaml_3d_L24_F4_bw19_N409600",
                  "S1_nerf_hash_3d_L16_F2_bw19_N2^20_fp16": "S1_nerf_hash_3d_L16_F2_bw19_N2^20"}
 SECONDARY = ["S2_kodak_2d_L16_F2_bw19_N2^20", "B_kodak_2d_L16_F2_bw11_N393216", "C_kodak24_2d_L16_F2_bw11_N9437184",
-             "D_nerf_lego_3d_L16_F2_bw19_N65536", "kodak_yaml_2d_L24_F1rep2_bw11_N393216",
+             "D_nerf_lego_3d_L16_F2_bw19_N65536", "E_shard_3d_L16_F2_bw19_N8192", "kodak_yaml_2d_L24_F1rep2_bw11_N393216",
              "nerf_lego_yaml_3d_L24_F4_bw19_N409600", "nerf_lego_yaml_3d_L24_F4_bw19_N409600_fp16",
              "S1_nerf_hash_3d_L16_F2_bw19_N2^20_fp16"]
 
@@ -72,7 +74,7 @@ def quick_measure(name, device, iters=20):
     table = (torch.randn(T, F, generator=g) * 0.01).to(device)
     if half:
         table = table.half()
-    if name.startswith("D_"):
+    if name.startswith("D_") or name.startswith("E_shard"):
         # NeRF-like ray points -- 4096 rays from the radius-3 sphere, 16 stratified samples inside the cube
         from shacira_amd import harness
         coords = harness.ray_points(n // 16, 16, g).contiguous().to(device)
@@ -272,6 +274,71 @@ def build_step(device, rank, world, dim, res, bw, F, n_local, ar_chunks=1, colle
             "grad_out": grad_out, "first": first}
 
 
+SWEEP_CASES = [
+    # (label, collective, ar_chunks, NCCL_ALGO or None)
+    ("allreduce", "allreduce", 1, None),
+    ("allreduce_ring", "allreduce", 1, "Ring"),
+    ("allreduce_tree", "allreduce", 1, "Tree"),
+    ("allreduce_chunks3", "allreduce", 3, None),
+    ("rs_ag", "rs_ag", 1, None),
+]
+SWEEP_LOADS = [("weak_S1", "S1_nerf_hash_3d_L16_F2_bw19_N2^20", "weak"),
+               ("strong_D", "D_nerf_lego_3d_L16_F2_bw19_N65536", "strong")]
+
+
+def run_sweep(args):
+    """bench.py --gpus N --sweep: every (collective setting) x (workload, scaling) pair as its own `bench.py --gpus N ...`
+    child (which in turn spawns its ranks as children): no process that has touched HIP is ever re-executed, and a hung or
+    failed configuration costs its own timeout only. One JSON line per configuration as it finishes + a summary line."""
+    import subprocess
+    if "RANK" in os.environ:
+        raise SystemExit("bench.py --sweep is a launcher mode: start it plainly (python bench.py --gpus N --sweep)")
+    assert not torch.cuda.is_initialized(), "the sweep parent must not initialise the GPU"
+    results = []
+    only = set(filter(None, args.sweep_filter.split(",")))
+    known = {f"{load}/{label}" for load, _, _ in SWEEP_LOADS for label, _, _, _ in SWEEP_CASES}
+    if only - known:
+        raise SystemExit(f"bench.py --sweep-filter: unknown configuration(s) {sorted(only - known)}; known: {sorted(known)}")
+    for load, workload, scaling in SWEEP_LOADS:
+        for label, collective, chunks, algo in SWEEP_CASES:
+            if args.gpus == 1 and label != "allreduce":
+                continue                      # one GPU: no collective to vary
+            if only and f"{load}/{label}" not in only:
+                continue
+            env = dict(os.environ)
+            env.pop("NCCL_ALGO", None)
+            if algo:
+                env["NCCL_ALGO"] = algo
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--workload", workload, "--scaling",
+                   scaling, "--collective", collective, "--ar-chunks", str(chunks), "--steps", str(args.steps), "--warmup",
+                   str(args.warmup), "--no-cpu-baseline", "--psnr-steps", "0", "--nerf-steps", "0", "--no-secondary"]
+            if args.selftest_launch:
+                cmd.append("--selftest-launch")
+            name = f"{load}/{label}"
+            try:
+                cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                rec = json.loads(lines[-1]) if lines else {"error": f"no JSON line (rc {cp.returncode})",
+                                                           "stderr_tail": cp.stderr[-400:]}
+            except subprocess.TimeoutExpired:
+                rec = {"error": "timeout (600 s)"}
+            rec.setdefault("config", {})
+            if isinstance(rec["config"], dict):
+                rec["config"].update({"sweep": name, "nccl_algo": algo or "unset (RCCL chooses)", "ar_chunks": chunks,
+                                      "collective": collective if args.gpus > 1 else None})
+            print(json.dumps(rec), flush=True)
+            results.append((name, rec))
+    ok = [(n, r) for n, r in results if r.get("value") is not None]
+    summary = {"sweep_summary": {n: {"value": r.get("value"), "ms_per_step": r.get("ms_per_step"),
+                                     "ms_allreduce": (r.get("ms") or {}).get("allreduce"), "error": r.get("error")}
+                                 for n, r in results},
+               "n_gpus": args.gpus, "unit": "samples/s (whole job)",
+               "best": {load: max(((n, r["value"]) for n, r in ok if n.startswith(load)), key=lambda t: t[1], default=None)
+                        for load, _, _ in SWEEP_LOADS}}
+    print(json.dumps(summary), flush=True)
+    return 0 if all("error" not in r for _, r in results) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,6 +365,15 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=1 << 17,
                     help="samples of the CPU baseline leg (a bounded slice of the headline batch)")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--sweep", action="store_true",
+                    help="the first node-hour in one command: with --gpus N, run {allreduce (NCCL_ALGO unset / Ring / Tree), "
+                         "rs_ag} x {--ar-chunks 1, 3} x {weak S1, strong D (config E: 65 536 samples over the ranks)} -- each "
+                         "in fresh child processes (this parent never touches HIP) -- and print one JSON line per "
+                         "configuration (config.sweep names it, config.nccl_algo records the RCCL algorithm setting), then "
+                         "a summary line. Combine with --selftest-launch to check the control flow without GPUs.")
+    ap.add_argument("--sweep-filter", default="",
+                    help="comma-separated subset of the sweep's configurations (names as in config.sweep, e.g. "
+                         "weak_S1/rs_ag,strong_D/allreduce_chunks3); default: all")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="only exercise the multi-rank launch (spawn, rendezvous, one all-reduce, JSON line with n_gpus); "
                          "needs no GPU: ranks use the gloo backend. The metric value is null.")
@@ -308,6 +384,8 @@ def main():
     # parent only waits and relays the children's output (rank 0 prints the JSON line) and exit code.
     if args.ar_chunks > 1 and args.collective != "allreduce":
         raise SystemExit("bench.py: --ar-chunks > 1 overlaps all-reduces of row ranges; it needs --collective allreduce")
+    if args.sweep:
+        raise SystemExit(run_sweep(args))
     if args.gpus > 1 and "RANK" not in os.environ:
         import socket
         import subprocess
@@ -439,6 +517,13 @@ def main():
                                "marcher, occupancy level 5 pruned every 100 steps), density 32-64-16 + colour 43-64-64-3 "
                                "decoders, analytic scene", "ms_per_step": fit["ms_per_step"],
                      "occupied_cells": fit["occupied_cells"], "seconds": time.perf_counter() - tp}
+        # the same fit with the step replayed from HIP graphs (harness.GraphedNerfFitter: capacity-sized sample buffers,
+        # no count read-back, re-captured when a prune moves the sample count): what a user who cares about wall time runs
+        tg = time.perf_counter()
+        gfit = harness.fit_nerf(device, steps=args.nerf_steps, graphed=True)
+        psnr_nerf["graph_replay"] = {"value": gfit["psnr"], "ms_per_step": gfit["ms_per_step"],
+                                     "graph_captures": gfit["graph_captures"], "sample_capacity": gfit["sample_capacity"],
+                                     "overflow_steps": gfit["overflow_steps"], "seconds": time.perf_counter() - tg}
 
     # the optimiser pass that follows the backward in training (SURVEY 8d "second figure"): fused Adam over the table
     ms_adam = None
@@ -559,6 +644,7 @@ def main():
             "config": {"workload": args.workload, "dim": dim, "levels": L, "feature_dim": F, "bitwidth": bw,
                        "table_rows": T, "samples_per_gpu": n_local, "scaling": args.scaling,
                        "collective": args.collective if world > 1 else None,
+                       "nccl_algo": (os.environ.get("NCCL_ALGO") or "unset (RCCL chooses)") if world > 1 else None,
                        "parallelism": f"dp{world}" + ("" if world == 1 else
                                                       (f"+one {args.collective}(grad_codebook) after the backward")
                                                       if len(groups) == 1 else

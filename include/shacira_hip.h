@@ -421,6 +421,14 @@ SHACIRA_API int shacira_raymarch_ray_emit(int64_t num_rays, int num_samples, con
                               float dist_min, float dist_max, const float *lin, const float *jitter,
                               const uint8_t *occupancy, int level, const int64_t *offsets, int64_t *ridx,
                               float *samples, float *depth, float *deltas, uint8_t *boundary, void *stream);
+/* ABI 9: the same into caller buffers of `capacity` rows -- survivors whose row would be >= capacity are dropped (the
+ * caller clamps `offsets` to capacity for its pack reductions). For steps captured into a HIP graph: the buffers cannot
+ * be sized from a count read back to the host there. Rows behind the last survivor are left untouched. */
+SHACIRA_API int shacira_raymarch_ray_emit_capped(int64_t num_rays, int num_samples, const float *origins,
+                              const float *dirs, float dist_min, float dist_max, const float *lin, const float *jitter,
+                              const uint8_t *occupancy, int level, const int64_t *offsets, int64_t capacity,
+                              int64_t *ridx, float *samples, float *depth, float *deltas, uint8_t *boundary,
+                              void *stream);
 SHACIRA_API int shacira_raytrace_dense_count(int64_t num_rays, const float *origins, const float *dirs,
                                  const uint8_t *occupancy, int level, int32_t *counts, void *stream);
 SHACIRA_API int shacira_raytrace_dense_emit(int64_t num_rays, const float *origins, const float *dirs,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "shacira_pack_broadcast": (_i, [_i64, _i64, _i, _p, _p, _p, _p]),
     "shacira_raymarch_ray_count": (_i, [_i64, _i, _p, _p, _f, _f, _p, _p, _p, _i, _p, _p]),
     "shacira_raymarch_ray_emit": (_i, [_i64, _i, _p, _p, _f, _f, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "shacira_raymarch_ray_emit_capped": (_i, [_i64, _i, _p, _p, _f, _f, _p, _p, _p, _i, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "shacira_raytrace_dense_count": (_i, [_i64, _p, _p, _p, _i, _p, _p]),
     "shacira_raytrace_dense_emit": (_i, [_i64, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "shacira_mlp_supported": (_i, [_i, _i, _i, _i]),

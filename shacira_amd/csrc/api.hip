@@ -3,6 +3,7 @@
 // snapshotted once per call).
 #include <atomic>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 
 #include "internal.h"
@@ -487,7 +488,7 @@ int shacira_raymarch_ray_count(int64_t num_rays, int num_samples, const float *o
     if (num_samples < 1 || (num_rays > 0 && (!lin || !jitter || !counts))) return SHACIRA_EINVAL;
     return (int)raymarch_ray_launch(false, num_rays, num_samples, origins, dirs, dist_min, dist_max, lin, jitter,
                                     occupancy, level, counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                    (hipStream_t)stream);
+                                    INT64_MAX, (hipStream_t)stream);
 }
 
 int shacira_raymarch_ray_emit(int64_t num_rays, int num_samples, const float *origins, const float *dirs,
@@ -498,7 +499,19 @@ int shacira_raymarch_ray_emit(int64_t num_rays, int num_samples, const float *or
     if (num_samples < 1 || (num_rays > 0 && (!lin || !jitter || !offsets))) return SHACIRA_EINVAL;
     return (int)raymarch_ray_launch(true, num_rays, num_samples, origins, dirs, dist_min, dist_max, lin, jitter,
                                     occupancy, level, nullptr, offsets, ridx, samples, depth, deltas, boundary,
-                                    (hipStream_t)stream);
+                                    INT64_MAX, (hipStream_t)stream);
+}
+
+int shacira_raymarch_ray_emit_capped(int64_t num_rays, int num_samples, const float *origins, const float *dirs,
+                                     float dist_min, float dist_max, const float *lin, const float *jitter,
+                                     const uint8_t *occupancy, int level, const int64_t *offsets, int64_t capacity,
+                                     int64_t *ridx, float *samples, float *depth, float *deltas, uint8_t *boundary,
+                                     void *stream) {
+    if (int rc = march_args_ok(num_rays, origins, dirs, occupancy, level)) return rc;
+    if (num_samples < 1 || capacity < 0 || (num_rays > 0 && (!lin || !jitter || !offsets))) return SHACIRA_EINVAL;
+    return (int)raymarch_ray_launch(true, num_rays, num_samples, origins, dirs, dist_min, dist_max, lin, jitter,
+                                    occupancy, level, nullptr, offsets, ridx, samples, depth, deltas, boundary,
+                                    capacity, (hipStream_t)stream);
 }
 
 int shacira_raytrace_dense_count(int64_t num_rays, const float *origins, const float *dirs, const uint8_t *occupancy,

@@ -122,7 +122,8 @@ hipError_t pack_sum_launch(bool broadcast, int64_t R, int C, const float *in, co
 hipError_t raymarch_ray_launch(bool emit, int64_t num_rays, int ns, const float *origins, const float *dirs,
                                float dist_min, float dist_max, const float *lin, const float *jitter,
                                const uint8_t *occ, int level, int32_t *counts, const int64_t *offsets, int64_t *ridx,
-                               float *samples, float *depth, float *deltas, uint8_t *boundary, hipStream_t s);
+                               float *samples, float *depth, float *deltas, uint8_t *boundary, int64_t capacity,
+                               hipStream_t s);
 hipError_t raytrace_dense_launch(bool emit, int64_t num_rays, const float *origins, const float *dirs,
                                  const uint8_t *occ, int level, int32_t *counts, const int64_t *offsets, int32_t *ridx,
                                  int32_t *pidx, float *depth, hipStream_t s);

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * kPackWaves) void raymarch_ray_kernel(
     float dist_max, const float *__restrict__ lin, const float *__restrict__ jitter, const uint8_t *__restrict__ occ,
     int G, int32_t *__restrict__ counts, const int64_t *__restrict__ offsets, int64_t *__restrict__ ridx,
     float *__restrict__ samples, float *__restrict__ depth_out, float *__restrict__ deltas,
-    uint8_t *__restrict__ boundary) {
+    uint8_t *__restrict__ boundary, int64_t capacity) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * kPackWaves + (threadIdx.x >> 6);
     if (r >= num_rays) return;
@@ -206,8 +206,10 @@ __global__ __launch_bounds__(64 * kPackWaves) void raymarch_ray_kernel(
         }
         const unsigned long long m = __ballot(keep);
         if constexpr (EMIT) {
-            if (keep) {
-                const int64_t k = out + __popcll(m & ((1ull << lane) - 1ull));
+            const int64_t k = out + __popcll(m & ((1ull << lane) - 1ull));
+            // (capacity: rows of the caller's fixed-size buffers -- a step captured into a HIP graph cannot size them from
+            // the count; survivors beyond it are dropped, the caller clamps its pack offsets the same way)
+            if (keep && k < capacity) {
                 ridx[k] = r;
                 samples[k * 3] = px;
                 samples[k * 3 + 1] = py;
@@ -354,15 +356,16 @@ hipError_t pack_sum_launch(bool broadcast, int64_t R, int C, const float *in, co
 hipError_t raymarch_ray_launch(bool emit, int64_t num_rays, int ns, const float *origins, const float *dirs,
                                float dist_min, float dist_max, const float *lin, const float *jitter,
                                const uint8_t *occ, int level, int32_t *counts, const int64_t *offsets, int64_t *ridx,
-                               float *samples, float *depth, float *deltas, uint8_t *boundary, hipStream_t s) {
+                               float *samples, float *depth, float *deltas, uint8_t *boundary, int64_t capacity,
+                               hipStream_t s) {
     if (num_rays == 0) return hipSuccess;
     const dim3 grid(pack_blocks(num_rays)), block(64 * kPackWaves);
     if (!emit)
         hipLaunchKernelGGL(raymarch_ray_kernel<false>, grid, block, 0, s, num_rays, ns, origins, dirs, dist_min, dist_max,
-                           lin, jitter, occ, 1 << level, counts, offsets, ridx, samples, depth, deltas, boundary);
+                           lin, jitter, occ, 1 << level, counts, offsets, ridx, samples, depth, deltas, boundary, capacity);
     else
         hipLaunchKernelGGL(raymarch_ray_kernel<true>, grid, block, 0, s, num_rays, ns, origins, dirs, dist_min, dist_max,
-                           lin, jitter, occ, 1 << level, counts, offsets, ridx, samples, depth, deltas, boundary);
+                           lin, jitter, occ, 1 << level, counts, offsets, ridx, samples, depth, deltas, boundary, capacity);
     return hipGetLastError();
 }
 

@@ -428,9 +428,121 @@ class _AnalyticNef:
         return dict(rgb=rgb, density=density)
 
 
+class GraphedNerfFitter:
+    """The NeRF render-and-fit step (multiview_trainer.py:80-156 through packed_rf_tracer.py:68-170) recorded into a HIP
+    graph and replayed. Eagerly the step is ~120 launches issued from Python with a count read-back in the middle (the
+    marcher's sample count sizes every later tensor): 1.8 ms per step with the GPU busy half of it.
+
+    What capture forces, and how it is met:
+    * no read-back: the marcher emits into buffers of a fixed CAPACITY (`shacira_raymarch_ray_emit_capped`); rows behind
+      the last survivor are padding that belongs to no ray pack, so whatever the field computes for them integrates into
+      nothing and receives a zero gradient (their positions are spread over the cube: identical positions would pile LDS
+      atomics onto a handful of table rows). Capacity = the largest count of a few probe batches x `margin`, re-measured
+      after every occupancy prune (the count only changes statistically in between: 4 096 rays average it to ~1.5 %);
+      a step whose count exceeds it drops the excess samples and is counted in `overflow_steps`;
+    * the occupancy lives in ONE device tensor that prunes update in place (the graph holds its address);
+    * rays are drawn with the device generator, Adam keeps its step count on the device (FusedAdam(capturable=True)).
+    A graph is re-captured when a prune changes the capacity (a few times per run)."""
+
+    def __init__(self, nef, truth, tracer, gt_tracer, groups, rays, near, far, device, margin=1.08, quantum=4096):
+        from .optim import FusedAdam
+        from .wisp.accelstructs import OctreeAS
+        self.nef, self.truth, self.tracer, self.gt_tracer = nef, truth, tracer, gt_tracer
+        self.rays, self.near, self.far, self.device = rays, near, far, device
+        self.margin, self.quantum = margin, quantum
+        self.opt = FusedAdam(groups, eps=1e-15, capturable=True)
+        self.o = torch.zeros(rays, 3, device=device)
+        self.d = torch.zeros(rays, 3, device=device)
+        self.loss = torch.zeros((), device=device)
+        self.overflow = torch.zeros((), dtype=torch.int64, device=device)
+        # the occupancy the graph reads: one persistent structure, updated in place by `after_prune`
+        blas = nef.grid.blas
+        self.blas = OctreeAS(blas.max_level, blas.occupancy_grid.to(device).clone())
+        nef.grid.blas = self.blas
+        truth.grid.blas._grid_on(device)
+        self.graph, self.capacity, self.gt_capacity, self.captures = None, None, None, 0
+
+    def _draw_rays(self):
+        o = torch.randn(self.rays, 3, device=self.device)
+        o = 3.0 * o / o.norm(dim=1, keepdim=True)
+        d = (torch.rand(self.rays, 3, device=self.device) - 0.5) * 1.4 - o
+        self.o.copy_(o)
+        self.d.copy_(d / d.norm(dim=1, keepdim=True))
+
+    def _batch(self):
+        from .wisp.core import Rays
+        return Rays(self.o, self.d, dist_min=self.near, dist_max=self.far)
+
+    def _body(self):
+        self._draw_rays()
+        batch = self._batch()
+        with torch.no_grad():
+            target = self.gt_tracer(self.truth, batch).rgb
+        self.opt.zero_grad(set_to_none=True)
+        rb = self.tracer(self.nef, batch)
+        loss = torch.abs(rb.rgb[..., :3] - target[..., :3]).mean()
+        loss.backward()
+        self.opt.step()
+        self.loss.copy_(loss.detach())
+        if self.capacity is not None:
+            over = (self.blas.last_sample_count > self.capacity) | (self.truth.grid.blas.last_sample_count > self.gt_capacity)
+            self.overflow.add_(over.to(torch.int64))
+
+    def _probe_capacity(self, probes=4):
+        """Sample counts of a few ray batches under the current occupancy (eager, with read-backs) -> capacities."""
+        self.blas.sample_capacity = self.truth.grid.blas.sample_capacity = None
+        need = gt_need = 1
+        with torch.no_grad():
+            for _ in range(probes):
+                self._draw_rays()
+                batch = self._batch()
+                m = self.nef.grid.raymarch(batch, level=None, num_samples=self.tracer.num_steps, raymarch_type="ray")
+                g = self.truth.grid.raymarch(batch, level=None, num_samples=self.gt_tracer.num_steps, raymarch_type="ray")
+                need, gt_need = max(need, m.samples.shape[0]), max(gt_need, g.samples.shape[0])
+        up = lambda n: int(-(-int(n * self.margin) // self.quantum) * self.quantum)
+        return up(need), up(gt_need)
+
+    def prepare(self):
+        """(Re)capture for the current occupancy. Call once after a few eager steps, and after every prune."""
+        cap, gt_cap = self._probe_capacity()
+        if self.graph is not None and (cap, gt_cap) == (self.capacity, self.gt_capacity):
+            self.blas.sample_capacity, self.truth.grid.blas.sample_capacity = cap, gt_cap
+            return
+        self.capacity, self.gt_capacity = cap, gt_cap
+        self.blas.sample_capacity, self.truth.grid.blas.sample_capacity = cap, gt_cap
+        self.graph = None               # release the previous graph's pool before the new capture
+        self._body()                    # one eager step at the new shapes (workspaces, kernel attributes)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._body()
+        self.graph = graph
+        self.captures += 1
+
+    def step(self):
+        if self.graph is None:
+            self._body()                # eager (warm-up) steps before the first capture
+        else:
+            self.graph.replay()
+
+    def after_prune(self):
+        """`nef.prune()` built a new acceleration structure: move its cells into the persistent one, then re-capture if the
+        sample count moved."""
+        new = self.nef.grid.blas
+        if new is not self.blas:
+            self.blas.occupancy_grid.copy_(new.occupancy_grid.to(self.device))
+            self.blas.points, self.blas.pyramid = new.points, new.pyramid
+            self.nef.grid.blas = self.blas
+        self.prepare()
+
+    def eager_mode(self):
+        """Back to read-back sized tensors (validation renders)."""
+        self.blas.sample_capacity = self.truth.grid.blas.sample_capacity = None
+
+
 def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwidth=19, max_grid_res=2048,
              num_lods=16, blas_level=5, prune_every=100, val_rays=8192, hidden_dim=64, latent=False,
-             entropy_reg=1.0e-4, feature_dim=2):
+             entropy_reg=1.0e-4, feature_dim=2, graphed=False):
     """NeRF-style fit of the analytic scene through the full pipeline the reference runs per step
     (multiview_trainer.py:88-150): ray marching on the occupancy grid ('ray' sampler) -> hash-grid lookup -> density /
     colour decoders -> volume integration -> L1 to the target pixels -> Adam; occupancy pruned every `prune_every` steps.
@@ -439,6 +551,7 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
     warm-up with temperature 1.0 until decay_period 0.9, entropy model with one layer, lambda = `entropy_reg`); the
     result then also carries the size estimate and the bytes of the entropy-coded model file. nerf_lego.yaml's shape is
     feature_dim=4, num_lods=24, max_grid_res=512, hidden_dim=128 (tools/lego_fit.py).
+    `graphed=True` (HashGrid variant only): the step replayed from a HIP graph (`GraphedNerfFitter`).
     Returns dict(psnr on held-out rays, ms_per_step, samples_per_step)."""
     import time
     from .optim import FusedAdam
@@ -476,11 +589,37 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
     tracer = PackedRFTracer(raymarch_type="ray", num_steps=num_steps, bg_color="white")
     gt_tracer = PackedRFTracer(raymarch_type="ray", num_steps=4 * num_steps, bg_color="white")
     groups = [g for g in param_groups(nef, lr=1e-3, grid_lr=1e-2) if g["params"]]
+    near, far = 1.2, 4.8
+    warm = min(20, steps // 10)          # first steps pay one-off costs (kernel attribute set-up, allocator growth)
+    if graphed:
+        if latent:
+            raise ValueError("the graphed NeRF fitter replays a fixed step: SGA temperature / entropy schedules change every step")
+        fitter = GraphedNerfFitter(nef, truth, tracer, gt_tracer, groups, rays, near, far, device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(steps):
+            if it == warm:
+                fitter.prepare()             # capture after the eager warm-up steps (timed from here, captures included)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            fitter.step()
+            if prune_every and (it + 1) % prune_every == 0:
+                nef.prune()
+                fitter.after_prune()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / max(1, steps - warm) * 1e3
+        fitter.eager_mode()
+        with torch.no_grad():
+            o, d = camera_rays(val_rays, torch.Generator().manual_seed(4242), device)
+            batch = Rays(o, d, dist_min=near, dist_max=far)
+            val = psnr_fn(tracer(nef, batch).rgb.clamp(0, 1), gt_tracer(truth, batch).rgb)
+        return dict(psnr=val, ms_per_step=ms, steps=steps, rays_per_step=rays, candidate_samples_per_step=rays * num_steps,
+                    occupied_cells=int(nef.grid.blas.points.shape[0]), total_cells=int(grid.num_cells),
+                    graph_captures=fitter.captures, sample_capacity=fitter.capacity,
+                    overflow_steps=int(fitter.overflow.item()))
     opt = FusedAdam(groups, eps=1e-15)
     gen = torch.Generator().manual_seed(seed + 1)
-    near, far = 1.2, 4.8
     samples_seen = 0
-    warm = min(20, steps // 10)          # first steps pay one-off costs (kernel attribute set-up, allocator growth)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(steps):

@@ -112,11 +112,31 @@ def _occupancy_u8(occupancy, level):
     return occupancy.to(torch.uint8).contiguous()
 
 
-def raymarch_ray(origins, dirs, dist_min, dist_max, occupancy, level, num_samples, jitter=None):
+_pad_cache = {}
+
+
+def _padding_positions(n, device):
+    """[n, 3] fixed positions spread over the cube for the padding rows of a capped emit: the field is still evaluated on
+    them (their gradient is zero), and identical positions would pile its scatter-add onto a handful of table rows."""
+    key = (n, device.index)
+    if key not in _pad_cache:
+        # (built on the host: never inside a graph capture -- GraphedNerfFitter runs one eager step at every new capacity)
+        if len(_pad_cache) >= 16:
+            _pad_cache.clear()
+        g = torch.Generator().manual_seed(12345)
+        _pad_cache[key] = (torch.rand(n, 3, generator=g) * 2 - 1).to(device)
+    return _pad_cache[key]
+
+
+def raymarch_ray(origins, dirs, dist_min, dist_max, occupancy, level, num_samples, jitter=None, capacity=None):
     """`OctreeAS._raymarch_ray` (reference octree_as.py:235-290) on a dense occupancy grid [G, G, G] (bool, [x][y][z]).
     -> ridx int64 [S], samples [S, 3], depth_samples [S, 1], deltas [S, 1], boundary bool [S], and the per-ray pack
     offsets int64 [num_rays + 1] (rays without samples have empty packs) for callers that want to integrate without
-    compacting the hit rays first."""
+    compacting the hit rays first.
+    ``capacity`` (for steps captured into a HIP graph): no count is read back -- the outputs have exactly ``capacity``
+    rows, survivors beyond it are dropped, the pack offsets are clamped to it, and the rows behind the last survivor are
+    padding that belongs to no pack (ray 0, position 0, delta 0: whatever is computed for them integrates into nothing
+    and receives a zero gradient). A seventh value is returned then: the true survivor count as a device int64 scalar."""
     _need_gpu(origins, dirs, occupancy)
     origins, dirs = origins.float().contiguous(), dirs.float().contiguous()
     N, dev = origins.shape[0], origins.device
@@ -133,6 +153,18 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, occupancy, level, num_sample
         _lib.check(L.shacira_raymarch_ray_count(*args, _ptr(counts), _stream(origins)), "shacira_raymarch_ray_count")
         offsets = torch.zeros((N + 1,), dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=offsets[1:])
+        if capacity is not None:
+            S = int(capacity)
+            ridx = torch.zeros((S,), dtype=torch.int64, device=dev)
+            samples = _padding_positions(S, dev).clone()     # rows behind the last survivor keep these
+            depth = torch.zeros((S, 1), dtype=torch.float32, device=dev)
+            deltas = torch.zeros((S, 1), dtype=torch.float32, device=dev)
+            boundary = torch.zeros((S,), dtype=torch.uint8, device=dev)
+            _lib.check(L.shacira_raymarch_ray_emit_capped(*args, _ptr(offsets), S, _ptr(ridx), _ptr(samples), _ptr(depth),
+                                                          _ptr(deltas), _ptr(boundary), _stream(origins)),
+                       "shacira_raymarch_ray_emit_capped")
+            total = offsets[-1].clone()
+            return ridx, samples, depth, deltas, boundary.bool(), offsets.clamp(max=S), total
         S = int(offsets[-1].item())
         ridx = torch.empty((S,), dtype=torch.int64, device=dev)
         samples = torch.empty((S, 3), dtype=torch.float32, device=dev)

@@ -137,9 +137,17 @@ class OctreeAS(BaseAS):
         octree_as.py:235-290): generation, occupancy filter and compaction in two HIP launches."""
         from ... import render
         level = self._level(level)
-        ridx, samples, depth, deltas, boundary, offsets = render.raymarch_ray(
-            rays.origins, rays.dirs, rays.dist_min, rays.dist_max, self._grid_on(rays.origins.device), level,
-            num_samples)
+        capacity = getattr(self, "sample_capacity", None)
+        if capacity is not None:
+            # fixed-size outputs for a step captured into a HIP graph (harness.GraphedNerfFitter): no count read-back;
+            # `last_sample_count` keeps the true count on the device so that the owner can watch for dropped samples
+            ridx, samples, depth, deltas, boundary, offsets, self.last_sample_count = render.raymarch_ray(
+                rays.origins, rays.dirs, rays.dist_min, rays.dist_max, self._grid_on(rays.origins.device), level,
+                num_samples, capacity=capacity)
+        else:
+            ridx, samples, depth, deltas, boundary, offsets = render.raymarch_ray(
+                rays.origins, rays.dirs, rays.dist_min, rays.dist_max, self._grid_on(rays.origins.device), level,
+                num_samples)
         return ASRaymarchResults(ridx=ridx, samples=samples, depth_samples=depth, deltas=deltas, boundary=boundary,
                                  ray_offsets=offsets)
 

@@ -38,3 +38,26 @@ def test_visible_gpu_count_reads_the_environment(monkeypatch):
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2")
     assert sdist.visible_gpu_count() == 1
+
+
+def test_sweep_control_flow_four_ranks():
+    """bench.py --gpus 4 --sweep (the one command for the first multi-GPU node-hour): every configuration runs in fresh child
+    processes, prints its own JSON line tagged with config.sweep / nccl_algo / ar_chunks, and a summary line closes the run.
+    Launch self-test mode (gloo, no kernels), three of the ten configurations to keep the CPU suite short."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "NCCL_ALGO")}
+    names = ["weak_S1/allreduce_ring", "weak_S1/rs_ag", "strong_D/allreduce_chunks3"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--sweep", "--selftest-launch",
+                          "--sweep-filter", ",".join(names)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(recs) == len(names) + 1
+    for rec, name in zip(recs, names):
+        assert rec["n_gpus"] == 4 and rec["config"]["sweep"] == name and rec["config"]["allreduce_check"] is True
+    assert recs[0]["config"]["nccl_algo"] == "Ring" and recs[1]["config"]["collective"] == "rs_ag"
+    assert recs[2]["config"]["ar_chunks"] == 3 and recs[2]["scaling"] == "strong"
+    assert sorted(recs[-1]["sweep_summary"]) == sorted(names)
+    # an unknown name is refused before anything is launched
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--sweep", "--selftest-launch",
+                          "--sweep-filter", "weak_S1/nope"], env=env, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "unknown configuration" in bad.stderr

@@ -789,6 +789,34 @@ def test_s3_ray_points_against_the_oracle(dev):
     _assert_grad_close(grad.cpu().numpy(), ref, first, sizes)
 
 
+def test_config_e_shard_ray_points_against_the_oracle(dev):
+    """BASELINE config 5's per-GPU shard: the 4096-ray batch of config 4 split over 8 ranks = 512 rays x 16 samples = 8 192 ray
+    points per GPU on the nerf_hash table (the binned backward at its smallest: 64 KiB images, no fixed point, every hashed
+    bucket a single small unit). Both directions against the oracle, for each of the 8 shards' worth of rays of one batch
+    (shard 0 and shard 7 checked), and the shard gradients sum to the whole batch's."""
+    from shacira_amd import harness
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T = table_layout(res, bw, dim)
+    g = torch.Generator().manual_seed(7)
+    coords = harness.ray_points(4096, 16, g).contiguous()
+    table = (torch.randn(T, 2, generator=g) * 0.01)
+    go = torch.randn(65536, 32, generator=g)
+    tf = torch.from_numpy(first).to(dev)
+    total = None
+    for shard in range(8):
+        lo, hi = shard * 8192, (shard + 1) * 8192
+        cs, gs = coords[lo:hi].contiguous(), go[lo:hi].contiguous()
+        grad = ops.hashgrid_backward(3, cs.to(dev), gs.to(dev), T, torch.float32, tf, res, bw, 2)
+        total = grad.double() if total is None else total + grad.double()
+        if shard in (0, 7):
+            feats = ops.hashgrid_interpolate_cuda(cs.to(dev), table.to(dev), tf, res, bw)
+            assert np.array_equal(feats.cpu().numpy(), oc.forward(cs.numpy(), table.numpy(), first, res, bw))
+            _assert_grad_close(grad.cpu().numpy(), oc.backward(cs.numpy(), gs.numpy(), (T, 2), first, res, bw), first, sizes)
+    whole = ops.hashgrid_backward(3, coords.to(dev), go.to(dev), T, torch.float32, tf, res, bw, 2)
+    _assert_grad_close(total.cpu().numpy(), whole.double().cpu().numpy(), first, sizes)   # what the all-reduce sums
+
+
 def test_concurrent_calls_from_two_threads(dev):
     """The boundary is reentrant (the backward runs on autograd worker threads): two host threads, each on its own
     stream and its own problem, interleave forward / backward calls (batches above and below the side-stream

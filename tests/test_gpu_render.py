@@ -195,3 +195,45 @@ def test_compressed_nerf_fit_trains_and_codes(dev):
     assert r["psnr"] > 15.0, r
     assert r["file_bytes"] < 0.25 * r["table_bytes_fp32"], r
     assert 0.5 < r["file_bytes"] / (r["latent_bytes_estimate"] + 60_000) < 2.0, r   # + decoders stored raw
+
+
+def test_capped_raymarch_emit(dev):
+    """shacira_raymarch_ray_emit_capped (ABI 9, for steps captured into a HIP graph): fixed-size outputs without a count
+    read-back. Capacity above the count: the first S rows equal the uncapped emit, the rows behind are padding (ray 0, delta
+    0, positions inside the cube) and no pack covers them. Capacity below the count: the first `capacity` rows equal the
+    uncapped emit's, offsets are clamped, the true count comes back on the device."""
+    from shacira_amd import render
+    rng = np.random.default_rng(11)
+    N, level, ns = 700, 5, 64
+    G = 1 << level
+    o, d = _rays(rng, N)
+    occ = torch.from_numpy(rng.random((G, G, G)) < 0.3).to(dev)
+    jit = torch.from_numpy(rng.random((N, ns)).astype(np.float32)).to(dev)
+    args = (o.to(dev), d.to(dev), 1.5, 4.5, occ, level, ns, jit)
+    r, s, dep, dl, b, off = render.raymarch_ray(*args)
+    S = r.shape[0]
+    for cap in (S + 1000, S, S - 777, 64):
+        rc, sc, depc, dlc, bc, offc, total = render.raymarch_ray(*args, capacity=cap)
+        assert int(total) == S and rc.shape[0] == cap and sc.shape == (cap, 3)
+        k = min(S, cap)
+        assert torch.equal(rc[:k], r[:k]) and torch.equal(sc[:k], s[:k]) and torch.equal(depc[:k], dep[:k])
+        assert torch.equal(dlc[:k], dl[:k]) and torch.equal(bc[:k], b[:k])
+        assert torch.equal(offc, off.clamp(max=cap)) and int(offc[-1]) == k
+        if cap > S:
+            assert not rc[S:].any() and not dlc[S:].any() and not bc[S:].any() and bool((sc[S:].abs() <= 1).all())
+            assert sc[S:].unique(dim=0).shape[0] > (cap - S) // 2          # spread, not one point
+
+
+def test_graphed_nerf_fit_matches_the_eager_fit(dev):
+    """The NeRF step replayed from HIP graphs (GraphedNerfFitter: capacity-sized sample buffers, occupancy updated in
+    place, device-side rays and Adam step count) learns the scene like the eager loop: same PSNR level at the same step
+    (different ray streams: +-1 dB), no step dropped samples, a re-capture per prune that moved the sample count."""
+    from shacira_amd import harness
+    kw = dict(steps=350, rays=2048, num_steps=96, codebook_bitwidth=16, max_grid_res=512, prune_every=100, val_rays=4096)
+    eager = harness.fit_nerf(dev, **kw)
+    graphed = harness.fit_nerf(dev, graphed=True, **kw)
+    assert graphed["overflow_steps"] == 0, graphed
+    assert 1 <= graphed["graph_captures"] <= 4, graphed
+    assert graphed["psnr"] > 17.5 and abs(graphed["psnr"] - eager["psnr"]) < 1.5, (eager, graphed)
+    assert 0 < graphed["occupied_cells"] < graphed["total_cells"], graphed
+    assert graphed["sample_capacity"] < kw["rays"] * kw["num_steps"] // 2, graphed     # sized to the pruned scene, not the maximum
