@@ -517,13 +517,19 @@ def main():
                                "marcher, occupancy level 5 pruned every 100 steps), density 32-64-16 + colour 43-64-64-3 "
                                "decoders, analytic scene", "ms_per_step": fit["ms_per_step"],
                      "occupied_cells": fit["occupied_cells"], "seconds": time.perf_counter() - tp}
-        # the same fit with the step replayed from HIP graphs (harness.GraphedNerfFitter: capacity-sized sample buffers,
-        # no count read-back, re-captured when a prune moves the sample count): what a user who cares about wall time runs
+        # the same fit fed from a resident pool of rays + target colours (the role of the reference's MultiviewDataset: the
+        # figure above renders its targets from the closed-form scene inside every step), eagerly and with the step replayed
+        # from HIP graphs (harness.GraphedNerfFitter: capacity-sized sample buffers, no count read-back, re-captured when a
+        # prune moves the sample count): what a user who cares about wall time runs
         tg = time.perf_counter()
-        gfit = harness.fit_nerf(device, steps=args.nerf_steps, graphed=True)
-        psnr_nerf["graph_replay"] = {"value": gfit["psnr"], "ms_per_step": gfit["ms_per_step"],
-                                     "graph_captures": gfit["graph_captures"], "sample_capacity": gfit["sample_capacity"],
-                                     "overflow_steps": gfit["overflow_steps"], "seconds": time.perf_counter() - tg}
+        efit = harness.fit_nerf(device, steps=args.nerf_steps, ray_pool=128)
+        gfit = harness.fit_nerf(device, steps=args.nerf_steps, ray_pool=128, graphed=True)
+        psnr_nerf["ray_pool_128_batches"] = {
+            "eager": {"value": efit["psnr"], "ms_per_step": efit["ms_per_step"]},
+            "graph_replay": {"value": gfit["psnr"], "ms_per_step": gfit["ms_per_step"],
+                             "graph_captures": gfit["graph_captures"], "sample_capacity_last": gfit["sample_capacity"],
+                             "overflow_steps": gfit["overflow_steps"], "capture_seconds": gfit["capture_seconds"]},
+            "seconds": time.perf_counter() - tg}
 
     # the optimiser pass that follows the backward in training (SURVEY 8d "second figure"): fused Adam over the table
     ms_adam = None

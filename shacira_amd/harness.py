@@ -396,11 +396,21 @@ def fit_field_3d(device, steps=500, rays=4096, samples_per_ray=16, seed=0, codeb
 
 
 # ------------------------------------------------------------------------------------------------ NeRF render-and-fit
+_scene_cache = {}
+
+
+def _scene_constants(device):
+    """Blob centres / radii on `device`, uploaded once (a host->device copy is not allowed inside a graph capture)."""
+    if device not in _scene_cache:
+        _scene_cache[device] = (torch.tensor([[0.35, 0.0, 0.1], [-0.3, 0.25, -0.2], [0.0, -0.4, 0.3]], device=device),
+                                torch.tensor([0.32, 0.26, 0.22], device=device))
+    return _scene_cache[device]
+
+
 def analytic_scene(points):
     """Closed-form radiance field inside [-1,1]^3: density = three soft blobs (particles per unit length), colour =
     a smooth position-dependent albedo. -> (density [N, 1], rgb [N, 3])."""
-    centers = torch.tensor([[0.35, 0.0, 0.1], [-0.3, 0.25, -0.2], [0.0, -0.4, 0.3]], device=points.device)
-    radii = torch.tensor([0.32, 0.26, 0.22], device=points.device)
+    centers, radii = _scene_constants(points.device)
     d2 = ((points[:, None, :] - centers[None]) ** 2).sum(-1)
     density = (40.0 * torch.sigmoid((radii[None] ** 2 - d2) * 60.0)).sum(-1, keepdim=True)
     rgb = 0.5 + 0.5 * torch.stack([torch.sin(3.0 * points[:, 0] + 0.5), torch.sin(4.0 * points[:, 1] - 1.0),
@@ -441,83 +451,84 @@ class GraphedNerfFitter:
       after every occupancy prune (the count only changes statistically in between: 4 096 rays average it to ~1.5 %);
       a step whose count exceeds it drops the excess samples and is counted in `overflow_steps`;
     * the occupancy lives in ONE device tensor that prunes update in place (the graph holds its address);
-    * rays are drawn with the device generator, Adam keeps its step count on the device (FusedAdam(capturable=True)).
+    * the batch comes from a pool of rays with their target colours resident on the device (the role of the reference's
+      MultiviewDataset: rays + pixels of the training images), indexed by a step counter kept on the device; Adam keeps its
+      step count on the device too (FusedAdam(capturable=True)).
     A graph is re-captured when a prune changes the capacity (a few times per run)."""
 
-    def __init__(self, nef, truth, tracer, gt_tracer, groups, rays, near, far, device, margin=1.08, quantum=4096):
+    def __init__(self, nef, tracer, groups, pool, near, far, device, margin=1.08, quantum=16384):
         from .optim import FusedAdam
         from .wisp.accelstructs import OctreeAS
-        self.nef, self.truth, self.tracer, self.gt_tracer = nef, truth, tracer, gt_tracer
-        self.rays, self.near, self.far, self.device = rays, near, far, device
+        self.nef, self.tracer = nef, tracer
+        self.pool_o, self.pool_d, self.pool_rgb = pool             # [P, rays, 3] each
+        self.near, self.far, self.device = near, far, device
         self.margin, self.quantum = margin, quantum
         self.opt = FusedAdam(groups, eps=1e-15, capturable=True)
-        self.o = torch.zeros(rays, 3, device=device)
-        self.d = torch.zeros(rays, 3, device=device)
+        self.index = torch.zeros(1, dtype=torch.int64, device=device)     # which pool batch the next step takes
         self.loss = torch.zeros((), device=device)
         self.overflow = torch.zeros((), dtype=torch.int64, device=device)
         # the occupancy the graph reads: one persistent structure, updated in place by `after_prune`
         blas = nef.grid.blas
         self.blas = OctreeAS(blas.max_level, blas.occupancy_grid.to(device).clone())
         nef.grid.blas = self.blas
-        truth.grid.blas._grid_on(device)
-        self.graph, self.capacity, self.gt_capacity, self.captures = None, None, None, 0
+        self.graph, self.capacity, self.captures, self.capture_seconds = None, None, 0, 0.0
+        self.graphs = {}                # capacity -> captured graph (a later prune may return to an earlier capacity)
 
-    def _draw_rays(self):
-        o = torch.randn(self.rays, 3, device=self.device)
-        o = 3.0 * o / o.norm(dim=1, keepdim=True)
-        d = (torch.rand(self.rays, 3, device=self.device) - 0.5) * 1.4 - o
-        self.o.copy_(o)
-        self.d.copy_(d / d.norm(dim=1, keepdim=True))
-
-    def _batch(self):
+    def _batch(self, k=None):
         from .wisp.core import Rays
-        return Rays(self.o, self.d, dist_min=self.near, dist_max=self.far)
+        if k is None:     # in the step: the device-side index (index_select keeps it a kernel argument, not a host value)
+            o = self.pool_o.index_select(0, self.index)[0]
+            d = self.pool_d.index_select(0, self.index)[0]
+            return Rays(o, d, dist_min=self.near, dist_max=self.far), self.pool_rgb.index_select(0, self.index)[0]
+        return Rays(self.pool_o[k], self.pool_d[k], dist_min=self.near, dist_max=self.far), self.pool_rgb[k]
 
     def _body(self):
-        self._draw_rays()
-        batch = self._batch()
-        with torch.no_grad():
-            target = self.gt_tracer(self.truth, batch).rgb
+        batch, target = self._batch()
         self.opt.zero_grad(set_to_none=True)
         rb = self.tracer(self.nef, batch)
         loss = torch.abs(rb.rgb[..., :3] - target[..., :3]).mean()
         loss.backward()
         self.opt.step()
         self.loss.copy_(loss.detach())
+        self.index.add_(1).remainder_(self.pool_o.shape[0])
         if self.capacity is not None:
-            over = (self.blas.last_sample_count > self.capacity) | (self.truth.grid.blas.last_sample_count > self.gt_capacity)
-            self.overflow.add_(over.to(torch.int64))
+            self.overflow.add_((self.blas.last_sample_count > self.capacity).to(torch.int64))
 
-    def _probe_capacity(self, probes=4):
-        """Sample counts of a few ray batches under the current occupancy (eager, with read-backs) -> capacities."""
-        self.blas.sample_capacity = self.truth.grid.blas.sample_capacity = None
-        need = gt_need = 1
+    def _probe_capacity(self, probes=6):
+        """Sample counts of a few pool batches under the current occupancy (eager, with read-backs) -> capacity."""
+        self.blas.sample_capacity = None
+        need = 1
+        P = self.pool_o.shape[0]
         with torch.no_grad():
-            for _ in range(probes):
-                self._draw_rays()
-                batch = self._batch()
+            for j in range(probes):
+                batch, _ = self._batch((j * 7919) % P)
                 m = self.nef.grid.raymarch(batch, level=None, num_samples=self.tracer.num_steps, raymarch_type="ray")
-                g = self.truth.grid.raymarch(batch, level=None, num_samples=self.gt_tracer.num_steps, raymarch_type="ray")
-                need, gt_need = max(need, m.samples.shape[0]), max(gt_need, g.samples.shape[0])
-        up = lambda n: int(-(-int(n * self.margin) // self.quantum) * self.quantum)
-        return up(need), up(gt_need)
+                need = max(need, m.samples.shape[0])
+        return int(-(-int(need * self.margin) // self.quantum) * self.quantum)
 
     def prepare(self):
         """(Re)capture for the current occupancy. Call once after a few eager steps, and after every prune."""
-        cap, gt_cap = self._probe_capacity()
-        if self.graph is not None and (cap, gt_cap) == (self.capacity, self.gt_capacity):
-            self.blas.sample_capacity, self.truth.grid.blas.sample_capacity = cap, gt_cap
+        import time
+        cap = self._probe_capacity()
+        self.blas.sample_capacity = cap
+        if self.graph is not None and cap == self.capacity:
             return
-        self.capacity, self.gt_capacity = cap, gt_cap
-        self.blas.sample_capacity, self.truth.grid.blas.sample_capacity = cap, gt_cap
-        self.graph = None               # release the previous graph's pool before the new capture
-        self._body()                    # one eager step at the new shapes (workspaces, kernel attributes)
+        self.capacity = cap
+        if cap in self.graphs:
+            self.graph = self.graphs[cap]
+            return
+        t0 = time.perf_counter()
+        if len(self.graphs) >= 4:       # bound the memory held by graph pools
+            self.graphs.clear()
+        self._body()                    # one eager step at the new shapes (workspaces, kernel attributes, padding rows)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._body()
-        self.graph = graph
+        self.graph = self.graphs[cap] = graph
         self.captures += 1
+        torch.cuda.synchronize()
+        self.capture_seconds += time.perf_counter() - t0
 
     def step(self):
         if self.graph is None:
@@ -537,12 +548,12 @@ class GraphedNerfFitter:
 
     def eager_mode(self):
         """Back to read-back sized tensors (validation renders)."""
-        self.blas.sample_capacity = self.truth.grid.blas.sample_capacity = None
+        self.blas.sample_capacity = None
 
 
 def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwidth=19, max_grid_res=2048,
              num_lods=16, blas_level=5, prune_every=100, val_rays=8192, hidden_dim=64, latent=False,
-             entropy_reg=1.0e-4, feature_dim=2, graphed=False):
+             entropy_reg=1.0e-4, feature_dim=2, graphed=False, ray_pool=0):
     """NeRF-style fit of the analytic scene through the full pipeline the reference runs per step
     (multiview_trainer.py:88-150): ray marching on the occupancy grid ('ray' sampler) -> hash-grid lookup -> density /
     colour decoders -> volume integration -> L1 to the target pixels -> Adam; occupancy pruned every `prune_every` steps.
@@ -551,7 +562,11 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
     warm-up with temperature 1.0 until decay_period 0.9, entropy model with one layer, lambda = `entropy_reg`); the
     result then also carries the size estimate and the bytes of the entropy-coded model file. nerf_lego.yaml's shape is
     feature_dim=4, num_lods=24, max_grid_res=512, hidden_dim=128 (tools/lego_fit.py).
-    `graphed=True` (HashGrid variant only): the step replayed from a HIP graph (`GraphedNerfFitter`).
+    `ray_pool=P` > 0: the P batches of rays and their target colours are rendered ONCE before the timed loop and the steps
+    walk them in order -- the role of the reference's MultiviewDataset (rays + pixels of the training images); with 0 every
+    step draws fresh rays and renders their targets from the closed-form scene inside the step (rounds 1-3 protocol).
+    `graphed=True` (HashGrid variant only; implies a ray pool, default 64 batches): the step replayed from a HIP graph
+    (`GraphedNerfFitter`).
     Returns dict(psnr on held-out rays, ms_per_step, samples_per_step)."""
     import time
     from .optim import FusedAdam
@@ -591,10 +606,23 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
     groups = [g for g in param_groups(nef, lr=1e-3, grid_lr=1e-2) if g["params"]]
     near, far = 1.2, 4.8
     warm = min(20, steps // 10)          # first steps pay one-off costs (kernel attribute set-up, allocator growth)
+    gen = torch.Generator().manual_seed(seed + 1)
+    pool = None
+    if graphed and not ray_pool:
+        ray_pool = 128
+    if ray_pool:
+        po, pd, prgb = [], [], []
+        with torch.no_grad():
+            for _ in range(ray_pool):
+                o, d = camera_rays(rays, gen, device)
+                po.append(o)
+                pd.append(d)
+                prgb.append(gt_tracer(truth, Rays(o, d, dist_min=near, dist_max=far)).rgb)
+        pool = (torch.stack(po), torch.stack(pd), torch.stack(prgb))
     if graphed:
         if latent:
             raise ValueError("the graphed NeRF fitter replays a fixed step: SGA temperature / entropy schedules change every step")
-        fitter = GraphedNerfFitter(nef, truth, tracer, gt_tracer, groups, rays, near, far, device)
+        fitter = GraphedNerfFitter(nef, tracer, groups, pool, near, far, device)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for it in range(steps):
@@ -616,9 +644,9 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
         return dict(psnr=val, ms_per_step=ms, steps=steps, rays_per_step=rays, candidate_samples_per_step=rays * num_steps,
                     occupied_cells=int(nef.grid.blas.points.shape[0]), total_cells=int(grid.num_cells),
                     graph_captures=fitter.captures, sample_capacity=fitter.capacity,
-                    overflow_steps=int(fitter.overflow.item()))
+                    overflow_steps=int(fitter.overflow.item()), ray_pool=ray_pool,
+                    capture_seconds=fitter.capture_seconds)
     opt = FusedAdam(groups, eps=1e-15)
-    gen = torch.Generator().manual_seed(seed + 1)
     samples_seen = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -626,10 +654,14 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
         if it == warm:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        o, d = camera_rays(rays, gen, device)
-        batch = Rays(o, d, dist_min=near, dist_max=far)
-        with torch.no_grad():
-            target = gt_tracer(truth, batch).rgb
+        if pool is not None:
+            k = it % ray_pool
+            batch, target = Rays(pool[0][k], pool[1][k], dist_min=near, dist_max=far), pool[2][k]
+        else:
+            o, d = camera_rays(rays, gen, device)
+            batch = Rays(o, d, dist_min=near, dist_max=far)
+            with torch.no_grad():
+                target = gt_tracer(truth, batch).rgb
         opt.zero_grad(set_to_none=True)
         if latent:
             grid.latent_dec.temperature = temperature_sched(it + 1)
@@ -653,7 +685,7 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
         val = psnr_fn(tracer(nef, batch).rgb.clamp(0, 1), gt_tracer(truth, batch).rgb)
     occupied = int(nef.grid.blas.points.shape[0])
     out = dict(psnr=val, ms_per_step=ms, steps=steps, rays_per_step=rays, candidate_samples_per_step=rays * num_steps,
-               occupied_cells=occupied, total_cells=int(grid.num_cells))
+               occupied_cells=occupied, total_cells=int(grid.num_cells), ray_pool=ray_pool)
     if latent:
         from . import codec
         ldec_bits, latent_bits = grid.size(use_torchac=False, use_prob_model=False)
