@@ -193,7 +193,7 @@ def hashgrid_debug_corners(dim, coords, resolution, codebook_bitwidth):
     N = coords.shape[0]
     rows = torch.empty((N, len(res), 1 << dim), dtype=torch.int32, device=coords.device)
     w = torch.empty((N, len(res), 1 << dim), dtype=torch.float32, device=coords.device)
-    with torch.cuda.device(coords.device):
+    with _on_device(coords.device):
         rc = _lib.lib().shacira_hashgrid_debug_corners(dim, N, len(res), int(codebook_bitwidth), _res_array(res),
                                                        _ptr(coords), _ptr(rows), _ptr(w), _stream(coords))
     _lib.check(rc, "hashgrid_debug_corners")
@@ -203,7 +203,7 @@ def hashgrid_debug_corners(dim, coords, resolution, codebook_bitwidth):
 def backward_workspace(dim, num_coords, table_rows, table_dtype, resolution, codebook_bitwidth, feature_dim, device):
     """Scratch buffer a caller can share between several ``hashgrid_backward(..., levels=...)`` calls."""
     res = tuple(int(r) for r in resolution)
-    with torch.cuda.device(device):
+    with _on_device(device):
         n = _lib.lib().shacira_hashgrid_backward_workspace_bytes(dim, int(num_coords), len(res), int(feature_dim),
                                                                  int(codebook_bitwidth), _res_array(res),
                                                                  int(table_rows), _DTYPES[table_dtype])
@@ -252,7 +252,7 @@ def latent_decode_forward(latent, div, matrix, colscale, shift, clamp_weights):
     T, ld = latent.shape
     F = matrix.shape[1]
     out = torch.empty((T, F), dtype=torch.float32, device=latent.device)
-    with torch.cuda.device(latent.device):
+    with _on_device(latent.device):
         rc = _lib.lib().shacira_latent_decode_forward(T, ld, F, _ptr(latent), _ptr(div), _ptr(matrix), _ptr(colscale),
                                                       _ptr(shift), float(clamp_weights), _ptr(out), _stream(latent))
     _lib.check(rc, "latent_decode_forward")
@@ -268,7 +268,7 @@ def latent_decode_backward(latent, div, matrix, colscale, shift, clamp_weights, 
     g_mat = torch.empty((ld, F), dtype=torch.float32, device=dev)
     g_cs = torch.empty((F,), dtype=torch.float32, device=dev) if need_colscale else None
     g_sh = torch.empty((F,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws = _latent_workspace(dev)
         rc = _lib.lib().shacira_latent_decode_backward(T, ld, F, _ptr(latent), _ptr(div), _ptr(matrix), _ptr(colscale),
                                                        _ptr(shift), float(clamp_weights), _ptr(grad_decoded),
@@ -286,7 +286,7 @@ def latent_decode_sga_forward(latent, uniforms, temperature, diff_sampling, div,
     if tuple(uniforms.shape) != (T, ld, 2) or uniforms.dtype != torch.float32 or not uniforms.is_contiguous():
         raise RuntimeError("uniforms must be a contiguous fp32 [rows, latent_dim, 2] tensor")
     out = torch.empty((T, F), dtype=torch.float32, device=latent.device)
-    with torch.cuda.device(latent.device):
+    with _on_device(latent.device):
         rc = _lib.lib().shacira_latent_decode_sga_forward(T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature),
                                                           int(bool(diff_sampling)), _ptr(div), _ptr(matrix),
                                                           _ptr(colscale), _ptr(shift), float(clamp_weights), _ptr(out),
@@ -305,7 +305,7 @@ def latent_decode_sga_backward(latent, uniforms, temperature, diff_sampling, div
     g_mat = torch.empty((ld, F), dtype=torch.float32, device=dev)
     g_cs = torch.empty((F,), dtype=torch.float32, device=dev) if need_colscale else None
     g_sh = torch.empty((F,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws = _latent_workspace(dev)
         rc = _lib.lib().shacira_latent_decode_sga_backward(
             T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature), int(bool(diff_sampling)), _ptr(div),
@@ -352,7 +352,7 @@ def latent_mlp_forward(latent, uniforms, temperature, diff_sampling, div, params
     with hidden layers). ``params``: per layer the effective matrix [in, out] row-major, then the shift [out]."""
     T = _check_mlp_operands(latent, uniforms, div, params, widths)
     out = torch.empty((T, widths[-1]), dtype=torch.float32, device=latent.device)
-    with torch.cuda.device(latent.device):
+    with _on_device(latent.device):
         rc = _lib.lib().shacira_latent_mlp_forward(
             T, len(widths) - 1, _widths_array(widths), _ptr(latent), _ptr(uniforms), float(temperature),
             int(bool(diff_sampling)), _ptr(div), _ptr(params), LATENT_ACTIVATIONS[activation],
@@ -372,7 +372,7 @@ def latent_mlp_backward(latent, uniforms, temperature, diff_sampling, div, param
     g_lat = torch.empty_like(latent)
     g_par = torch.empty_like(params)
     wa = _widths_array(widths)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         n = _lib.lib().shacira_latent_mlp_backward_workspace_bytes(len(widths) - 1, wa)
         ws = torch.empty((n,), dtype=torch.uint8, device=dev)
         rc = _lib.lib().shacira_latent_mlp_backward(
@@ -395,7 +395,7 @@ def latent_decode_levels_forward(latent, offsets, uniforms, temperature, diff_sa
     T, ld = latent.shape
     F = matrix.shape[-1]
     out = torch.empty((T, F), dtype=torch.float32, device=latent.device)
-    with torch.cuda.device(latent.device):
+    with _on_device(latent.device):
         rc = _lib.lib().shacira_latent_decode_levels_forward(
             len(offsets) - 1, _offsets_array(offsets), T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature),
             int(bool(diff_sampling)), _ptr(div), _ptr(matrix), _ptr(colscale), _ptr(shift), float(clamp_weights),
@@ -414,7 +414,7 @@ def latent_decode_levels_backward(latent, offsets, uniforms, temperature, diff_s
     g_mat = torch.empty((L, ld, F), dtype=torch.float32, device=dev)
     g_cs = torch.empty((L, F), dtype=torch.float32, device=dev) if colscale is not None else None
     g_sh = torch.empty((L, F), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws = _latent_workspace(dev)
         rc = _lib.lib().shacira_latent_decode_levels_backward(
             L, _offsets_array(offsets), T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature),
@@ -435,7 +435,7 @@ def latent_multi_decode_forward(latent, alpha, uniforms, temperature, straight_t
     T, ld = latent.shape
     K, F = scale.shape[0], scale.shape[-1]
     out = torch.empty((T, F), dtype=torch.float32, device=latent.device)
-    with torch.cuda.device(latent.device):
+    with _on_device(latent.device):
         rc = _lib.lib().shacira_latent_multi_decode_forward(
             T, ld, F, K, _ptr(latent), _ptr(alpha), _ptr(uniforms), float(temperature), int(bool(straight_through)),
             int(bool(diff_sampling)), _ptr(div), _ptr(scale), _ptr(dft), _ptr(shift), float(clamp_weights), _ptr(out),
@@ -454,7 +454,7 @@ def latent_multi_decode_backward(latent, alpha, uniforms, temperature, straight_
     g_alpha = torch.empty_like(alpha)
     g_scale = torch.empty_like(scale)
     g_shift = torch.empty((K, F), dtype=torch.float32, device=dev) if shift is not None else None
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws = _latent_workspace(dev)
         rc = _lib.lib().shacira_latent_multi_decode_backward(
             T, ld, F, K, _ptr(latent), _ptr(alpha), _ptr(uniforms), float(temperature), int(bool(straight_through)),
@@ -474,7 +474,7 @@ def entropy_bits_forward(latent, noise, params, num_layers):
     T, ld = latent.shape
     dev = latent.device
     total = torch.empty((), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws = _latent_workspace(dev)
         rc = _lib.lib().shacira_entropy_bits_forward(T, ld, int(num_layers), _ptr(latent), _ptr(noise), _ptr(params),
                                                      _ptr(total), _ptr(ws), ws.numel(), _stream(latent))
@@ -488,7 +488,7 @@ def entropy_bits_backward(latent, noise, params, num_layers, grad_total, need_la
     dev = latent.device
     g_lat = torch.empty_like(latent) if need_latent else None
     g_par = torch.empty((4, 3, ld), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws = _latent_workspace(dev)
         rc = _lib.lib().shacira_entropy_bits_backward(T, ld, int(num_layers), _ptr(latent), _ptr(noise), _ptr(params),
                                                       _ptr(grad_total), _ptr(g_lat), _ptr(g_par), _ptr(ws), ws.numel(),
@@ -505,7 +505,7 @@ def mlp_supported(in_dim, hidden_dim, num_hidden, out_dim):
 def mlp_forward(x, params, in_dim, hidden_dim, num_hidden, out_dim):
     _need_gpu(x, params)
     y = torch.empty((x.shape[0], out_dim), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = _lib.lib().shacira_mlp_forward(x.shape[0], in_dim, hidden_dim, num_hidden, out_dim, _ptr(x), _ptr(params),
                                             _ptr(y), _stream(x))
     _lib.check(rc, "mlp_forward")
@@ -518,7 +518,7 @@ def mlp_backward(x, params, grad_y, in_dim, hidden_dim, num_hidden, out_dim, nee
     gx = torch.empty_like(x) if need_grad_x else None
     gp = torch.empty_like(params)
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         n = L.shacira_mlp_backward_workspace_bytes(in_dim, hidden_dim, num_hidden, out_dim)
         ws = torch.empty((n,), dtype=torch.uint8, device=dev)
         rc = L.shacira_mlp_backward(x.shape[0], in_dim, hidden_dim, num_hidden, out_dim, _ptr(x), _ptr(params),
@@ -545,7 +545,7 @@ def latent_symbol_counts(latent):
     latent = latent.detach().contiguous()
     rows, ld = latent.shape
     L = _lib.lib()
-    with torch.cuda.device(latent.device):
+    with _on_device(latent.device):
         minmax = torch.empty((ld, 2), dtype=torch.int32, device=latent.device)
         _lib.check(L.shacira_latent_symbol_range(rows, ld, _ptr(latent), _ptr(minmax), _stream(latent)),
                    "shacira_latent_symbol_range")

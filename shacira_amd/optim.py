@@ -15,6 +15,7 @@ import math
 import torch
 
 from . import _lib
+from .hip_ops import _on_device
 
 _MAX = 32
 
@@ -43,7 +44,7 @@ class FusedAdam(torch.optim.Optimizer):
         lrs = FArr(*[float(lr) for _, _, _, _, lr, _ in batch])
         wds = FArr(*[float(wd) for _, _, _, _, _, wd in batch])
         sd = ctypes.c_void_p(step_dev.data_ptr()) if step_dev is not None else None
-        with torch.cuda.device(device):
+        with _on_device(device):
             rc = _lib.lib().shacira_adam_step_multi(k, ns, ps, gs, ms, vs, lrs, wds, float(b1), float(b2), float(eps),
                                                     int(step), sd, int(self.zero_grad_in_step),
                                                     ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))

@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .hip_ops import _need_gpu, _ptr, _stream
+from .hip_ops import _need_gpu, _on_device, _ptr, _stream
 
 
 def mark_pack_boundaries(ridx):
@@ -38,7 +38,7 @@ class _ExponentialIntegration(torch.autograd.Function):
         R = pack_start.shape[0] - 1
         ray_feats = torch.empty((R, C), dtype=torch.float32, device=feats.device)
         weights = torch.empty((S,), dtype=torch.float32, device=feats.device)
-        with torch.cuda.device(feats.device):
+        with _on_device(feats.device):
             _lib.check(_lib.lib().shacira_pack_integrate_forward(S, R, C, _ptr(feats), _ptr(tau), _ptr(pack_start),
                                                                  _ptr(ray_feats), _ptr(weights), _stream(feats)),
                        "shacira_pack_integrate_forward")
@@ -54,7 +54,7 @@ class _ExponentialIntegration(torch.autograd.Function):
         g_w = g_w.float().contiguous().reshape(-1) if g_w is not None else None
         g_feats = torch.zeros_like(feats)
         g_tau = torch.zeros_like(tau)
-        with torch.cuda.device(feats.device):
+        with _on_device(feats.device):
             _lib.check(_lib.lib().shacira_pack_integrate_backward(S, R, C, _ptr(feats), _ptr(tau), _ptr(pack_start),
                                                                   _ptr(g_ray), _ptr(g_w), _ptr(g_feats), _ptr(g_tau),
                                                                   _stream(feats)), "shacira_pack_integrate_backward")
@@ -69,7 +69,7 @@ class _SumReduce(torch.autograd.Function):
         S, C = x.shape
         R = pack_start.shape[0] - 1
         out = torch.empty((R, C), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             _lib.check(_lib.lib().shacira_pack_sum(S, R, C, _ptr(x), _ptr(pack_start), _ptr(out), _stream(x)),
                        "shacira_pack_sum")
         ctx.save_for_backward(pack_start)
@@ -83,7 +83,7 @@ class _SumReduce(torch.autograd.Function):
         R = pack_start.shape[0] - 1
         g_out = g_out.float().contiguous()
         g_x = torch.zeros((S, C), dtype=torch.float32, device=g_out.device)
-        with torch.cuda.device(g_out.device):
+        with _on_device(g_out.device):
             _lib.check(_lib.lib().shacira_pack_broadcast(S, R, C, _ptr(g_out), _ptr(pack_start), _ptr(g_x),
                                                          _stream(g_out)), "shacira_pack_broadcast")
         return g_x, None
@@ -146,7 +146,7 @@ def raymarch_ray(origins, dirs, dist_min, dist_max, occupancy, level, num_sample
     lin = torch.linspace(0, 1.0, num_samples, device=dev)
     occ = _occupancy_u8(occupancy, level)
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         counts = torch.empty((N,), dtype=torch.int32, device=dev)
         args = (N, int(num_samples), _ptr(origins), _ptr(dirs), float(dist_min), float(dist_max), _ptr(lin),
                 _ptr(jitter), _ptr(occ), int(level))
@@ -185,7 +185,7 @@ def raytrace_dense(origins, dirs, occupancy, level):
     N, dev = origins.shape[0], origins.device
     occ = _occupancy_u8(occupancy, level)
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         counts = torch.empty((N,), dtype=torch.int32, device=dev)
         _lib.check(L.shacira_raytrace_dense_count(N, _ptr(origins), _ptr(dirs), _ptr(occ), int(level), _ptr(counts),
                                                   _stream(origins)), "shacira_raytrace_dense_count")
