@@ -107,9 +107,24 @@ def quick_measure(name, device, iters=20):
     esz = 2 if half else 4
     stream = (2 * dim * 4 + 2 * L * F * esz) * n / ((tf + tb) * 1e-3) / 1e9
     table_mb = T * F * esz / 1e6
+    # What binds these operators is not the precision of the bytes: the forward pays one L2 -> L1 line
+    # transfer (2 clk per 128-byte line and CU) per x-pair of corners on every level finer than the batch's density, whatever
+    # the row size; the backward pays one 64-bit LDS atomic per (corner, feature) (2.3 T/s measured, profiles/r01_microbench2)
+    # and moves its items once out and once in (8 + 4F bytes per x-pair with fp32 payloads, 8 / 16 bytes with half payloads;
+    # levels that fit LDS images move none). fp16 tables halve only the last term -- which is why they gain 15-20 %, not 2x.
+    n_fine = sum(1 for r in res if float(r) ** dim > 4.0 * n) if dim == 3 else 0
+    fwd_floor = n_fine * n * (2 ** (dim - 1)) * 2.0 / (256 * 2.4e9) * 1e3
+    lds_floor = n * L * (2 ** dim) * F / 2.3e12 * 1e3
+    binned = sum(1 for sz in sizes if sz * F * 8 > 128 * 1024)            # levels larger than one 128 KiB image
+    item_b = (8 if F == 2 else 16) if half else 8 + 4 * F
+    stream_floor = 2.0 * binned * n * (2 ** (dim - 1)) * item_b / 5.4e12 * 1e3
     return {"samples_per_s": n / ((tf + tb) * 1e-3), "ms_forward": tf, "ms_backward": tb, "samples": n,
             "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS, "table_MB": table_mb,
-            "sample_streams_GBps": stream, "dtype": "f16" if half else "f32"}
+            "sample_streams_GBps": stream, "dtype": "f16" if half else "f32",
+            "bound_model": {"forward_line_rate_floor_ms": fwd_floor, "backward_lds_atomic_floor_ms": lds_floor,
+                            "backward_item_stream_floor_ms": stream_floor,
+                            "note": "floors of the binding resources (L2->L1 lines of the fine levels; 64-bit LDS atomics at "
+                                    "2.3 T/s; item stream written + read at 5.4 TB/s), not of HBM bytes"}}
 
 
 def kernel_source_hash():
@@ -494,7 +509,7 @@ def main():
                 "file_bytes": fit["file_bytes"], "rgb_loss": fit["rgb_loss"],
                 "seconds": time.perf_counter() - tp, "ms_per_step": fit["ms_per_step"], "n_gpus": world,
                 "mode": "eager step, cold (Python issues ~60 launches per step; warmed up it takes ~1 ms with the GPU busy "
-                        "a third of it: profiles/r03_imagefit_step.md)"}
+                        "a third of it: profiles/r04_imagefit_step.md)"}
         if world == 1:
             # the same fit with the step captured once into a HIP graph and replayed (GraphedImageFitter: device-side
             # entropy noise and Adam step count): what a user who cares about wall time runs
@@ -570,14 +585,17 @@ def main():
         # the same operators and workload; see the note inside the file). Only valid for the workload it was taken on.
         # Attached ONLY when the file was measured on exactly these kernel sources (kernel_source_hash); else null.
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        # (the newest round's file: profiles/rNN_pmc_traffic.json)
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+        tpath = tfiles[-1] if tfiles else os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
         if args.workload.startswith("S1_") and os.path.exists(tpath):
             with open(tpath) as fh:
                 rec = json.load(fh)
             if rec.get("kernel_source_hash") == kernel_source_hash():
                 traffic = rec["operators"].get(dom[0], {}).get("hbm_bytes_per_launch")
             else:
-                traffic_note = ("profiles/r03_pmc_traffic.json was measured on other kernel sources "
+                traffic_note = (f"profiles/{os.path.basename(tpath)} was measured on other kernel sources "
                                 f"({rec.get('kernel_source_hash')} != {kernel_source_hash()}): not attached")
         achieved = dom[2] * n_local / (dom[1] * 1e-3) / 1e9
         path_gbs = (b_fwd + b_bwd) * n_local / ((ms_fwd + ms_bwd) * 1e-3) / 1e9
@@ -617,7 +635,7 @@ def main():
         #  forward: a hashed level's x-pair of corners is one 128-byte line; with uniformly random samples every pair of a
         #   level finer than the batch's density is its own line, and a CU's L2 -> L1 path moves 64 B/clk: 2 clk per line
         #   (measured: 38 TCP->TCC requests and 81 TA-busy cycles per gather instruction, profiles/r02_fwd_counters.md).
-        #  backward: the traffic its kernels move (PMC counters, profiles/r03_pmc_traffic.json; without them: algorithmic
+        #  backward: the traffic its kernels move (PMC counters, profiles/rNN_pmc_traffic.json; without them: algorithmic
         #   bytes x the 1.93 measured in round 2) at the copy rate this chip sustains in the same run.
         n_fine = sum(1 for r in res if float(r) ** dim > 4.0 * n_local) if dim == 3 else 0
         lines = n_fine * n_local * (2 ** (dim - 1))

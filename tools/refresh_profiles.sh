@@ -1,7 +1,7 @@
 # Regenerates the raw material of profiles/ on the GPU box (run through gpurun): bash tools/refresh_profiles.sh [tag]
 # then, back in the repo: python tools/make_profiles.py gpurun_out/<tag>f <tag>
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}f
 mkdir -p $OUT
@@ -46,7 +46,7 @@ timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_s
 fi
 if has steps; then
 # what the operators sit inside: one eager step of the NeRF fit / the image fit (kernel time vs wall time), and the graphed image fit
-for w in nerf image image_graphed; do
+for w in nerf nerf_pool nerf_graphed image image_graphed; do
 timeout 300 python3 $GRAFT_REPO_ROOT/tools/step_breakdown.py $w 1000 > $OUT/step_${w}_plain.json 2>/dev/null   # the unprofiled wall time
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_$w -- python3 $GRAFT_REPO_ROOT/tools/step_breakdown.py $w 1000 > $OUT/step_$w.json 2>/dev/null
 find $OUT/step_$w -name "*kernel_trace.csv" -delete    # 10^5 rows each: only the stats summary is used (gpurun_out merges <= 64 MiB)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One workload's training loop for `rocprofv3 --kernel-trace --stats`: prints wall ms/step so that the kernel-time sum of
-the trace can be set against it (host gaps). usage: step_breakdown.py nerf|image|image_graphed [steps]"""
+the trace can be set against it (host gaps). usage: step_breakdown.py nerf|nerf_pool|nerf_graphed|image|image_graphed [steps]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,6 +14,10 @@ WARM = 30      # a short fit first: module loading, allocator growth and autotun
 def fit(n):
     if what == "nerf":
         return harness.fit_nerf(dev, steps=n)
+    if what == "nerf_pool":
+        return harness.fit_nerf(dev, steps=n, ray_pool=128)
+    if what == "nerf_graphed":
+        return harness.fit_nerf(dev, steps=n, ray_pool=128, graphed=True)
     return harness.fit_image(dev, steps=n, graphed=(what == "image_graphed"))
 
 
