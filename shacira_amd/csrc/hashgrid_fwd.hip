@@ -842,7 +842,9 @@ static bool use_staged(int dim, const LevelTable &lt, int64_t n) {
     const int v = opt().fwd_variant;
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return false;
     if (v == 6) return true;
-    return v < 0 && dim == 3 && n >= 16384;   // measured: 3-D large batches; 2-D and small batches: variant 3
+    // measured: 3-D batches from 8 192 samples (config E's per-GPU shard: 16.7 vs 19.0 us; 16 384: 19.9 vs 22.5);
+    // 2-D and smaller batches: variant 3
+    return v < 0 && dim == 3 && n >= 8192;
 }
 
 template <int DIM, typename T, int F>
