@@ -593,6 +593,31 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
 
     const bool single = d.single != 0 && !force_atomic;
     const int64_t grow0 = (int64_t)first_idx[lvl] + row0;
+    // Single-unit buckets overwrite their rows: 16-byte stores of four consecutive elements per lane (round 4: the
+    // one-dword-per-lane form below cost 37 us of S1's backward -- 44 MB at 1.2 TB/s -- and 7-11 us of the 65 536- / 8 192-sample
+    // calls; ablation in profiles/r04_experiments.md)
+    {
+        float *dst0 = grad_table + grow0 * F;
+        const uint32_t nelem = nrows * F;
+        if (single && grow0 + (int64_t)nrows <= lt.table_rows) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            auto value = [&](uint32_t e) { return (FX && fx.fixed) ? fx_decode(s_fix[e], fx.inv) : (float)s_acc[e]; };
+            // elements in front of the first 16-byte boundary (a level may start on an odd row: the dense levels in front of
+            // it have odd sizes), whole vectors, then the elements behind the last one
+            uint32_t head = (uint32_t)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst0) & 15u)) & 15u) / 4u);
+            if (head > nelem) head = nelem;
+            const uint32_t body = (nelem - head) & ~3u;
+            if (threadIdx.x < head) dst0[threadIdx.x] = value(threadIdx.x);
+            for (uint32_t e = head + threadIdx.x * 4u; e < head + body; e += kConsumeThreads * 4u) {
+                f32x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = value(e + k);
+                *reinterpret_cast<f32x4 *>(dst0 + e) = v;
+            }
+            if (head + body + threadIdx.x < nelem) dst0[head + body + threadIdx.x] = value(head + body + threadIdx.x);
+            return;
+        }
+    }
     for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) {
         const int64_t grow = grow0 + e / F;
         if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
