@@ -63,7 +63,7 @@ def _check_coords(dim, coords):
 # engine's backward thread therefore gets a buffer of its own). Exceptions: while the stream is being captured into a HIP
 # graph the buffer comes from the graph's own pool (a cached buffer could be replaced -- freed -- by a later, larger eager
 # call while the graph still replays into it), and a caller-supplied workspace wins.
-_scratch = {}
+_tls = threading.local()     # per-thread: a thread's buffers are dropped with the thread (no entries of dead threads linger)
 
 
 def _workspace(device, nbytes):
@@ -71,19 +71,23 @@ def _workspace(device, nbytes):
         return None
     if torch.cuda.is_current_stream_capturing():
         return torch.empty((nbytes,), dtype=torch.uint8, device=device)
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
-    buf = _scratch.get(key)
+    scratch = getattr(_tls, "scratch", None)
+    if scratch is None:
+        scratch = _tls.scratch = {}
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None
-        _scratch.pop(key, None)          # release the old buffer before the larger one is allocated
+        scratch.pop(key, None)           # release the old buffer before the larger one is allocated
         buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        _scratch[key] = buf
+        scratch[key] = buf
     return buf
 
 
 def release_workspaces():
-    """Drop the cached scratch buffers (they are returned to torch's caching allocator)."""
-    _scratch.clear()
+    """Drop the calling thread's cached scratch buffers (they are returned to torch's caching allocator)."""
+    if getattr(_tls, "scratch", None):
+        _tls.scratch.clear()
 
 
 # workspace sizes are pure functions of the shape and the library's tunables: one C call per new shape, not per call
