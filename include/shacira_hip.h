@@ -259,6 +259,18 @@ SHACIRA_API int shacira_latent_decode_sga_backward(int64_t num_rows, int latent_
                                        float clamp_weights, const float *grad_decoded, float *grad_latent,
                                        float *grad_matrix, float *grad_colscale, float *grad_shift, void *workspace,
                                        size_t workspace_bytes, void *stream);
+/* ABI 9: the same pair with the temperature in DEVICE memory (one float the kernels read): a training step captured into a
+ * HIP graph anneals it between replays (base_trainer.py:155-157 decays it every iteration) without re-capturing. */
+SHACIRA_API int shacira_latent_decode_sga_forward_tdev(int64_t num_rows, int latent_dim, int feature_dim,
+                                       const float *latent, const float *uniforms, const float *temperature_dev,
+                                       int diff_sampling, const float *div, const float *matrix, const float *colscale,
+                                       const float *shift, float clamp_weights, float *decoded, void *stream);
+SHACIRA_API int shacira_latent_decode_sga_backward_tdev(int64_t num_rows, int latent_dim, int feature_dim,
+                                       const float *latent, const float *uniforms, const float *temperature_dev,
+                                       int diff_sampling, const float *div, const float *matrix, const float *colscale,
+                                       const float *shift, float clamp_weights, const float *grad_decoded,
+                                       float *grad_latent, float *grad_matrix, float *grad_colscale, float *grad_shift,
+                                       void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Latent decoder WITH hidden layers / activations -- LatentDecoder with num_layers_dec > 0 and / or activation,

@@ -41,8 +41,11 @@ SIGNATURES = {
     "shacira_entropy_bits_forward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "shacira_entropy_bits_backward": (_i, [_i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "shacira_latent_decode_sga_forward": (_i, [_i64, _i, _i, _p, _p, _f, _i, _p, _p, _p, _p, _f, _p, _p]),
+    "shacira_latent_decode_sga_forward_tdev": (_i, [_i64, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _f, _p, _p]),
     "shacira_latent_decode_sga_backward": (_i, [_i64, _i, _i, _p, _p, _f, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p,
                                                 _p, _sz, _p]),
+    "shacira_latent_decode_sga_backward_tdev": (_i, [_i64, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p,
+                                                     _p, _sz, _p]),
     "shacira_latent_mlp_supported": (_i, [_i, _p]),
     "shacira_latent_mlp_backward_workspace_bytes": (_sz, [_i, _p]),
     "shacira_latent_mlp_forward": (_i, [_i64, _i, _p, _p, _p, _f, _i, _p, _p, _i, _i, _f, _p, _p]),

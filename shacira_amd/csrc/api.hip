@@ -307,6 +307,42 @@ int shacira_latent_decode_sga_backward(int64_t num_rows, int latent_dim, int fea
     return (int)latent_decode_dispatch(true, latent_dim, feature_dim, a, (hipStream_t)stream);
 }
 
+// The same pair with the temperature in DEVICE memory (one float, read by the kernels): a training step captured into a HIP
+// graph anneals the temperature between replays (base_trainer.py:155-157 decays it every iteration) without re-capturing.
+int shacira_latent_decode_sga_forward_tdev(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,
+                                           const float *uniforms, const float *temperature_dev, int diff_sampling,
+                                           const float *div, const float *matrix, const float *colscale, const float *shift,
+                                           float clamp_weights, float *decoded, void *stream) {
+    if (num_rows < 0 || latent_dim < 1 || feature_dim < 1 || !temperature_dev) return SHACIRA_EINVAL;
+    if (!latent_decode_supported(latent_dim, feature_dim)) return SHACIRA_EDTYPE;
+    if (num_rows == 0) return 0;
+    if (!latent || !uniforms || !div || !matrix || !decoded) return SHACIRA_EINVAL;
+    DecodeArgs a{};
+    a.latent = latent; a.div = div; a.matrix = matrix; a.colscale = colscale; a.shift = shift;
+    a.clampw = clamp_weights; a.decoded = decoded; a.rows = num_rows;
+    a.uniforms = uniforms; a.temperature = 1.0f; a.temperature_dev = temperature_dev; a.diff_sampling = diff_sampling;
+    return (int)latent_decode_dispatch(false, latent_dim, feature_dim, a, (hipStream_t)stream);
+}
+
+int shacira_latent_decode_sga_backward_tdev(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,
+                                            const float *uniforms, const float *temperature_dev, int diff_sampling,
+                                            const float *div, const float *matrix, const float *colscale, const float *shift,
+                                            float clamp_weights, const float *grad_decoded, float *grad_latent,
+                                            float *grad_matrix, float *grad_colscale, float *grad_shift, void *workspace,
+                                            size_t workspace_bytes, void *stream) {
+    if (num_rows < 0 || latent_dim < 1 || feature_dim < 1 || !temperature_dev) return SHACIRA_EINVAL;
+    if (!latent_decode_supported(latent_dim, feature_dim)) return SHACIRA_EDTYPE;
+    if (!workspace || workspace_bytes < latent_workspace_bytes()) return SHACIRA_EWORKSPACE;
+    if (num_rows > 0 && (!latent || !uniforms || !div || !matrix || !grad_decoded)) return SHACIRA_EINVAL;
+    DecodeArgs a{};
+    a.latent = latent; a.div = div; a.matrix = matrix; a.colscale = colscale; a.shift = shift;
+    a.clampw = clamp_weights; a.grad_decoded = grad_decoded; a.grad_latent = grad_latent;
+    a.grad_matrix = grad_matrix; a.grad_colscale = grad_colscale; a.grad_shift = grad_shift;
+    a.partials = static_cast<double *>(workspace); a.rows = num_rows;
+    a.uniforms = uniforms; a.temperature = 1.0f; a.temperature_dev = temperature_dev; a.diff_sampling = diff_sampling;
+    return (int)latent_decode_dispatch(true, latent_dim, feature_dim, a, (hipStream_t)stream);
+}
+
 static int levels_args_ok(int num_levels, const int64_t *row_offsets_host, int64_t num_rows, int latent_dim,
                           int feature_dim) {
     if (num_levels < 1 || num_levels > SHACIRA_MAX_LODS || !row_offsets_host) return SHACIRA_EINVAL;

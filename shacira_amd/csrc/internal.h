@@ -63,6 +63,7 @@ struct DecodeArgs {
     const float *uniforms;   // non-NULL: stochastic Gumbel annealing instead of rounding ([rows, ld, 2] uniforms)
     float temperature;
     int diff_sampling;
+    const float *temperature_dev;   // non-NULL: SGA temperature read on the device (single / per-level decoders)
 };
 struct EntropyArgs {
     const float *latent, *noise, *params, *grad_total;

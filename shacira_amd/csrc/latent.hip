@@ -108,7 +108,12 @@ struct SgaArgs {
     const float *uniforms;  // [rows, LD, 2]
     float temperature;
     int diff;
+    const float *temperature_dev;   // non-NULL: the temperature is read from device memory (a step captured into a HIP graph
+                                    // anneals it between replays without re-capturing), `temperature` is ignored
 };
+__device__ __forceinline__ float sga_temperature(const SgaArgs &sga) {
+    return sga.temperature_dev ? *sga.temperature_dev : sga.temperature;
+}
 __device__ __forceinline__ void sga_quantise(float w, float u0, float u1, float T, bool diff, float &q, float &dq) {
     const float lim = 1.0f - 1e-6f, eps = 1.1920929e-07f;
     const float wf = floorf(w), wc = wf + 1.0f;
@@ -139,7 +144,7 @@ __device__ __forceinline__ void decode_row(const DecodeConsts<LD, F> &p, const f
         if constexpr (SGA) {
             float q;
             const float2 u = *reinterpret_cast<const float2 *>(sga.uniforms + (r * LD + c) * 2);
-            sga_quantise(latent[r * LD + c], u.x, u.y, sga.temperature, sga.diff != 0, q, dq[c]);
+            sga_quantise(latent[r * LD + c], u.x, u.y, sga_temperature(sga), sga.diff != 0, q, dq[c]);
             z[c] = q / p.div[c];
         } else {
             z[c] = rintf(latent[r * LD + c]) / p.div[c];  // torch.round: half to even
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(kThreads) void latent_decode_bwd_kernel(
 
 template <int LD, int F> static hipError_t decode_launch(bool bwd, const DecodeArgs &a, hipStream_t s) {
     const int blocks = grid_for(a.rows);
-    const SgaArgs sga{a.uniforms, a.temperature, a.diff_sampling};
+    const SgaArgs sga{a.uniforms, a.temperature, a.diff_sampling, a.temperature_dev};
     if (!bwd) {
         if (a.uniforms)
             hipLaunchKernelGGL((latent_decode_fwd_kernel<LD, F, true>), dim3(blocks), dim3(kThreads), 0, s, a.latent,
@@ -357,7 +362,7 @@ static hipError_t decode_levels_launch(bool bwd, int levels, const int64_t *offs
     int blocks = grid_for(longest);
     const int cap = kMaxPartialBlocks / levels;   // the fp64 partials of all levels share the one workspace
     if (blocks > cap) blocks = cap < 1 ? 1 : cap;
-    const SgaArgs sga{a.uniforms, a.temperature, a.diff_sampling};
+    const SgaArgs sga{a.uniforms, a.temperature, a.diff_sampling, a.temperature_dev};
     const dim3 grid(blocks, levels);
     if (!bwd) {
         if (a.uniforms)

@@ -456,7 +456,7 @@ class GraphedNerfFitter:
       step count on the device too (FusedAdam(capturable=True)).
     A graph is re-captured when a prune changes the capacity (a few times per run)."""
 
-    def __init__(self, nef, tracer, groups, pool, near, far, device, margin=1.08, quantum=16384):
+    def __init__(self, nef, tracer, groups, pool, near, far, device, margin=1.08, quantum=16384, latent=None):
         from .optim import FusedAdam
         from .wisp.accelstructs import OctreeAS
         self.nef, self.tracer = nef, tracer
@@ -473,6 +473,16 @@ class GraphedNerfFitter:
         nef.grid.blas = self.blas
         self.graph, self.capacity, self.captures, self.capture_seconds = None, None, 0, 0.0
         self.graphs = {}                # capacity -> captured graph (a later prune may return to an earlier capacity)
+        # compressed variant (3-D LatentGrid, the reference's nerf_lego.yaml mode): `latent` = dict(temperature_sched,
+        # decay_period, steps, entropy_reg). The SGA temperature lives in ONE device float the decode kernels read
+        # (shacira_latent_decode_sga_*_tdev), refreshed before every replay; the entropy noise is drawn on the device; when
+        # SGA is switched off (after decay_period of the run) the graphs are dropped and re-captured once.
+        self.latent = latent
+        self.iteration = 0
+        if latent is not None:
+            self.temperature = torch.ones(1, device=device)
+            nef.grid.latent_dec.temperature = self.temperature
+            nef.grid.device_noise = True
 
     def _batch(self, k=None):
         from .wisp.core import Rays
@@ -487,6 +497,9 @@ class GraphedNerfFitter:
         self.opt.zero_grad(set_to_none=True)
         rb = self.tracer(self.nef, batch)
         loss = torch.abs(rb.rgb[..., :3] - target[..., :3]).mean()
+        if self.latent is not None and self.latent["entropy_reg"] > 0:
+            avg_bits, _ = self.nef.grid.ent_loss(1, is_val=False)       # multiview_trainer.py:109-113
+            loss = loss + self.latent["entropy_reg"] * avg_bits
         loss.backward()
         self.opt.step()
         self.loss.copy_(loss.detach())
@@ -531,6 +544,19 @@ class GraphedNerfFitter:
         self.capture_seconds += time.perf_counter() - t0
 
     def step(self):
+        self.iteration += 1
+        if self.latent is not None:
+            dec = self.nef.grid.latent_dec
+            self.temperature.fill_(float(self.latent["temperature_sched"](self.iteration)))
+            if dec.use_sga and self.iteration / self.latent["steps"] > self.latent["decay_period"]:
+                dec.use_sga = False                 # rounding from here on: another kernel, so the step is re-captured
+                had_graph = self.graph is not None
+                self.graphs.clear()
+                self.graph = None
+                if had_graph:
+                    self.capacity = None
+                    self.prepare()
+                    return self.graph.replay()
         if self.graph is None:
             self._body()                # eager (warm-up) steps before the first capture
         else:
@@ -565,8 +591,8 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
     `ray_pool=P` > 0: the P batches of rays and their target colours are rendered ONCE before the timed loop and the steps
     walk them in order -- the role of the reference's MultiviewDataset (rays + pixels of the training images); with 0 every
     step draws fresh rays and renders their targets from the closed-form scene inside the step (rounds 1-3 protocol).
-    `graphed=True` (HashGrid variant only; implies a ray pool, default 64 batches): the step replayed from a HIP graph
-    (`GraphedNerfFitter`).
+    `graphed=True` (implies a ray pool, default 128 batches): the step replayed from HIP graphs (`GraphedNerfFitter`); with
+    `latent=True` the SGA temperature is annealed through a device float between replays.
     Returns dict(psnr on held-out rays, ms_per_step, samples_per_step)."""
     import time
     from .optim import FusedAdam
@@ -620,9 +646,11 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
                 prgb.append(gt_tracer(truth, Rays(o, d, dist_min=near, dist_max=far)).rgb)
         pool = (torch.stack(po), torch.stack(pd), torch.stack(prgb))
     if graphed:
+        lat = None
         if latent:
-            raise ValueError("the graphed NeRF fitter replays a fixed step: SGA temperature / entropy schedules change every step")
-        fitter = GraphedNerfFitter(nef, tracer, groups, pool, near, far, device)
+            lat = dict(temperature_sched=temperature_sched, decay_period=cdec["decay_period"], steps=steps,
+                       entropy_reg=entropy_reg)
+        fitter = GraphedNerfFitter(nef, tracer, groups, pool, near, far, device, latent=lat)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for it in range(steps):
@@ -641,11 +669,18 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
             o, d = camera_rays(val_rays, torch.Generator().manual_seed(4242), device)
             batch = Rays(o, d, dist_min=near, dist_max=far)
             val = psnr_fn(tracer(nef, batch).rgb.clamp(0, 1), gt_tracer(truth, batch).rgb)
-        return dict(psnr=val, ms_per_step=ms, steps=steps, rays_per_step=rays, candidate_samples_per_step=rays * num_steps,
-                    occupied_cells=int(nef.grid.blas.points.shape[0]), total_cells=int(grid.num_cells),
-                    graph_captures=fitter.captures, sample_capacity=fitter.capacity,
-                    overflow_steps=int(fitter.overflow.item()), ray_pool=ray_pool,
-                    capture_seconds=fitter.capture_seconds)
+        out = dict(psnr=val, ms_per_step=ms, steps=steps, rays_per_step=rays, candidate_samples_per_step=rays * num_steps,
+                   occupied_cells=int(nef.grid.blas.points.shape[0]), total_cells=int(grid.num_cells),
+                   graph_captures=fitter.captures, sample_capacity=fitter.capacity,
+                   overflow_steps=int(fitter.overflow.item()), ray_pool=ray_pool,
+                   capture_seconds=fitter.capture_seconds)
+        if latent:
+            from . import codec
+            grid.latent_dec.temperature = float(fitter.temperature.item())
+            ldec_bits, latent_bits = grid.size(use_torchac=False, use_prob_model=False)
+            out.update(table_bytes_fp32=grid.codebook.numel() * 4, latent_bytes_estimate=latent_bits / 8,
+                       file_bytes=len(codec.save_model(nef)))
+        return out
     opt = FusedAdam(groups, eps=1e-15)
     samples_seen = 0
     torch.cuda.synchronize()

@@ -291,12 +291,23 @@ def latent_decode_sga_forward(latent, uniforms, temperature, diff_sampling, div,
         raise RuntimeError("uniforms must be a contiguous fp32 [rows, latent_dim, 2] tensor")
     out = torch.empty((T, F), dtype=torch.float32, device=latent.device)
     with _on_device(latent.device):
-        rc = _lib.lib().shacira_latent_decode_sga_forward(T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature),
-                                                          int(bool(diff_sampling)), _ptr(div), _ptr(matrix),
-                                                          _ptr(colscale), _ptr(shift), float(clamp_weights), _ptr(out),
-                                                          _stream(latent))
+        if torch.is_tensor(temperature):     # one fp32 value in device memory (graph-captured steps anneal it between replays)
+            _check_device_scalar(temperature, latent.device)
+            rc = _lib.lib().shacira_latent_decode_sga_forward_tdev(
+                T, ld, F, _ptr(latent), _ptr(uniforms), _ptr(temperature), int(bool(diff_sampling)), _ptr(div), _ptr(matrix),
+                _ptr(colscale), _ptr(shift), float(clamp_weights), _ptr(out), _stream(latent))
+        else:
+            rc = _lib.lib().shacira_latent_decode_sga_forward(T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature),
+                                                              int(bool(diff_sampling)), _ptr(div), _ptr(matrix),
+                                                              _ptr(colscale), _ptr(shift), float(clamp_weights), _ptr(out),
+                                                              _stream(latent))
     _lib.check(rc, "latent_decode_sga_forward")
     return out
+
+
+def _check_device_scalar(t, device):
+    if t.device != device or t.dtype != torch.float32 or t.numel() != 1:
+        raise RuntimeError("a device-side temperature must be one fp32 value on the table's device")
 
 
 def latent_decode_sga_backward(latent, uniforms, temperature, diff_sampling, div, matrix, colscale, shift, clamp_weights,
@@ -311,10 +322,17 @@ def latent_decode_sga_backward(latent, uniforms, temperature, diff_sampling, div
     g_sh = torch.empty((F,), dtype=torch.float32, device=dev)
     with _on_device(dev):
         ws = _latent_workspace(dev)
-        rc = _lib.lib().shacira_latent_decode_sga_backward(
-            T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature), int(bool(diff_sampling)), _ptr(div),
-            _ptr(matrix), _ptr(colscale), _ptr(shift), float(clamp_weights), _ptr(grad_decoded), _ptr(g_lat),
-            _ptr(g_mat), _ptr(g_cs), _ptr(g_sh), _ptr(ws), ws.numel(), _stream(latent))
+        if torch.is_tensor(temperature):
+            _check_device_scalar(temperature, dev)
+            rc = _lib.lib().shacira_latent_decode_sga_backward_tdev(
+                T, ld, F, _ptr(latent), _ptr(uniforms), _ptr(temperature), int(bool(diff_sampling)), _ptr(div),
+                _ptr(matrix), _ptr(colscale), _ptr(shift), float(clamp_weights), _ptr(grad_decoded), _ptr(g_lat),
+                _ptr(g_mat), _ptr(g_cs), _ptr(g_sh), _ptr(ws), ws.numel(), _stream(latent))
+        else:
+            rc = _lib.lib().shacira_latent_decode_sga_backward(
+                T, ld, F, _ptr(latent), _ptr(uniforms), float(temperature), int(bool(diff_sampling)), _ptr(div),
+                _ptr(matrix), _ptr(colscale), _ptr(shift), float(clamp_weights), _ptr(grad_decoded), _ptr(g_lat),
+                _ptr(g_mat), _ptr(g_cs), _ptr(g_sh), _ptr(ws), ws.numel(), _stream(latent))
     _lib.check(rc, "latent_decode_sga_backward")
     return g_lat, g_mat, g_cs, g_sh
 

@@ -128,7 +128,8 @@ class LatentDecoder(nn.Module):
             matrix, colscale, shift = self._decoder_layers()[0].fused_operands()
             if self.use_sga:
                 uniforms = torch.rand(weight.shape + (2,), dtype=weight.dtype, device=weight.device)
-                return _FusedLatentDecodeSGA.apply(weight, uniforms, float(self.temperature), bool(self.diff_sampling),
+                temperature = self.temperature if torch.is_tensor(self.temperature) else float(self.temperature)
+                return _FusedLatentDecodeSGA.apply(weight, uniforms, temperature, bool(self.diff_sampling),
                                                    self.div, matrix, colscale, shift, float(self.clamp_weights))
             return _FusedLatentDecode.apply(weight, self.div, matrix, colscale, shift, float(self.clamp_weights))
         if self._mlp_fusable(weight):

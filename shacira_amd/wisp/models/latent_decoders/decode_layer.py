@@ -54,7 +54,8 @@ class _FusedLatentDecodeSGA(torch.autograd.Function):
     def forward(ctx, latent, uniforms, temperature, diff_sampling, div, matrix, colscale, shift, clamp_weights):
         latent = latent.contiguous()
         ctx.save_for_backward(latent, uniforms, div, matrix, colscale, shift)
-        ctx.opts = (float(temperature), bool(diff_sampling), clamp_weights)
+        # (a tensor temperature = one fp32 value on the device, read by the kernels: graph-captured steps anneal it in place)
+        ctx.opts = (temperature if torch.is_tensor(temperature) else float(temperature), bool(diff_sampling), clamp_weights)
         return hip_ops.latent_decode_sga_forward(latent, uniforms, temperature, diff_sampling, div, matrix.contiguous(),
                                                  colscale, shift, clamp_weights)
 

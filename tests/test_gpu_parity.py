@@ -1563,3 +1563,31 @@ def test_double_tables(dev, name):
     assert out.dtype == torch.float64 and np.array_equal(out.detach().cpu().numpy(), feats.cpu().numpy())
     out.backward(tg)
     _assert_grad_close(cb.grad.cpu().numpy(), ref, first, sizes, rtol=1e-12)
+
+
+def test_sga_decode_with_the_temperature_on_the_device(dev):
+    """shacira_latent_decode_sga_{forward,backward}_tdev (ABI 9): the temperature read from one device float instead of a
+    kernel argument -- bit-identical to the host-temperature entry points for the same value, and a new value written into
+    the SAME tensor takes effect without any other change (what a graph-captured step relies on)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    T, ld, F = 40_003, 2, 2
+    latent = (torch.rand(T, ld, generator=g) * 8 - 4).to(dev)
+    uniforms = torch.rand(T, ld, 2, generator=g).to(dev)
+    div = torch.tensor([1.5, 0.75], device=dev)
+    matrix = torch.randn(ld, F, generator=g).to(dev)
+    shift = torch.randn(F, generator=g).to(dev)
+    gd = torch.randn(T, F, generator=g).to(dev)
+    tdev = torch.ones(1, device=dev)
+    for temp in (1.0, 0.37, 0.1):
+        tdev.fill_(temp)
+        for diff in (False, True):
+            a = ops.latent_decode_sga_forward(latent, uniforms, temp, diff, div, matrix, None, shift, 0.0)
+            b = ops.latent_decode_sga_forward(latent, uniforms, tdev, diff, div, matrix, None, shift, 0.0)
+            assert torch.equal(a, b), (temp, diff)
+            ga = ops.latent_decode_sga_backward(latent, uniforms, temp, diff, div, matrix, None, shift, 0.0, gd, False)
+            gb = ops.latent_decode_sga_backward(latent, uniforms, tdev, diff, div, matrix, None, shift, 0.0, gd, False)
+            for x, y in zip(ga, gb):
+                assert (x is None and y is None) or torch.equal(x, y), (temp, diff)
+    with pytest.raises(RuntimeError):
+        ops.latent_decode_sga_forward(latent, uniforms, torch.ones(1), False, div, matrix, None, shift, 0.0)   # host tensor

@@ -237,3 +237,17 @@ def test_graphed_nerf_fit_matches_the_eager_fit(dev):
     assert graphed["psnr"] > 17.5 and abs(graphed["psnr"] - eager["psnr"]) < 1.5, (eager, graphed)
     assert 0 < graphed["occupied_cells"] < graphed["total_cells"], graphed
     assert graphed["sample_capacity"] < kw["rays"] * kw["num_steps"] // 2, graphed     # sized to the pruned scene, not the maximum
+
+
+def test_graphed_compressed_nerf_fit(dev):
+    """The reference's nerf_lego.yaml mode (3-D LatentGrid, SGA warm-up, entropy model) replayed from HIP graphs: the SGA
+    temperature is annealed through ONE device float the decode kernels read (shacira_latent_decode_sga_*_tdev), the step is
+    re-captured once when SGA is switched off; it learns like the eager loop and codes to a small fraction of the fp32 table."""
+    from shacira_amd import harness
+    kw = dict(steps=300, rays=2048, num_steps=96, codebook_bitwidth=16, max_grid_res=512, prune_every=100, val_rays=4096,
+              latent=True, ray_pool=32)
+    eager = harness.fit_nerf(dev, **kw)
+    graphed = harness.fit_nerf(dev, graphed=True, **kw)
+    assert graphed["overflow_steps"] == 0 and graphed["graph_captures"] >= 2, graphed       # >= one capture per SGA mode
+    assert graphed["psnr"] > 15.0 and abs(graphed["psnr"] - eager["psnr"]) < 2.0, (eager, graphed)
+    assert graphed["file_bytes"] < 0.25 * graphed["table_bytes_fp32"], graphed
