@@ -199,7 +199,7 @@ class GraphedImageFitter(ImageFitter):
     Differences from the eager fitter, all forced by capture: the entropy noise is drawn with the device generator
     (`grid.device_noise`), Adam keeps its step count on the device (`FusedAdam(capturable=True)`), the entropy weight
     lambda(step) is a device scalar refreshed before each replay, and PSNR is evaluated on request (`psnr()`), not
-    every step. The `div` normaliser updates (iterations 1, 2, 5, 10 with norm_every = 10) happen in the eager
+    every step; with the SGA warm-up of the shipped configs the temperature is a device float too. The `div` normaliser updates (iterations 1, 2, 5, 10 with norm_every = 10) happen in the eager
     warm-up steps that precede the capture."""
 
     def __init__(self, nef, coords, rgb, total_steps, cdec, cent, warmup_steps=11, **kw):
@@ -214,6 +214,13 @@ class GraphedImageFitter(ImageFitter):
         self.stats = torch.zeros(2, dtype=torch.float64, device=coords.device)
         self.warmup_steps = warmup_steps
         self.graph = None
+        # SGA warm-up (the shipped configs): the temperature decays every iteration -- it lives in one device float the decode
+        # kernel reads (shacira_latent_decode_sga_*_tdev) and is refreshed before each replay; switching SGA off after
+        # `decay_period` of the run changes the kernel, so the step is captured a second time then
+        self.temperature = None
+        if self.temperature_sched is not None:
+            self.temperature = torch.ones(1, device=coords.device)
+            nef.grid.latent_dec.temperature = self.temperature
 
     def _body(self):
         self.optimizer.zero_grad(set_to_none=True)
@@ -230,6 +237,12 @@ class GraphedImageFitter(ImageFitter):
     def step(self):
         self.iteration += 1
         self.lam.fill_(float(self.lambda_sched(self.iteration - 1)))
+        if self.temperature is not None:
+            dec = self.nef.grid.latent_dec
+            self.temperature.fill_(float(self.temperature_sched(self.iteration)))
+            if dec.use_sga and self.iteration / self.total_steps > self.cdec["decay_period"]:
+                dec.use_sga = False
+                self.graph = None                   # rounding instead of sampling from here on: re-capture
         if self.iteration <= self.warmup_steps:
             with torch.no_grad():
                 self._update_div()
@@ -255,8 +268,6 @@ def fit_image(device, steps=1000, height=512, width=768, seed=0, num_lods=16, lo
     With world > 1 the (shuffled) pixel batch is sharded over ranks; results are identical on every rank."""
     from .dist import shard_batch
     torch.manual_seed(seed)
-    if use_sga and graphed:
-        raise ValueError("the SGA temperature changes every step; the graphed fitter replays a fixed step")
     grid, cdec, cent = kodak_like_grid(num_lods=num_lods, use_sga=use_sga)
     nef = NeuralImage(grid, hidden_dim=hidden_dim, num_layers=1).to(device)
     img = torch.from_numpy(make_test_image(height, width, seed)).reshape(-1, 3)
