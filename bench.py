@@ -518,16 +518,6 @@ def main():
             torch.cuda.synchronize()
             psnr["graph_replay"] = {"value": gfit["psnr"], "bpp": gfit["bpp"], "ms_per_step": gfit["ms_per_step"],
                                     "seconds": time.perf_counter() - tg}
-        # the compressed variant the reference's nerf_lego.yaml trains (3-D LatentGrid: SGA warm-up, entropy model, lambda 1e-4)
-        # on the same ray pool, eager and graph-replayed (the SGA temperature annealed through a device float between replays)
-        tc = time.perf_counter()
-        ce = harness.fit_nerf(device, steps=args.nerf_steps, ray_pool=128, latent=True)
-        cg = harness.fit_nerf(device, steps=args.nerf_steps, ray_pool=128, latent=True, graphed=True)
-        psnr_nerf["compressed_latent_grid_ray_pool_128"] = {
-            "eager": {"value": ce["psnr"], "ms_per_step": ce["ms_per_step"], "file_bytes": ce["file_bytes"]},
-            "graph_replay": {"value": cg["psnr"], "ms_per_step": cg["ms_per_step"], "file_bytes": cg["file_bytes"],
-                             "graph_captures": cg["graph_captures"], "overflow_steps": cg["overflow_steps"]},
-            "table_bytes_fp32": ce["table_bytes_fp32"], "seconds": time.perf_counter() - tc}
 
     # second PSNR figure (rank 0 only, outside the timed region): the reference's per-step NeRF pipeline -- ray marching
     # on the occupancy grid, hash-grid lookup, MFMA decoders, volume integration, L1, fused Adam -- on a closed-form scene
@@ -555,6 +545,16 @@ def main():
                              "graph_captures": gfit["graph_captures"], "sample_capacity_last": gfit["sample_capacity"],
                              "overflow_steps": gfit["overflow_steps"], "capture_seconds": gfit["capture_seconds"]},
             "seconds": time.perf_counter() - tg}
+        # the compressed variant the reference's nerf_lego.yaml trains (3-D LatentGrid: SGA warm-up, entropy model, lambda 1e-4)
+        # on the same ray pool, eager and graph-replayed (the SGA temperature annealed through a device float between replays)
+        tc = time.perf_counter()
+        ce = harness.fit_nerf(device, steps=args.nerf_steps, ray_pool=128, latent=True)
+        cg = harness.fit_nerf(device, steps=args.nerf_steps, ray_pool=128, latent=True, graphed=True)
+        psnr_nerf["compressed_latent_grid_ray_pool_128"] = {
+            "eager": {"value": ce["psnr"], "ms_per_step": ce["ms_per_step"], "file_bytes": ce["file_bytes"]},
+            "graph_replay": {"value": cg["psnr"], "ms_per_step": cg["ms_per_step"], "file_bytes": cg["file_bytes"],
+                             "graph_captures": cg["graph_captures"], "overflow_steps": cg["overflow_steps"]},
+            "table_bytes_fp32": ce["table_bytes_fp32"], "seconds": time.perf_counter() - tc}
 
     # the optimiser pass that follows the backward in training (SURVEY 8d "second figure"): fused Adam over the table
     ms_adam = None
