@@ -109,9 +109,10 @@ def quick_measure(name, device, iters=20):
     table_mb = T * F * esz / 1e6
     # What binds these operators is not the precision of the bytes: the forward pays one L2 -> L1 line
     # transfer (2 clk per 128-byte line and CU) per x-pair of corners on every level finer than the batch's density, whatever
-    # the row size; the backward pays one 64-bit LDS atomic per (corner, feature) (2.3 T/s measured, profiles/r01_microbench2)
-    # and moves its items once out and once in (8 + 4F bytes per x-pair with fp32 payloads, 8 / 16 bytes with half payloads;
-    # levels that fit LDS images move none). fp16 tables halve only the last term -- which is why they gain 15-20 %, not 2x.
+    # the row size; the backward moves its items once out and once in (8 + 4F bytes per x-pair with fp32 payloads, 8 / 16 bytes
+    # with half payloads; levels that fit LDS images move none) -- the binding part for binned levels -- and pays one 64-bit LDS
+    # atomic per (corner, feature) (2.3 T/s measured, profiles/r01_microbench2), which binds only where there is no item stream
+    # (direct levels: the image configs).
     n_fine = sum(1 for r in res if float(r) ** dim > 4.0 * n) if dim == 3 else 0
     fwd_floor = n_fine * n * (2 ** (dim - 1)) * 2.0 / (256 * 2.4e9) * 1e3
     lds_floor = n * L * (2 ** dim) * F / 2.3e12 * 1e3
