@@ -131,13 +131,15 @@ __device__ __forceinline__ void store_item_nt(ItemH4 *p, const ItemH4 &it) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 v;
     __builtin_memcpy(&v, &it, 16);
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+    *reinterpret_cast<u32x4 *>(p) = v;     // plain, like the 8-byte items below (nerf_lego table, fp16: backward -2.5 %)
 }
 __device__ __forceinline__ void store_item_nt(ItemH *p, const ItemH &it) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     u32x2 v;
     __builtin_memcpy(&v, &it, 8);
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p));
+    // PLAIN 8-byte stores (round 4): as non-temporal stores the half-size items of fp16 tables cost the S1 backward 7 % (a wave's
+    // store covers 512 bytes: partial lines at both ends of every run, which a streaming store does not merge in L2)
+    *reinterpret_cast<u32x2 *>(p) = v;
 }
 
 // One consumer work unit, written by the bucket scan: everything a consume workgroup needs in ONE 32-byte load (it used to
@@ -161,6 +163,8 @@ template <int F> __device__ __forceinline__ void store_item_nt(Item<F> *p, const
     if constexpr (sizeof(Item<F>) == 16) {
         u32x4 v;
         __builtin_memcpy(&v, &it, 16);
+        // (16-byte fp32 items stay non-temporal: plain stores change nothing on S1 and trade -3 % on the 2-D backward
+        // against a slower forward right behind it; profiles/r04_experiments.md 9)
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
     } else {   // 24-byte items (F = 4, 8-byte aligned): three 8-byte stores instead of six dwords
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -169,6 +173,7 @@ template <int F> __device__ __forceinline__ void store_item_nt(Item<F> *p, const
         u32x2 d[sizeof(Item<F>) / 8];
         __builtin_memcpy(d, &it, sizeof(Item<F>));
 #pragma unroll
+        // (non-temporal: plain stores measured +8 % on the nerf_lego table's backward)
         for (int k = 0; k < (int)(sizeof(Item<F>) / 8); ++k) __builtin_nontemporal_store(d[k], q + k);
     }
 }
@@ -179,12 +184,13 @@ template <int F> __device__ __forceinline__ Item<F> load_item_nt(const Item<F> *
     if constexpr (sizeof(Item<F>) == 16) {
         const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
         __builtin_memcpy(&it, &v, 16);
-    } else {   // 24-byte items: three 8-byte loads
+    } else {   // 24-byte items: three 8-byte loads. PLAIN loads, not non-temporal ones (round 4): the 16- and 8-byte pieces of
+               // neighbouring items share lines, and a streaming load does not keep them (nerf_lego table backward -5 %)
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 *q = reinterpret_cast<const u32x2 *>(p);
         u32x2 d[sizeof(Item<F>) / 8];
 #pragma unroll
-        for (int k = 0; k < (int)(sizeof(Item<F>) / 8); ++k) d[k] = __builtin_nontemporal_load(q + k);
+        for (int k = 0; k < (int)(sizeof(Item<F>) / 8); ++k) d[k] = q[k];
         __builtin_memcpy(&it, d, sizeof(Item<F>));
     }
     return it;
