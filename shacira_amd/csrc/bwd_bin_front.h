@@ -212,7 +212,11 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
                 const f32x4 val = *reinterpret_cast<const f32x4 *>(&s_tile[l * pitch + smo]);
                 float *dst = gT + ((int64_t)l * NP + s0 + smo) * F;
                 if (smo + M <= ns) {
-                    __builtin_nontemporal_store(val, reinterpret_cast<f32x4 *>(dst));
+                    // fp32 gradients: PLAIN stores (round 4) -- the scatter pass reads these 134 MB back within ~100 us, and the
+                    // Infinity Cache keeps what a streaming store would have sent to HBM (S1 backward -2.8 %,
+                    // profiles/r04_experiments.md 9); fp16 gradients (half the input bytes in flight) measured 2 % better streaming
+                    if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4 *>(dst) = val;
+                    else __builtin_nontemporal_store(val, reinterpret_cast<f32x4 *>(dst));
                     if constexpr (GMAX) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {

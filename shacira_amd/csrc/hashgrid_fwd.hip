@@ -700,10 +700,12 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
                 }
             }
             T *dstT = feats + ((int64_t)lvl * N + idx[u]) * F;
-            if constexpr (sizeof(T) == 4 && F == 2) {   // staging stream: written once, read once
+            if constexpr (sizeof(T) == 4 && F == 2) {   // staging stream: written once, read once (soon)
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
                 f32x2 o = {acc[0], acc[1]};
-                __builtin_nontemporal_store(o, reinterpret_cast<f32x2 *>(dstT));
+                // PLAIN 8-byte stores (round 4; they were non-temporal): the rows kernel reads the staged features back right
+                // behind this kernel, from L2 / the Infinity Cache when the stores were allowed to stay there (S1 forward -7 %)
+                *reinterpret_cast<f32x2 *>(dstT) = o;
             } else {
                 store_row<T, F>(dstT, acc);
             }
