@@ -12,7 +12,7 @@ namespace shacira {
 // returning atomic on the bucket's cursor (set to the bucket's base by the bucket scan): runs of different tiles land in
 // the bucket in arrival order -- the consumer's fixed-point sums do not depend on it.
 // H: half-precision item stream (fp16 tables, F = 2): 8-byte pair items, 16-byte compact items.
-template <int DIM, int F, bool H>
+template <int DIM, int F, bool H, bool STREAM = true>
 __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt, BinPlan plan,
                                                                   const float *__restrict__ coords,
                                                                   const float *__restrict__ gT,
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     for (uint32_t pos = threadIdx.x; pos < staged; pos += kBinThreads) {
         const uint32_t b = s_bucket[pos];
         // write-once / read-once stream: non-temporal stores (measured -7 % on the whole backward)
-        store_item_nt(items + s_gbase[b] + (pos - s_start[b]), s_items[pos]);
+        store_item_nt<STREAM>(items + s_gbase[b] + (pos - s_start[b]), s_items[pos]);
     }
     // selective table zeroing, second half (zero_unowned_rows_kernel did the rows no bucket covers): a hashed bucket with
     // exactly one work unit is overwritten by the consume pass; one with none is never written and one with several is
@@ -290,6 +290,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
 // (`stream` below): the first round of 16-byte loads goes out BEFORE the image is zeroed, so the zeroing and its barrier sit
 // inside the loads' latency instead of in front of it; `hook()` runs once after the first round has been added (the
 // persistent kernel fetches its next unit's descriptor there). The fixed-point scale comes with the descriptor.
+// (FX also selects the item loads' cache policy: fixed-point images <=> batches from 2^17 samples <=> streaming loads; the
+// fp64 form of small batches reads its items with plain loads -- the scatter pass wrote them with plain stores, see
+// store_item_nt)
 template <int F, bool FX, bool H, class Hook>
 __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan &plan, const int32_t *__restrict__ first_idx,
                                              const UnitDesc d, const typename ItemSel<F, H>::type *__restrict__ items,
@@ -365,7 +368,7 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
 #pragma unroll
                        for (int u = 0; u < UD; ++u) {
                            const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
-                           if (pp < end) it[u] = load_item_nt<F>(itf + pp);
+                           if (pp < end) it[u] = load_item_nt<F, FX>(itf + pp);
                            else it[u].key = 0;
                        }
                    },
@@ -473,8 +476,8 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
                            for (int u = 0; u < UC; ++u) {
                                const uint64_t p = p0 + 2ull * u * kConsumeThreads;
                                if (p + 1 < end) {
-                                   ia[u] = load_item_nt<F>(itf + p);
-                                   ib[u] = load_item_nt<F>(itf + p + 1);
+                                   ia[u] = load_item_nt<F, FX>(itf + p);
+                                   ib[u] = load_item_nt<F, FX>(itf + p + 1);
                                } else {
                                    ia[u].key = 0;
                                }
@@ -578,7 +581,7 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
 #pragma unroll
                    for (int u = 0; u < UN; ++u) {
                        const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
-                       if (pp < end) it[u] = load_item_nt<F>(itf + pp);
+                       if (pp < end) it[u] = load_item_nt<F, FX>(itf + pp);
                        else it[u].key = 0;
                    }
                },

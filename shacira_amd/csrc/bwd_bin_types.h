@@ -127,13 +127,13 @@ __device__ __forceinline__ float2 half2_bits_to_float2(uint32_t bits) {
     return make_float2(__half2float(__ushort_as_half((unsigned short)(bits & 0xFFFFu))),
                        __half2float(__ushort_as_half((unsigned short)(bits >> 16))));
 }
-__device__ __forceinline__ void store_item_nt(ItemH4 *p, const ItemH4 &it) {
+template <bool STREAM = true> __device__ __forceinline__ void store_item_nt(ItemH4 *p, const ItemH4 &it) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 v;
     __builtin_memcpy(&v, &it, 16);
     *reinterpret_cast<u32x4 *>(p) = v;     // plain, like the 8-byte items below (nerf_lego table, fp16: backward -2.5 %)
 }
-__device__ __forceinline__ void store_item_nt(ItemH *p, const ItemH &it) {
+template <bool STREAM = true> __device__ __forceinline__ void store_item_nt(ItemH *p, const ItemH &it) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     u32x2 v;
     __builtin_memcpy(&v, &it, 8);
@@ -158,14 +158,20 @@ struct alignas(16) UnitDesc {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Items are written once and read once: stream them past the caches (non-temporal).
-template <int F> __device__ __forceinline__ void store_item_nt(Item<F> *p, const Item<F> &it) {
+// STREAM (compile time: a run-time choice between the two load instructions made the compiler serialise the round's loads):
+// the call's item array is larger than the caches hold between the two passes, so the write-once / read-once accesses go past
+// them. Batches below 2^17 samples (<= ~60 MB of items; they are the ones that accumulate in fp64 images) are written and read
+// with PLAIN accesses instead and the consume pass finds its items in L2 / the Infinity Cache (round 4: -4 % on the
+// 65 536-sample fwd+bwd pair; from 2^18 samples on plain accesses lose).
+template <bool STREAM = true, int F> __device__ __forceinline__ void store_item_nt(Item<F> *p, const Item<F> &it) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     if constexpr (sizeof(Item<F>) == 16) {
         u32x4 v;
         __builtin_memcpy(&v, &it, 16);
-        // (16-byte fp32 items stay non-temporal: plain stores change nothing on S1 and trade -3 % on the 2-D backward
-        // against a slower forward right behind it; profiles/r04_experiments.md 9)
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+        // (large batches: non-temporal -- plain stores change nothing on S1 and trade -3 % on the 2-D backward against a slower
+        // forward right behind it; profiles/r04_experiments.md 9)
+        if constexpr (STREAM) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+        else *reinterpret_cast<u32x4 *>(p) = v;
     } else {   // 24-byte items (F = 4, 8-byte aligned): three 8-byte stores instead of six dwords
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         static_assert(sizeof(Item<F>) % 8 == 0, "item size");
@@ -178,11 +184,13 @@ template <int F> __device__ __forceinline__ void store_item_nt(Item<F> *p, const
     }
 }
 
-template <int F> __device__ __forceinline__ Item<F> load_item_nt(const Item<F> *p) {
+template <int F, bool STREAM = true> __device__ __forceinline__ Item<F> load_item_nt(const Item<F> *p) {
     Item<F> it;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     if constexpr (sizeof(Item<F>) == 16) {
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        u32x4 v;
+        if constexpr (STREAM) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        else v = *reinterpret_cast<const u32x4 *>(p);
         __builtin_memcpy(&it, &v, 16);
     } else {   // 24-byte items: three 8-byte loads. PLAIN loads, not non-temporal ones (round 4): the 16- and 8-byte pieces of
                // neighbouring items share lines, and a streaming load does not keep them (nerf_lego table backward -5 %)

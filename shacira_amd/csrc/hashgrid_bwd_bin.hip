@@ -674,8 +674,12 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                                stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
                                reinterpret_cast<typename ItemSel<F, true>::type *>(w.items), s0, hi, NP, zacc, first_idx,
                                w.unit_first);
-        else
+        else if (use_fx)
             hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
+                               stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                               reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
+        else   // batches below 2^17 samples: plain item stores, the consume pass reads them back from the caches
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false, false>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
                                stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
                                reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
         SHACIRA_CHECK_LAUNCH();
@@ -755,6 +759,10 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, false>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<4>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, false>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
         set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, false>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, false, false>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, false, false>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, false, false>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, false, false>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
         return attr_err;
     });
     if (attr_err != hipSuccess) return attr_err;
