@@ -34,6 +34,9 @@ def lib():
         L.shacira_oracle_hashgrid_fwd.restype = None
         L.shacira_oracle_hashgrid_fwd.argtypes = [ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   p, p, i64, p, p, p, p, p]
+        L.shacira_oracle_hashgrid_fwd_last64.restype = None
+        L.shacira_oracle_hashgrid_fwd_last64.argtypes = [ctypes.c_int, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                         p, p, i64, p, p, p]
         for name in ("shacira_oracle_hashgrid_bwd", "shacira_oracle_hashgrid_bwd_f32", "shacira_oracle_hashgrid_bwd_f64"):
             fn = getattr(L, name)
             fn.restype = None
@@ -86,6 +89,48 @@ def forward(coords, table, first_idx, resolutions, bitwidth, want_corners=False)
     lib().shacira_oracle_hashgrid_fwd(dim, N, L, F, int(bitwidth), _ptr(res), _ptr(fi), T, _ptr(coords),
                                       _ptr(table), _ptr(feats), _ptr(idx), _ptr(w))
     return (feats, idx, w) if want_corners else feats
+
+
+def forward_half_llvm(coords, table16, first_idx, resolutions, bitwidth):
+    """fp16 table as the HIPCC build of the reference evaluates it (oracle/_ref; read from the ISA of the built code object
+    and confirmed on the vectors): the feature loop of .cu:96-107 is unrolled by four -- features j < 4*(F//4): packed
+    fp32 fmas in LLVM's contraction order (mode 1), rounded to fp32, then converted to half; the remainder loop
+    (j >= 4*(F//4)): t0*c0 and t2*c2 from one packed multiply, fma(t1,c1, t0*c0), a plain ADD of t2*c2, then a `v_fma_mix_f32`
+    chain whose last step is fused with the conversion into `v_fma_mixlo_f16` = ONE rounding of the exact sum (mode 2). Explains tests/golden/ref_kernels.npz's fp16 cases bit for bit; NOT
+    what the product is held to (nvcc rounds to fp32 first: `forward(...).astype(float16)`)."""
+    coords, table, res, fi = _prep(coords, np.asarray(table16, dtype=np.float16).astype(np.float32), resolutions, first_idx)
+    N, dim = coords.shape
+    T, F = table.shape
+    L = len(res)
+    pair = np.empty((N, L * F, 2), np.float64)
+    old = set_contraction(1)
+    try:
+        plain = forward(coords, table, fi, res, bitwidth).astype(np.float16)
+        set_contraction(2)
+        lib().shacira_oracle_hashgrid_fwd_last64(dim, N, L, F, int(bitwidth), _ptr(res), _ptr(fi), T, _ptr(coords),
+                                                 _ptr(table), _ptr(pair))
+    finally:
+        set_contraction(old)
+    # one rounding of s + e (exact) to half: RNE of the double s is right unless s is a half-way point and e != 0
+    s, e = pair[..., 0], pair[..., 1]
+    h = s.astype(np.float16)
+    hd = h.astype(np.float64)
+    other = np.nextafter(h, np.where(s > hd, np.float16(np.inf), np.float16(-np.inf)).astype(np.float16))
+    od = other.astype(np.float64)
+    tie = (s != hd) & (s - hd == od - s)
+    lo16 = np.where(hd <= od, h, other)
+    hi16 = np.where(hd <= od, other, h)
+    fused = np.where(tie & (e < 0), lo16, np.where(tie & (e > 0), hi16, h))
+    jj = np.arange(L * F) % F
+    return np.where((jj >= 4 * (F // 4))[None, :], fused, plain).astype(np.float16)
+
+
+def set_contraction(mode):
+    """0 (default): nvcc's contraction order of the feature sum; 1: LLVM's, i.e. what the reference's kernels compute when
+    built by hipcc (oracle/_ref). See the header of hashgrid_oracle.c. Returns the previous mode."""
+    old = lib().shacira_oracle_get_contraction()
+    lib().shacira_oracle_set_contraction(int(mode))
+    return old
 
 
 def backward(coords, grad_out, table_shape, first_idx, resolutions, bitwidth, accumulate="f64"):

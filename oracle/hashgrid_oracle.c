@@ -24,7 +24,15 @@
  *  - `1.0 - x_` is a double subtraction narrowed to fp32 == a correctly rounded fp32 subtraction.
  *  - weights are products evaluated left to right in fp32 (no FMA possible: pure products).
  *  - the feature sum `t0*c0 + t1*c1 + ...` is contracted by nvcc (-fmad=true default) into
- *    fma(t7,c7, ... fma(t1,c1, t0*c0)); restated with fmaf in that order.
+ *    fma(t7,c7, ... fma(t1,c1, t0*c0)); restated with fmaf in that order (contraction mode 0, the default).
+ *    PINNED (round 4) through contraction mode 1: the reference's own kernels built for gfx950 (oracle/ref_build.py:
+ *    torch hipify + hipcc -O3) contract the same expression as fma(t7,c7, ... fma(t2,c2, fma(t0,c0, t1*c1))) -- LLVM
+ *    folds the LEFT product of `a*b + c*d` into the fma, nvcc the right one; only which of the first two products is
+ *    rounded differs (<= 1 ulp of the result). In mode 1 this file reproduces those kernels' output BIT FOR BIT on every
+ *    vector of tests/golden/ref_kernels.npz (fp32, fp16 and double tables, 2-D and 3-D; tests/test_ref_kernel_vectors.py),
+ *    which pins everything else here -- transform, clamp, floor, hash, dense test, corner order, weights, layout --
+ *    against reference-produced numbers. Mode 0 (what nvcc emits for the reference on the hardware it was written
+ *    for: mul, fma, fma ...) stays the default the product is held to; the nvcc order itself cannot be executed here.
  *  - dense-vs-hash test uses int32 products with short-circuit; restated with wraparound uint32
  *    products reinterpreted as int32 (what the hardware does where C leaves it undefined).
  *  - where the reference would touch memory outside the whole table (dense level, coord >= 1 exactly,
@@ -37,6 +45,12 @@
 #include <string.h>
 
 #define ORACLE_API __attribute__((visibility("default")))
+
+/* 0: nvcc's contraction of the feature sum (default); 1: LLVM's (the hipcc build of the reference, oracle/_ref);
+ * 2: mode 0 with the third product added unfused (remainder loop of that build's Half kernel, see hashgrid_c.py). */
+static int g_contraction = 0;
+ORACLE_API void shacira_oracle_set_contraction(int mode) { g_contraction = mode; }
+ORACLE_API int shacira_oracle_get_contraction(void) { return g_contraction; }
 
 static inline int32_t wrap_mul_i32(int32_t a, int32_t b) {
     return (int32_t)((uint32_t)a * (uint32_t)b);
@@ -106,9 +120,9 @@ static void corners(int dim, const float *c, int32_t res, int32_t cs, int32_t *i
  * w_out   (optional, may be NULL): float [N, L, 2^dim] weights.
  * T = total rows of the concatenated table (memory guard only).
  */
-ORACLE_API void shacira_oracle_hashgrid_fwd(int dim, int64_t N, int L, int F, int bw, const int32_t *res,
-                                            const int32_t *first_idx, int64_t T, const float *coords,
-                                            const float *table, float *feats, int32_t *idx_out, float *w_out) {
+static void hashgrid_fwd_impl(int dim, int64_t N, int L, int F, int bw, const int32_t *res, const int32_t *first_idx,
+                              int64_t T, const float *coords, const float *table, float *feats, double *feats_last64,
+                              int32_t *idx_out, float *w_out) {
     const int nc = 1 << dim;
     const int32_t cs = (int32_t)pow(2.0, (double)bw); /* .cpp:56 */
     for (int64_t i = 0; i < N; ++i) {
@@ -121,16 +135,54 @@ ORACLE_API void shacira_oracle_hashgrid_fwd(int dim, int64_t N, int L, int F, in
                 if (w_out) w_out[(i * L + l) * nc + k] = w[k];
             }
             for (int j = 0; j < F; ++j) {
-                float acc = 0.0f;
+                float acc = 0.0f, t0 = 0.0f;
                 for (int k = 0; k < nc; ++k) {
                     int64_t row = (int64_t)first_idx[l] + idx[k];
                     float t = (row >= 0 && row < T) ? table[row * F + j] : 0.0f;
-                    acc = (k == 0) ? t * w[0] : fmaf(t, w[k], acc);
+                    if (k == 0) {
+                        t0 = t;
+                        acc = t * w[0];
+                    } else if (k == 1 && g_contraction == 1) {
+                        acc = fmaf(t0, w[0], t * w[1]); /* LLVM: fma(t0,c0, t1*c1) */
+                    } else if (k == 2 && g_contraction == 2) {
+                        acc = acc + t * w[2]; /* hipcc's remainder loop of the Half kernel: this product came out of a
+                                                 packed multiply with t0*c0 and is ADDED, not fused */
+                    } else {
+                        /* the last step before its fp32 rounding: exact product (48 bits) + acc in double */
+                        if (feats_last64 && k == nc - 1) {
+                            /* s + e == t*w + acc EXACTLY (the product of two floats is exact in double; TwoSum) */
+                            double p = (double)t * (double)w[k], a = (double)acc, s2 = p + a, bb = s2 - p;
+                            double e = (p - (s2 - bb)) + (a - bb);
+                            int64_t o = 2 * (i * (int64_t)L * F + (int64_t)l * F + j);
+                            feats_last64[o] = s2;
+                            feats_last64[o + 1] = e;
+                        }
+                        acc = fmaf(t, w[k], acc);
+                    }
                 }
-                feats[i * (int64_t)L * F + (int64_t)l * F + j] = acc;
+                if (feats) feats[i * (int64_t)L * F + (int64_t)l * F + j] = acc;
             }
         }
     }
+}
+
+ORACLE_API void shacira_oracle_hashgrid_fwd(int dim, int64_t N, int L, int F, int bw, const int32_t *res,
+                                            const int32_t *first_idx, int64_t T, const float *coords,
+                                            const float *table, float *feats, int32_t *idx_out, float *w_out) {
+    hashgrid_fwd_impl(dim, N, L, F, bw, res, first_idx, T, coords, table, feats, NULL, idx_out, w_out);
+}
+
+/*
+ * The same sum with its LAST fma left unrounded, as an exact pair (sum, error) of doubles [N, L*F, 2]: what a
+ * half-precision table's result is rounded FROM in the hipcc build of the reference wherever LLVM fuses the last fma and
+ * the `static_cast<scalar_t>` of .cu:106 into one `v_fma_mixlo_f16` (one rounding; fp32 -> half ties go the other way in
+ * ~1 of 10^4 values). Used only to explain tests/golden/ref_kernels.npz's fp16 cases bit for bit (contraction mode 1,
+ * oracle/hashgrid_c.py: forward_half_llvm); nvcc rounds to fp32 first.
+ */
+ORACLE_API void shacira_oracle_hashgrid_fwd_last64(int dim, int64_t N, int L, int F, int bw, const int32_t *res,
+                                                   const int32_t *first_idx, int64_t T, const float *coords,
+                                                   const float *table, double *feats_last64) {
+    hashgrid_fwd_impl(dim, N, L, F, bw, res, first_idx, T, coords, table, NULL, feats_last64, NULL, NULL);
 }
 
 /*

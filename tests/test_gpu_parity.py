@@ -1591,3 +1591,63 @@ def test_sga_decode_with_the_temperature_on_the_device(dev):
                 assert (x is None and y is None) or torch.equal(x, y), (temp, diff)
     with pytest.raises(RuntimeError):
         ops.latent_decode_sga_forward(latent, uniforms, torch.ones(1), False, div, matrix, None, shift, 0.0)   # host tensor
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Against the reference's OWN operators (oracle/_ref/shacira_ref_ops.so: reference hashgrid_interpolate{,2d}_cuda.cu +
+# hashgrid_interpolate.cpp built for gfx950 by oracle/ref_build.py). The checker only: nothing in shacira_amd/ loads it.
+# ---------------------------------------------------------------------------------------------------------------------
+def _ref_ops():
+    from oracle import ref_build
+    if not os.path.exists(ref_build.OUT):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    return ref_build.load()
+
+
+_REF_CASES = {
+    "A": CONFIGS["A"] + (2,), "B": CONFIGS["B"] + (2,), "Bp": CONFIGS["Bp"] + (2,), "D": CONFIGS["D"] + (2,),
+    "nerf_lego_F4": (3, geo(16, 512, 24), 19, 4), "dense_edge": (3, [4, 7, 12, 33, 80, 81], 19, 2),
+}
+
+
+@pytest.mark.parametrize("name", list(_REF_CASES))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.float64])
+def test_against_the_reference_kernels(dev, name, dtype):
+    """Same inputs (incl. +-1, NaN, out-of-range, 1 - 2^-24 coordinates) through the reference's operators and through the
+    C-ABI. Forward: the hipcc build of the reference fuses the first two products of the 8-term sum the other way round
+    than nvcc does (tests/test_ref_kernel_vectors.py), so the bar is one rounding of the result, not bit equality (measured:
+    <= 3.8e-9 abs on values of ~0.03; fp16 <= 1 half ulp). Backward (fp32; the reference's fp16 / double backward needs
+    `__CUDA_ARCH__`, see make_ref_kernel_vectors.py): 1e-5 of each level's largest gradient, as against the oracle
+    (measured 4e-7 ... 4e-6, the same as two runs of the reference's atomics against each other)."""
+    ref = _ref_ops()
+    ops = _ops()
+    dim, res, bw, F = _REF_CASES[name]
+    N = (1 << 17) + 3
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, N, F=F, seed=11)
+    tc = torch.from_numpy(coords).to(dev)
+    tt = torch.from_numpy(table).to(dev).to(dtype)
+    tg = torch.from_numpy(go).to(dev).to(dtype)
+    tf = torch.from_numpy(first).to(dev)
+    three = dim == 3
+    rf = (ref.hashgrid_interpolate_cuda if three else ref.hashgrid_interpolate2d_cuda)(tc, tt, tf, res, bw)
+    hf = (ops.hashgrid_interpolate_cuda if three else ops.hashgrid_interpolate2d_cuda)(tc, tt, tf, res, bw)
+    torch.cuda.synchronize()
+    assert hf.dtype == rf.dtype and hf.shape == rf.shape
+    r, h = rf.double().cpu().numpy(), hf.double().cpu().numpy()
+    assert np.isfinite(r).all() and np.isfinite(h).all()
+    if dtype == torch.float16:
+        ulp = np.spacing(np.abs(rf.cpu().numpy())).astype(np.float64)
+        assert np.all(np.abs(h - r) <= ulp)
+        assert (h != r).mean() < 2e-3            # ties of the double rounding only
+    else:
+        one_rounding = float(np.spacing(np.float32(np.abs(table).max() * (1 << dim) / 2)))
+        assert np.abs(h - r).max() <= one_rounding
+        np.testing.assert_allclose(h, r, rtol=RTOL, atol=one_rounding)
+    if dtype != torch.float32:
+        return
+    rb = (ref.hashgrid_interpolate_backward_cuda if three else ref.hashgrid_interpolate2d_backward_cuda)(
+        tc, tg, tt, tf, res, bw, F, False)
+    hb = (ops.hashgrid_interpolate_backward_cuda if three else ops.hashgrid_interpolate2d_backward_cuda)(
+        tc, tg, tt, tf, res, bw, F, False)
+    torch.cuda.synchronize()
+    _assert_grad_close(hb.cpu().numpy(), rb.double().cpu().numpy(), first, sizes)
