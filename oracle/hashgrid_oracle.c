@@ -12,9 +12,12 @@
  *   wisp/csrc/ops/hashgrid_interpolate2d_cuda.cu:17-36, 44-99, 133-208   the 2-D twins
  *   wisp/csrc/ops/hashgrid_interpolate.cpp:44-66, 68-100, 130-186        host loops over levels
  *
- * PARITY STATUS: "parity unpinned" for this file. The reference ships no tests, golden vectors or
- * CPU path for these kernels (they are CUDA-only and there is no nvcc / NVIDIA GPU here), so this
- * restatement is pinned only by known answers derived by hand from the source (tests/test_oracle_kat.py).
+ * PARITY STATUS: pinned (round 4) against outputs of the reference's own kernels: oracle/ref_build.py compiles the
+ * reference's hashgrid_interpolate{,2d}_cuda.cu + hashgrid_interpolate.cpp for gfx950 (torch hipify + hipcc -O3) into
+ * oracle/_ref/, tests/golden/make_ref_kernel_vectors.py ran them on an MI355X, tests/test_ref_kernel_vectors.py holds this
+ * file to the committed vectors bit for bit (forward, every table type) -- see the contraction note below -- and within the
+ * reference's own atomics spread (fp32 backward). The reference's fp16 / double BACKWARD is not covered (its `__half2`
+ * branch is compiled under `__CUDA_ARCH__ >= 600`); there the hand-derived known answers (tests/test_oracle_kat.py) remain.
  *
  * Arithmetic notes (all reproduced on purpose):
  *  - `resolution * (coords[i] * 0.5 + 0.5)` is evaluated in fp64 (0.5 is a double literal) and narrowed
