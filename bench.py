@@ -184,6 +184,42 @@ def cpu_baseline(dim, res, bw, F, first, T, n_samples, budget_s, seed=0):
             "s_per_pass": dt, "c_oracle_1thread_samples_per_s": n_c / dt_c}
 
 
+def reference_kernels_on_this_gpu(device, dim, res, bw, F, first, T, n_samples, seed=0, iters=3):
+    """Part of the cpu_baseline leg (a reported baseline, never the thing measured): the reference's OWN operators
+    (oracle/_ref/shacira_ref_ops.so = reference hashgrid_interpolate{,2d}_cuda.cu + hashgrid_interpolate.cpp built for gfx950,
+    oracle/ref_build.py) timed on the same GPU, the same workload at full size. None when that library did not travel."""
+    from oracle import ref_build
+    if not os.path.exists(ref_build.OUT):
+        return None
+    ref = ref_build.load()
+    g = torch.Generator().manual_seed(seed)
+    coords = (torch.rand(n_samples, dim, generator=g) * 2 - 1).to(device)
+    table = (torch.randn(T, F, generator=g) * 0.01).to(device)
+    go = torch.randn(n_samples, len(res) * F, generator=g).to(device)
+    tf = torch.as_tensor(first, dtype=torch.int32, device=device)
+    fwd = ref.hashgrid_interpolate_cuda if dim == 3 else ref.hashgrid_interpolate2d_cuda
+    bwd = ref.hashgrid_interpolate_backward_cuda if dim == 3 else ref.hashgrid_interpolate2d_backward_cuda
+    res = [int(r) for r in res]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_f = t_b = 0.0
+    for it in range(iters + 1):
+        ev[0].record()
+        fwd(coords, table, tf, res, bw)
+        ev[1].record()
+        bwd(coords, go, table, tf, res, bw, F, False)
+        ev[2].record()
+        torch.cuda.synchronize()
+        if it:  # first pass = warm-up
+            t_f += ev[0].elapsed_time(ev[1])
+            t_b += ev[1].elapsed_time(ev[2])
+    t_f /= iters
+    t_b /= iters
+    return {"value": n_samples / ((t_f + t_b) * 1e-3), "unit": "samples/s", "ms_forward": t_f, "ms_backward": t_b,
+            "samples": n_samples, "kind": "reference",
+            "what": "the reference's hash-grid operators (L launches each way, one atomicAdd per corner and feature) built "
+                    "for gfx950 by oracle/ref_build.py, torch events on the current stream"}
+
+
 def psnr_parity(device, steps=200, height=64, width=96, seeds=(2, 3, 4, 5)):
     """PSNR at a fixed step, HIP path vs the CPU restatement of the reference kernels (the C
     oracle behind the same host code), same init / batches / entropy noise. A reduced image so that the scalar CPU leg
@@ -710,6 +746,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, res, bw, F, first_np, T, min(args.cpu_samples, n_local),
                                                args.cpu_budget_s)
+            out["cpu_baseline"]["reference_kernels_on_this_gpu"] = reference_kernels_on_this_gpu(
+                device, dim, res, bw, F, first_np, T, n_local)
             if args.psnr_steps > 0:
                 out["psnr_parity"] = psnr_parity(device)
         else:

@@ -452,13 +452,25 @@ __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__restrict__ 
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0u;
 }
 
-// a[j] for a lane-dependent j without a scratch array (select chain)
-template <int F> __device__ __forceinline__ float pick(const float (&a)[F], int j) {
-    float v = a[0];
+// Feature order rotated by a lane-dependent amount WITHOUT a private array: r[k] = a[(k + rot) mod F]. (Round 4: the previous
+// form, a select chain `pick(a, j)` per atomic, was turned back into a dynamically indexed stack array by the compiler for
+// F = 4 -- `scratch_store_dwordx4` + one `scratch_load_dword` per LDS atomic, 1 254 scratch instructions in the consume
+// kernel: nerf_lego.yaml's table paid 2x on its consume pass for it.) A butterfly of conditional swaps on the bits of `rot`,
+// once per gradient vector; the opaque barrier on the conditions keeps the optimiser from recognising an indexed array again.
+template <int F> __device__ __forceinline__ void rotate_features(const float (&a)[F], int rot, float (&r)[F]) {
+    static_assert(F == 1 || F == 2 || F == 4 || F == 8, "power-of-two feature counts");
 #pragma unroll
-    for (int k = 1; k < F; ++k) v = (j == k) ? a[k] : v;
-    return v;
+    for (int k = 0; k < F; ++k) r[k] = a[k];
+#pragma unroll
+    for (int bit = 1; bit < F; bit <<= 1) {
+        int on = rot & bit;
+        asm volatile("" : "+v"(on));   // opaque: a plain v_cndmask per element, never a table lookup
+        float t[F];
+#pragma unroll
+        for (int k = 0; k < F; ++k) t[k] = on ? r[(k + bit) & (F - 1)] : r[k];
+#pragma unroll
+        for (int k = 0; k < F; ++k) r[k] = t[k];
+    }
 }
-
 
 }  // namespace shacira

@@ -285,6 +285,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     }
 }
 
+#ifdef CONSUME_TRACE
+// Instrumented build only (make variant ... EXTRA=-DCONSUME_TRACE; tools/consume_trace.py): per work unit, wave 0's clock
+// (100 MHz) at the phase boundaries of consume_unit. Never compiled into the shipped library.
+__device__ unsigned long long g_consume_trace[16384 * 8];
+__device__ unsigned int g_consume_trace_n;
+#define CTRACE(k) do { if (threadIdx.x == 0) ctr[k] = wall_clock64(); } while (0)
+#else
+#define CTRACE(k) do { } while (0)
+#endif
 // ------------------------------------------------------------------------------------------------- pass C
 // One work unit (a bucket, or a chunk of an over-full one) on the calling workgroup. Every item format streams the same way
 // (`stream` below): the first round of 16-byte loads goes out BEFORE the image is zeroed, so the zeroing and its barrier sit
@@ -310,6 +319,25 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
     FxScale fx{1.0, 1.0, false};
     if constexpr (FX) fx = fx_scale_of(d.gmax_bits, headroom);
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_acc);
+#ifdef CONSUME_TRACE
+    unsigned long long ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    struct TraceOut {
+        unsigned long long *c; UnitDesc dd;
+        __device__ ~TraceOut() {
+            if (threadIdx.x == 0) {
+                c[5] = wall_clock64();
+                const unsigned int slot = atomicAdd(&g_consume_trace_n, 1u);
+                if (slot < 16384u) {
+                    unsigned long long *o = g_consume_trace + (size_t)slot * 8;
+                    o[0] = ((unsigned long long)dd.level << 32) | dd.bucket;
+                    o[1] = dd.end - dd.begin;
+                    for (int k = 0; k < 6; ++k) o[2 + k] = c[k];
+                }
+            }
+        }
+    } trace_out{ctr, d};
+#endif
+    CTRACE(0);
     auto zero_image = [&]() {
         for (uint32_t e = threadIdx.x; e < nrows * F; e += kConsumeThreads) s_acc[e] = 0.0;   // all-zero bits either way
         lds_barrier();
@@ -320,39 +348,49 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
     auto stream = [&](uint64_t first, uint64_t lim, uint64_t stride, auto &&load, auto &&proc) {
         uint64_t p0 = first;
         load(p0);
+        CTRACE(1);      // first round issued
         zero_image();
+        CTRACE(2);      // image zeroed (barrier passed)
         proc();
+        CTRACE(3);      // first round added (its loads have arrived)
         hook();
         for (p0 += stride; p0 < lim; p0 += stride) {
             load(p0);
             proc();
         }
+        CTRACE(4);      // every round of this wave added
     };
     const int rot = (int)(threadIdx.x & (F - 1));
     // feature order rotated by lane: the F slots of a row are consecutive 8-byte words, so with every lane adding feature j
     // in the same instruction only 1 / F of the LDS banks were addressed (half of the pass's LDS cycles were bank conflicts)
-    auto add_row = [&](uint32_t row, const float (&v)[F], float w) {
+    // `vr` = the gradient vector ALREADY rotated by the lane's `rot` (rotate_features, once per item): step jj adds feature
+    // (jj + rot) mod F
+    auto add_row = [&](uint32_t row, const float (&vr)[F], float w) {
 #pragma unroll
         for (int jj = 0; jj < F; ++jj) {
             const int j = (jj + rot) & (F - 1);
-            const float c = pick<F>(v, j) * w;
+            const float c = vr[jj] * w;
             if (FX && fx.fixed) atomicAdd(&s_fix[row * F + j], fx_encode(c, fx.scale));
             else atomicAdd(&s_acc[row * F + j], (double)c);
         }
     };
     auto add_pair = [&](uint32_t ra, uint32_t rb, bool va, bool vb, float fxv, const float (&a)[F]) {
-        if (va) add_row(ra, a, 1.0f - fxv);
-        if (vb) add_row(rb, a, fxv);
+        float ar[F];
+        rotate_features<F>(a, rot, ar);
+        if (va) add_row(ra, ar, 1.0f - fxv);
+        if (vb) add_row(rb, ar, fxv);
     };
     const uint32_t r2 = r1 * r1;
     auto add_compact = [&](uint32_t base_row, float fxx, float fyy, float fzz, const float (&gg)[F]) {
         const float gxx = 1.0f - fxx, gyy = 1.0f - fyy, gzz = 1.0f - fzz;
         const float wxy[4] = {gxx * gyy, gxx * fyy, fxx * gyy, fxx * fyy};   // reference order: (x * y) * z
+        float gr[F];
+        rotate_features<F>(gg, rot, gr);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t row = base_row + ((c >> 2) & 1) + ((c >> 1) & 1) * r1 + (c & 1) * r2;
             if (row >= nrows) continue;   // cannot happen for in-range cells; keeps the image safe
-            add_row(row, gg, wxy[c >> 1] * ((c & 1) ? fzz : gzz));
+            add_row(row, gr, wxy[c >> 1] * ((c & 1) ? fzz : gzz));
         }
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -381,19 +419,21 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
                            const float q = 1.0f / 33554432.0f;
                            const float fxx = (float)qx * q, fyy = (float)qy * q;
                            const float gxx = 1.0f - fxx, gyy = 1.0f - fyy;
+                           float ar[F];
+                           rotate_features<F>(it[u].a, rot, ar);
                            // a zero fraction = a corner of weight 0 (it lies outside the level when the coordinate was clamped
                            // onto the last line / column): skipped, like the pair items' validity bits
                            if (local + r1 + 1u < nrows) {
-                               add_row(local, it[u].a, gxx * gyy);
-                               if (qx) add_row(local + 1u, it[u].a, fxx * gyy);
+                               add_row(local, ar, gxx * gyy);
+                               if (qx) add_row(local + 1u, ar, fxx * gyy);
                                if (qy) {
-                                   add_row(local + r1, it[u].a, gxx * fyy);
-                                   if (qx) add_row(local + r1 + 1u, it[u].a, fxx * fyy);
+                                   add_row(local + r1, ar, gxx * fyy);
+                                   if (qx) add_row(local + r1 + 1u, ar, fxx * fyy);
                                }
                            } else {   // the level's last line: only rows inside the image
-                               if (local < nrows) add_row(local, it[u].a, gxx * gyy);
-                               if (qx && local + 1u < nrows) add_row(local + 1u, it[u].a, fxx * gyy);
-                               if (qy && local + r1 < nrows) add_row(local + r1, it[u].a, gxx * fyy);
+                               if (local < nrows) add_row(local, ar, gxx * gyy);
+                               if (qx && local + 1u < nrows) add_row(local + 1u, ar, fxx * gyy);
+                               if (qy && local + r1 < nrows) add_row(local + r1, ar, gxx * fyy);
                            }
                        }
                    });
@@ -661,7 +701,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
     const uint32_t unit_end = unit_first[plan.total_buckets];
     if (unit_end == 0u) return;
     uint32_t nxt = 0;          // thread 0: the unit after the current one
-    UnitDesc dn;               // thread 0: its descriptor
+    __shared__ UnitDesc s_desc_nxt;   // its descriptor (in LDS: as a local of thread 0 it lived in scratch memory)
     if (threadIdx.x == 0) {
         const uint32_t u = atomicAdd(work_counter, 1u);
         s_unit = u;
@@ -674,12 +714,12 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         const UnitDesc d = s_desc;
         if (threadIdx.x == 0) nxt = atomicAdd(work_counter, 1u);
         consume_unit<F, FX, H>(lt, plan, first_idx, d, items, grad_table, force_atomic, headroom, s_acc, [&]() {
-            if (threadIdx.x == 0) dn = unit_desc[nxt < unit_end ? nxt : unit_end - 1u];
+            if (threadIdx.x == 0) s_desc_nxt = unit_desc[nxt < unit_end ? nxt : unit_end - 1u];
         });
         // (every thread read s_unit / s_desc before the barriers inside consume_unit: thread 0 may overwrite them now)
         if (threadIdx.x == 0) {
             s_unit = nxt;
-            s_desc = dn;
+            s_desc = s_desc_nxt;
         }
         lds_barrier();   // the next unit is known and the image is free again; the flush stores keep draining
     }
@@ -833,6 +873,8 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
                 bool in_range = true;
 #pragma unroll
                 for (int j = 0; j < F; ++j) in_range = in_range && (fabsf(g[k][j]) <= lim);
+                float gr[F];   // g[k] in the lane's rotated feature order
+                rotate_features<F>(g[k], rotd, gr);
 #pragma unroll
                 for (int kc = 0; kc < NC; ++kc) {
                     if (c.row[kc] < bl.used) {
@@ -841,7 +883,7 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
 #pragma unroll
                             for (int jj = 0; jj < F; ++jj) {   // feature order rotated by lane (LDS bank spreading)
                                 const int j = (jj + rotd) & (F - 1);
-                                atomicAdd(s_fix + slot + j, fx_encode(pick<F>(g[k], j) * c.w[kc], scale));
+                                atomicAdd(s_fix + slot + j, fx_encode(gr[jj] * c.w[kc], scale));
                             }
                         } else if (fixed) {
                             // a gradient beyond the pilot's limit, or non-finite (rare): that feature goes straight to the table
@@ -859,7 +901,7 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
 #pragma unroll
                             for (int jj = 0; jj < F; ++jj) {
                                 const int j = (jj + rotd) & (F - 1);
-                                atomicAdd(s_acc + slot + j, (double)(pick<F>(g[k], j) * c.w[kc]));
+                                atomicAdd(s_acc + slot + j, (double)(gr[jj] * c.w[kc]));
                             }
                         }
                     }

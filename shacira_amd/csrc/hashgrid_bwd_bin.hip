@@ -775,3 +775,20 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
 }
 
 }  // namespace shacira
+
+#ifdef CONSUME_TRACE
+// instrumented build only: copies the trace out and clears it (tools/consume_trace.py)
+extern "C" __attribute__((visibility("default"))) int shacira_debug_consume_trace(unsigned long long *host, unsigned int cap,
+                                                                                   unsigned int *count) {
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(shacira::g_consume_trace_n), sizeof(n)) != hipSuccess) return 1;
+    *count = n;
+    if (n > cap) n = cap;
+    if (n > 16384u) n = 16384u;
+    if (n && hipMemcpyFromSymbol(host, HIP_SYMBOL(shacira::g_consume_trace), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess)
+        return 2;
+    unsigned int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(shacira::g_consume_trace_n), &zero, sizeof(zero)) != hipSuccess) return 3;
+    return 0;
+}
+#endif
