@@ -78,7 +78,15 @@ template <> struct Scalar<double> {   // fp64 tables: values narrowed to float a
 };
 template <> struct Scalar<__half> {
     static __device__ __forceinline__ float load(const __half *p) { return __half2float(*p); }
-    static __device__ __forceinline__ void store(__half *p, float v) { *p = __float2half_rn(v); }
+    // The fp32 value is made opaque before it is narrowed: the reference rounds its fmaf chain to fp32 and THEN converts
+    // (static_cast<scalar_t>(feat), .cu:106). Left visible, the compiler fuses the chain's last fma with the conversion into
+    // v_fma_mixlo_f16 -- one rounding instead of two, a different half in ~1 of 10^4 values (seen in round 4 when the gathers
+    // became unconditional; the hipcc build of the reference itself does it, tests/test_ref_kernel_vectors.py).
+    static __device__ __forceinline__ float rounded_fp32(float v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
+    static __device__ __forceinline__ void store(__half *p, float v) { *p = __float2half_rn(rounded_fp32(v)); }
 };
 
 // Corner bookkeeping for one (sample, level). NC = 2^DIM.

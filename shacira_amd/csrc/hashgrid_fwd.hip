@@ -48,13 +48,25 @@ template <typename T, int F> __device__ __forceinline__ void load_row(const T *p
     }
 }
 
+// One table row for a lane that may have none (sample beyond the batch, row beyond the table): the load is UNCONDITIONAL from
+// a clamped row and the result is masked afterwards. (Round 4: as `if (ok) load else 0` every gather sat in its own
+// lane-dependent branch and the compiler closed each branch with `s_waitcnt vmcnt(0)` -- the four corner gathers of a sample
+// went out one round trip after the other instead of together; ISA of hashgrid_fwd_level_pair_kernel.)
+template <typename T, int F>
+__device__ __forceinline__ void gather_row(const T *__restrict__ table, int64_t grow, bool ok, float (&v)[F]) {
+    const int64_t safe = ok ? grow : 0;
+    load_row<T, F>(table + safe * F, v);
+#pragma unroll
+    for (int j = 0; j < F; ++j) v[j] = ok ? v[j] : 0.0f;
+}
+
 template <typename T, int F> __device__ __forceinline__ void store_row(T *p, const float (&v)[F]) {
     if constexpr (sizeof(T) == 4 && F == 2) {
         *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
     } else if constexpr (sizeof(T) == 4 && F == 4) {
         *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
     } else if constexpr (sizeof(T) == 2 && F == 2) {
-        *reinterpret_cast<__half2 *>(p) = __floats2half2_rn(v[0], v[1]);
+        *reinterpret_cast<__half2 *>(p) = __floats2half2_rn(Scalar<__half>::rounded_fp32(v[0]), Scalar<__half>::rounded_fp32(v[1]));
     } else {
 #pragma unroll
         for (int j = 0; j < F; ++j) Scalar<T>::store(p + j, v[j]);
@@ -98,12 +110,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(LevelTable lt, const 
             for (int k = 0; k < NC; ++k) {
                 const int64_t row = base + (int64_t)c.row[k];
                 float v[F];
-                if ((uint64_t)row < (uint64_t)lt.table_rows) {
-                    load_row<T, F>(table + row * F, v);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < F; ++j) v[j] = 0.0f;
-                }
+                gather_row<T, F>(table, row, (uint64_t)row < (uint64_t)lt.table_rows, v);
 #pragma unroll
                 for (int j = 0; j < F; ++j) acc[j] = (k == 0) ? v[j] * c.w[0] : fmaf(v[j], c.w[k], acc[j]);
             }
@@ -355,12 +362,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_pair_kernel(LevelTable lt, c
                 row &= lt.mask;
             }
             const int64_t grow = base + (int64_t)row;
-            if (live && (uint64_t)grow < (uint64_t)lt.table_rows) {
-                load_row<T, F>(table + grow * F, v[q]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < F; ++j) v[q][j] = 0.0f;
-            }
+            gather_row<T, F>(table, grow, live && (uint64_t)grow < (uint64_t)lt.table_rows, v[q]);
         }
         // partner's values: lane ^ 1 (DPP quad_perm [1,0,3,2])
         float pv[NH][F];
@@ -443,8 +445,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
     const int64_t i = wave_s0 + sl;
     const bool live = i < N;
     // one 16-byte record per sample: {x, y, z (0 in 2-D), bit pattern of the sample's original index}
-    float4 c4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (live) c4 = sorted4[i];
+    const float4 c4 = sorted4[live ? i : N - 1];   // (clamped, unconditional: a dead lane's values are never stored)
     double t[DIM];
     t[0] = axis_unit(c4.x);
     t[1] = axis_unit(c4.y);
@@ -472,16 +473,14 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
                 for (int dz = 0; dz < 2; ++dz) {
                     const uint32_t row = (uint32_t)p[0] + ((uint32_t)p[1] + (uint32_t)dx) * r + ((uint32_t)p[2] + dz) * r * r;
                     const int64_t grow = base + (int64_t)row;
-                    if (live && (uint64_t)(grow + 1) < (uint64_t)lt.table_rows) {
-                        const f32x4u q4 = *reinterpret_cast<const f32x4u *>(table + grow * 2);
-                        w4[dz][0] = q4.x; w4[dz][1] = q4.y; w4[dz][2] = q4.z; w4[dz][3] = q4.w;
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) w4[dz][c] = 0.0f;
-                        if (live && (uint64_t)grow < (uint64_t)lt.table_rows) {   // last row of the table: x only
-                            w4[dz][0] = Scalar<T>::load(table + grow * 2);
-                            w4[dz][1] = Scalar<T>::load(table + grow * 2 + 1);
-                        }
+                    // (unconditional load from a clamped row, masked afterwards: see gather_row)
+                    const bool ok16 = live && (uint64_t)(grow + 1) < (uint64_t)lt.table_rows;
+                    const f32x4u q4 = *reinterpret_cast<const f32x4u *>(table + (ok16 ? grow : 0) * 2);
+                    w4[dz][0] = ok16 ? q4.x : 0.0f; w4[dz][1] = ok16 ? q4.y : 0.0f;
+                    w4[dz][2] = ok16 ? q4.z : 0.0f; w4[dz][3] = ok16 ? q4.w : 0.0f;
+                    if (!ok16 && live && (uint64_t)grow < (uint64_t)lt.table_rows) {   // last row of the table: x only (rare)
+                        w4[dz][0] = Scalar<T>::load(table + grow * 2);
+                        w4[dz][1] = Scalar<T>::load(table + grow * 2 + 1);
                     }
                 }
                 float o4[2][4];
@@ -524,12 +523,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
                 row &= lt.mask;
             }
             const int64_t grow = base + (int64_t)row;
-            if (live && (uint64_t)grow < (uint64_t)lt.table_rows) {
-                load_row<T, F>(table + grow * F, v[q]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < F; ++j) v[q][j] = 0.0f;
-            }
+            gather_row<T, F>(table, grow, live && (uint64_t)grow < (uint64_t)lt.table_rows, v[q]);
         }
         float pv[NH][F];
 #pragma unroll
@@ -640,8 +634,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
         live[u] = i < N;
         double t[DIM];
         if constexpr (PACKED) {
-            float4 c4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (live[u]) c4 = reinterpret_cast<const float4 *>(coords)[i];
+            const float4 c4 = reinterpret_cast<const float4 *>(coords)[live[u] ? i : N - 1];   // clamped, unconditional
             t[0] = axis_unit(c4.x);
             t[1] = axis_unit(c4.y);
             if constexpr (DIM == 3) t[2] = axis_unit(c4.z);
@@ -667,12 +660,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
                 row &= lt.mask;
             }
             const int64_t grow = base + (int64_t)row;
-            if (live[u] && (uint64_t)grow < (uint64_t)lt.table_rows) {
-                load_row<T, F>(table + grow * F, v[u][q]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < F; ++j) v[u][q][j] = 0.0f;
-            }
+            gather_row<T, F>(table, grow, live[u] && (uint64_t)grow < (uint64_t)lt.table_rows, v[u][q]);
         }
     }
 #pragma unroll
