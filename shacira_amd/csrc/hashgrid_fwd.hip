@@ -469,18 +469,28 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
                 // the partner's four pieces come over DPP and lane 0 runs the corner sum in the reference's order.
                 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(8)));
                 float w4[2][4];
+                // both 16-byte loads first (unconditional, from a clamped row: see gather_row), masks and the rare single-row
+                // fallback afterwards -- with the fallback between them the second load waited for the first (round 4)
+                int64_t grow2[2];
+                bool ok16[2];
+                f32x4u q4[2];
 #pragma unroll
                 for (int dz = 0; dz < 2; ++dz) {
                     const uint32_t row = (uint32_t)p[0] + ((uint32_t)p[1] + (uint32_t)dx) * r + ((uint32_t)p[2] + dz) * r * r;
-                    const int64_t grow = base + (int64_t)row;
-                    // (unconditional load from a clamped row, masked afterwards: see gather_row)
-                    const bool ok16 = live && (uint64_t)(grow + 1) < (uint64_t)lt.table_rows;
-                    const f32x4u q4 = *reinterpret_cast<const f32x4u *>(table + (ok16 ? grow : 0) * 2);
-                    w4[dz][0] = ok16 ? q4.x : 0.0f; w4[dz][1] = ok16 ? q4.y : 0.0f;
-                    w4[dz][2] = ok16 ? q4.z : 0.0f; w4[dz][3] = ok16 ? q4.w : 0.0f;
-                    if (!ok16 && live && (uint64_t)grow < (uint64_t)lt.table_rows) {   // last row of the table: x only (rare)
-                        w4[dz][0] = Scalar<T>::load(table + grow * 2);
-                        w4[dz][1] = Scalar<T>::load(table + grow * 2 + 1);
+                    grow2[dz] = base + (int64_t)row;
+                    ok16[dz] = live && (uint64_t)(grow2[dz] + 1) < (uint64_t)lt.table_rows;
+                    q4[dz] = *reinterpret_cast<const f32x4u *>(table + (ok16[dz] ? grow2[dz] : 0) * 2);
+                }
+#pragma unroll
+                for (int dz = 0; dz < 2; ++dz) {
+                    w4[dz][0] = ok16[dz] ? q4[dz].x : 0.0f; w4[dz][1] = ok16[dz] ? q4[dz].y : 0.0f;
+                    w4[dz][2] = ok16[dz] ? q4[dz].z : 0.0f; w4[dz][3] = ok16[dz] ? q4[dz].w : 0.0f;
+                }
+#pragma unroll
+                for (int dz = 0; dz < 2; ++dz) {
+                    if (!ok16[dz] && live && (uint64_t)grow2[dz] < (uint64_t)lt.table_rows) {   // last row of the table: x only
+                        w4[dz][0] = Scalar<T>::load(table + grow2[dz] * 2);
+                        w4[dz][1] = Scalar<T>::load(table + grow2[dz] * 2 + 1);
                     }
                 }
                 float o4[2][4];
@@ -555,10 +565,22 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
     // fine levels: pieces of the wave's 32 samples, lanes consecutive along the samples
     const Piece *fine = reinterpret_cast<const Piece *>(staged);
     const int nf = L - lc;
-    for (int e = lane; e < 32 * nf; e += 64) {
-        const int rr = e & 31, lf = e >> 5;
-        if (rr < rows)
-            reinterpret_cast<Piece *>(my + (size_t)rr * pitch)[lc + lf] = fine[(int64_t)(lc + lf) * N + wave_s0 + rr];
+    // (four loads in flight per lane, then their LDS writes: one load -> wait -> write per trip was a chain of nf / 2 round trips)
+    for (int e0 = lane; e0 < 32 * nf; e0 += 256) {
+        Piece pc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = e0 + 64 * k;
+            const int rr = e & 31, lf = e >> 5;
+            const bool ok = e < 32 * nf && rr < rows;
+            pc[k] = fine[ok ? (int64_t)(lc + lf) * N + wave_s0 + rr : (int64_t)lc * N + wave_s0];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = e0 + 64 * k;
+            const int rr = e & 31, lf = e >> 5;
+            if (e < 32 * nf && rr < rows) reinterpret_cast<Piece *>(my + (size_t)rr * pitch)[lc + lf] = pc[k];
+        }
     }
     if (dx == 0 && sl < rows) *reinterpret_cast<uint32_t *>(my + (size_t)sl * pitch + pitch - 16u) = __float_as_uint(c4.w);
     // wave-private staging: no workgroup barrier (the wave's own LDS writes are visible to it after the wait below)
