@@ -149,15 +149,21 @@ __global__ __launch_bounds__(kSortThreadsS) void ctx_count_kernel(TilePlan tp, c
     for (uint32_t k = threadIdx.x; k < tp.num_blocks; k += kSortThreadsS) s_hist[k] = 0;
     __syncthreads();
     const int64_t s0 = (int64_t)blockIdx.x * kSortTileS;
+    constexpr int U = kSortTileS / kSortThreadsS;
+    // every coordinate load of the thread first, unconditional from a clamped index (round 4: under `if (i < N)` each
+    // iteration's loads were closed by their own s_waitcnt -- U serialised round trips per thread)
+    float c[U][DIM];
 #pragma unroll
-    for (int u = 0; u < kSortTileS / kSortThreadsS; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
-        if (i < N) {
-            float c[DIM];
+        const int64_t ic = i < N ? i : N - 1;
 #pragma unroll
-            for (int a = 0; a < DIM; ++a) c[a] = coords[i * DIM + a];
-            atomicAdd(&s_hist[block_key<DIM>(c, tp)], 1u);
-        }
+        for (int a = 0; a < DIM; ++a) c[u][a] = coords[ic * DIM + a];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
+        if (i < N) atomicAdd(&s_hist[block_key<DIM>(c[u], tp)], 1u);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < tp.num_blocks; k += kSortThreadsS)
@@ -243,18 +249,35 @@ __global__ __launch_bounds__(kSortThreadsS) void ctx_scatter_kernel(TilePlan tp,
     for (uint32_t k = threadIdx.x; k < tp.num_blocks; k += kSortThreadsS) s_hist[k] = 0;
     __syncthreads();
     const int64_t s0 = (int64_t)blockIdx.x * kSortTileS;
+    constexpr int U = kSortTileS / kSortThreadsS;
+    // three batches of memory operations instead of U dependent chains (see ctx_count_kernel): coordinates, then the two
+    // offsets of every sample, then the records
+    float c[U][DIM];
 #pragma unroll
-    for (int u = 0; u < kSortTileS / kSortThreadsS; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
-        if (i < N) {
-            float c[DIM];
+        const int64_t ic = i < N ? i : N - 1;
 #pragma unroll
-            for (int a = 0; a < DIM; ++a) c[a] = coords[i * DIM + a];
-            const uint32_t key = block_key<DIM>(c, tp);
-            const uint32_t rank = atomicAdd(&s_hist[key], 1u);
-            const uint32_t pos = block_start[key] + tile_off[(size_t)key * tp.num_tiles + blockIdx.x] + rank;
-            sorted4[pos] = make_float4(c[0], c[1], DIM == 3 ? c[DIM - 1] : 0.0f, __uint_as_float((uint32_t)i));
-        }
+        for (int a = 0; a < DIM; ++a) c[u][a] = coords[ic * DIM + a];
+    }
+    uint32_t key[U], rank[U], b0[U], t0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
+        key[u] = block_key<DIM>(c[u], tp);
+        rank[u] = (i < N) ? atomicAdd(&s_hist[key[u]], 1u) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        b0[u] = block_start[key[u]];
+        t0[u] = tile_off[(size_t)key[u] * tp.num_tiles + blockIdx.x];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
+        if (i < N)
+            sorted4[b0[u] + t0[u] + rank[u]] =
+                make_float4(c[u][0], c[u][1], DIM == 3 ? c[u][DIM - 1] : 0.0f, __uint_as_float((uint32_t)i));
     }
 }
 
