@@ -127,26 +127,47 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
     int hcol[HE];
     uint32_t hsum[HE];
     if constexpr (COUNT) {
+        // word k = tid + j * 512 <-> (level slot k / 128, bucket k % 128): the slot is uniform over a wave (128 = two waves), so
+        // it is made a scalar and the two plan words come by scalar loads. (Round 4: with a lane-dependent index into the
+        // by-value plan the compiler read the kernel arguments through VECTOR loads -- blevel[li] -> lv[..].nb -> bstart[li],
+        // 3 dependent global loads x 8 words, each behind its own s_waitcnt: 24 serialised round trips at the start of
+        // every workgroup, most of this kernel's time on the small NeRF batches.)
+        static_assert(kFrontThreads % kMaxLevelBuckets == 0, "a wave maps to one level slot");
+        const uint32_t li0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kMaxLevelBuckets));
+        const uint32_t b = threadIdx.x % kMaxLevelBuckets;
 #pragma unroll
         for (int j = 0; j < HE; ++j) {
-            const uint32_t k = threadIdx.x + j * kFrontThreads, li = k / kMaxLevelBuckets, b = k % kMaxLevelBuckets;
-            hcol[j] = (li < plan.nbl && b < plan.lv[plan.blevel[li < plan.nbl ? li : 0]].nb) ? (int)(plan.bstart[li] + b) : -1;
+            const uint32_t li = li0 + (uint32_t)j * (kFrontThreads / kMaxLevelBuckets);
+            const uint32_t lc = li < (uint32_t)SHACIRA_MAX_LODS ? li : 0u;
+            const uint32_t nbq = li < plan.nbl ? plan.bnb[lc] : 0u, bsq = plan.bstart[lc];
+            hcol[j] = (b < nbq) ? (int)(bsq + b) : -1;
             hsum[j] = 0;
         }
+    }
+    // The counting thread's coordinates, loaded ONE ROUND AHEAD as a loop-carried value. (Round 4, ISA: loaded at the top of
+    // the round the compiler sank them into the `csm < ns` block below -- behind the eight row loads -- and the counting began
+    // with s_waitcnt vmcnt(0), i.e. after every row had arrived instead of while they were in flight. A value carried over
+    // the back edge cannot be sunk; being older than the round's row loads it costs vmcnt(8), not vmcnt(0).)
+    float cc[DIM];
+    auto load_coords = [&](int r) {
+        int64_t t = tile0 + r;
+        if (t >= tiles) t = tiles - 1;
+        const int64_t s0r = t << ts_log2;
+        const int nsr = (int)((N - s0r < TS) ? (N - s0r) : TS);
+        const int64_t ci = s0r + (csm < nsr ? csm : nsr - 1);
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) cc[a] = coords[ci * DIM + a];
+    };
+    if constexpr (COUNT) {
+        if (tile0 < tiles) load_coords(0);
     }
     for (int r = 0; r < rounds && tile0 + r < tiles; ++r) {
         const int64_t s0 = (tile0 + r) << ts_log2;
         const int ns = (int)((N - s0 < TS) ? (N - s0) : TS);
         const int total = ns * VPR;
-        // the sample's coordinates FIRST (vmcnt counts in order: the counting then waits for them only), then the row
-        // vectors; all loads unconditional with clamped indices (a branch around a load makes the compiler wait with
+        // row vectors: all loads unconditional with clamped indices (a branch around a load makes the compiler wait with
         // vmcnt(0) in front of the counting, which would serialise it with the row loads)
-        float cc[DIM];
-        if constexpr (COUNT) {
-            const int64_t ci = s0 + (csm < ns ? csm : ns - 1);
-#pragma unroll
-            for (int a = 0; a < DIM; ++a) cc[a] = coords[ci * DIM + a];
-        }
+        // (the sample's coordinates are already in flight or in: loaded one round ahead, see the end of the loop body)
         const u32x4 *in = reinterpret_cast<const u32x4 *>(go) + s0 * VPR;
         u32x4 raw[UL];
 #pragma unroll
@@ -155,10 +176,11 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
             raw[u] = __builtin_nontemporal_load(in + (e < total ? e : total - 1));   // idle lanes: one merged request
         }
         if constexpr (COUNT) {
-            if (csm < ns) {
-                double t[DIM];
+            double t[DIM];
 #pragma unroll
-                for (int a = 0; a < DIM; ++a) t[a] = axis_unit(cc[a]);
+            for (int a = 0; a < DIM; ++a) t[a] = axis_unit(cc[a]);
+            load_coords(r + 1);   // next round's (clamped to the last tile): in flight behind this round's rows
+            if (csm < ns) {
 #pragma unroll 2
                 for (uint32_t li = (uint32_t)cslot; li < plan.nbl; li += (uint32_t)cslots)
                     count_level<DIM>(t, plan.cl[li], lt.mask, s_hist + li * kMaxLevelBuckets);

@@ -307,7 +307,10 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
                                              const UnitDesc d, const typename ItemSel<F, H>::type *__restrict__ items,
                                              float *__restrict__ grad_table, int force_atomic, int headroom, double *s_acc,
                                              Hook &&hook) {
-    const uint32_t gb = d.bucket, lvl = d.level;
+    // (uniform over the workgroup -- every thread copied the same descriptor out of LDS; as scalars the level's record comes
+    // out of the kernel arguments by scalar loads instead of one vector load per field)
+    const uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.bucket);
+    const uint32_t lvl = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.level);
     const BinLevel bl = plan.lv[lvl];
     const uint32_t b = gb - bl.bucket0;
     const uint32_t r1 = (uint32_t)lt.res[lvl];

@@ -65,6 +65,7 @@ struct BinPlan {
     uint32_t nbl;       // number of binned levels
     uint32_t blevel[SHACIRA_MAX_LODS];  // their level indices (grid.y of passes A/B); 32-bit = scalar loads
     uint32_t bstart[SHACIRA_MAX_LODS];  // first global bucket of binned level q (= lv[blevel[q]].bucket0)
+    uint32_t bnb[SHACIRA_MAX_LODS];     // its number of buckets (= lv[blevel[q]].nb): one unchained scalar load in the front kernel
     uint32_t ngroups;   // groups of direct levels
     uint32_t gmask[SHACIRA_MAX_LODS];   // levels of each group (bit l)
     uint32_t grows[SHACIRA_MAX_LODS];   // rows of each group's LDS image

@@ -284,7 +284,10 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
             }
         }
     }
-    for (uint32_t q = 0; q < plan.nbl; ++q) plan.bstart[q] = plan.lv[plan.blevel[q]].bucket0;
+    for (uint32_t q = 0; q < (uint32_t)SHACIRA_MAX_LODS; ++q) {
+        plan.bstart[q] = q < plan.nbl ? plan.lv[plan.blevel[q]].bucket0 : 0u;
+        plan.bnb[q] = q < plan.nbl ? plan.lv[plan.blevel[q]].nb : 0u;
+    }
     plan.total_buckets = nbk;
     plan.BR = BR;
     plan.num_tiles = (uint32_t)((n_batch + tile_samples(dim) - 1) / tile_samples(dim));
