@@ -91,6 +91,10 @@ def lib():
                     raise RuntimeError(
                         f"shacira_amd: HIP library not built ({LIB_PATH} missing). Build it with "
                         "`make -C shacira_amd/csrc` (hipcc --offload-arch=gfx950); there is no CPU fallback.")
+                # torch's own HIP runtime must be the one in the process: loaded first, libshacira_hip.so binds to it. Loaded
+                # the other way round (this library pulling in the system libamdhip64 before `import torch`) the two
+                # runtimes disagree and every launch fails with "no ROCm-capable device" (seen on the GPU box, round 4).
+                import torch  # noqa: F401
                 handle = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(handle, name)
