@@ -28,7 +28,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     constexpr int NP = 1 << (DIM - 1);
     constexpr int kTileD = TileOf<DIM>::value;
     constexpr int SPT = kTileD / kBinThreads;  // samples per thread
-    constexpr int kStage = kTileD * NP;        // staged items per block
+    // staged items per PASS: the tile's kTileD * NP items (sorted by bucket) go through the LDS buffer in kScatterSplit windows
+    // of their sorted order, so the buffer is 1 / kScatterSplit of the tile and more workgroups share a CU (round 4: F = 2
+    // 69 -> 35 KiB = four instead of two, F = 4 100 -> 51 KiB = three instead of one) while a (tile, bucket) run keeps its
+    // length -- it is written in one window, or in two parts where a window boundary falls inside it
+    constexpr int kScatterSplit = ScatterSplit<ItemT>::value;
+    constexpr int kStage = kTileD * NP / kScatterSplit;
+    static_assert(kStage % 2 == 0, "two-slot items never straddle a window");
     extern __shared__ __align__(16) unsigned char s_raw[];
     ItemT *s_items = reinterpret_cast<ItemT *>(s_raw);
     uint8_t *s_bucket = reinterpret_cast<uint8_t *>(s_items + kStage);
@@ -156,12 +162,21 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         if (lane == 63) s_start[bl.nb] = incl;
     }
     lds_barrier();
+    // one window (kScatterSplit == 1: the loop and the window test vanish at compile time -- the formats that do not gain
+    // from windows keep the code they had) or ceil(staged / kStage) of them; an item's position in the tile's sorted order is
+    // re-read per window (an array of positions cost ten registers and 1-3 % on every format)
+    const uint32_t staged = s_start[bl.nb];
+    const uint32_t n_win = (kScatterSplit == 1) ? 1u : (staged + (uint32_t)kStage - 1u) / (uint32_t)kStage;
+    for (uint32_t wi = 0; wi < n_win; ++wi) {
+    const uint32_t w0 = wi * (uint32_t)kStage;
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             if (ps[u][q].key >> 26) {
-                const uint32_t pos = s_start[ps[u][q].bucket] + rank[u][q];
+                const uint32_t gp = s_start[ps[u][q].bucket] + rank[u][q];
+                if (kScatterSplit > 1 && gp - w0 >= (uint32_t)kStage) continue;   // (unsigned: other windows' items)
+                const uint32_t pos = gp - w0;
                 if constexpr (H && F == 4) {
                     ItemH4 it;
                     it.key = ps[u][q].key;
@@ -261,13 +276,19 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
             }
         }
     }
-    if (reserver) s_gbase[threadIdx.x - 64] = run_base;
-    __syncthreads();
-    const uint32_t staged = s_start[bl.nb];
-    for (uint32_t pos = threadIdx.x; pos < staged; pos += kBinThreads) {
+    if (wi == 0) {
+        if (reserver) s_gbase[threadIdx.x - 64] = run_base;   // (waits for the reservation's return: the first use of it)
+        __syncthreads();
+    } else {
+        lds_barrier();
+    }
+    const uint32_t in_window = (kScatterSplit == 1 || staged - w0 < (uint32_t)kStage) ? (staged - w0) : (uint32_t)kStage;
+    for (uint32_t pos = threadIdx.x; pos < in_window; pos += kBinThreads) {
         const uint32_t b = s_bucket[pos];
         // write-once / read-once stream: non-temporal stores (measured -7 % on the whole backward)
-        store_item_nt<STREAM>(items + s_gbase[b] + (pos - s_start[b]), s_items[pos]);
+        store_item_nt<STREAM>(items + s_gbase[b] + (w0 + pos - s_start[b]), s_items[pos]);
+    }
+    if (kScatterSplit > 1 && wi + 1u < n_win) lds_barrier();   // the buffer is refilled by the next window
     }
     // selective table zeroing, second half (zero_unowned_rows_kernel did the rows no bucket covers): a hashed bucket with
     // exactly one work unit is overwritten by the consume pass; one with none is never written and one with several is

@@ -105,6 +105,16 @@ template <int F, bool H> struct ItemSel { typedef Item<F> type; };
 template <> struct ItemSel<2, true> { typedef ItemH type; };
 template <> struct ItemSel<4, true> { typedef ItemH4 type; };
 
+// LDS staging windows per scatter tile (bwd_bin_passes.h, pass B), by item format; measured same-box (profiles/
+// r04_experiments.md 14): the 16-byte fp32 and 8-byte half items of F = 2 and the 16-byte half items of F = 4 lose 1-3 % with windows; the
+// 24-byte items of F = 4 win 8 % with four (their 100 KiB of staging allowed ONE workgroup per CU). -DSHACIRA_SCATTER_SPLIT=n forces one value for every format (A/B builds).
+#ifdef SHACIRA_SCATTER_SPLIT
+template <class ItemT> struct ScatterSplit { static constexpr int value = SHACIRA_SCATTER_SPLIT; };
+#else
+template <class ItemT> struct ScatterSplit { static constexpr int value = 1; };
+template <> struct ScatterSplit<Item<4>> { static constexpr int value = 4; };
+#endif
+
 __device__ __forceinline__ uint32_t pack_half_key(uint32_t key, float fx, bool dense) {
     const uint32_t ra = key & 0x1FFFu, rb = (key >> 13) & 0x1FFFu;
     const uint32_t kx = dense ? 0u : (32u - (uint32_t)__clz((int)(ra ^ rb)));

@@ -648,7 +648,9 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     constexpr int NPAIR = 1 << (DIM - 1);
     // half-precision item stream: fp16 tables with F = 2 (8-byte units)
     const bool half = half_items(dtype, lt);
-    const size_t stage = (size_t)TileOf<DIM>::value * NPAIR * ((half ? sizeof(typename ItemSel<F, true>::type) : sizeof(Item<F>)) + 1);
+    const size_t stage = half ? (size_t)TileOf<DIM>::value * NPAIR / ScatterSplit<typename ItemSel<F, true>::type>::value *
+                                    (sizeof(typename ItemSel<F, true>::type) + 1)
+                              : (size_t)TileOf<DIM>::value * NPAIR / ScatterSplit<Item<F>>::value * (sizeof(Item<F>) + 1);
     bool first_batch = true;
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
