@@ -1406,6 +1406,28 @@ def test_random_shapes_large_batches(dev, seed):
     _assert_grad_close(got, ref_g, first, sizes, rtol=RTOL if dtype == torch.float32 else 2e-3)
 
 
+@pytest.mark.parametrize("n", [30_000, (1 << 17) + 5])
+@pytest.mark.parametrize("kind", ["one_point", "clustered", "half_and_half"])
+def test_skewed_sample_distributions_four_features(dev, kind, n):
+    """nerf_lego.yaml's table shape (24 levels, F = 4: 24-byte items, staged through LDS in four WINDOWS of the tile's sorted
+    order since round 4) under maximally uneven bucket loads: every item of a tile in one bucket (a run that spans all four
+    windows), a tight cluster, and half the samples on one point with the rest uniform; both image sizes (fp64 images below
+    2^17 samples, fixed-point above)."""
+    dim, res, bw, F = 3, geo(16, 512, 24), 19, 4
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, F=F, seed=77, edge=False)
+    rng = np.random.default_rng(6)
+    if kind == "one_point":
+        coords[:] = np.array([0.123, -0.456, 0.789], np.float32)
+    elif kind == "clustered":
+        coords[:] = (np.array([0.3, 0.3, -0.2]) + rng.normal(0, 0.004, coords.shape)).astype(np.float32)
+    else:
+        coords[: n // 2] = np.float32(-0.6183)
+    feats, grad = _run(dev, dim, res, bw, coords, table, go, first)
+    assert np.array_equal(feats.cpu().numpy(), oc.forward(coords, table, first, res, bw))
+    ref_g = oc.backward(coords, go, (T, F), first, res, bw)
+    _assert_grad_close(grad.cpu().numpy(), ref_g, first, sizes)
+
+
 @pytest.mark.parametrize("n", [50_000, (1 << 18) + 9])
 @pytest.mark.parametrize("selective", [1, 0])
 def test_zeroing_with_empty_and_overfull_buckets(dev, n, selective):
