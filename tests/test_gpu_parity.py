@@ -1673,3 +1673,28 @@ def test_against_the_reference_kernels(dev, name, dtype):
         tc, tg, tt, tf, res, bw, F, False)
     torch.cuda.synchronize()
     _assert_grad_close(hb.cpu().numpy(), rb.double().cpu().numpy(), first, sizes)
+
+
+@pytest.mark.parametrize("name,n", [("D", 1 << 20), ("Bp", 1 << 20), ("B", 393_216), ("D", 65_536)])
+def test_full_size_against_the_reference_kernels(dev, name, n):
+    """BASELINE.json's configurations at their own batch sizes (S1 = the config-D table at 2^20 samples, the 2-D bw-19 table at
+    2^20, one Kodak image, the NeRF ray batch), fp32, this library against the reference's own operators on the same inputs:
+    forward within one rounding of the result (see test_against_the_reference_kernels), gradients within 1e-5 of each level's
+    largest value -- the default paths at these sizes: cell-sorted forward, binned fixed-point backward, LDS-resident tables."""
+    ref = _ref_ops()
+    ops = _ops()
+    dim, res, bw = CONFIGS[name]
+    F = 2
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, F=F, seed=5)
+    tc, tt, tg, tf = (torch.from_numpy(a).to(dev) for a in (coords, table, go, first))
+    three = dim == 3
+    rf = (ref.hashgrid_interpolate_cuda if three else ref.hashgrid_interpolate2d_cuda)(tc, tt, tf, res, bw)
+    hf = (ops.hashgrid_interpolate_cuda if three else ops.hashgrid_interpolate2d_cuda)(tc, tt, tf, res, bw)
+    rb = (ref.hashgrid_interpolate_backward_cuda if three else ref.hashgrid_interpolate2d_backward_cuda)(
+        tc, tg, tt, tf, res, bw, F, False)
+    hb = (ops.hashgrid_interpolate_backward_cuda if three else ops.hashgrid_interpolate2d_backward_cuda)(
+        tc, tg, tt, tf, res, bw, F, False)
+    torch.cuda.synchronize()
+    one_rounding = float(np.spacing(np.float32(np.abs(table).max() * (1 << dim) / 2)))
+    assert float((hf - rf).abs().max()) <= one_rounding
+    _assert_grad_close(hb.cpu().numpy(), rb.double().cpu().numpy(), first, sizes)
