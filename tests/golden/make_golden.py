@@ -11,6 +11,8 @@ What is pinned by the real reference code (executed, not restated):
                       (written by `python tests/golden/make_golden.py sga`, leaves the other files untouched)
   latent_decoder_mlp.npz  LatentDecoder with hidden layers / activations (num_layers_dec, activation, final_activation),
                       rounding and SGA paths   basic_latent_decoder.py:139-147,182-198       (python make_golden.py mlp)
+  multi_decoder_mlp.npz  MultiLatentDecoder with hidden layers / activations (every layer mixes the K decoders), straight-through
+                      and soft selector, clamp, SGA   multi_latent_decoder.py:27-68,112-135   (python make_golden.py multi_mlp)
   hierarchical_decoder.npz  HierarchicalLatentDecoder.forward/backward over row ranges, incl. an empty level and the
                       (sic) last offset of latent_grid.py:182 (`python tests/golden/make_golden.py hier`)   hierarchical_latent_decoder.py:3-36
   bit_estimator.npz   BitEstimator CDF + gradients for num_layers 1..4                               bit_estimator.py:9-65
@@ -538,6 +540,64 @@ def make_mlp():
     print("hidden-layer decoder golden vectors written")
 
 
+def make_multi_mlp():
+    """MultiLatentDecoder of the reference WITH hidden layers / activations (num_layers_dec > 0: every layer mixes the K decoders
+    by the selector, multi_latent_decoder.py:112-135, :27-68 for the layer), executed: straight-through and soft selector, 'sq' and
+    'dft', clamp, SGA. No shipped configuration selects this form; this library evaluates it with torch ops like the reference, and
+    these vectors pin that path (`python tests/golden/make_golden.py multi_mlp`)."""
+    _install_shims()
+    import importlib
+    core_mod = importlib.import_module("wisp.core.wisp_module")
+    sys.modules["wisp.core"].WispModule = core_mod.WispModule
+    ldec = importlib.import_module("wisp.models.latent_decoders")
+    out, cases = {}, []
+    g = torch.Generator().manual_seed(1357)
+    rows = 131
+    for ci, (ld, fd, mat, shift, K, st, nl, hid, act, fact, clampw, sga, temp) in enumerate([
+            # ('sq' layers of the reference only run square: `out[i] = matmul(input, scale[i])` is assigned into a buffer shaped
+            # like the INPUT, multi_latent_decoder.py:71-73 -- so latent_dim == hidden == feature_dim there; 'dft' takes any widths)
+            (2, 2, "sq", True, 3, True, 1, 2, "relu", "none", 0.0, False, 0.7),
+            (2, 4, "dft", True, 2, False, 2, (4, 4), "tanh", "none", 0.0, False, 0.9),
+            (2, 2, "sq", False, 4, True, 1, 0, "sigmoid", "tanh", 0.0, False, 1.0),
+            (4, 4, "sq", True, 2, False, 2, 4, "relu", "none", 0.3, False, 0.5),
+            (2, 2, "sq", True, 3, True, 1, 2, "tanh", "none", 0.0, True, 0.6)]):
+        torch.manual_seed(700 + ci)
+        dec = ldec.MultiLatentDecoder(latent_dim=ld, feature_dim=fd, norm="none", ldecode_matrix=mat, use_shift=shift,
+                                      num_entries=rows, num_layers_dec=nl, hidden_dim_dec=hid, activation=act,
+                                      final_activation=fact, clamp_weights=clampw, ldec_std=0.4, num_decoders=K,
+                                      alpha_std=1.0, use_sga=sga)
+        dec.straight_through = st
+        dec.temperature = temp
+        with torch.no_grad():
+            dec.div.fill_(1.3)
+            for n_, p_ in dec.named_parameters():
+                if n_.endswith("use_shift"):
+                    p_.copy_(torch.randn(p_.shape, generator=g) * 0.05)
+        lat = ((torch.rand(rows, ld, generator=g) - 0.5) * 7.0)
+        lat[0] = 0.5; lat[1] = -0.5; lat[2] = 1.5
+        lat.requires_grad_(True)
+        seed = 1900 + ci
+        torch.manual_seed(seed)
+        y = dec(lat)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        pre = f"h{ci}_"
+        out[pre + "latent"] = lat.detach().numpy()
+        out[pre + "out"] = y.detach().numpy()
+        out[pre + "grad_out"] = gy.numpy()
+        out[pre + "grad_latent"] = lat.grad.numpy()
+        for n_, p_ in dec.named_parameters():
+            out[pre + "p_" + n_] = p_.detach().numpy()
+            out[pre + "g_" + n_] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy()
+        cases.append(dict(latent_dim=ld, feature_dim=fd, ldecode_matrix=mat, use_shift=shift, num_decoders=K,
+                          straight_through=st, num_layers_dec=nl, hidden_dim_dec=hid, activation=act, final_activation=fact,
+                          clamp_weights=clampw, use_sga=sga, temperature=temp, seed=seed,
+                          state_keys=sorted(dec.state_dict().keys())))
+    out["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "multi_decoder_mlp.npz"), **out)
+    print("multi decoder (hidden layers) golden vectors written")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; goldens can only be regenerated in the dev container")
@@ -547,5 +607,7 @@ if __name__ == "__main__":
         make_hier()
     elif len(sys.argv) > 1 and sys.argv[1] == "mlp":
         make_mlp()
+    elif len(sys.argv) > 1 and sys.argv[1] == "multi_mlp":
+        make_multi_mlp()
     else:
         main()

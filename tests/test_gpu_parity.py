@@ -1698,3 +1698,17 @@ def test_full_size_against_the_reference_kernels(dev, name, n):
     one_rounding = float(np.spacing(np.float32(np.abs(table).max() * (1 << dim) / 2)))
     assert float((hf - rf).abs().max()) <= one_rounding
     _assert_grad_close(hb.cpu().numpy(), rb.double().cpu().numpy(), first, sizes)
+
+
+def test_multi_decoder_with_hidden_layers_on_the_gpu(dev, golden):
+    """MultiLatentDecoder with hidden layers (the one decoder form without a fused kernel: torch ops on the device, as in the
+    reference) against the vectors of the executed reference module -- the same cases as the CPU mirror test."""
+    from test_host_mirror import _multi_mlp_case
+    g = golden("multi_decoder_mlp.npz")
+    ran = 0
+    for ci, case in enumerate(npz_json(g["cases_json"])):
+        if case["use_sga"]:
+            continue   # the sampler's noise comes from the device generator there
+        _multi_mlp_case(g, ci, case, dev)
+        ran += 1
+    assert ran >= 4

@@ -227,6 +227,45 @@ def test_multi_latent_decoder_module(golden):
         assert dec.size() == pytest.approx(float(g[p + "size"]), rel=1e-6)
 
 
+def _multi_mlp_case(g, ci, case, device):
+    p = f"h{ci}_"
+    torch.manual_seed(700 + ci)
+    dec = MultiLatentDecoder(latent_dim=case["latent_dim"], feature_dim=case["feature_dim"], norm="none",
+                             ldecode_matrix=case["ldecode_matrix"], use_shift=case["use_shift"], num_entries=131,
+                             num_layers_dec=case["num_layers_dec"], hidden_dim_dec=case["hidden_dim_dec"],
+                             activation=case["activation"], final_activation=case["final_activation"],
+                             clamp_weights=case["clamp_weights"], ldec_std=0.4, num_decoders=case["num_decoders"],
+                             alpha_std=1.0, use_sga=case["use_sga"])
+    assert sorted(dec.state_dict().keys()) == case["state_keys"]
+    assert (dec.alpha.detach().numpy() == g[p + "p_alpha"]).all()                 # same RNG draw order as the reference
+    dec.load_state_dict({k[len(p) + 2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(p + "p_")})
+    dec.straight_through = case["straight_through"]
+    dec.temperature = case["temperature"]
+    dec = dec.to(device)
+    lat = torch.from_numpy(g[p + "latent"]).to(device).requires_grad_(True)
+    if case["use_sga"] and device.type != "cpu":
+        # the sampler's noise comes from the device generator on the GPU: draw it on the CPU with the reference's seed instead
+        pytest.skip("SGA case: noise parity is a CPU-generator property")
+    torch.manual_seed(case["seed"])
+    y = dec(lat)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[p + "out"], rtol=2e-5, atol=1e-6)
+    y.backward(torch.from_numpy(g[p + "grad_out"]).to(device))
+    np.testing.assert_allclose(lat.grad.cpu().numpy(), g[p + "grad_latent"], rtol=1e-4, atol=1e-6)
+    for n, prm in dec.named_parameters():
+        want = g[p + "g_" + n]
+        got = prm.grad.cpu().numpy() if prm.grad is not None else np.zeros_like(want)
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6, err_msg=n)
+
+
+def test_multi_latent_decoder_with_hidden_layers(golden):
+    """Row f4, the one form that stays a torch-op chain (no shipped configuration selects it): MultiLatentDecoder with hidden
+    layers / activations -- every layer mixes the K decoders by the selector (reference multi_latent_decoder.py:27-68, 112-135) --
+    against vectors of the executed reference module: straight-through and soft selector, 'sq' and 'dft', clamp, SGA."""
+    g = golden("multi_decoder_mlp.npz")
+    for ci, case in enumerate(npz_json(g["cases_json"])):
+        _multi_mlp_case(g, ci, case, torch.device("cpu"))
+
+
 def _hier_case(g, ci, case, device):
     p = f"c{ci}_"
     L = len(case["offsets"]) - 1
