@@ -989,6 +989,12 @@ size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int6
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                      const float *coords, const void *table, void *feats, void *ws, int64_t n,
                                      hipStream_t s) {
+    if (lt.table_rows == 0) {
+        // an empty table has no corner inside it: every feature is zero (and gather_row, which reads row 0 on behalf of lanes
+        // that have no row, must not run; the dense 16-byte form that reads rows 0-1 is only reached by tables >= 8 MB)
+        const size_t bytes = (size_t)n * lt.num_lods * lt.feature_dim * (dtype == SHACIRA_F64 ? 8 : dtype == SHACIRA_F32 ? 4 : 2);
+        return zero_fill_async(static_cast<float *>(feats), (int64_t)(bytes / 4), s);   // (F is even: a multiple of 4 bytes)
+    }
     if (dtype == SHACIRA_F64)
         return dim == 3 ? launch_fwd_f64<3>(lt, first_idx, coords, table, feats, n, s)
                         : launch_fwd_f64<2>(lt, first_idx, coords, table, feats, n, s);

@@ -297,6 +297,27 @@ def test_out_of_table_corner_is_memory_safe(dev):
     assert float(grad.sum()) == pytest.approx(6.0, rel=1e-6)
 
 
+def test_forward_on_an_empty_table_is_all_zero(dev):
+    """table_rows == 0 through the C-ABI with a non-null table pointer: no corner lies inside the table, every feature is zero
+    and nothing is read (the gathers load row 0 on behalf of lanes without a row: an empty table must not reach them)."""
+    import ctypes
+    from shacira_amd import _lib
+    lib = _lib.lib()
+    for dim, dtype, tdt in ((3, _lib.F32, torch.float32), (2, _lib.F16, torch.float16)):
+        res = np.asarray([4, 9, 33], np.int32)
+        first = torch.zeros(3, dtype=torch.int32, device=dev)
+        coords = torch.rand(1000, dim, device=dev) * 2 - 1
+        dummy = torch.full((8,), 5.0, device=dev, dtype=tdt)            # a valid pointer; table_rows = 0
+        feats = torch.full((1000, 3 * 2), 7.0, device=dev, dtype=tdt)
+        ws_bytes = lib.shacira_hashgrid_forward_workspace_bytes(dim, 1000, 3, 2, 12, res.ctypes.data, 0, dtype)
+        ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=dev)
+        rc = lib.shacira_hashgrid_forward(dim, 1000, 3, 2, 12, res.ctypes.data, first.data_ptr(), 0, coords.data_ptr(),
+                                          dummy.data_ptr(), dtype, feats.data_ptr(), ws.data_ptr(), int(ws_bytes),
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert rc == 0 and float(feats.float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("n", [20_000, 1 << 17, 1 << 18])
 def test_half_precision_tables(dev, n):
     """fp16 instantiation (what the reference's NeRF AMP path runs, grid.py:73 + .cu:198-211); the larger batches run
