@@ -90,3 +90,13 @@ def test_backward_within_the_reference_s_own_atomics_spread(case):
     # fp32 sample-order accumulation (the reference's arithmetic, one of its possible orders) is as close
     got32 = oc.backward(c["coords"], c["grad_out"], (c["T"], c["F"]), c["first"], c["res"], c["bw"], accumulate="f32")
     assert np.abs(got32 - ref).max() <= max(4 * info["grad_run_to_run_max_abs"], 4e-6 * info["grad_max_abs"])
+
+
+def test_the_reference_build_leaves_only_a_library_behind():
+    """oracle/_ref/ (git-ignored, travels with gpurun) may hold the built library and nothing else: no translated or copied
+    reference source text stays in the tree after oracle/ref_build.py has run."""
+    ref_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    if not os.path.isdir(ref_dir):
+        pytest.skip("oracle/_ref not built here")
+    left = sorted(os.listdir(ref_dir))
+    assert left == ["shacira_ref_ops.so"], left
