@@ -327,7 +327,7 @@ template <int F, bool FX, bool H, class Hook>
 __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan &plan, const int32_t *__restrict__ first_idx,
                                              const UnitDesc d, const typename ItemSel<F, H>::type *__restrict__ items,
                                              float *__restrict__ grad_table, int force_atomic, int headroom, double *s_acc,
-                                             Hook &&hook) {
+                                             Hook &&hook, __half *__restrict__ half_out = nullptr) {
     // (uniform over the workgroup -- every thread copied the same descriptor out of LDS; as scalars the level's record comes
     // out of the kernel arguments by scalar loads instead of one vector load per field)
     const uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.bucket);
@@ -694,6 +694,28 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
         if (single && grow0 + (int64_t)nrows <= lt.table_rows) {
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             auto value = [&](uint32_t e) { return (FX && fx.fixed) ? fx_decode(s_fix[e], fx.inv) : (float)s_acc[e]; };
+            if constexpr (H) {
+                if (half_out != nullptr) {
+                    // fp16 table, single-unit bucket: the rounded sums go straight into the caller's half table (round 4)
+                    // instead of through the fp32 accumulation image and the conversion pass behind it (which skips this
+                    // bucket: f32_to_f16_skip_kernel). 8-byte stores of four consecutive halves, scalar head / tail.
+                    __half *h0 = half_out + grow0 * F;
+                    uint32_t hh = (uint32_t)(((8u - (uint32_t)(reinterpret_cast<uintptr_t>(h0) & 7u)) & 7u) / 2u);
+                    if (hh > nelem) hh = nelem;
+                    const uint32_t hb = (nelem - hh) & ~3u;
+                    if (threadIdx.x < hh) h0[threadIdx.x] = __float2half_rn(value(threadIdx.x));
+                    for (uint32_t e = hh + threadIdx.x * 4u; e < hh + hb; e += kConsumeThreads * 4u) {
+                        const __half2 lo = __floats2half2_rn(value(e), value(e + 1));
+                        const __half2 hi2 = __floats2half2_rn(value(e + 2), value(e + 3));
+                        uint2 pk;
+                        __builtin_memcpy(&pk.x, &lo, 4);
+                        __builtin_memcpy(&pk.y, &hi2, 4);
+                        *reinterpret_cast<uint2 *>(h0 + e) = pk;
+                    }
+                    if (hh + hb + threadIdx.x < nelem) h0[hh + hb + threadIdx.x] = __float2half_rn(value(hh + hb + threadIdx.x));
+                    return;
+                }
+            }
             // elements in front of the first 16-byte boundary (a level may start on an odd row: the dense levels in front of
             // it have odd sizes), whole vectors, then the elements behind the last one
             uint32_t head = (uint32_t)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst0) & 15u)) & 15u) / 4u);
@@ -715,6 +737,12 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
         if ((uint64_t)grow >= (uint64_t)lt.table_rows) continue;
         const float v = (FX && fx.fixed) ? fx_decode(s_fix[e], fx.inv) : (float)s_acc[e];
         float *dst = grad_table + grow * F + (e % F);
+        if constexpr (H) {
+            if (single && half_out != nullptr) {   // (a table shorter than this bucket: element-wise, same destination rule)
+                half_out[grow * F + (e % F)] = __float2half_rn(v);
+                continue;
+            }
+        }
         if (single) *dst = v;
         else if (v != 0.0f) unsafeAtomicAdd(dst, v);
     }
@@ -735,7 +763,8 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
                                                                       const typename ItemSel<F, H>::type *__restrict__ items,
                                                                       float *__restrict__ grad_table,
                                                                       int force_atomic, int headroom,
-                                                                      uint32_t *__restrict__ work_counter) {
+                                                                      uint32_t *__restrict__ work_counter,
+                                                                      __half *__restrict__ half_out = nullptr) {
     extern __shared__ double s_acc[];  // [rows_pb][F]: fp64, or 64-bit fixed point (same size)
     __shared__ UnitDesc s_desc;
     __shared__ uint32_t s_unit;
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         const UnitDesc d = unit_desc[blockIdx.x];
         const uint32_t unit_end = unit_first[plan.total_buckets];
         if (blockIdx.x >= unit_end) return;
-        consume_unit<F, FX, H>(lt, plan, first_idx, d, items, grad_table, force_atomic, headroom, s_acc, []() {});
+        consume_unit<F, FX, H>(lt, plan, first_idx, d, items, grad_table, force_atomic, headroom, s_acc, []() {}, half_out);
         return;
     }
     const uint32_t unit_end = unit_first[plan.total_buckets];
@@ -764,13 +793,42 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         if (threadIdx.x == 0) nxt = atomicAdd(work_counter, 1u);
         consume_unit<F, FX, H>(lt, plan, first_idx, d, items, grad_table, force_atomic, headroom, s_acc, [&]() {
             if (threadIdx.x == 0) s_desc_nxt = unit_desc[nxt < unit_end ? nxt : unit_end - 1u];
-        });
+        }, half_out);
         // (every thread read s_unit / s_desc before the barriers inside consume_unit: thread 0 may overwrite them now)
         if (threadIdx.x == 0) {
             s_unit = nxt;
             s_desc = s_desc_nxt;
         }
         lds_barrier();   // the next unit is known and the image is free again; the flush stores keep draining
+    }
+}
+
+// fp16 tables: fp32 accumulation image -> the caller's half table, MINUS the row-partitioning buckets with exactly one work unit, whose
+// rows the consume pass wrote into the half table itself. grid (x, num_lods): level l = rows [first_idx[l], first_idx[l + 1])
+// (level 0 from row 0, the last one to the end of the table), walked in chunks of one bucket (hashed binned levels) or 4 096 rows.
+__global__ __launch_bounds__(256) void f32_to_f16_skip_kernel(const float *__restrict__ acc, __half *__restrict__ dst,
+                                                             const int32_t *__restrict__ first_idx, LevelTable lt,
+                                                             BinPlan plan, const uint32_t *__restrict__ unit_first, int F) {
+    const int l = (int)blockIdx.y;
+    const int64_t lo = (l == 0) ? 0 : (int64_t)first_idx[l];
+    const int64_t hi = (l + 1 < lt.num_lods) ? (int64_t)first_idx[l + 1] : lt.table_rows;
+    const BinLevel bl = plan.lv[l];
+    // buckets that partition the level's rows (hashed levels: 2^k consecutive rows; dense levels binned by whole x-lines): a
+    // single-unit one is overwritten by the consume pass. Compact levels share halo planes and direct levels have no buckets.
+    const bool hashed_binned = bl.bucket0 != 0xFFFFFFFFu && bl.nb > 0 && bl.compact == 0;
+    const int64_t chunk = hashed_binned ? (int64_t)bl.rows_pb : 4096;
+    const int64_t level0 = (int64_t)first_idx[l];   // buckets count from the level's first row
+    for (int64_t c = blockIdx.x;; c += gridDim.x) {
+        // chunk c of the level proper; rows in front of first_idx[0] (l == 0, lo < level0) ride with chunk 0
+        int64_t r0 = level0 + c * chunk, r1 = r0 + chunk;
+        if (c == 0 && lo < r0) r0 = lo;
+        if (r0 >= hi) break;
+        if (r1 > hi) r1 = hi;
+        if (hashed_binned && c < (int64_t)bl.nb) {
+            const uint32_t gb = bl.bucket0 + (uint32_t)c;
+            if (unit_first[gb + 1] - unit_first[gb] == 1u) continue;   // written by the consume pass
+        }
+        for (int64_t e = r0 * F + threadIdx.x; e < r1 * F; e += 256) dst[e] = __float2half_rn(acc[e]);
     }
 }
 

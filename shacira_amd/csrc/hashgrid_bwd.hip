@@ -192,7 +192,8 @@ bool bin_all_direct(int dim, const LevelTable &lt);
 size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n);
 float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace);
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table);
+                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table,
+                        void *half_table, bool *converted);
 
 // variant 1 ("bin") whenever the shape allows it and the batch is big enough to amortise its fixed passes
 static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
@@ -244,8 +245,10 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
         e = hipGetLastError();
     }
     if (e != hipSuccess) return e;
+    bool converted = false;   // fp16 tables: the binned path may write the half table itself (single-unit buckets + a skipping conversion)
     if (bin) {
-        e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s, full);
+        e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s, full,
+                         (dtype == SHACIRA_F16 && full) ? grad_table : nullptr, &converted);
         if (e != hipSuccess) return e;
     } else if (n > 0) {
         if (dim == 3) {
@@ -257,7 +260,7 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
         }
         if (e != hipSuccess) return e;
     }
-    if (dtype == SHACIRA_F16) {
+    if (dtype == SHACIRA_F16 && !converted) {
         int64_t blocks = (numel + 255) / 256;
         if (blocks > 4096) blocks = 4096;
         if (blocks > 0)

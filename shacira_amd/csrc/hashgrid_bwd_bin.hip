@@ -500,7 +500,7 @@ static int front_tile(int L, int F, uint32_t nbl, int64_t n, size_t *shmem) {
 template <int DIM, int F>
 static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                           const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s,
-                          bool zero_table) {
+                          bool zero_table, __half *half_table, bool *converted) {
     const int L = lt.num_lods;
     const int64_t NP = level_pitch(n);
     BinPlan whole;
@@ -525,6 +525,11 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     const bool t16 = ts16 > 0 && (L % kvec) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0;
     // counting fused into the front kernel: a call that transposes, single sub-batch
     const bool front_counts = need_T && !staged && !multi && t16 && whole.nbl > 0;
+    // fp16 tables, one sub-batch over all levels: single-unit hashed buckets flush straight into the caller's half table and
+    // the conversion of the fp32 accumulation image skips them (f32_to_f16_skip_kernel) -- most of the table never makes the
+    // round trip through the image (round 4)
+    const bool direct_half = half_table != nullptr && half_items(dtype, lt) && !multi && !stage_all && !staged &&
+                             whole.nbl > 0 && lt.level_begin == 0 && lt.level_end == L;
     // side stream (option bwd_fork): table zeroing + direct levels beside the critical path. Worth an event pair once the
     // batch is large (threshold in units of n * L * F: heavier tables fork earlier)
     const int64_t fork_work = n * lt.num_lods * lt.feature_dim;
@@ -698,14 +703,15 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         if (wc != nullptr && grid_units > 512u) grid_units = 512u;
         const int headroom = use_fx ? fx_headroom((uint64_t)plan.chunk + 1) : -1;   // a unit streams <= chunk items
         const int fa = multi ? 1 : 0;
+        __half *hout = direct_half ? half_table : nullptr;
         if (half && use_fx)
             hipLaunchKernelGGL((bin_consume_kernel<F, true, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s,
                                lt, plan, first_idx, w.unit_first, w.unit_desc,
-                               reinterpret_cast<const typename ItemSel<F, true>::type *>(w.items), acc, fa, headroom, wc);
+                               reinterpret_cast<const typename ItemSel<F, true>::type *>(w.items), acc, fa, headroom, wc, hout);
         else if (half)
             hipLaunchKernelGGL((bin_consume_kernel<F, false, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s,
                                lt, plan, first_idx, w.unit_first, w.unit_desc,
-                               reinterpret_cast<const typename ItemSel<F, true>::type *>(w.items), acc, fa, headroom, wc);
+                               reinterpret_cast<const typename ItemSel<F, true>::type *>(w.items), acc, fa, headroom, wc, hout);
         else if (use_fx)
             hipLaunchKernelGGL((bin_consume_kernel<F, true, false>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,
                                plan, first_idx, w.unit_first, w.unit_desc,
@@ -716,11 +722,20 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                                reinterpret_cast<const Item<F> *>(w.items), acc, fa, headroom, wc);
         SHACIRA_CHECK_LAUNCH();
     }
+    if (direct_half) {
+        hipLaunchKernelGGL(f32_to_f16_skip_kernel, dim3(128, (uint32_t)L), dim3(256), 0, s, acc, half_table, first_idx, lt,
+                           whole, w.unit_first, F);
+        SHACIRA_CHECK_LAUNCH();
+        if (converted != nullptr) *converted = true;
+    }
     return hipSuccess;
 }
 
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table) {
+                        const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table,
+                        void *half_table, bool *converted) {
+    if (converted != nullptr) *converted = false;
+    __half *ht = (dtype == SHACIRA_F16) ? static_cast<__half *>(half_table) : nullptr;
     const BinWorkspace w = carve(dim, dtype, lt, n, workspace);
     static PerDeviceOnce once;  // kernels that use more than 64 KiB of dynamic LDS must opt in once per device
     const hipError_t attr_err = once.run([]() -> hipError_t {
@@ -772,11 +787,11 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
     });
     if (attr_err != hipSuccess) return attr_err;
     if (dim == 3) {
-        return lt.feature_dim == 2 ? run_bin<3, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table)
-                                   : run_bin<3, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table);
+        return lt.feature_dim == 2 ? run_bin<3, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted)
+                                   : run_bin<3, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted);
     }
-    return lt.feature_dim == 2 ? run_bin<2, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table)
-                               : run_bin<2, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table);
+    return lt.feature_dim == 2 ? run_bin<2, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted)
+                               : run_bin<2, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted);
 }
 
 }  // namespace shacira
