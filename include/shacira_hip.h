@@ -122,7 +122,8 @@ SHACIRA_API int shacira_hashgrid_backward(int dim, int64_t num_coords, int num_l
  * Same, restricted to levels [level_begin, level_end): writes (completely) only the rows of those levels,
  * [codebook_first_idx[level_begin], codebook_first_idx[level_end]) (to table_rows for level_end == num_lods), and leaves
  * the rest of grad_codebook untouched. Lets a data-parallel caller start the all-reduce of the finished rows while the
- * remaining levels are still being computed. fp32 tables only; same workspace size as the full call.
+ * remaining levels are still being computed. fp32 tables, and fp16 tables without the two flags below (a half table converts
+ * only the call's own rows of its fp32 accumulation image); double tables take whole calls. Same workspace size as the full call.
  *   flags: SHACIRA_BWD_STAGE_ALL_LEVELS  stage (transpose) the gradients of ALL levels into the workspace, not only
  *                                        this call's, so that later calls on the SAME workspace can skip that pass;
  *          SHACIRA_BWD_REUSE_STAGED      the workspace already holds them (set by an earlier call with the flag above,

@@ -175,7 +175,10 @@ int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, int num_lods, 
     if (rc) return rc;
     if (level_begin < 0 || level_end > num_lods || level_begin >= level_end) return SHACIRA_EINVAL;
     const bool partial = !(level_begin == 0 && level_end == num_lods);
-    if (partial && dtype != SHACIRA_F32) return SHACIRA_EDTYPE;   // level ranges: fp32 tables only
+    // level ranges: fp32 tables, and (round 4) fp16 tables without the staged-gradient flags -- each call then converts its own
+    // rows of the fp32 accumulation image only; double tables take whole calls
+    if (partial && dtype == SHACIRA_F64) return SHACIRA_EDTYPE;
+    if (dtype == SHACIRA_F16 && (flags & (SHACIRA_BWD_STAGE_ALL_LEVELS | SHACIRA_BWD_REUSE_STAGED)) != 0) return SHACIRA_EDTYPE;
     lt.level_begin = level_begin;
     lt.level_end = level_end;
     lt.stage_flags = flags & (SHACIRA_BWD_STAGE_ALL_LEVELS | SHACIRA_BWD_REUSE_STAGED);

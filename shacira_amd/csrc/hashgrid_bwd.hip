@@ -129,6 +129,17 @@ __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float *__restrict
     for (; i < n; i += stride) dst[i] = __float2half_rn(src[i]);
 }
 
+// fp32 image -> half table for the rows of levels [level_begin, level_end) only: a level-range call (the all-reduce overlap of
+// shacira_hashgrid_backward_levels) used to convert the WHOLE table every time
+__global__ __launch_bounds__(256) void f32_to_f16_levels_kernel(const float *__restrict__ src, __half *__restrict__ dst,
+                                                               const int32_t *__restrict__ first_idx, int level_begin,
+                                                               int level_end, int num_lods, int64_t table_rows, int F) {
+    const int64_t lo = (int64_t)first_idx[level_begin] * F;
+    const int64_t hi = ((level_end < num_lods) ? (int64_t)first_idx[level_end] : table_rows) * F;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; e < hi; e += stride) dst[e] = __float2half_rn(src[e]);
+}
+
 // zeroes the rows of levels [level_begin, level_end) (first_idx lives on the device)
 __global__ __launch_bounds__(256) void zero_level_rows_kernel(float *__restrict__ acc,
                                                               const int32_t *__restrict__ first_idx, int level_begin,
@@ -263,9 +274,12 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
     if (dtype == SHACIRA_F16 && !converted) {
         int64_t blocks = (numel + 255) / 256;
         if (blocks > 4096) blocks = 4096;
-        if (blocks > 0)
+        if (blocks > 0 && full)
             hipLaunchKernelGGL(f32_to_f16_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, acc,
                                static_cast<__half *>(grad_table), numel);
+        else if (blocks > 0)   // only the rows this call computed (the other levels' rows of the half table stay as they are)
+            hipLaunchKernelGGL(f32_to_f16_levels_kernel, dim3(2048), dim3(256), 0, s, acc, static_cast<__half *>(grad_table),
+                               first_idx, lt.level_begin, lt.level_end, lt.num_lods, lt.table_rows, lt.feature_dim);
         return hipGetLastError();
     }
     return hipSuccess;

@@ -209,6 +209,36 @@ def test_backward_by_level_ranges(dev, name, bvar):
     np.testing.assert_allclose(out2.cpu().numpy(), ref, rtol=RTOL, atol=RTOL * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("n", [30_001, (1 << 17) + 3])
+def test_backward_by_level_ranges_half_tables(dev, n):
+    """The same hook with an fp16 table: a level-range call converts ONLY its own rows of the fp32 accumulation image (round 4: it
+    converted the whole image every time -- correct only while the calls shared one workspace), so rows outside the range keep
+    what they held (each call with its own scratch workspace)."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, seed=19)
+    go16 = go.astype(np.float16)
+    tc, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(first).to(dev)
+    tg = torch.from_numpy(go16).to(dev)
+    full = ops.hashgrid_backward(dim, tc, tg, T, torch.float16, tf, res, bw, 2)
+    ref = oc.backward(coords, go16.astype(np.float32), (T, 2), first, res, bw)
+    _assert_grad_close(full.float().cpu().numpy(), ref, first, sizes, rtol=2e-3)
+    split = 7
+    lo = int(first[split])
+    out = torch.full((T, 2), 7.0, device=dev, dtype=torch.float16)
+    ops.hashgrid_backward(dim, tc, tg, T, torch.float16, tf, res, bw, 2, levels=(split, len(res)), out=out)
+    assert float((out[:lo].float() - 7.0).abs().max()) == 0.0                  # rows of the other levels untouched
+    ops.hashgrid_backward(dim, tc, tg, T, torch.float16, tf, res, bw, 2, levels=(0, split), out=out)
+    assert torch.equal(out[lo:], full[lo:]) or float((out[lo:].float() - full[lo:].float()).abs().max()) <= 2e-3 * float(full.float().abs().max())
+    _assert_grad_close(out.float().cpu().numpy(), ref, first, sizes, rtol=2e-3)
+    # (the staged-gradient flags of a shared workspace are an fp32-table feature: the C-ABI refuses them for half tables)
+    with pytest.raises(RuntimeError):
+        ws = ops.backward_workspace(dim, n, T, torch.float16, res, bw, 2, dev)
+        ops.hashgrid_backward(dim, tc, tg, T, torch.float16, tf, res, bw, 2, levels=(0, split), out=out, workspace=ws,
+                              flags=_lib.BWD_STAGE_ALL_LEVELS)
+
+
 @pytest.mark.parametrize("name", ["D", "Bp"])
 def test_backward_side_stream_fork(dev, name):
     """Large batches with LDS-resident (direct) levels: the table zeroing and those levels run on the library's side stream
