@@ -25,6 +25,8 @@ static OptionSlot g_slots[] = {
     {"bwd_selective_zero", &Options::bwd_selective_zero, 0, 1, {1}},
     {"bwd_persistent", &Options::bwd_persistent, 0, 1, {1}},
     {"bwd_fork", &Options::bwd_fork, 0, 1, {1}},
+    {"bwd_run_pad", &Options::bwd_run_pad, 0, 1, {1}},
+    {"bwd_item12", &Options::bwd_item12, 0, 1, {0}},
     {"bin_acc_kib", &Options::bin_acc_kib, 0, 128, {0}},
     {"bin_batch_mib", &Options::bin_batch_mib, 1, 1 << 20, {1536}},
     {"tiled", &Options::tiled, -1, 1, {-1}},

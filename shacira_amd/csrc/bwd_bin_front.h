@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
                                                                 float *__restrict__ gT, const float *__restrict__ coords,
                                                                 uint32_t *__restrict__ totals, uint32_t *__restrict__ cnt,
                                                                 int64_t N, int64_t NP, int lb, int le, int ts_log2,
-                                                                int rounds, uint32_t *__restrict__ gmax) {
+                                                                int rounds, uint32_t *__restrict__ gmax, uint32_t cps) {
     constexpr int K = 16 / (int)(sizeof(T) * F);   // level pieces per 16-byte input vector
     constexpr int HE = SHACIRA_MAX_LODS * kMaxLevelBuckets / kFrontThreads;   // histogram words per thread (<= 8)
     constexpr int M = 16 / (4 * F);                // samples per 16-byte output vector
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
     // anything -- and keeps the workgroup's sums in registers for the totals
     int hcol[HE];
     uint32_t hsum[HE];
+    uint32_t hacc[HE];   // items of the current SCATTER tile (cps counting tiles) so far: its runs are reserved in multiples of plan.pad
     if constexpr (COUNT) {
         // word k = tid + j * 512 <-> (level slot k / 128, bucket k % 128): the slot is uniform over a wave (128 = two waves), so
         // it is made a scalar and the two plan words come by scalar loads. (Round 4: with a lane-dependent index into the
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
             const uint32_t nbq = li < plan.nbl ? plan.bnb[lc] : 0u, bsq = plan.bstart[lc];
             hcol[j] = (b < nbq) ? (int)(bsq + b) : -1;
             hsum[j] = 0;
+            hacc[j] = 0;
         }
     }
     // The counting thread's coordinates, loaded ONE ROUND AHEAD as a loop-carried value. (Round 4, ISA: loaded at the top of
@@ -214,14 +216,24 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
         }
         lds_barrier();
         if constexpr (COUNT) {
+            // Counts leave as one row of cnt[counting tile][bucket] with the ACTUAL number of item units; the totals -- the bucket
+            // bases -- take every (scatter tile, bucket) run rounded up to plan.pad units (line-aligned runs, plan.pad > 1: the
+            // scatter pass reserves its runs in such multiples; a workgroup's counting tiles are then whole scatter tiles, the
+            // host makes `rounds` a multiple of cps)
             uint32_t *row = cnt + (size_t)(tile0 + r) * plan.total_buckets;
+            const bool close = plan.pad > 1u && ((uint32_t)((tile0 + r + 1) % (int64_t)cps) == 0u || tile0 + r + 1 == tiles);
 #pragma unroll
             for (int j = 0; j < HE; ++j) {
                 if (hcol[j] >= 0) {
                     const uint32_t h = s_hist[threadIdx.x + j * kFrontThreads];
                     s_hist[threadIdx.x + j * kFrontThreads] = 0;
                     row[hcol[j]] = h;
+                    hacc[j] += h;
                     hsum[j] += h;
+                    if (close) {
+                        hsum[j] += (0u - hacc[j]) & (plan.pad - 1u);
+                        hacc[j] = 0;
+                    }
                 }
             }
         }
@@ -429,9 +441,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_levels_kernel(LevelTabl
         const BinLevel bl = plan.lv[plan.blevel[bi]];
         for (uint32_t b = threadIdx.x; b < bl.nb; b += kBinThreads)
         {
-            cnt[(size_t)tile * plan.total_buckets + bl.bucket0 + b] = s_hist[bi][b];
-            if (s_hist[bi][b])
-                atomicAdd(&totals[(size_t)((blockIdx.x + blockIdx.y) % kTotalShards) * kMaxBuckets + bl.bucket0 + b], s_hist[bi][b]);
+            const uint32_t c = (s_hist[bi][b] + plan.pad - 1u) & ~(plan.pad - 1u);   // (tile = scatter tile: padded run length)
+            cnt[(size_t)tile * plan.total_buckets + bl.bucket0 + b] = s_hist[bi][b];     // (rows: actual counts; totals: padded)
+            if (c)
+                atomicAdd(&totals[(size_t)((blockIdx.x + blockIdx.y) % kTotalShards) * kMaxBuckets + bl.bucket0 + b], c);
         }
     }
 }

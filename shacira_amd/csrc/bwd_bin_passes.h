@@ -12,19 +12,27 @@ namespace shacira {
 // returning atomic on the bucket's cursor (set to the bucket's base by the bucket scan): runs of different tiles land in
 // the bucket in arrival order -- the consumer's fixed-point sums do not depend on it.
 // H: half-precision item stream (fp16 tables, F = 2): 8-byte pair items, 16-byte compact items.
-template <int DIM, int F, bool H, bool STREAM = true>
-__global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt, BinPlan plan,
+#ifdef SHACIRA_SCATTER_WAVES   // A/B builds: cap the registers so that this many waves share a SIMD
+#define SHACIRA_SCATTER_ATTR __attribute__((amdgpu_waves_per_eu(SHACIRA_SCATTER_WAVES)))
+#else
+#define SHACIRA_SCATTER_ATTR
+#endif
+template <int DIM, int F, int FMT, bool STREAM = true>
+__global__ __launch_bounds__(kBinThreads) SHACIRA_SCATTER_ATTR void bin_scatter_kernel(LevelTable lt, BinPlan plan,
                                                                   const float *__restrict__ coords,
                                                                   const float *__restrict__ gT,
                                                                   unsigned long long *__restrict__ cursor,
                                                                   const uint32_t *__restrict__ cnt, uint32_t cps,
                                                                   uint32_t cnt_rows,
-                                                                  typename ItemSel<F, H>::type *__restrict__ items,
+                                                                  typename ItemSel<F, FMT>::type *__restrict__ items,
                                                                   int64_t sample0, int64_t N, int64_t gpitch,
                                                                   float *__restrict__ zero_acc,
                                                                   const int32_t *__restrict__ first_idx,
                                                                   const uint32_t *__restrict__ unit_first) {
-    typedef typename ItemSel<F, H>::type ItemT;
+    typedef typename ItemSel<F, FMT>::type ItemT;
+    constexpr bool H = FMT == 1;      // half-precision stream (fp16 tables)
+    constexpr bool P12 = FMT == 2;    // 12-byte units (fp32 tables, 3-D, F = 2, large batches)
+    static_assert(!P12 || (DIM == 3 && F == 2), "12-byte units: 3-D, F = 2");
     constexpr int NP = 1 << (DIM - 1);
     constexpr int kTileD = TileOf<DIM>::value;
     constexpr int SPT = kTileD / kBinThreads;  // samples per thread
@@ -37,7 +45,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     static_assert(kStage % 2 == 0, "two-slot items never straddle a window");
     extern __shared__ __align__(16) unsigned char s_raw[];
     ItemT *s_items = reinterpret_cast<ItemT *>(s_raw);
-    uint8_t *s_bucket = reinterpret_cast<uint8_t *>(s_items + kStage);
+    // (one window: the buffer holds the tile's items plus the pad units of its runs, plan.stage_cap >= kStage; windows: exact runs)
+    uint8_t *s_bucket = reinterpret_cast<uint8_t *>(s_items + (kScatterSplit == 1 ? plan.stage_cap : (uint32_t)kStage));
     __shared__ uint32_t s_hist[kMaxLevelBuckets];
     __shared__ uint32_t s_start[kMaxLevelBuckets + 1];
     __shared__ uint64_t s_gbase[kMaxLevelBuckets];
@@ -69,6 +78,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     for (int u = 0; u < SPT; ++u) {
         int64_t i = sample0 + (int64_t)tile * kTileD + threadIdx.x + u * kBinThreads;
         i = i < N ? i : N - 1;
+#ifdef ABL_NO_LOAD    // every thread reads the same few samples: cached loads, same arithmetic downstream
+        i = (i * 2654435761ll) & 1023;
+#endif
 #pragma unroll
         for (int a = 0; a < DIM; ++a) craw[u][a] = coords[i * DIM + a];
         const float *gp = gT + ((int64_t)lvl * gpitch + i) * F;
@@ -80,13 +92,18 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
             for (int j = 0; j < F; ++j) graw[u][j] = gp[j];
         }
     }
+    // (round 5, tried and dropped: wave 1 laying out the tile's runs from the counting pass's numbers up front -- scan, pad fill
+    // and final staging positions drawn by the ranking atomics themselves, two barriers and the scan phase fewer -- made this
+    // kernel 75 us SLOWER on S1: every wave then waits behind one wave's global loads; profiles/r05_experiments.md)
     const bool reserver = threadIdx.x >= 64 && threadIdx.x - 64 < bl.nb;
     unsigned long long run_base = 0ull;
     if (reserver) {
+        // cnt[counting tile][bucket] holds the ACTUAL numbers of item units; the run is reserved in multiples of plan.pad
         const uint32_t gb = bl.bucket0 + threadIdx.x - 64;
         const uint32_t *row = cnt + (size_t)tile * cps * plan.total_buckets + gb;
         uint32_t c = 0;
         for (uint32_t k = 0; k < cps && tile * cps + k < cnt_rows; ++k) c += row[(size_t)k * plan.total_buckets];
+        c = (c + plan.pad - 1u) & ~(plan.pad - 1u);
         if (c) run_base = atomicAdd(&cursor[gb], (unsigned long long)c);
     }
 #pragma unroll
@@ -148,8 +165,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     lds_barrier();   // (not __syncthreads(): its vmcnt(0) would wait for the reservation)
     if (threadIdx.x < 64) {  // wave 0: exclusive scan of the <= 128 bucket counts, two per lane
         const uint32_t lane = threadIdx.x;
-        const uint32_t c0 = (2 * lane < bl.nb) ? s_hist[2 * lane] : 0u;
-        const uint32_t c1 = (2 * lane + 1 < bl.nb) ? s_hist[2 * lane + 1] : 0u;
+        // run lengths in multiples of plan.pad (line-aligned runs; what the reservation above took)
+        const uint32_t pm = plan.pad - 1u;
+        const uint32_t c0 = (2 * lane < bl.nb) ? ((s_hist[2 * lane] + pm) & ~pm) : 0u;
+        const uint32_t c1 = (2 * lane + 1 < bl.nb) ? ((s_hist[2 * lane + 1] + pm) & ~pm) : 0u;
         uint32_t incl = c0 + c1;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -165,6 +184,16 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
     // one window (kScatterSplit == 1: the loop and the window test vanish at compile time -- the formats that do not gain
     // from windows keep the code they had) or ceil(staged / kStage) of them; an item's position in the tile's sorted order is
     // re-read per window (an array of positions cost ten registers and 1-3 % on every format)
+    if (kScatterSplit == 1 && plan.pad > 1u && threadIdx.x < bl.nb) {
+        // pad units behind the bucket's items: all-zero units (no valid corner in any item format), written out with the run
+        const uint32_t b = threadIdx.x;
+        for (uint32_t pos = s_start[b] + s_hist[b]; pos < s_start[b + 1]; ++pos) {
+            uint32_t *w = reinterpret_cast<uint32_t *>(&s_items[pos]);
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(ItemT) / 4); ++k) w[k] = 0u;
+            s_bucket[pos] = (uint8_t)b;
+        }
+    }
     const uint32_t staged = s_start[bl.nb];
     const uint32_t n_win = (kScatterSplit == 1) ? 1u : (staged + (uint32_t)kStage - 1u) / (uint32_t)kStage;
     for (uint32_t wi = 0; wi < n_win; ++wi) {
@@ -202,6 +231,25 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                     }
                     continue;
                 }
+                if constexpr (P12) {
+                    if (compact) {   // two 12-byte units {key, fx, fy} {fz, g0, g1}
+                        Item12 u0, u1;
+                        u0.w[0] = ps[u][q].key;
+                        u0.w[1] = __float_as_uint(fx[u]);
+                        u0.w[2] = __float_as_uint(fyz[u][0]);
+                        u1.w[0] = __float_as_uint(fyz[u][1]);
+                        u1.w[1] = __float_as_uint(g[u][0]);
+                        u1.w[2] = __float_as_uint(g[u][1]);
+                        s_items[pos] = u0;
+                        s_items[pos + 1] = u1;
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                        s_bucket[pos + 1] = (uint8_t)ps[u][q].bucket;
+                    } else {
+                        s_items[pos] = pack_item12(ps[u][q].key, fx[u], dense, g[u][0] * ps[u][q].wrest, g[u][1] * ps[u][q].wrest);
+                        s_bucket[pos] = (uint8_t)ps[u][q].bucket;
+                    }
+                    continue;
+                }
                 if constexpr (H && F == 2) {
                     if (compact) {   // one 16-byte item = two 8-byte units (pos is even: every count of the level is)
                         ItemHC c;
@@ -223,6 +271,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                     }
                     continue;
                 }
+                if constexpr (!H && !P12) {
                 Item<F> it;
                 it.key = ps[u][q].key;
                 it.fx = fx[u];
@@ -273,6 +322,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
                     *reinterpret_cast<Item<F> *>(&s_items[pos]) = it;
                     s_bucket[pos] = (uint8_t)ps[u][q].bucket;
                 }
+                }
             }
         }
     }
@@ -283,11 +333,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_scatter_kernel(LevelTable lt,
         lds_barrier();
     }
     const uint32_t in_window = (kScatterSplit == 1 || staged - w0 < (uint32_t)kStage) ? (staged - w0) : (uint32_t)kStage;
+#ifndef ABL_NO_STORE   // (ablation builds: make variant ... EXTRA=-DABL_*; wrong results on purpose)
     for (uint32_t pos = threadIdx.x; pos < in_window; pos += kBinThreads) {
         const uint32_t b = s_bucket[pos];
         // write-once / read-once stream: non-temporal stores (measured -7 % on the whole backward)
         store_item_nt<STREAM>(items + s_gbase[b] + (w0 + pos - s_start[b]), s_items[pos]);
     }
+#endif
     if (kScatterSplit > 1 && wi + 1u < n_win) lds_barrier();   // the buffer is refilled by the next window
     }
     // selective table zeroing, second half (zero_unowned_rows_kernel did the rows no bucket covers): a hashed bucket with
@@ -323,11 +375,13 @@ __device__ unsigned int g_consume_trace_n;
 // (FX also selects the item loads' cache policy: fixed-point images <=> batches from 2^17 samples <=> streaming loads; the
 // fp64 form of small batches reads its items with plain loads -- the scatter pass wrote them with plain stores, see
 // store_item_nt)
-template <int F, bool FX, bool H, class Hook>
+template <int F, bool FX, int FMT, class Hook>
 __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan &plan, const int32_t *__restrict__ first_idx,
-                                             const UnitDesc d, const typename ItemSel<F, H>::type *__restrict__ items,
+                                             const UnitDesc d, const typename ItemSel<F, FMT>::type *__restrict__ items,
                                              float *__restrict__ grad_table, int force_atomic, int headroom, double *s_acc,
                                              Hook &&hook, __half *__restrict__ half_out = nullptr) {
+    constexpr bool H = FMT == 1;      // half-precision stream (fp16 tables)
+    constexpr bool P12 = FMT == 2;    // 12-byte units (Item12)
     // (uniform over the workgroup -- every thread copied the same descriptor out of LDS; as scalars the level's record comes
     // out of the kernel arguments by scalar loads instead of one vector load per field)
     const uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.bucket);
@@ -398,7 +452,15 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
             else atomicAdd(&s_acc[row * F + j], (double)c);
         }
     };
+#ifdef ABL_CONSUME_STREAM_ONLY   // ablation: the item loads alone (everything loaded is folded into one word so nothing is dropped)
+    uint32_t abl_sink = 0;
+#endif
     auto add_pair = [&](uint32_t ra, uint32_t rb, bool va, bool vb, float fxv, const float (&a)[F]) {
+#ifdef ABL_CONSUME_STREAM_ONLY
+        abl_sink ^= ra ^ rb ^ (uint32_t)va ^ (uint32_t)vb ^ __float_as_uint(fxv) ^ __float_as_uint(a[0]) ^ __float_as_uint(a[F - 1]);
+        if (abl_sink == 0x12345678u) s_fix[ra] = abl_sink;
+        return;
+#endif
         float ar[F];
         rotate_features<F>(a, rot, ar);
         if (va) add_row(ra, ar, 1.0f - fxv);
@@ -419,7 +481,7 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    if constexpr ((F == 2 || F == 4) && !H) {
+    if constexpr ((F == 2 || F == 4) && !H && !P12) {
         if (bl.compact && two_d) {
             // 2-D: one sample per item {local base row | valid | fx, fy (25-bit fixed point), g[F]}; 4 corners
             const Item<F> *itf = reinterpret_cast<const Item<F> *>(items);
@@ -476,7 +538,34 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
         if (bl.compact) {
             constexpr int UC = 2;
             const uint64_t first = begin + 2ull * threadIdx.x, stride = 2ull * kConsumeThreads * UC;
-            if constexpr (H && F == 4) {
+            if constexpr (P12) {
+                // one sample per two 12-byte units {local base row | valid, fx, fy} {fz, g0, g1}
+                // (loads unconditional from a clamped unit pair, validity kept beside them: a load under `if (p + 1 < end)` with the
+                // key cleared in the else branch is closed by s_waitcnt vmcnt(0) -- every load of the round waited for on its own)
+                Item12 ia[UC], ib[UC];
+                uint64_t pcur = 0;
+                stream(first, end, stride,
+                       [&](uint64_t p0) {
+                           pcur = p0;
+#pragma unroll
+                           for (int u = 0; u < UC; ++u) {
+                               const uint64_t p = p0 + 2ull * u * kConsumeThreads;
+                               const uint64_t pc = (p + 1 < end) ? p : begin;
+                               ia[u] = load_item12_nt(items + pc);
+                               ib[u] = load_item12_nt(items + pc + 1);
+                           }
+                       },
+                       [&]() {
+#pragma unroll
+                           for (int u = 0; u < UC; ++u) {
+                               if (pcur + 2ull * u * kConsumeThreads + 1 >= end) continue;
+                               if (!(ia[u].w[0] & (1u << 26))) continue;
+                               const float gg[F] = {__uint_as_float(ib[u].w[1]), __uint_as_float(ib[u].w[2])};
+                               add_compact(ia[u].w[0] & 0x1FFFu, __uint_as_float(ia[u].w[1]), __uint_as_float(ia[u].w[2]),
+                                           __uint_as_float(ib[u].w[0]), gg);
+                           }
+                       });
+            } else if constexpr (H && F == 4) {
                 // one sample per two 16-byte units: {local base row | valid, fx, fy, fz (fp32)} {half2 g01, half2 g23, -, -}
                 u32x4 va[UC], vb2[UC];
                 stream(first, end, stride,
@@ -586,7 +675,30 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
         }
     }
     constexpr int UN = 8;  // 16-byte loads in flight per thread (4: -1 %, 16: +3 % with the fixed-point atomics)
-    if constexpr (H && F == 4) {
+    if constexpr (P12) {
+        Item12 it[UN];
+        uint64_t pcur = 0;
+        stream(begin + threadIdx.x, end, (uint64_t)kConsumeThreads * UN,
+               [&](uint64_t p0) {
+                   pcur = p0;
+#pragma unroll
+                   for (int u = 0; u < UN; ++u) {   // unconditional, clamped; validity checked at use (see the compact form)
+                       const uint64_t pp = p0 + (uint64_t)u * kConsumeThreads;
+                       it[u] = load_item12_nt(items + (pp < end ? pp : end - 1));
+                   }
+               },
+               [&]() {
+#pragma unroll
+                   for (int u = 0; u < UN; ++u) {
+                       uint32_t ra, rb;
+                       bool va, vb;
+                       float fxv, a[F];
+                       unpack_item12(it[u].w, ra, rb, va, vb, fxv, a);
+                       const bool in = pcur + (uint64_t)u * kConsumeThreads < end;
+                       add_pair(ra, rb, va && in, vb && in, fxv, a);
+                   }
+               });
+    } else if constexpr (H && F == 4) {
         u32x4 v[UN];
         stream(begin + threadIdx.x, end, (uint64_t)kConsumeThreads * UN,
                [&](uint64_t p0) {
@@ -755,12 +867,12 @@ __device__ __forceinline__ void consume_unit(const LevelTable &lt, const BinPlan
 // consume_unit are LDS-only). The fetch is pipelined one unit ahead: thread 0 draws the NEXT unit's number when a unit
 // starts and loads its descriptor once the first round of items is in (consume_unit's hook), so that neither the returning
 // atomic nor the descriptor load stands between two units. `work_counter` NULL: one unit per workgroup (small batches).
-template <int F, bool FX, bool H>
+template <int F, bool FX, int FMT>
 __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable lt, BinPlan plan,
                                                                       const int32_t *__restrict__ first_idx,
                                                                       const uint32_t *__restrict__ unit_first,
                                                                       const UnitDesc *__restrict__ unit_desc,
-                                                                      const typename ItemSel<F, H>::type *__restrict__ items,
+                                                                      const typename ItemSel<F, FMT>::type *__restrict__ items,
                                                                       float *__restrict__ grad_table,
                                                                       int force_atomic, int headroom,
                                                                       uint32_t *__restrict__ work_counter,
@@ -773,7 +885,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         const UnitDesc d = unit_desc[blockIdx.x];
         const uint32_t unit_end = unit_first[plan.total_buckets];
         if (blockIdx.x >= unit_end) return;
-        consume_unit<F, FX, H>(lt, plan, first_idx, d, items, grad_table, force_atomic, headroom, s_acc, []() {}, half_out);
+        consume_unit<F, FX, FMT>(lt, plan, first_idx, d, items, grad_table, force_atomic, headroom, s_acc, []() {}, half_out);
         return;
     }
     const uint32_t unit_end = unit_first[plan.total_buckets];
@@ -791,7 +903,7 @@ __global__ __launch_bounds__(kConsumeThreads) void bin_consume_kernel(LevelTable
         if (unit >= unit_end) return;
         const UnitDesc d = s_desc;
         if (threadIdx.x == 0) nxt = atomicAdd(work_counter, 1u);
-        consume_unit<F, FX, H>(lt, plan, first_idx, d, items, grad_table, force_atomic, headroom, s_acc, [&]() {
+        consume_unit<F, FX, FMT>(lt, plan, first_idx, d, items, grad_table, force_atomic, headroom, s_acc, [&]() {
             if (threadIdx.x == 0) s_desc_nxt = unit_desc[nxt < unit_end ? nxt : unit_end - 1u];
         }, half_out);
         // (every thread read s_unit / s_desc before the barriers inside consume_unit: thread 0 may overwrite them now)
@@ -826,7 +938,19 @@ __global__ __launch_bounds__(256) void f32_to_f16_skip_kernel(const float *__res
         if (r1 > hi) r1 = hi;
         if (hashed_binned && c < (int64_t)bl.nb) {
             const uint32_t gb = bl.bucket0 + (uint32_t)c;
-            if (unit_first[gb + 1] - unit_first[gb] == 1u) continue;   // written by the consume pass
+            if (unit_first[gb + 1] - unit_first[gb] == 1u) {
+                // written by the consume pass -- exactly the bucket's rows INSIDE the level, [w0, w1): what the chunk holds
+                // besides them (rows in front of the level's start that ride with chunk 0, padding rows behind a level whose
+                // last bucket is partial) is still converted here, or the caller's `empty` half table would keep garbage there
+                // (round-4 advisor finding: the fp32 path and the reference's zeros_like both leave zeros)
+                const int64_t w0 = level0 + c * chunk;
+                int64_t w1 = level0 + (int64_t)bl.used;
+                if (w1 > w0 + chunk) w1 = w0 + chunk;
+                if (w1 > hi) w1 = hi;
+                for (int64_t e = r0 * F + threadIdx.x; e < w0 * F; e += 256) dst[e] = __float2half_rn(acc[e]);
+                for (int64_t e = w1 * F + threadIdx.x; e < r1 * F; e += 256) dst[e] = __float2half_rn(acc[e]);
+                continue;
+            }
         }
         for (int64_t e = r0 * F + threadIdx.x; e < r1 * F; e += 256) dst[e] = __float2half_rn(acc[e]);
     }

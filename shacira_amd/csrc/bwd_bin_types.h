@@ -63,6 +63,9 @@ struct BinPlan {
     uint32_t chunk;     // items per consumer work unit
     uint32_t chunk_min; // smallest unit size of the plan (sizes the unit list)
     uint32_t nbl;       // number of binned levels
+    uint32_t pad;       // a (tile, bucket) run is reserved in multiples of this many item units (power of two; 1 = exact): with 128 / unit
+                        // bytes every run starts and ends on a 128-byte line, see make_plan
+    uint32_t stage_cap; // item units the scatter pass's LDS staging buffer holds: the tile's items + the pad units of its runs
     uint32_t blevel[SHACIRA_MAX_LODS];  // their level indices (grid.y of passes A/B); 32-bit = scalar loads
     uint32_t bstart[SHACIRA_MAX_LODS];  // first global bucket of binned level q (= lv[blevel[q]].bucket0)
     uint32_t bnb[SHACIRA_MAX_LODS];     // its number of buckets (= lv[blevel[q]].nb): one unchained scalar load in the front kernel
@@ -101,9 +104,62 @@ struct alignas(16) ItemH4 {
     float fx;
     uint32_t p2, p3;   // two half2 as raw bits (pair item: a01, a23; compact unit 0: fy, fz as fp32 bits)
 };
-template <int F, bool H> struct ItemSel { typedef Item<F> type; };
-template <> struct ItemSel<2, true> { typedef ItemH type; };
-template <> struct ItemSel<4, true> { typedef ItemH4 type; };
+// fp32 tables, 3-D, F = 2, large batches (round 5): 12-byte units. Both item passes move nothing but this stream at the
+// memory system's rate, so its bytes are the backward's time: 16 -> 12 bytes per x-pair, 32 -> 24 per compact sample.
+//   pair item:     w0 = rowA (13) | code (4) << 13 | fx bits [6, 21) << 17
+//                  w1 = a0 rounded to a 21-bit mantissa | fx bits [3, 6);   w2 = a1 likewise | fx bits [0, 3)
+//                  code: 0 no corner (pad unit), 1..13 hashed level: rowB = rowA ^ (2^code - 1), 14 dense: rowB = rowA + 1,
+//                  15 dense: rowA only (x + 1 outside the level). fx = 21-bit fixed point.
+//   compact item:  two units {local base row | valid << 26, fx, fy} {fz, g0, g1}: exact, as in the 16-byte stream.
+// Error of a pair item: |a| * (2^-22 from the mantissa + 2^-22 from fx) per contribution, against the 1e-5 bar on the level's
+// largest gradient (measured ~5e-7 of it where the 16-byte stream measures 1e-7); fp16 / F = 4 / 2-D streams are unchanged.
+struct alignas(4) Item12 {
+    uint32_t w[3];
+};
+// FMT: 0 = fp32 payloads (16- / 24-byte units), 1 = half-precision stream of fp16 tables, 2 = 12-byte units (Item12)
+template <int F, int FMT> struct ItemSel { typedef Item<F> type; };
+template <> struct ItemSel<2, 1> { typedef ItemH type; };
+template <> struct ItemSel<4, 1> { typedef ItemH4 type; };
+template <> struct ItemSel<2, 2> { typedef Item12 type; };
+
+__device__ __forceinline__ Item12 pack_item12(uint32_t key, float fx, bool dense, float a0, float a1) {
+    const uint32_t ra = key & 0x1FFFu, rb = (key >> 13) & 0x1FFFu;
+    const uint32_t vb = (key >> 27) & 1u;
+    const uint32_t code = dense ? (vb ? 14u : 15u) : (32u - (uint32_t)__clz((int)(ra ^ rb)));
+    uint32_t q = (uint32_t)(fx * 2097152.0f + 0.5f);   // fx in [0, 1): 21 bits, round to nearest
+    q = q > 2097151u ? 2097151u : q;
+    Item12 it;
+    it.w[0] = ra | (code << 13) | ((q >> 6) << 17);
+    it.w[1] = ((__float_as_uint(a0) + 4u) & ~7u) | ((q >> 3) & 7u);   // (mantissa rounded half-up in magnitude; inf stays inf)
+    it.w[2] = ((__float_as_uint(a1) + 4u) & ~7u) | (q & 7u);
+    return it;
+}
+__device__ __forceinline__ void unpack_item12(const uint32_t (&w)[3], uint32_t &ra, uint32_t &rb, bool &va, bool &vb, float &fx,
+                                              float (&a)[2]) {
+    const uint32_t code = (w[0] >> 13) & 15u;
+    ra = w[0] & 0x1FFFu;
+    rb = code >= 14u ? ((ra + 1u) & 0x1FFFu) : (ra ^ ((1u << code) - 1u));
+    va = code != 0u;
+    vb = code != 0u && code != 15u;
+    const uint32_t q = ((w[0] >> 17) << 6) | ((w[1] & 7u) << 3) | (w[2] & 7u);
+    fx = (float)q * (1.0f / 2097152.0f);
+    a[0] = __uint_as_float(w[1] & ~7u);
+    a[1] = __uint_as_float(w[2] & ~7u);
+}
+template <bool STREAM = true> __device__ __forceinline__ void store_item_nt(Item12 *p, const Item12 &it) {
+    // three dword stores that the compiler merges into one global_store_dwordx3 nt (a 3-vector store would be widened to four
+    // elements by the front end); 12-byte lane accesses stream as fast as 16-byte ones (tools/microbench3.hip)
+    __builtin_nontemporal_store(it.w[0], &p->w[0]);
+    __builtin_nontemporal_store(it.w[1], &p->w[1]);
+    __builtin_nontemporal_store(it.w[2], &p->w[2]);
+}
+__device__ __forceinline__ Item12 load_item12_nt(const Item12 *p) {
+    Item12 it;
+    it.w[0] = __builtin_nontemporal_load(&p->w[0]);
+    it.w[1] = __builtin_nontemporal_load(&p->w[1]);
+    it.w[2] = __builtin_nontemporal_load(&p->w[2]);
+    return it;
+}
 
 // LDS staging windows per scatter tile (bwd_bin_passes.h, pass B), by item format; measured same-box (profiles/
 // r04_experiments.md 14): the 16-byte fp32 and 8-byte half items of F = 2 and the 16-byte half items of F = 4 lose 1-3 % with windows; the
@@ -235,6 +291,17 @@ __device__ __forceinline__ void enumerate_pairs(const double (&t)[DIM], int32_t 
     const uint32_t ux = (uint32_t)p[0];
     const uint32_t r = (uint32_t)res;
     constexpr int NP = 1 << (DIM - 1);
+    // hashed levels: the two products per axis once ((y + 1) * P = y * P + P mod 2^32) -- written per pair, each pair's
+    // v_mul_lo_u32 (a quarter-rate instruction) stayed inside its own uniform branch: eight per sample instead of two
+    uint32_t hyv[2] = {0u, 0u}, hzv[2] = {0u, 0u};
+    if (!dense) {
+        hyv[0] = (uint32_t)p[1] * kPrimeY;
+        hyv[1] = hyv[0] + kPrimeY;
+        if constexpr (DIM == 3) {
+            hzv[0] = (uint32_t)p[2] * kPrimeZ;
+            hzv[1] = hzv[0] + kPrimeZ;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         // q bit (DIM-2) -> y offset, bit 0 -> z offset (3-D); q -> y offset (2-D): same order as the corner bits
@@ -261,8 +328,8 @@ __device__ __forceinline__ void enumerate_pairs(const double (&t)[DIM], int32_t 
             out[q].bucket = ok ? b : 0u;
             out[q].key = (ra & 0x1FFFu) | (((ra + 1u) & 0x1FFFu) << 13) | (va << 26) | (vb << 27);
         } else {
-            uint32_t h = uy * kPrimeY;
-            if constexpr (DIM == 3) h ^= uz * kPrimeZ;
+            uint32_t h = hyv[dy];
+            if constexpr (DIM == 3) h ^= hzv[dz];
             const uint32_t rowA = (ux ^ h) & mask;
             const uint32_t rowB = ((ux + 1u) ^ h) & mask;
             out[q].bucket = rowA >> bl.shift;

@@ -47,6 +47,13 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
                       bool one_image_compact);
 static inline bool half_items(int dtype, const LevelTable &lt);
+static inline int item_format(int dim, int dtype, const LevelTable &lt, int64_t n);
+static inline size_t item_unit_bytes(int fmt, const LevelTable &lt);
+#ifndef SHACIRA_RUN_ALIGN
+#define SHACIRA_RUN_ALIGN 64           // bytes a (tile, bucket) run is padded to: the memory system's write atom (measured:
+                                       // runs on 64-byte boundaries stream at 4.7-5.0 TB/s, on 128-byte ones at 5.2-5.4, on
+                                       // 16 / 32 / 48-byte ones at 2.5-3.5; 64 costs half the pad units of 128)
+#endif
 #ifndef SHACIRA_FX_MIN
 #define SHACIRA_FX_MIN (1 << 17)       // fixed-point images from this batch size (below: fp64 images)
 #endif
@@ -127,7 +134,7 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
 static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
                       bool one_image_compact) {
     struct Key {
-        int dim, dtype, acc_kib, oic, compact;
+        int dim, dtype, acc_kib, oic, compact, run_pad, item12;
         int64_t n_batch;
         LevelTable lt;
     };
@@ -142,6 +149,8 @@ static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch,
     Key k;
     std::memset(&k, 0, sizeof(k));     // (padding bytes take part in the comparison)
     k.dim = dim; k.dtype = dtype; k.acc_kib = acc_kib; k.oic = one_image_compact ? 1 : 0; k.compact = opt().bwd_compact;
+    k.run_pad = opt().bwd_run_pad;
+    k.item12 = opt().bwd_item12;
     k.n_batch = n_batch;
     std::memcpy(&k.lt, &lt, sizeof(LevelTable));
     for (int e = 0; e < kEntries; ++e) {
@@ -297,7 +306,35 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
     uint64_t chunk = (uint64_t)n_batch * plan.pairs / 48 + 1024;
     if (chunk < 8192) chunk = 8192;
     if (chunk > (1u << 22)) chunk = 1u << 22;
-    plan.chunk = (uint32_t)chunk & ~1u;   // even: a compact item (two 16-byte slots) never straddles two work units
+    // Line-aligned runs (round 5). A (tile, bucket) run used to start wherever the bucket's cursor stood: every 128-byte line of
+    // the item array was then written in two pieces by different 16-lane groups of a store (and the lines at a run's ends by
+    // different workgroups), and scattered runs written that way reach 3.2 TB/s at 1 KB per run against 5.3 TB/s for the same
+    // runs on line boundaries -- where the run LENGTH stops mattering at all (tools/microbench3.hip, profiles/r05_experiments.md).
+    // So runs are reserved in multiples of 128 bytes (pad units = all-zero items, which no consumer adds): large batches only
+    // (below 2^17 samples the item array lives in the caches, which merge the pieces), 16-byte units only (a 24-byte unit would
+    // need 384-byte multiples; the 8-byte half-precision units are written with plain stores, which the L2 merges, and 16 of
+    // them per line cost more pad bytes than they return: S1 fp16 backward 0.438 -> 0.461 ms with pads), and only while two
+    // scatter workgroups still share a CU with the pad slots staged.
+    plan.pad = 1;
+    {
+        const size_t unit = item_unit_bytes(item_format(dim, dtype, lt, n_batch), lt);
+        const uint32_t tile_units = (uint32_t)tile_samples(dim) * plan.pairs;
+        uint32_t maxnb = 0;
+        for (uint32_t q = 0; q < plan.nbl; ++q) maxnb = plan.lv[plan.blevel[q]].nb > maxnb ? plan.lv[plan.blevel[q]].nb : maxnb;
+        bool windows = false;
+#ifdef SHACIRA_SCATTER_SPLIT
+        windows = SHACIRA_SCATTER_SPLIT > 1;
+#endif
+        if (opt().bwd_run_pad != 0 && !windows && plan.nbl > 0 && n_batch >= SHACIRA_FX_MIN && (unit == 16 || unit == 12)) {
+            const uint32_t P = unit == 12 ? (uint32_t)(SHACIRA_RUN_ALIGN / 4) : (uint32_t)(SHACIRA_RUN_ALIGN / unit);   // 12-byte units: lcm(12, 64) = 16 of them
+            const size_t staged = (size_t)(tile_units + maxnb * (P - 1u)) * (unit + 1);
+            if (staged <= (size_t)78 * 1024 || (size_t)tile_units * (unit + 1) > (size_t)78 * 1024) plan.pad = P;
+        }
+        plan.stage_cap = tile_units + maxnb * (plan.pad - 1u);
+    }
+    const uint32_t cmask = plan.pad > 2u ? plan.pad - 1u : 1u;
+    plan.chunk = (uint32_t)chunk & ~cmask;   // even: a compact item (two 16-byte slots) never straddles two work units; a
+                                             // multiple of the run pad: every unit starts on a 128-byte line
     // Unit order = bucket order (dense compact levels first, then the hashed levels, coarse to fine) is the measured best for
     // the persistent consume pass: hashed levels first or reverse order cost +45 us on S1, smaller units for the dense levels
     // or for the last hashed levels changed nothing (round 3, tools/r3_ab.py).
@@ -328,13 +365,21 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
 static inline bool half_items(int dtype, const LevelTable &lt) {
     return dtype == SHACIRA_F16 && (lt.feature_dim == 2 || lt.feature_dim == 4);
 }
-static inline size_t item_unit_bytes(int dtype, const LevelTable &lt) {
-    if (half_items(dtype, lt)) return lt.feature_dim == 2 ? 8 : 16;
+// item stream format of a call: 0 = fp32 payloads (8 + 4 F bytes per unit), 1 = half-precision stream (fp16 tables), 2 = 12-byte
+// units (fp32 tables, 3-D, F = 2, batches that accumulate in fixed-point images; option "bwd_item12")
+static inline int item_format(int dim, int dtype, const LevelTable &lt, int64_t n) {
+    if (half_items(dtype, lt)) return 1;
+    if (dim == 3 && lt.feature_dim == 2 && dtype == SHACIRA_F32 && n >= SHACIRA_FX_MIN && opt().bwd_item12 != 0) return 2;
+    return 0;
+}
+static inline size_t item_unit_bytes(int fmt, const LevelTable &lt) {
+    if (fmt == 1) return lt.feature_dim == 2 ? 8 : 16;
+    if (fmt == 2) return 12;
     return 8 + 4 * (size_t)lt.feature_dim;
 }
 
 static int64_t bin_batch_samples(int dim, int dtype, const LevelTable &lt, int64_t n) {
-    const size_t item = item_unit_bytes(dtype, lt);
+    const size_t item = item_unit_bytes(item_format(dim, dtype, lt, n), lt);
     BinPlan plan;
     make_plan(dim, dtype, lt, kTile, plan, choose_acc_kib(dim, dtype, lt, n), one_image_compact_rule(n));
     const size_t per_sample = (size_t)(plan.nbl ? plan.nbl : 1) * (1u << (dim - 1)) * item;
@@ -387,7 +432,7 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     BinPlan plan;
     const int64_t nb = bin_batch_samples(dim, dtype, lt, n);
     make_plan(dim, dtype, lt, nb, plan, choose_acc_kib(dim, dtype, lt, n), one_image_compact_rule(n));
-    const size_t item = item_unit_bytes(dtype, lt);
+    const size_t item = item_unit_bytes(item_format(dim, dtype, lt, n), lt);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     // gT and gmax first: their offsets must not depend on the level range of the call (REUSE_STAGED calls share them).
@@ -397,12 +442,14 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     const bool no_stage = table_all_direct(dim, dtype, lt, n);
     const size_t o_gT = take(no_stage ? 0 : (size_t)level_pitch(n) * lt.num_lods * lt.feature_dim * sizeof(float));
     const size_t o_ctrl = take((size_t)(kTotalShards * kMaxBuckets + SHACIRA_MAX_LODS) * sizeof(uint32_t));   // totals | gmax: one memset
-    const size_t o_items = take((size_t)nb * slots_per_sample(plan) * item);
+    // (+ the pad units of line-aligned runs: at most pad - 1 per (scatter tile, bucket))
+    const uint64_t pad_units = (uint64_t)plan.num_tiles * plan.total_buckets * (plan.pad - 1u);
+    const size_t o_items = take(((size_t)nb * slots_per_sample(plan) + (size_t)pad_units) * item);
     const size_t o_base = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
     const size_t o_cur = take((size_t)(kMaxBuckets + 2) * sizeof(uint64_t));
     const size_t o_cnt = take((size_t)(nb / 128 + 8) * plan.total_buckets * sizeof(uint32_t));   // smallest counting tile: 128
     const size_t o_unit = take((size_t)(kMaxBuckets + 2) * sizeof(uint32_t));
-    const uint64_t max_items_ws = (uint64_t)nb * plan.nbl * plan.pairs;
+    const uint64_t max_items_ws = (uint64_t)nb * plan.nbl * plan.pairs + pad_units;
     const size_t o_ub = take((size_t)(max_items_ws / plan.chunk_min + plan.total_buckets + 2) * sizeof(UnitDesc));
     const size_t o_wc = take(256);
     const size_t o_acc = take(dtype == SHACIRA_F16 ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0);
@@ -574,12 +621,15 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             const int64_t tiles = (n + ts16 - 1) / ts16;
             int ts_log2 = 7;
             while ((1 << ts_log2) < ts16) ++ts_log2;
-            const int rounds = (int)((tiles + 511) / 512);
+            int rounds = (int)((tiles + 511) / 512);
+            // padded runs: a workgroup's counting tiles must be whole scatter tiles (the pad units are per scatter tile)
+            const int cps16 = TileOf<DIM>::value / ts16;
+            if (whole.pad > 1u && front_counts) rounds = (rounds + cps16 - 1) / cps16 * cps16;
             const uint32_t blocks = (uint32_t)((tiles + rounds - 1) / rounds);
 #define SHACIRA_FRONT(TT, GM, CN)                                                                                         \
             hipLaunchKernelGGL((front16_kernel<DIM, TT, F, GM, CN>), dim3(blocks), dim3(kFrontThreads), front_shmem, s, lt, \
                                whole, static_cast<const TT *>(grad_out), w.gT, coords, w.totals, w.cnt, n, NP, t_lb, t_le, ts_log2, \
-                               rounds, GM ? w.gmax : nullptr)
+                               rounds, GM ? w.gmax : nullptr, (uint32_t)cps16)
             if (dtype == SHACIRA_F32) {
                 if (use_fx && front_counts) SHACIRA_FRONT(float, true, true);
                 else if (use_fx) SHACIRA_FRONT(float, true, false);
@@ -652,10 +702,15 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     if (whole.nbl == 0) return hipSuccess;   // (fork implies binned levels)
     constexpr int NPAIR = 1 << (DIM - 1);
     // half-precision item stream: fp16 tables with F = 2 (8-byte units)
-    const bool half = half_items(dtype, lt);
-    const size_t stage = half ? (size_t)TileOf<DIM>::value * NPAIR / ScatterSplit<typename ItemSel<F, true>::type>::value *
-                                    (sizeof(typename ItemSel<F, true>::type) + 1)
-                              : (size_t)TileOf<DIM>::value * NPAIR / ScatterSplit<Item<F>>::value * (sizeof(Item<F>) + 1);
+    const int fmt = item_format(DIM, dtype, lt, n);
+    const bool half = fmt == 1;
+    // (one staging window: the tile's items + the pad units of its runs, plan.stage_cap; windows: exact runs, 1 / split of the tile)
+    auto stage_bytes = [&](const BinPlan &pl) -> size_t {
+        const size_t isz = fmt == 2 ? sizeof(Item12) : half ? sizeof(typename ItemSel<F, true>::type) : sizeof(Item<F>);
+        const int split = half ? ScatterSplit<typename ItemSel<F, true>::type>::value : ScatterSplit<Item<F>>::value;
+        const size_t units = split == 1 ? (size_t)pl.stage_cap : (size_t)TileOf<DIM>::value * NPAIR / split;
+        return units * (isz + 1);
+    };
     bool first_batch = true;
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
@@ -679,22 +734,28 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         float *zacc = selective ? acc : nullptr;
         const uint32_t cps = fused_now ? (uint32_t)(TileOf<DIM>::value / ts16) : 1u;
         const uint32_t cnt_rows = fused_now ? (uint32_t)((n + ts16 - 1) / ts16) : plan.num_tiles;
-        if (half)
+        if (fmt == 2) {
+            if constexpr (DIM == 3 && F == 2)
+                hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, 2>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
+                                   stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                                   reinterpret_cast<Item12 *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
+        } else if (half)
             hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
-                               stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                               stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
                                reinterpret_cast<typename ItemSel<F, true>::type *>(w.items), s0, hi, NP, zacc, first_idx,
                                w.unit_first);
         else if (use_fx)
             hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
-                               stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                               stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
                                reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
         else   // batches below 2^17 samples: plain item stores, the consume pass reads them back from the caches
             hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false, false>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
-                               stage, s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                               stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
                                reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
         SHACIRA_CHECK_LAUNCH();
         if (fork) SHACIRA_CHECK(hipStreamWaitEvent(s, ss->join, 0));   // table zeroed, direct levels in
-        const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NPAIR;
+        const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NPAIR +
+                                   (uint64_t)plan.num_tiles * plan.total_buckets * (plan.pad - 1u);
         uint32_t grid_units = (uint32_t)(max_items / plan.chunk_min) + plan.total_buckets + 1;
         const size_t acc_bytes = (size_t)plan.BR * F * sizeof(double);
         // persistent: as many workgroups as the chip holds fetch units from the work counter (measured: S1 backward
@@ -704,7 +765,12 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const int headroom = use_fx ? fx_headroom((uint64_t)plan.chunk + 1) : -1;   // a unit streams <= chunk items
         const int fa = multi ? 1 : 0;
         __half *hout = direct_half ? half_table : nullptr;
-        if (half && use_fx)
+        if (fmt == 2) {
+            if constexpr (DIM == 3 && F == 2)
+                hipLaunchKernelGGL((bin_consume_kernel<F, true, 2>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s, lt,
+                                   plan, first_idx, w.unit_first, w.unit_desc, reinterpret_cast<const Item12 *>(w.items), acc,
+                                   fa, headroom, wc);
+        } else if (half && use_fx)
             hipLaunchKernelGGL((bin_consume_kernel<F, true, true>), dim3(grid_units), dim3(kConsumeThreads), acc_bytes, s,
                                lt, plan, first_idx, w.unit_first, w.unit_desc,
                                reinterpret_cast<const typename ItemSel<F, true>::type *>(w.items), acc, fa, headroom, wc, hout);
@@ -729,6 +795,14 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         if (converted != nullptr) *converted = true;
     }
     return hipSuccess;
+}
+
+// largest dynamic LDS a scatter launch can ask for: one staging window of the tile's item units (+ the pad units of
+// line-aligned runs when the tile goes through in one window) and one bucket byte per unit
+template <class ItemT> static constexpr size_t stage_max(size_t tile_units) {
+    constexpr size_t split = ScatterSplit<ItemT>::value;
+    constexpr size_t padu = split != 1 ? 0 : sizeof(ItemT) == 16 ? SHACIRA_RUN_ALIGN / 16 - 1 : sizeof(ItemT) == 12 ? SHACIRA_RUN_ALIGN / 4 - 1 : 0;
+    return (tile_units / split + (size_t)kMaxLevelBuckets * padu) * (sizeof(ItemT) + 1);
 }
 
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
@@ -765,6 +839,8 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&direct_accumulate_kernel<D, FF, __half, false, true>), 16384 * sizeof(double));
         SHACIRA_DIRECT_ATTR(2, 2) SHACIRA_DIRECT_ATTR(2, 4) SHACIRA_DIRECT_ATTR(3, 2) SHACIRA_DIRECT_ATTR(3, 4)
 #undef SHACIRA_DIRECT_ATTR
+        set(reinterpret_cast<const void *>(&bin_consume_kernel<2, true, 2>), 16384 * sizeof(double));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, 2>), stage_max<Item12>(TileOf<3>::value << 2));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2, true, false>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, true, false>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2, false, false>), 16384 * sizeof(double));
@@ -773,16 +849,18 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&bin_consume_kernel<2, false, true>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, true, true>), 16384 * sizeof(double));
         set(reinterpret_cast<const void *>(&bin_consume_kernel<4, false, true>), 16384 * sizeof(double));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, true>), (size_t)TileOf<2>::value * 2 * (sizeof(ItemH4) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, true>), (size_t)kTile * 4 * (sizeof(ItemH4) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, false>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, false>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<4>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, false>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, false>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, false, false>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, false, false>), (size_t)TileOf<2>::value * 2 * (sizeof(Item<4>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, false, false>), (size_t)kTile * 4 * (sizeof(Item<2>) + 1));
-        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, false, false>), (size_t)kTile * 4 * (sizeof(Item<4>) + 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, true>), stage_max<ItemH>(TileOf<2>::value << 1));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, true>), stage_max<ItemH>(TileOf<3>::value << 2));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, true>), stage_max<typename ItemSel<4, true>::type>(TileOf<2>::value << (2 - 1)));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, true>), stage_max<typename ItemSel<4, true>::type>(TileOf<3>::value << (3 - 1)));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, false>), stage_max<Item<2>>(TileOf<2>::value << (2 - 1)));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, false>), stage_max<Item<4>>(TileOf<2>::value << (2 - 1)));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, false>), stage_max<Item<2>>(TileOf<3>::value << (3 - 1)));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, false>), stage_max<Item<4>>(TileOf<3>::value << (3 - 1)));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 2, false, false>), stage_max<Item<2>>(TileOf<2>::value << (2 - 1)));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<2, 4, false, false>), stage_max<Item<4>>(TileOf<2>::value << (2 - 1)));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 2, false, false>), stage_max<Item<2>>(TileOf<3>::value << (3 - 1)));
+        set(reinterpret_cast<const void *>(&bin_scatter_kernel<3, 4, false, false>), stage_max<Item<4>>(TileOf<3>::value << (3 - 1)));
         return attr_err;
     });
     if (attr_err != hipSuccess) return attr_err;

@@ -109,5 +109,15 @@ def test_backward_workspace_is_sized_by_the_selected_path():
     n = 1 << 20
     s1 = query(dim, res, bw, n)
     staged = n * 16 * 2 * 4                                         # gT [L][N][F] fp32
+    # round 5: runs are reserved in whole 64-byte pieces = multiples of 4 item units: at most 3 pad units per (1 024-sample
+    # tile, bucket): 1 024 tiles x 733 buckets
     slots = n * (5 * 2 + 11 * 4) * 16                               # 5 compact levels (2 slots), 11 hashed (4 pair items)
-    assert staged + slots <= s1 <= staged + slots + (32 << 20), s1  # S1: 1.07 GB (24 MB of count rows, unit list, control words)
+    pads = 1024 * 733 * 3 * 16
+    assert staged + slots <= s1 <= staged + slots + pads + (32 << 20), s1  # S1: 1.10 GB (round 4: 1.07)
+    _lib.set_option("bwd_item12", 1)                                # the optional 12-byte stream: 16 units per 192 bytes
+    try:
+        s1 = query(dim, res, bw, n)
+    finally:
+        _lib.set_option("bwd_item12", 0)
+    slots, pads = n * (5 * 2 + 11 * 4) * 12, 1024 * 733 * 15 * 12
+    assert staged + slots <= s1 <= staged + slots + pads + (48 << 20), s1  # 0.98 GB

@@ -26,6 +26,10 @@ T = int(sum(sizes))
 g = torch.Generator().manual_seed(0)
 coords = (torch.rand(N, dim, generator=g) * 2 - 1).cuda()
 go = torch.randn(N, L * F, generator=g).cuda().to(DT)
+for kv in filter(None, os.environ.get("SHACIRA_OPTS", "").split(",")):   # e.g. SHACIRA_OPTS=bwd_item12=1,bwd_run_pad=0
+    from shacira_amd import _lib
+    k, v = kv.split("=")
+    _lib.set_option(k, int(v))
 for _ in range(iters):
     hip_ops.hashgrid_backward(dim, coords, go, T, DT, first, res, bw, F)
 torch.cuda.synchronize()
