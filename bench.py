@@ -261,6 +261,35 @@ def psnr_parity(device, steps=200, height=64, width=96, seeds=(2, 3, 4, 5)):
             "cpu_seconds": time.perf_counter() - t0}
 
 
+def ranks_proof(rank, world, device):
+    """What lets a reader of the JSON line see that the collective backend really joined `world` ranks:
+    a ones tensor summed over the ranks, every rank's device ordinal gathered, the backend's name and version. Raises
+    SystemExit(3) on every rank when the sum is not `world`, so a launch that silently ran N independent replicas -- or lost
+    a rank -- cannot produce a scaling figure."""
+    info = {"ranks_seen": 1, "backend": None, "nccl_version": None, "rank_devices": None, "hostname_count": 1}
+    if device.type == "cuda":
+        info["rank_devices"] = [int(torch.cuda.current_device())]
+    if world > 1 or dist.is_initialized():
+        ones = torch.ones(1, dtype=torch.float32, device=device)
+        dist.all_reduce(ones)
+        info["ranks_seen"] = int(round(float(ones.item())))
+        info["backend"] = dist.get_backend()
+        dev_id = torch.tensor([torch.cuda.current_device() if device.type == "cuda" else -1], dtype=torch.int64, device=device)
+        gathered = [torch.zeros_like(dev_id) for _ in range(world)]
+        dist.all_gather(gathered, dev_id)
+        info["rank_devices"] = [int(g.item()) for g in gathered]
+        if device.type == "cuda" and info["backend"] == "nccl":
+            try:
+                info["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as exc:   # noqa: BLE001 -- a reported extra
+                info["nccl_version"] = f"unavailable ({type(exc).__name__})"
+        if info["ranks_seen"] != world:
+            if rank == 0:
+                print(f"bench.py: the all-reduce of ones saw {info['ranks_seen']} ranks, expected {world}", file=sys.stderr)
+            raise SystemExit(3)
+    return info
+
+
 def build_step(device, rank, world, dim, res, bw, F, n_local, ar_chunks=1, collective="allreduce"):
     """The benchmark step on this rank: synthetic inputs resident on `device` (parameters replicated: same seed; samples
     per rank), forward operator, backward operator into the communication buffer, gradient reduction. Used by main() and,
@@ -474,12 +503,13 @@ def main():
         if world > 1:
             dist.all_reduce(t)
             dist.barrier()
+        proof = ranks_proof(rank, world, torch.device("cpu"))
         if rank == 0:
             print(json.dumps({"metric": "hash-grid samples/sec fwd+bwd (16 lvl, F=2)", "value": None, "unit": "samples/s",
                               "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
                               "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "none",
                               "config": {"workload": "launch self-test (gloo, no kernels)", "scaling": args.scaling,
-                                         "allreduce_check": float(t.item()) == world * (world + 1) / 2}}), flush=True)
+                                         "allreduce_check": float(t.item()) == world * (world + 1) / 2, **proof}}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -494,6 +524,7 @@ def main():
         args.gpus = world
     if device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    proof = ranks_proof(rank, world, device)   # exits non-zero unless the collective backend joined exactly `world` ranks
 
     dim, res, bw, F, n_local = WORKLOADS[args.workload]
     if args.scaling == "strong":
@@ -716,6 +747,7 @@ def main():
                        "table_rows": T, "samples_per_gpu": n_local, "scaling": args.scaling,
                        "collective": args.collective if world > 1 else None,
                        "nccl_algo": (os.environ.get("NCCL_ALGO") or "unset (RCCL chooses)") if world > 1 else None,
+                       **proof,
                        "parallelism": f"dp{world}" + ("" if world == 1 else
                                                       (f"+one {args.collective}(grad_codebook) after the backward")
                                                       if len(groups) == 1 else

@@ -16,6 +16,9 @@ def test_bench_self_launches_ranks():
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["config"]["scaling"] == "strong"
     assert rec["config"]["allreduce_check"] is True
+    # the line proves by itself that the backend joined both ranks
+    assert rec["config"]["ranks_seen"] == 2 and rec["config"]["backend"] == "gloo"
+    assert rec["config"]["rank_devices"] == [-1, -1] and "nccl_version" in rec["config"]
 
 
 def test_bench_self_launch_eight_ranks_never_touches_the_gpu_in_the_parent():
@@ -26,7 +29,7 @@ def test_bench_self_launch_eight_ranks_never_touches_the_gpu_in_the_parent():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert rec["n_gpus"] == 8 and rec["config"]["allreduce_check"] is True
+    assert rec["n_gpus"] == 8 and rec["config"]["allreduce_check"] is True and rec["config"]["ranks_seen"] == 8
 
 
 def test_visible_gpu_count_reads_the_environment(monkeypatch):
@@ -61,3 +64,36 @@ def test_sweep_control_flow_four_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--sweep", "--selftest-launch",
                           "--sweep-filter", "weak_S1/nope"], env=env, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "unknown configuration" in bad.stderr
+
+
+def test_ranks_proof_refuses_a_short_world(monkeypatch):
+    """ranks_proof() must end the run (exit code 3) when the all-reduce of ones does not see `world` ranks."""
+    import importlib.util
+    import pytest
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class FakeDist:
+        @staticmethod
+        def is_initialized():
+            return True
+
+        @staticmethod
+        def all_reduce(t):
+            t.fill_(3.0)          # three ranks answered ...
+
+        @staticmethod
+        def get_backend():
+            return "gloo"
+
+        @staticmethod
+        def all_gather(out, t):
+            for o in out:
+                o.copy_(t)
+    monkeypatch.setattr(bench, "dist", FakeDist)
+    with pytest.raises(SystemExit) as exc:
+        bench.ranks_proof(0, 4, torch.device("cpu"))   # ... of four
+    assert exc.value.code == 3
+    assert bench.ranks_proof(0, 3, torch.device("cpu"))["ranks_seen"] == 3
