@@ -152,6 +152,41 @@ def backward(coords, grad_out, table_shape, first_idx, resolutions, bitwidth, ac
     return out
 
 
+def half_round(x):
+    """The C model's float -> binary16 -> float rounding (RNE), element-wise (checked against numpy's float16 in the tests)."""
+    L = lib()
+    L.shacira_oracle_half_round.restype = ctypes.c_float
+    L.shacira_oracle_half_round.argtypes = [ctypes.c_float]
+    return np.array([L.shacira_oracle_half_round(float(v)) for v in np.asarray(x, dtype=np.float32).ravel()],
+                    dtype=np.float32).reshape(np.shape(x))
+
+
+def backward_half_model(coords, grad_out16, table_shape, first_idx, resolutions, bitwidth):
+    """Software model of the reference's `__half2` backward (hashgrid_interpolate_cuda.cu:198-211): every fp32 product
+    rounded to half, the table entry takes `half(entry + product)` per atomicAdd, sample order. Returns
+    (table float32 holding half values, bound, sumabs, sumg): `bound` = this schedule's rigorous |model - exact sum| bound,
+    `sumabs` = sum of |fp32 products| per entry (what any schedule's rounding walk is bounded with), `sumg` = sum of the
+    |gradients| that reach the entry (bounds the effect of a quantised weight)."""
+    T, F = table_shape
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    res = np.ascontiguousarray(resolutions, dtype=np.int32)
+    fi = np.ascontiguousarray(first_idx, dtype=np.int32)
+    N, dim = coords.shape
+    L = len(res)
+    go = np.ascontiguousarray(np.asarray(grad_out16, dtype=np.float16).astype(np.float32)).reshape(N, L * F)
+    out = np.zeros((T, F), np.float32)
+    bound = np.zeros((T, F), np.float32)
+    sumabs = np.zeros((T, F), np.float32)
+    sumg = np.zeros((T, F), np.float32)
+    fn = lib().shacira_oracle_hashgrid_bwd_half_model
+    p = ctypes.c_void_p
+    fn.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, p, p, ctypes.c_int64, p, p, p, p, p, p]
+    fn.restype = None
+    fn(dim, N, L, F, int(bitwidth), _ptr(res), _ptr(fi), T, _ptr(coords), _ptr(go), _ptr(out), _ptr(bound), _ptr(sumabs),
+       _ptr(sumg))
+    return out, bound, sumabs, sumg
+
+
 def forward_f64(coords, table64, first_idx, resolutions, bitwidth):
     """scalar_t = double (the third type of the reference's dispatch, hashgrid_interpolate_cuda.cu:125): every table value is
     narrowed with static_cast<float>, the interpolation runs in fp32 and the result is widened (.cu:96-107)."""

@@ -266,6 +266,74 @@ ORACLE_API void shacira_oracle_hashgrid_bwd_f32(int dim, int64_t N, int L, int F
     }
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * fp16 tables: software model of the reference's `__half2` branch (.cu:198-211; what AMP training runs, grid.py:73).
+ * Per sample, per level, per corner k (0..7 in the kernel's order), per feature pair:
+ *     grad = __floats2half2_rn(__half2float(g.x) * coeffs[k], __half2float(g.y) * coeffs[k]);      (.cu:205-206)
+ *     atomicAdd((__half2*)(grad_codebook + ...), grad);                                             (.cu:207)
+ * i.e. the fp32 product is rounded to half (RNE), and the table entry -- a half -- takes `half(entry + grad)`, one RNE
+ * rounding of the RUNNING SUM per add (an atomicAdd on __half2 is two independent half additions). The order of the adds
+ * across samples is unspecified; this model takes sample order, one admissible schedule.
+ * Besides the modelled table it returns, per entry,
+ *     bound[e] = sum over the entry's adds of (half ulp of the rounded product) / 2 ... the products' roundings
+ *              + sum over the adds of (half ulp of the new running sum) / 2       ... the running sum's roundings
+ * = a rigorous bound on |model - exact sum of the fp32 products| for THIS schedule, and `maxabs[e]` = the largest |running
+ * sum| (any other schedule's roundings are bounded by n * 2^-12 * its own largest running sum; the tests bound that by
+ * the sum of |products|, `sumabs[e]`).
+ * half values travel as floats holding exactly representable values. */
+static float half_round(float x) {
+    /* round-to-nearest-even of a float to IEEE binary16, returned as float (handles subnormals, overflow -> inf, NaN) */
+    if (!(x == x)) return x;
+    const float ax = fabsf(x);
+    if (ax >= 65520.0f) return copysignf(INFINITY, x); /* ties to even at the top: 65520 rounds to inf */
+    if (ax < 6.103515625e-05f) {                        /* below the smallest normal half: spacing 2^-24 */
+        const float q = rintf(ax * 16777216.0f);        /* rintf: ties to even (default rounding mode) */
+        return copysignf(q * (1.0f / 16777216.0f), x);
+    }
+    int e;
+    (void)frexpf(ax, &e);                               /* ax = m * 2^e, m in [0.5, 1): ulp_half = 2^(e - 11) */
+    const float ulp = ldexpf(1.0f, e - 11);
+    return copysignf(rintf(ax / ulp) * ulp, x);
+}
+static float half_ulp(float x) {
+    const float ax = fabsf(x);
+    if (!(ax == ax) || ax >= 65520.0f) return 0.0f;
+    if (ax < 6.103515625e-05f) return 1.0f / 16777216.0f;
+    int e;
+    (void)frexpf(ax, &e);
+    return ldexpf(1.0f, e - 11);
+}
+ORACLE_API float shacira_oracle_half_round(float x) { return half_round(x); }
+
+ORACLE_API void shacira_oracle_hashgrid_bwd_half_model(int dim, int64_t N, int L, int F, int bw, const int32_t *res,
+                                                       const int32_t *first_idx, int64_t T, const float *coords,
+                                                       const float *grad_out_half, float *grad_table_half, float *bound,
+                                                       float *sumabs, float *sumg) {
+    const int nc = 1 << dim;
+    const int32_t cs = (int32_t)pow(2.0, (double)bw);
+    for (int64_t i = 0; i < N; ++i) {
+        for (int l = 0; l < L; ++l) {
+            int32_t idx[8];
+            float w[8];
+            corners(dim, coords + i * dim, res[l], cs, idx, w);
+            for (int j = 0; j < F; ++j) {
+                const float g = grad_out_half[i * (int64_t)L * F + (int64_t)l * F + j];
+                for (int k = 0; k < nc; ++k) {
+                    const int64_t row = (int64_t)first_idx[l] + idx[k];
+                    if (row < 0 || row >= T) continue;
+                    const float prod = g * w[k];                /* fp32 product (.cu:205) */
+                    const float c = half_round(prod);           /* __floats2half2_rn */
+                    const float s = half_round(grad_table_half[row * F + j] + c);   /* half + half, one rounding */
+                    grad_table_half[row * F + j] = s;
+                    if (bound) bound[row * F + j] += 0.5f * half_ulp(c) + 0.5f * half_ulp(s);
+                    if (sumabs) sumabs[row * F + j] += fabsf(prod);
+                    if (sumg) sumg[row * F + j] += fabsf(g);   /* >= |g * any partial weight|: bounds a quantised-weight error */
+                }
+            }
+        }
+    }
+}
+
 /* Exposes the per-axis transform for the clamp/floor edge-case KATs. */
 ORACLE_API void shacira_oracle_axis(float c, int32_t res, int32_t *pos, float *frac, float *ifrac) {
     axis_transform(c, res, pos, frac, ifrac);

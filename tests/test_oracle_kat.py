@@ -170,3 +170,58 @@ def test_double_table_restatement():
     assert np.array_equal(g_a, oc.backward(coords, ones.astype(np.float32), (T, 2), first, res, bw))
     for l in range(len(res)):                                         # partition of unity: every sample adds 1 per level, feature
         assert abs(g_a[first[l]:first[l] + sizes[l]].sum() - 257 * 2) < 1e-3
+
+
+# ----------------------------------------------------------------------------------------------- fp16 tables: `__half2` atomics
+def test_half_rounding_of_the_model_equals_ieee_binary16():
+    """The C model's float -> half -> float rounding against numpy's float16 (RNE, subnormals, overflow to inf)."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(4000).astype(np.float32) * s for s in (1e-7, 1e-5, 1e-3, 1.0, 300.0, 7e4)]
+                       + [np.array([0.0, -0.0, 65504.0, 65519.99, 65520.0, -65520.0, 6.1035e-5, 6.0976e-5, 5.96e-8, 2.98e-8,
+                                    2.9e-8, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, np.inf, -np.inf], dtype=np.float32)])
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).astype(np.float32)
+    assert np.array_equal(oc.half_round(x), want)
+
+
+def test_half2_atomics_model_known_answers():
+    """hashgrid_interpolate_cuda.cu:198-211 by hand. One level of resolution 2 with bw 4 is dense (8 rows = the 8 corners of
+    the single cell); a sample at the cell centre has all weights 0.125 exactly. Gradient 1.0 (a half): every product is
+    0.125, every entry takes half(0 + 0.125) = 0.125. 2 049 such samples: the running sum climbs in steps of 0.125 until
+    the half spacing exceeds twice the step (at 256 the spacing is 0.25: 256 + 0.125 ties back to 256, round-to-even), so
+    the reference's table entry STOPS at 256 while the exact sum is 256.125 -- the model must show exactly that."""
+    res, bw, F = [2], 4, 2
+    first = np.array([0], dtype=np.int32)
+    coords = np.full((2049, 3), -0.5, dtype=np.float32)     # 2 * (-0.5 * 0.5 + 0.5) = position 0.5 in each axis: weights 1/8
+    go = np.ones((2049, 2), dtype=np.float16)
+    go[:, 1] = -0.5
+    tab, bound, sumabs, sumg = oc.backward_half_model(coords, go, (8, F), first, res, bw)
+    assert np.all(tab[:, 0] == 256.0) and np.all(tab[:, 1] == -128.0), tab     # stuck where spacing / 2 == the step
+    exact = np.array([2049 * 0.125, -2049 * 0.0625])
+    assert np.allclose(sumabs, np.abs(exact)[None, :]) and np.allclose(sumg, np.array([2049.0, 1024.5])[None, :])
+    assert np.all(np.abs(tab - exact[None, :]) <= bound), (tab[0], bound[0])   # the schedule's own bound is rigorous
+    # products that need rounding: g = half(0.3), position 0.25 in x (weights 0.75 / 0.25), 0.5 in y and z
+    coords = np.array([[-0.75, -0.5, -0.5]], dtype=np.float32)
+    go = np.array([[0.3, 0.0]], dtype=np.float16)
+    tab, bound, _, _ = oc.backward_half_model(coords, go, (8, F), first, res, bw)
+    g = np.float32(go[0, 0])
+    # every entry equals half(g * w_k) for the kernel's left-to-right weight products (one add from zero: no sum rounding)
+    idx_w = oc.forward(coords, np.zeros((8, F), np.float32), first, res, bw, want_corners=True)
+    rows, ws = idx_w[1].reshape(-1), idx_w[2].reshape(-1)
+    for r, w in zip(rows, ws):
+        assert tab[r, 0] == np.float32(np.float16(g * np.float32(w))), (r, w)
+
+
+def test_half2_atomics_model_stays_within_its_bound_of_the_exact_sum():
+    """On a random problem the model differs from the fp64 sum of the same fp32 products by no more than its own per-entry
+    bound, and by far less than the crude n * 2^-11 * sum|product| any schedule obeys."""
+    dim, res, bw = CONFIGS["A"]
+    sizes, first, T = table_layout(res, bw, dim)
+    rng = np.random.default_rng(9)
+    coords = rng.uniform(-1, 1, (3000, dim)).astype(np.float32)
+    go = rng.standard_normal((3000, len(res) * 2)).astype(np.float16)
+    tab, bound, sumabs, _ = oc.backward_half_model(coords, go, (T, 2), first, res, bw)
+    exact = oc.backward(coords, go.astype(np.float32), (T, 2), first, res, bw)
+    err = np.abs(tab.astype(np.float64) - exact)
+    assert np.all(err <= bound.astype(np.float64) * (1 + 1e-6) + 1e-30)
+    assert err.max() > 0                                         # the roundings are real
