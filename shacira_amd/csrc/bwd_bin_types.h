@@ -206,7 +206,11 @@ template <bool STREAM = true> __device__ __forceinline__ void store_item_nt(Item
     __builtin_memcpy(&v, &it, 8);
     // PLAIN 8-byte stores (round 4): as non-temporal stores the half-size items of fp16 tables cost the S1 backward 7 % (a wave's
     // store covers 512 bytes: partial lines at both ends of every run, which a streaming store does not merge in L2)
+#ifdef SHACIRA_HALF_NT   // A/B builds
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p));
+#else
     *reinterpret_cast<u32x2 *>(p) = v;
+#endif
 }
 
 // One consumer work unit, written by the bucket scan: everything a consume workgroup needs in ONE 32-byte load (it used to

@@ -69,6 +69,62 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(LevelTable lt,
     }
 }
 
+// F = 2, lane PAIR per (sample, level) (round 5): lane parity = feature, so the two atomics of a row sit in adjacent lanes
+// of ONE instruction and leave the CU as one 8-byte request -- the memory-side atomic units retire ~41 G such requests per
+// second against ~10 G/s for the two-instructions-per-lane form above (profiles/r01_microbench_rates.txt: "atomic f32 pair
+// (lane pair)" vs "(2/thread)"). Both lanes compute the corners (the arithmetic is nothing beside the atomics). This is what
+// small batches on large tables run (a few thousand ray points on the 48.8 MB NeRF table), where the binned form's
+// table-sized passes cost more than the atomics.
+template <int DIM, typename T, int F>
+__global__ __launch_bounds__(256) void hashgrid_bwd_atomic_pair_kernel(LevelTable lt, const int32_t *__restrict__ first_idx,
+                                                                       const float *__restrict__ coords,
+                                                                       const T *__restrict__ grad_out,
+                                                                       float *__restrict__ grad_table, int64_t sample0,
+                                                                       uint32_t num_items) {
+    constexpr int NC = 1 << DIM;
+    const uint32_t L = (uint32_t)lt.num_lods;
+    __shared__ int32_t s_res[SHACIRA_MAX_LODS];
+    __shared__ float s_hi[SHACIRA_MAX_LODS];
+    __shared__ int32_t s_first[SHACIRA_MAX_LODS];
+    __shared__ uint8_t s_dense[SHACIRA_MAX_LODS];
+    if (threadIdx.x < L) {
+        s_res[threadIdx.x] = lt.res[threadIdx.x];
+        s_hi[threadIdx.x] = lt.hi[threadIdx.x];
+        s_dense[threadIdx.x] = lt.dense[threadIdx.x];
+        s_first[threadIdx.x] = first_idx[threadIdx.x];
+    }
+    __syncthreads();
+    const uint32_t stride = gridDim.x * blockDim.x;
+    static_assert(F == 2 || F == 4, "2 F lanes per (sample, level)");
+    constexpr uint32_t LOGF = (F == 2) ? 1u : 2u;
+    for (uint32_t t2 = blockIdx.x * blockDim.x + threadIdx.x; (t2 >> (LOGF + 1u)) < num_items; t2 += stride) {
+        // four lanes per (sample, level): (x offset, feature). The rows x and x + 1 of a corner pair are neighbours (dense
+        // levels) or differ in a few low bits (hashed levels: x ^ (x + 1)), so the four lanes' atomics of one instruction
+        // mostly fall into one 64-byte piece and travel as ONE request: 8 192 ray points 67 -> ~45 us (pairs only: 121 -> 67)
+        // (F = 4: eight lanes, a row's four features = one 16-byte piece)
+        const uint32_t w = t2 >> (LOGF + 1u), dx = (t2 >> LOGF) & 1u, j = t2 & (uint32_t)(F - 1);
+        const uint32_t s = w / L;
+        const uint32_t lvl = w - s * L;
+        if ((int32_t)lvl < lt.level_begin || (int32_t)lvl >= lt.level_end) continue;
+        const int64_t i = sample0 + s;
+        double t[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) t[a] = axis_unit(coords[i * DIM + a]);
+        Corners<DIM> c;
+        compute_corners<DIM>(t, s_res[lvl], s_hi[lvl], s_dense[lvl] != 0, lt.mask, c);
+        const int64_t base = (int64_t)s_first[lvl];
+        const float gj = Scalar<T>::load(grad_out + (i * L + lvl) * F + j);
+#pragma unroll
+        for (int q = 0; q < NC / 2; ++q) {   // corner bit (DIM - 1) is the x offset (.cu:88-94, 2d.cu:83-88)
+            const int k0 = q, k1 = q | (NC / 2);
+            const uint32_t r = dx ? c.row[k1] : c.row[k0];
+            const float wk = dx ? c.w[k1] : c.w[k0];
+            const int64_t row = base + (int64_t)r;
+            if ((uint64_t)row < (uint64_t)lt.table_rows) unsafeAtomicAdd(grad_table + row * F + j, gj * wk);
+        }
+    }
+}
+
 // fp64 tables: contribution = (float)(grad * weight) with the product formed in double (`float grad = grad_output[..] *
 // coeffs[k]`, .cu:215-217, scalar_t = double), accumulated with atomicAdd(double). The reference then adds that float
 // through `(float*)(grad_codebook + ...)` -- into the low word of each double, a bug; this is the intended gradient.
@@ -177,10 +233,18 @@ template <int DIM, typename T, int F>
 static hipError_t launch_bwd_atomic(const LevelTable &lt, const int32_t *first_idx, const float *coords,
                                     const void *grad_out, float *acc, int64_t num_coords, hipStream_t stream) {
     const int64_t L = lt.num_lods;
-    const int64_t max_samples = ((int64_t)1 << 31) / L - 1;
+    const int64_t max_samples = ((int64_t)1 << (F == 2 ? 29 : F == 4 ? 28 : 31)) / L - 1;
     for (int64_t s0 = 0; s0 < num_coords; s0 += max_samples) {
         const int64_t ns = (num_coords - s0 < max_samples) ? (num_coords - s0) : max_samples;
         const uint32_t items = (uint32_t)(ns * L);
+        if constexpr (F == 2 || F == 4) {   // 2 F lanes per (sample, level) (items * 2 F < 2^31: see max_samples)
+            const uint32_t blocks2 = (uint32_t)(((uint64_t)items * (2u * F) + 255u) / 256u);
+            hipLaunchKernelGGL((hashgrid_bwd_atomic_pair_kernel<DIM, T, F>), dim3(blocks2), dim3(256), 0, stream, lt, first_idx,
+                               coords, static_cast<const T *>(grad_out), acc, s0, items);
+            hipError_t e2 = hipGetLastError();
+            if (e2 != hipSuccess) return e2;
+            continue;
+        }
         const uint32_t blocks = (items + 255u) / 256u;
         hipLaunchKernelGGL((hashgrid_bwd_atomic_kernel<DIM, T, F>), dim3(blocks), dim3(256), 0, stream, lt, first_idx,
                            coords, static_cast<const T *>(grad_out), acc, s0, items);
@@ -194,6 +258,7 @@ template <int DIM, typename T>
 static hipError_t bwd_atomic_f(const LevelTable &lt, const int32_t *first_idx, const float *coords,
                                const void *grad_out, float *acc, int64_t n, hipStream_t s) {
     if (lt.feature_dim == 2) return launch_bwd_atomic<DIM, T, 2>(lt, first_idx, coords, grad_out, acc, n, s);
+    if (lt.feature_dim == 4) return launch_bwd_atomic<DIM, T, 4>(lt, first_idx, coords, grad_out, acc, n, s);
     return launch_bwd_atomic<DIM, T, 0>(lt, first_idx, coords, grad_out, acc, n, s);
 }
 
@@ -214,7 +279,14 @@ static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
     // tables whose levels all fit LDS images need no partitioning pass at all: one kernel, ahead of the scattered atomics
     // from ~2 K samples (Kodak table: 21.7 vs 49.8 us at 4 096 samples, 21.4 vs 18.6 us at 1 024)
     // (config D's 48.8 MB table: binned 62 us at 4 096 - 8 192 samples against 66 / 122 us for the atomics; 64 vs 40 us at 2 048)
-    return n >= (bin_all_direct(dim, lt) ? 2048 : 4096);
+    // Round 5, with the lane-group atomics (2 F lanes per (sample, level): one request per x-pair of rows instead of four):
+    // config D's table 20 / 29 / 47 / 82 us at 2 048 / 4 096 / 8 192 / 16 384 samples against 58-64 us for the binned form
+    // (64 vs 62 at 12 288); 2-D bw-19 table 36 / 38 / 65 / 118 us at 4 096 / 8 192 / 16 384 / 32 768 against 65-69
+    if (bin_all_direct(dim, lt)) return n >= 2048;
+    // (nerf_lego.yaml's F = 4 table: 54 / 77 / 126 us at 4 096 / 8 192 / 16 384 against 115-121)
+    if (lt.feature_dim == 2) return n >= (dim == 3 ? 12288 : 16384);
+    if (lt.feature_dim == 4) return n >= 16384;
+    return n >= 4096;
 }
 
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {

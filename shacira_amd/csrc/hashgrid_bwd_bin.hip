@@ -54,6 +54,9 @@ static inline size_t item_unit_bytes(int fmt, const LevelTable &lt);
                                        // runs on 64-byte boundaries stream at 4.7-5.0 TB/s, on 128-byte ones at 5.2-5.4, on
                                        // 16 / 32 / 48-byte ones at 2.5-3.5; 64 costs half the pad units of 128)
 #endif
+#ifndef SHACIRA_PAD_HALF
+#define SHACIRA_PAD_HALF 0             // A/B builds: pad the 8-byte half-precision units' runs too
+#endif
 #ifndef SHACIRA_FX_MIN
 #define SHACIRA_FX_MIN (1 << 17)       // fixed-point images from this batch size (below: fp64 images)
 #endif
@@ -325,7 +328,7 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
 #ifdef SHACIRA_SCATTER_SPLIT
         windows = SHACIRA_SCATTER_SPLIT > 1;
 #endif
-        if (opt().bwd_run_pad != 0 && !windows && plan.nbl > 0 && n_batch >= SHACIRA_FX_MIN && (unit == 16 || unit == 12)) {
+        if (opt().bwd_run_pad != 0 && !windows && plan.nbl > 0 && n_batch >= SHACIRA_FX_MIN && (unit == 16 || unit == 12 || (SHACIRA_PAD_HALF && unit == 8))) {
             const uint32_t P = unit == 12 ? (uint32_t)(SHACIRA_RUN_ALIGN / 4) : (uint32_t)(SHACIRA_RUN_ALIGN / unit);   // 12-byte units: lcm(12, 64) = 16 of them
             const size_t staged = (size_t)(tile_units + maxnb * (P - 1u)) * (unit + 1);
             if (staged <= (size_t)78 * 1024 || (size_t)tile_units * (unit + 1) > (size_t)78 * 1024) plan.pad = P;
@@ -801,7 +804,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
 // line-aligned runs when the tile goes through in one window) and one bucket byte per unit
 template <class ItemT> static constexpr size_t stage_max(size_t tile_units) {
     constexpr size_t split = ScatterSplit<ItemT>::value;
-    constexpr size_t padu = split != 1 ? 0 : sizeof(ItemT) == 16 ? SHACIRA_RUN_ALIGN / 16 - 1 : sizeof(ItemT) == 12 ? SHACIRA_RUN_ALIGN / 4 - 1 : 0;
+    constexpr size_t padu = split != 1 ? 0 : sizeof(ItemT) == 16 ? SHACIRA_RUN_ALIGN / 16 - 1 : sizeof(ItemT) == 12 ? SHACIRA_RUN_ALIGN / 4 - 1
+                            : (SHACIRA_PAD_HALF && sizeof(ItemT) == 8) ? SHACIRA_RUN_ALIGN / 8 - 1 : 0;
     return (tile_units / split + (size_t)kMaxLevelBuckets * padu) * (sizeof(ItemT) + 1);
 }
 

@@ -31,7 +31,10 @@ def timed(fn, it=20):
 
 W = {"S1": (3, 19, 1 << 20, 2048, 16, 2), "S1b18": (3, 18, 1 << 20, 2048, 16, 2), "S2": (2, 19, 1 << 20, 2048, 16, 2), "D": (3, 19, 65536, 2048, 16, 2),
      "B": (2, 11, 393216, 512, 16, 2), "LEGO": (3, 19, 1 << 18, 512, 24, 4), "S1h": (3, 19, 1 << 19, 2048, 16, 2),
-     "S1q": (3, 19, 1 << 18, 2048, 16, 2), "S1e": (3, 19, 1 << 17, 2048, 16, 2), "S2q": (2, 19, 1 << 18, 2048, 16, 2), "S2e": (2, 19, 1 << 17, 2048, 16, 2), "KY": (2, 11, 393216, 512, 24, 2), "B64k": (2, 11, 65536, 512, 16, 2), "B16k": (2, 11, 16384, 512, 16, 2), "B4k": (2, 11, 4096, 512, 16, 2), "B1k": (2, 11, 1024, 512, 16, 2), "B256": (2, 11, 256, 512, 16, 2), "Dh": (3, 19, 32768, 2048, 16, 2), "D8k": (3, 19, 8192, 2048, 16, 2), "D4k": (3, 19, 4096, 2048, 16, 2), "D2k": (3, 19, 2048, 2048, 16, 2), "Dq": (3, 19, 16384, 2048, 16, 2), "C": (2, 11, 9437184, 512, 16, 2)}
+     "S1q": (3, 19, 1 << 18, 2048, 16, 2), "S1e": (3, 19, 1 << 17, 2048, 16, 2), "S2q": (2, 19, 1 << 18, 2048, 16, 2), "S2e": (2, 19, 1 << 17, 2048, 16, 2), "KY": (2, 11, 393216, 512, 24, 2), "B64k": (2, 11, 65536, 512, 16, 2), "B16k": (2, 11, 16384, 512, 16, 2), "B4k": (2, 11, 4096, 512, 16, 2), "B1k": (2, 11, 1024, 512, 16, 2), "B256": (2, 11, 256, 512, 16, 2), "Dh": (3, 19, 32768, 2048, 16, 2), "D8k": (3, 19, 8192, 2048, 16, 2), "D4k": (3, 19, 4096, 2048, 16, 2), "D2k": (3, 19, 2048, 2048, 16, 2), "Dq": (3, 19, 16384, 2048, 16, 2), "C": (2, 11, 9437184, 512, 16, 2),
+     "S2_4k": (2, 19, 4096, 2048, 16, 2), "S2_8k": (2, 19, 8192, 2048, 16, 2), "S2_16k": (2, 19, 16384, 2048, 16, 2),
+     "S2_32k": (2, 19, 32768, 2048, 16, 2), "L4k": (3, 19, 4096, 512, 24, 4), "L8k": (3, 19, 8192, 512, 24, 4),
+     "L16k": (3, 19, 16384, 512, 24, 4), "D12k": (3, 19, 12288, 2048, 16, 2)}
 name = sys.argv[1]
 DT = torch.float16 if os.environ.get("R3_DTYPE") == "f16" else torch.float32
 dim, bw, N, mx, L, F = W[name]
