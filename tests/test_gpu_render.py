@@ -65,6 +65,28 @@ def test_exponential_integration_forward_backward(dev, C, R, max_len):
         render.exponential_integration(feats, tau, boundary)   # host tensors: no CPU fallback
 
 
+def test_parity_unpinned_dependency_absent__hip_integration_of_a_homogeneous_medium(dev):
+    """The HIP kernel against the CLOSED FORM, not against the restatement: constant density sigma and colour c over n equal
+    steps -> weights exp(-k sigma d) (1 - exp(-sigma d)), ray colour c (1 - exp(-sigma n d)), and d(ray colour)/d(sigma) = c n d
+    exp(-sigma n d) through the kernel's backward (every sample's tau = sigma d, so the gradients of the n samples add up)."""
+    from shacira_amd import render
+    for n, sigma, d in ((16, 2.0, 0.05), (200, 0.3, 0.01), (1, 0.7, 0.3)):
+        colour = torch.tensor([0.2, 0.5, 0.9], device=dev)
+        sig = torch.tensor(sigma, device=dev, requires_grad=True)
+        tau = (sig * d).expand(2 * n, 1)
+        feats = colour[None].repeat(2 * n, 1)
+        boundary = torch.zeros(2 * n, dtype=torch.bool, device=dev)
+        boundary[0] = boundary[n] = True                       # two identical rays
+        ray, w = render.exponential_integration(feats, tau, boundary)
+        k = np.arange(n)
+        np.testing.assert_allclose(w[:n, 0].detach().cpu().numpy(), np.exp(-k * sigma * d) * (1 - np.exp(-sigma * d)), rtol=2e-5)
+        want = colour.cpu().numpy() * (1 - np.exp(-sigma * n * d))
+        np.testing.assert_allclose(ray[0].detach().cpu().numpy(), want, rtol=2e-5)
+        np.testing.assert_allclose(ray[1].detach().cpu().numpy(), want, rtol=2e-5)
+        ray[0].sum().backward()
+        np.testing.assert_allclose(sig.grad.item(), float(colour.sum()) * n * d * np.exp(-sigma * n * d), rtol=1e-4)
+
+
 def _rays(rng, n):
     o = rng.standard_normal((n, 3))
     o = 3.0 * o / np.linalg.norm(o, axis=1, keepdims=True)

@@ -110,3 +110,77 @@ def test_points_outside_the_cube_have_no_cell():
                         [1.0, 0.0, 0.0], [0.0, 1.0001, 0.0], [0.0, 0.0, -1.0001],       # on the +1 face / outside
                         [2.5, 0.0, 0.0], [float("nan"), 0.0, 0.0]])
     assert orr.query_dense(occ, pts, level).tolist() == [True, True, True, False, False, False, False, False]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Closed-form known answers for the kaolin half. kaolin 0.13.0 is not vendored: these pin the restatement to
+# the PUBLISHED formula (kaolin/render/spc/raytrace.py: alpha = 1 - exp(-tau); T = exp(-exclusive_cumsum(tau)); w = T * alpha;
+# out = sum_reduce(w * feats)) and to analytic results, not to kaolin's output -- "parity unpinned (dependency absent)".
+def test_parity_unpinned_dependency_absent__constant_medium_has_analytic_transmittance():
+    """Constant density sigma and constant colour c over n equal steps of length d: tau = sigma d per sample, so
+    w_k = exp(-k sigma d) (1 - exp(-sigma d)), the weights sum to 1 - exp(-n sigma d) (a geometric series) and the ray colour
+    is c (1 - exp(-sigma L)), L = n d -- the closed form of the volume-rendering integral for a homogeneous medium."""
+    for n, sigma, d in ((1, 0.7, 0.3), (16, 2.0, 0.05), (200, 0.3, 0.01), (64, 40.0, 0.02)):
+        colour = torch.tensor([0.2, 0.5, 0.9], dtype=torch.float64)
+        tau = torch.full((n, 1), sigma * d, dtype=torch.float64)
+        feats = colour[None].repeat(n, 1)
+        ray, w = orr.exponential_integration(feats, tau, _boundary([n]))
+        k = np.arange(n)
+        np.testing.assert_allclose(w[:, 0].numpy(), np.exp(-k * sigma * d) * (1 - np.exp(-sigma * d)), rtol=1e-12)
+        np.testing.assert_allclose(w.sum().item(), 1 - np.exp(-n * sigma * d), rtol=1e-12)
+        np.testing.assert_allclose(ray[0].numpy(), colour.numpy() * (1 - np.exp(-sigma * n * d)), rtol=1e-12)
+
+
+def test_parity_unpinned_dependency_absent__opaque_and_empty_samples():
+    """tau = 0 contributes nothing and hides nothing; a sample with tau -> infinity takes all the remaining transmittance and
+    everything behind it gets weight 0; packs are independent (the second ray does not see the first ray's wall)."""
+    tau = torch.tensor([[0.0], [0.5], [1e9], [0.5], [0.0], [0.25]], dtype=torch.float64)
+    feats = torch.tensor([[1.0], [2.0], [3.0], [4.0], [5.0], [6.0]], dtype=torch.float64)
+    ray, w = orr.exponential_integration(feats, tau, _boundary([4, 2]))
+    a = 1 - np.exp(-0.5)
+    np.testing.assert_allclose(w[:, 0].numpy(), [0.0, a, np.exp(-0.5), 0.0, 0.0, 1 - np.exp(-0.25)], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(ray[:, 0].numpy(), [2.0 * a + 3.0 * np.exp(-0.5), 6.0 * (1 - np.exp(-0.25))], rtol=1e-12)
+    # inclusive form (exclusive=False): the sample's own tau already attenuates it
+    _, wi = orr.exponential_integration(feats, tau, _boundary([4, 2]), exclusive=False)
+    np.testing.assert_allclose(wi[1, 0].item(), np.exp(-0.5) * a, rtol=1e-12)
+
+
+def test_parity_unpinned_dependency_absent__ray_cell_slab_cases_by_hand():
+    """Ray / cell intersections of a level-1 grid (2 x 2 x 2 cells of side 1 on [-1, 1]^3), worked by hand with the slab
+    method: entry = max over axes of the near plane's t, exit = min over axes of the far plane's t."""
+    occ = torch.zeros(2, 2, 2, dtype=torch.bool)
+    occ[0, 0, 0] = True            # cell [-1, 0]^3
+    occ[1, 0, 0] = True            # cell [0, 1] x [-1, 0]^2
+    occ[1, 1, 1] = True            # cell [0, 1]^3
+    o = torch.tensor([[-2.0, -0.5, -0.5],      # along +x through the two lower cells: [1, 2] then [2, 3]
+                      [-2.0, 0.5, 0.5],        # along +x at y = z = 0.5: only cell (1, 1, 1): [2, 3]
+                      [-0.5, -0.5, -0.5],      # starts INSIDE cell (0, 0, 0): entry clipped to 0, exit 0.5; then [0.5, 1.5]
+                      [-2.0, -2.0, -2.0],      # the main diagonal, direction (1, 1, 1) / sqrt 3: cell 0 [sqrt 3, 2 sqrt 3], cell 7 [2 sqrt 3, 3 sqrt 3]
+                      [-2.0, 1.5, 0.0]])       # misses the cube
+    d = torch.tensor([[1.0, 0, 0], [1.0, 0, 0], [1.0, 0, 0], [3 ** -0.5] * 3, [1.0, 0, 0]])
+    ridx, cell, depth = orr.raytrace_dense(o, d, occ, 1)
+    got = {}
+    for r, c, t in zip(ridx.tolist(), cell.tolist(), depth.tolist()):
+        got.setdefault(r, []).append((tuple(c), t))
+    r3 = 3 ** 0.5
+    want = {0: [((0, 0, 0), [1.0, 2.0]), ((1, 0, 0), [2.0, 3.0])],
+            1: [((1, 1, 1), [2.0, 3.0])],
+            2: [((0, 0, 0), [0.0, 0.5]), ((1, 0, 0), [0.5, 1.5])],
+            3: [((0, 0, 0), [r3, 2 * r3]), ((1, 1, 1), [2 * r3, 3 * r3])]}
+    assert sorted(got) == sorted(want)
+    for r in want:
+        assert [c for c, _ in got[r]] == [c for c, _ in want[r]], r
+        np.testing.assert_allclose([t for _, t in got[r]], [t for _, t in want[r]], rtol=1e-6, atol=1e-6)
+
+
+def test_parity_unpinned_dependency_absent__depth_interval_sampling_by_hand():
+    """sampling.py:49-55 on one interval [2, 4] with 4 samples and jitter 0.5: depths 2 + 2 (k + 0.5) / 4 = 2.25, 2.75, 3.25,
+    3.75; the deltas start from the interval's entry: 0.25, then 0.5 each (octree_as.py:212-216)."""
+    depth = torch.tensor([[2.0, 4.0]])
+    z = orr.sample_from_depth_intervals(depth, 4, torch.full((1, 4), 0.5))
+    np.testing.assert_allclose(z[0].numpy(), [2.25, 2.75, 3.25, 3.75], rtol=1e-7)
+    o, d = torch.zeros(1, 3), torch.tensor([[0.0, 0.0, 1.0]])
+    ridx_s, samples, ds, deltas, boundary = orr.raymarch_voxel(o, d, torch.tensor([0]), depth, 4, torch.full((1, 4), 0.5))
+    np.testing.assert_allclose(deltas[:, 0].numpy(), [0.25, 0.5, 0.5, 0.5], rtol=1e-6)
+    np.testing.assert_allclose(samples[:, 2].numpy(), [2.25, 2.75, 3.25, 3.75], rtol=1e-6)
+    assert boundary.tolist() == [True, False, False, False] and ridx_s.tolist() == [0, 0, 0, 0]
