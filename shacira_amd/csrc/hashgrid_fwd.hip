@@ -609,8 +609,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
 // Level-per-XCD pair kernel (variant 6, and the fine levels of the cell-sorted forward): one level per XCD at a time, so
 // the XCD's 4 MiB L2 holds exactly that level's table and every table is pulled from the Infinity Cache by one XCD only
 // (measured: fabric reads 50 M -> 8 M), + variant 3's lane pairing (corners x / x+1 in one instruction -> one L2
-// request). The per-level feature piece of a sample (F scalars) goes to a level-major staging image [L][N][F] with a
-// non-temporal store (a plain 8-byte store into [N, L*F] allocates a whole 128-byte line per piece: 0.2 ms on S1).
+// request). The per-level feature piece of a sample (F scalars) goes to a level-major staging image [L][N][F] -- coalesced,
+// where an 8-byte store into [N, L*F] allocates a whole 128-byte line per piece (0.2 ms on S1) -- with a PLAIN store since
+// round 4: the rows kernel right behind reads the image back from the Infinity Cache (non-temporal: S1 forward +7 %).
 // PACKED: `coords` is an array of 16-byte records {x, y, z (0 in 2-D), bits} (the cell-sorted copy of hashgrid_tiled.hip):
 // one dwordx4 load per sample instead of DIM dword loads -- the kernel is bound by vector-memory instructions.
 // (Round 3 pruned the unstaged forms of this kernel and the per-sample / per-level variants 1, 2, 4, 5, 7: git 4a7dfa7.)

@@ -192,6 +192,21 @@ class ImageFitter:
         return rgb_loss, psnr, float(avg_bits.detach()) if torch.is_tensor(avg_bits) else float(avg_bits)
 
 
+def _require_device_temperature(latent_dec, who):
+    """The graph-captured fitters keep the SGA temperature in ONE device float that the decode kernel reads. Only the single
+    fused SGA decode (`shacira_latent_decode_sga_*_tdev`) has such an entry point: the per-row MLP decoder, the hierarchical and
+    the multi decoders call `float(self.temperature)` -- a host read-back, which aborts a stream capture with an opaque HIP
+    error or, taken outside the capture, freezes the temperature into the graph. Refuse those up front."""
+    import torch as _torch
+    from .wisp.models.latent_decoders.basic_latent_decoder import LatentDecoder
+    ok = (isinstance(latent_dec, LatentDecoder) and type(latent_dec) is LatentDecoder
+          and latent_dec._fusable(_torch.empty(1, latent_dec.latent_dim, device=latent_dec.div.device)))
+    if not ok:
+        raise ValueError(f"{who}: an SGA temperature schedule inside a captured step needs the single fused latent decoder "
+                         f"(no hidden layers, identity activations, a latent_dim / feature_dim pair the fused kernel has); "
+                         f"got {type(latent_dec).__name__}. Run this decoder with the eager fitter instead.")
+
+
 class GraphedImageFitter(ImageFitter):
     """The same step recorded ONCE into a HIP graph and replayed: the per-step work of the image configs is a few
     hundred microseconds of GPU time behind ~150 launches, i.e. launch-bound when issued eagerly from Python.
@@ -219,6 +234,7 @@ class GraphedImageFitter(ImageFitter):
         # `decay_period` of the run changes the kernel, so the step is captured a second time then
         self.temperature = None
         if self.temperature_sched is not None:
+            _require_device_temperature(nef.grid.latent_dec, "GraphedImageFitter")
             self.temperature = torch.ones(1, device=coords.device)
             nef.grid.latent_dec.temperature = self.temperature
 
@@ -490,7 +506,9 @@ class GraphedNerfFitter:
         # SGA is switched off (after decay_period of the run) the graphs are dropped and re-captured once.
         self.latent = latent
         self.iteration = 0
+        self.extra_eager_steps = 0      # optimizer steps taken by prepare()'s shape warm-ups (reported, see fit_nerf)
         if latent is not None:
+            _require_device_temperature(nef.grid.latent_dec, "GraphedNerfFitter")
             self.temperature = torch.ones(1, device=device)
             nef.grid.latent_dec.temperature = self.temperature
             nef.grid.device_noise = True
@@ -544,7 +562,11 @@ class GraphedNerfFitter:
         t0 = time.perf_counter()
         if len(self.graphs) >= 4:       # bound the memory held by graph pools
             self.graphs.clear()
-        self._body()                    # one eager step at the new shapes (workspaces, kernel attributes, padding rows)
+        # one eager step at the new shapes (workspaces, kernel attributes, padding rows). It IS a real optimizer step on the
+        # next pool batch -- counted, so that the reported step totals and ms_per_step include it (round-4 advisor finding: the
+        # graph-replay figures came from runs with uncounted parameter updates)
+        self._body()
+        self.extra_eager_steps += 1
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -674,7 +696,8 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
                 nef.prune()
                 fitter.after_prune()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / max(1, steps - warm) * 1e3
+        # (the timed region holds steps - warm loop steps plus the shape warm-up steps prepare() took inside it)
+        ms = (time.perf_counter() - t0) / max(1, steps - warm + fitter.extra_eager_steps) * 1e3
         fitter.eager_mode()
         with torch.no_grad():
             o, d = camera_rays(val_rays, torch.Generator().manual_seed(4242), device)
@@ -683,6 +706,7 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
         out = dict(psnr=val, ms_per_step=ms, steps=steps, rays_per_step=rays, candidate_samples_per_step=rays * num_steps,
                    occupied_cells=int(nef.grid.blas.points.shape[0]), total_cells=int(grid.num_cells),
                    graph_captures=fitter.captures, sample_capacity=fitter.capacity,
+                   optimizer_steps=steps + fitter.extra_eager_steps, shape_warmup_steps=fitter.extra_eager_steps,
                    overflow_steps=int(fitter.overflow.item()), ray_pool=ray_pool,
                    capture_seconds=fitter.capture_seconds)
         if latent:

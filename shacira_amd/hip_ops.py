@@ -8,6 +8,7 @@ Inputs must live on a HIP device; there is no CPU path (RuntimeError otherwise).
 import ctypes
 import functools
 import threading
+import weakref
 
 import torch
 
@@ -66,6 +67,21 @@ def _check_coords(dim, coords):
 _tls = threading.local()     # per-thread: a thread's buffers are dropped with the thread (no entries of dead threads linger)
 
 
+class _Scratch:
+    """One thread's buffers: {(device, stream): [buffer, calls in a row that asked for less than a quarter of it]}."""
+    __slots__ = ("buffers", "__weakref__")
+
+    def __init__(self):
+        self.buffers = {}
+
+
+# every live thread's _Scratch (weak: a finished thread's entry goes with its thread-local storage), so that
+# release_workspaces() can reach the gigabyte the autograd engine's backward thread holds (round-4 advisor finding)
+_all_scratch = weakref.WeakSet()
+_all_scratch_lock = threading.Lock()
+_SHRINK_AFTER = 64           # calls in a row far below the buffer's size before it is given back
+
+
 def _workspace(device, nbytes):
     if nbytes <= 0:
         return None
@@ -73,25 +89,53 @@ def _workspace(device, nbytes):
         return torch.empty((nbytes,), dtype=torch.uint8, device=device)
     scratch = getattr(_tls, "scratch", None)
     if scratch is None:
-        scratch = _tls.scratch = {}
+        scratch = _tls.scratch = _Scratch()
+        with _all_scratch_lock:
+            _all_scratch.add(scratch)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = scratch.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = None
-        scratch.pop(key, None)           # release the old buffer before the larger one is allocated
-        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        scratch[key] = buf
+    entry = scratch.buffers.get(key)
+    if entry is not None and entry[0].numel() >= nbytes:
+        # retained memory is bounded in time, too: a buffer grown by one large call (1.1 GB for a 2^20-sample backward) is
+        # given back once _SHRINK_AFTER calls in a row needed less than a quarter of it
+        if nbytes * 4 < entry[0].numel():
+            entry[1] += 1
+            if entry[1] < _SHRINK_AFTER:
+                return entry[0]
+        else:
+            entry[1] = 0
+            return entry[0]
+    scratch.buffers.pop(key, None)       # release the old buffer before the new one is allocated
+    entry = None
+    buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    scratch.buffers[key] = [buf, 0]
     return buf
 
 
-def release_workspaces():
-    """Drop the calling thread's cached scratch buffers (they are returned to torch's caching allocator)."""
-    if getattr(_tls, "scratch", None):
-        _tls.scratch.clear()
+def release_workspaces(all_threads=True):
+    """Drop the cached scratch buffers (they go back to torch's caching allocator): the calling thread's, and -- by default
+    -- every other thread's too (the autograd engine's backward thread keeps its own ~1 GB after a large backward). Call it
+    between steps, not while another thread is inside an operator of this library. Returns the number of bytes released."""
+    freed = 0
+    with _all_scratch_lock:
+        targets = list(_all_scratch) if all_threads else [getattr(_tls, "scratch", None)]
+    for sc in targets:
+        if sc is None:
+            continue
+        for key in list(sc.buffers):
+            entry = sc.buffers.pop(key, None)
+            if entry is not None:
+                freed += entry[0].numel()
+    return freed
+
+
+def retained_workspace_bytes():
+    """Bytes currently held in scratch buffers over all threads (what release_workspaces() would give back)."""
+    with _all_scratch_lock:
+        return sum(e[0].numel() for sc in list(_all_scratch) for e in list(sc.buffers.values()))
 
 
 # workspace sizes are pure functions of the shape and the library's tunables: one C call per new shape, not per call
-@functools.lru_cache(maxsize=256)
+@functools.lru_cache(maxsize=4096)   # (NeRF steps change N every step: 256 entries thrashed)
 def _ws_bytes(kind, dim, N, L, F, bw, res, T, dt, epoch):
     fn = _lib.lib().shacira_hashgrid_forward_workspace_bytes if kind == 0 else _lib.lib().shacira_hashgrid_backward_workspace_bytes
     return int(fn(dim, N, L, F, bw, _res_array(res), T, dt))
