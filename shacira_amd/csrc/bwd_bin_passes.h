@@ -18,7 +18,7 @@ namespace shacira {
 #define SHACIRA_SCATTER_ATTR
 #endif
 template <int DIM, int F, int FMT, bool STREAM = true>
-__global__ __launch_bounds__(kBinThreads) SHACIRA_SCATTER_ATTR void bin_scatter_kernel(LevelTable lt, BinPlan plan,
+__global__ __launch_bounds__((ScatterThreads<DIM, F, FMT>::value)) SHACIRA_SCATTER_ATTR void bin_scatter_kernel(LevelTable lt, BinPlan plan,
                                                                   const float *__restrict__ coords,
                                                                   const float *__restrict__ gT,
                                                                   unsigned long long *__restrict__ cursor,
@@ -35,7 +35,8 @@ __global__ __launch_bounds__(kBinThreads) SHACIRA_SCATTER_ATTR void bin_scatter_
     static_assert(!P12 || (DIM == 3 && F == 2), "12-byte units: 3-D, F = 2");
     constexpr int NP = 1 << (DIM - 1);
     constexpr int kTileD = TileOf<DIM>::value;
-    constexpr int SPT = kTileD / kBinThreads;  // samples per thread
+    constexpr int kThreads = ScatterThreads<DIM, F, FMT>::value;
+    constexpr int SPT = kTileD / kThreads;  // samples per thread
     // staged items per PASS: the tile's kTileD * NP items (sorted by bucket) go through the LDS buffer in kScatterSplit windows
     // of their sorted order, so the buffer is 1 / kScatterSplit of the tile and more workgroups share a CU (round 4: F = 2
     // 69 -> 35 KiB = four instead of two, F = 4 100 -> 51 KiB = three instead of one) while a (tile, bucket) run keeps its
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kBinThreads) SHACIRA_SCATTER_ATTR void bin_scatter_
     float craw[SPT][DIM], graw[SPT][F];
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
-        int64_t i = sample0 + (int64_t)tile * kTileD + threadIdx.x + u * kBinThreads;
+        int64_t i = sample0 + (int64_t)tile * kTileD + threadIdx.x + u * kThreads;
         i = i < N ? i : N - 1;
 #ifdef ABL_NO_LOAD    // every thread reads the same few samples: cached loads, same arithmetic downstream
         i = (i * 2654435761ll) & 1023;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(kBinThreads) SHACIRA_SCATTER_ATTR void bin_scatter_
     }
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
-        const int k = threadIdx.x + u * kBinThreads;
+        const int k = threadIdx.x + u * kThreads;
         const int64_t i = sample0 + (int64_t)tile * kTileD + k;
         const bool live = i < N;
         double t[DIM];
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(kBinThreads) SHACIRA_SCATTER_ATTR void bin_scatter_
     }
     const uint32_t in_window = (kScatterSplit == 1 || staged - w0 < (uint32_t)kStage) ? (staged - w0) : (uint32_t)kStage;
 #ifndef ABL_NO_STORE   // (ablation builds: make variant ... EXTRA=-DABL_*; wrong results on purpose)
-    for (uint32_t pos = threadIdx.x; pos < in_window; pos += kBinThreads) {
+    for (uint32_t pos = threadIdx.x; pos < in_window; pos += kThreads) {
         const uint32_t b = s_bucket[pos];
         // write-once / read-once stream: non-temporal stores (measured -7 % on the whole backward)
         store_item_nt<STREAM>(items + s_gbase[b] + (w0 + pos - s_start[b]), s_items[pos]);
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(kBinThreads) SHACIRA_SCATTER_ATTR void bin_scatter_
             const uint32_t row0 = b * bl.rows_pb;
             const uint32_t nrows = (bl.used - row0 < bl.rows_pb) ? (bl.used - row0) : bl.rows_pb;
             float *dst = zero_acc + ((int64_t)first_idx[lvl] + row0) * F;
-            for (uint32_t e = threadIdx.x; e < nrows * (uint32_t)F; e += kBinThreads) dst[e] = 0.0f;
+            for (uint32_t e = threadIdx.x; e < nrows * (uint32_t)F; e += kThreads) dst[e] = 0.0f;
         }
     }
 }

@@ -22,6 +22,16 @@ constexpr int kTile = SHACIRA_KTILE;       // samples per (level, tile) block in
 template <int DIM> struct TileOf { static constexpr int value = (DIM == 2) ? SHACIRA_TILE2D_MUL * kTile : kTile; };
 static inline int tile_samples(int dim) { return dim == 2 ? SHACIRA_TILE2D_MUL * kTile : kTile; }
 constexpr int kBinThreads = SHACIRA_KBIN;  // threads of passes A and B
+// Scatter pass, 3-D with F = 2: 1 024 threads = one sample per thread (38 instead of 64 VGPRs, 32 waves per CU with the same two
+// workgroups' worth of staging): S1 backward -2 % (0.509 -> 0.498 ms, 2^19 samples 0.281 -> 0.275); 2-D and config D equal;
+// the F = 4 kernels (staging windows) lose 25 % with it and keep 512 (profiles/r05_experiments.md 4).
+#ifndef SHACIRA_KSCATTER3D
+#define SHACIRA_KSCATTER3D 1024
+#endif
+// (fp32 item streams only: the 8-byte half-precision stream of fp16 tables loses 8 % with it, S1 fp16 0.435 -> 0.470 ms)
+template <int DIM, int F, int FMT> struct ScatterThreads {
+    static constexpr int value = (DIM == 3 && F == 2 && FMT != 1) ? SHACIRA_KSCATTER3D : kBinThreads;
+};
 constexpr int kConsumeThreads = 1024;
 constexpr int kMaxBuckets = 2048;     // over all levels
 constexpr int kMaxLevelBuckets = 128; // per level (LDS histogram size)

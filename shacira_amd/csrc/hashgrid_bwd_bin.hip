@@ -739,20 +739,20 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const uint32_t cnt_rows = fused_now ? (uint32_t)((n + ts16 - 1) / ts16) : plan.num_tiles;
         if (fmt == 2) {
             if constexpr (DIM == 3 && F == 2)
-                hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, 2>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
+                hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, 2>), dim3(plan.num_tiles, plan.nbl), dim3(ScatterThreads<DIM, F, 2>::value),
                                    stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
                                    reinterpret_cast<Item12 *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
         } else if (half)
-            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), dim3(plan.num_tiles, plan.nbl), dim3(ScatterThreads<DIM, F, 1>::value),
                                stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
                                reinterpret_cast<typename ItemSel<F, true>::type *>(w.items), s0, hi, NP, zacc, first_idx,
                                w.unit_first);
         else if (use_fx)
-            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), dim3(plan.num_tiles, plan.nbl), dim3(ScatterThreads<DIM, F, 0>::value),
                                stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
                                reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
         else   // batches below 2^17 samples: plain item stores, the consume pass reads them back from the caches
-            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false, false>), dim3(plan.num_tiles, plan.nbl), dim3(kBinThreads),
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false, false>), dim3(plan.num_tiles, plan.nbl), dim3(ScatterThreads<DIM, F, 0>::value),
                                stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
                                reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
         SHACIRA_CHECK_LAUNCH();
