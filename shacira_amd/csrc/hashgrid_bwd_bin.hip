@@ -315,12 +315,14 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
     // runs on line boundaries -- where the run LENGTH stops mattering at all (tools/microbench3.hip, profiles/r05_experiments.md).
     // So runs are reserved in multiples of 128 bytes (pad units = all-zero items, which no consumer adds): large batches only
     // (below 2^17 samples the item array lives in the caches, which merge the pieces), 16-byte units only (a 24-byte unit would
-    // need 384-byte multiples; the 8-byte half-precision units are written with plain stores, which the L2 merges, and 16 of
-    // them per line cost more pad bytes than they return: S1 fp16 backward 0.438 -> 0.461 ms with pads), and only while two
-    // scatter workgroups still share a CU with the pad slots staged.
+    // need 192-byte multiples and goes through staging windows; the half-precision streams of fp16 tables -- 8-byte units, and
+    // the 16-byte units of F = 4 -- are written with plain stores, which the L2 merges, and lose with pads: S1 fp16 backward
+    // 0.438 -> 0.461 ms, nerf_lego table fp16 0.349 -> 0.363), and only while two scatter workgroups still share a CU with the
+    // pad slots staged.
     plan.pad = 1;
     {
-        const size_t unit = item_unit_bytes(item_format(dim, dtype, lt, n_batch), lt);
+        const int fmt_p = item_format(dim, dtype, lt, n_batch);
+        const size_t unit = item_unit_bytes(fmt_p, lt);
         const uint32_t tile_units = (uint32_t)tile_samples(dim) * plan.pairs;
         uint32_t maxnb = 0;
         for (uint32_t q = 0; q < plan.nbl; ++q) maxnb = plan.lv[plan.blevel[q]].nb > maxnb ? plan.lv[plan.blevel[q]].nb : maxnb;
@@ -328,7 +330,8 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
 #ifdef SHACIRA_SCATTER_SPLIT
         windows = SHACIRA_SCATTER_SPLIT > 1;
 #endif
-        if (opt().bwd_run_pad != 0 && !windows && plan.nbl > 0 && n_batch >= SHACIRA_FX_MIN && (unit == 16 || unit == 12 || (SHACIRA_PAD_HALF && unit == 8))) {
+        if (opt().bwd_run_pad != 0 && !windows && plan.nbl > 0 && n_batch >= SHACIRA_FX_MIN &&
+            ((fmt_p != 1 && (unit == 16 || unit == 12)) || (SHACIRA_PAD_HALF && fmt_p == 1 && (unit == 8 || unit == 16)))) {
             const uint32_t P = unit == 12 ? (uint32_t)(SHACIRA_RUN_ALIGN / 4) : (uint32_t)(SHACIRA_RUN_ALIGN / unit);   // 12-byte units: lcm(12, 64) = 16 of them
             const size_t staged = (size_t)(tile_units + maxnb * (P - 1u)) * (unit + 1);
             if (staged <= (size_t)78 * 1024 || (size_t)tile_units * (unit + 1) > (size_t)78 * 1024) plan.pad = P;
