@@ -171,18 +171,21 @@ def test_skewed_sample_distributions(dev, kind):
     np.testing.assert_allclose(grad.cpu().numpy(), ref_g, rtol=RTOL, atol=RTOL * np.abs(ref_g).max())
 
 
-def test_backward_in_sub_batches(dev):
-    """Item array capped to 1 MiB: the backward walks the batch in many sub-batches and accumulates across them."""
+@pytest.mark.parametrize("n,cap_mib", [(50_000, 1), (300_001, 128)])
+def test_backward_in_sub_batches(dev, n, cap_mib):
+    """Item array capped: the backward walks the batch in sub-batches and accumulates across them. 1 MiB: many small ones
+    (exact runs); 128 MiB on 300 001 samples: two sub-batches of >= 2^17 samples each, i.e. line-aligned (padded) runs, fixed-point
+    images and the standalone counting pass together (round 5)."""
     from shacira_amd import _lib
     dim, res, bw = CONFIGS["D"]
-    sizes, first, T, coords, table, go = _problem(dim, res, bw, 50_000)
-    _lib.set_option("bin_batch_mib", 1)
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n)
+    _lib.set_option("bin_batch_mib", cap_mib)
     try:
         _, grad = _run(dev, dim, res, bw, coords, table, go, first)
     finally:
         _lib.set_option("bin_batch_mib", 1536)
     ref_g = oc.backward(coords, go, (T, 2), first, res, bw)
-    np.testing.assert_allclose(grad.cpu().numpy(), ref_g, rtol=RTOL, atol=RTOL * np.abs(ref_g).max())
+    _assert_grad_close(grad.cpu().numpy(), ref_g, first, sizes)
 
 
 @pytest.mark.parametrize("name,bvar", [("D", -1), ("Bp", -1), ("B", -1), ("D", 0)])
