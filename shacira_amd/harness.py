@@ -150,8 +150,12 @@ class ImageFitter:
             elif self.cdec["norm"] == "std":
                 grid.latent_dec.div.data = lat.std(dim=0)
 
-    def step(self):
-        """Returns (rgb_loss, clamped PSNR, avg bits per latent row) of this step's prediction."""
+    def step(self, read=True):
+        """Returns (rgb_loss, clamped PSNR, avg bits per latent row) of this step's prediction. `read=False` leaves the
+        step's statistics on the device (`read_last()` fetches them later) and returns None: the three host read-backs per
+        step are device synchronisations -- the reference's trainers make them too (`.item()` on the losses,
+        image_trainer.py:320-324) -- and with them the step costs host time PLUS kernel time instead of the larger of the two
+        (config-B image fit: 0.84 -> ~0.6 ms per eager step)."""
         self.iteration += 1
         if self.bucket is not None:
             self.bucket.zero_()
@@ -174,22 +178,33 @@ class ImageFitter:
             avg_bits, _ = self.nef.grid.ent_loss(self.iteration - 1, is_val=not self.nef.training)
             loss = loss + lam * avg_bits / self.world   # every rank evaluates the (table-only) entropy term
         loss.backward()
-        with torch.no_grad():
-            q = lambda t: (torch.clamp(t, 0, 1) * 255).to(torch.uint8).float()
-            stats = torch.stack([sq_sum.detach(), ((q(pred) - q(self.rgb)) ** 2).sum()]).double()
         hidden = []
         if self.bucket is not None:
             self.bucket.allreduce()
-            if dist.is_initialized():
-                dist.all_reduce(stats)
             hidden = self.bucket.hide_untouched()      # e.g. the entropy model while lambda == 0
         self.optimizer.step()
         if self.bucket is not None:
             self.bucket.restore(hidden)
+        # the step's statistics (clamped PSNR: a dozen tensor ops of pure logging) are formed only when they are read
+        self._last = (sq_sum.detach(), pred.detach(), avg_bits.detach() if torch.is_tensor(avg_bits) else avg_bits)
+        return self.read_last() if read else None
+
+    def read_last(self):
+        """(rgb_loss, clamped PSNR, avg bits) of the last step: the statistics and their host read-back (a device
+        synchronisation; with several ranks also one small all-reduce -- every rank must read the same steps)."""
+        sq_sum, pred, avg_bits = self._last
+        with torch.no_grad():
+            q = lambda t: (torch.clamp(t, 0, 1) * 255).to(torch.uint8).float()
+            if getattr(self, "_rgb_q", None) is None:
+                self._rgb_q = q(self.rgb)              # (the target is the same every step)
+            stats = torch.stack([sq_sum, ((q(pred) - self._rgb_q) ** 2).sum()]).double()
+            if self.bucket is not None and dist.is_initialized():
+                dist.all_reduce(stats)
         n = self.global_pixels * 3
-        rgb_loss = float(stats[0]) / n
-        psnr = 20 * math.log10(255.0) - 10 * math.log10(max(float(stats[1]) / n, 1e-12))   # clamped_psnr, globally
-        return rgb_loss, psnr, float(avg_bits.detach()) if torch.is_tensor(avg_bits) else float(avg_bits)
+        st = stats.tolist()                                                                  # one read-back for both sums
+        rgb_loss = st[0] / n
+        psnr = 20 * math.log10(255.0) - 10 * math.log10(max(st[1] / n, 1e-12))               # clamped_psnr, globally
+        return rgb_loss, psnr, float(avg_bits)
 
 
 def _require_device_temperature(latent_dec, who):
@@ -308,7 +323,9 @@ def fit_image(device, steps=1000, height=512, width=768, seed=0, num_lods=16, lo
     else:
         fitter = ImageFitter(nef, coords, rgb, steps, cdec, cent, world=world, global_pixels=height * width)
         for it in range(steps):
-            out = fitter.step()
+            # statistics are read back only where they are used (a logged step, the last one): the host runs ahead of the GPU
+            want = (log_every and (it + 1) % log_every == 0) or it == steps - 1
+            out = fitter.step(read=bool(want))
             if log_every and (it + 1) % log_every == 0:
                 history.append((it + 1,) + out)
     if device.type == "cuda":
