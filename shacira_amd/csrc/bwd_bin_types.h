@@ -73,8 +73,8 @@ struct BinPlan {
     uint32_t chunk;     // items per consumer work unit
     uint32_t chunk_min; // smallest unit size of the plan (sizes the unit list)
     uint32_t nbl;       // number of binned levels
-    uint32_t pad;       // a (tile, bucket) run is reserved in multiples of this many item units (power of two; 1 = exact): with 128 / unit
-                        // bytes every run starts and ends on a 128-byte line, see make_plan
+    uint32_t pad;       // a (tile, bucket) run is reserved in multiples of this many item units (power of two; 1 = exact): with
+                        // SHACIRA_RUN_ALIGN / unit bytes every run starts and ends on a 64-byte boundary, see make_plan
     uint32_t stage_cap; // item units the scatter pass's LDS staging buffer holds: the tile's items + the pad units of its runs
     uint32_t blevel[SHACIRA_MAX_LODS];  // their level indices (grid.y of passes A/B); 32-bit = scalar loads
     uint32_t bstart[SHACIRA_MAX_LODS];  // first global bucket of binned level q (= lv[blevel[q]].bucket0)

@@ -11,7 +11,9 @@
 //   pass S  scan        one workgroup: exclusive scan of the totals -> first item of every bucket, the cursors the
 //                       scatter pass reserves its runs from, and the consumer work list
 //   pass B  bin         recompute the corners, stage the tile's items in LDS sorted by bucket, reserve each (tile, bucket)
-//                       run with one returning atomic on the bucket's cursor, write it with coalesced 16-byte stores
+//                       run with one returning atomic on the bucket's cursor, write it with coalesced 16-byte stores. Runs are
+//                       reserved in whole 64-byte pieces (round 5, BinPlan::pad: pad units = all-zero items): scattered runs
+//                       stream at 5.3 TB/s when they start and end on 64-byte boundaries, at 2.5-3.6 TB/s when they do not
 //   pass C  consume     persistent workgroups fetch (bucket, chunk) units: accumulate the items into an LDS-resident
 //                       64-bit fixed-point (or fp64) image of the bucket's rows, then write the rows out (plain coalesced
 //                       stores when the bucket has a single unit, coalesced float atomics otherwise)

@@ -10,12 +10,16 @@ try:
     subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", "lib.so"], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for co in glob.glob(os.path.join(tmp, "lib.so.*gfx950*")):
         notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
-        for m in re.finditer(r"\.name:\s+(\S+)(.*?)(?=\.name:\s+_Z|\Z)", notes, re.S):
-            if flt not in m.group(1):
+        # one metadata block per kernel: the YAML list items of amdhsa.kernels start at `- .agpr_count:` (keys are alphabetical, so
+        # the kernel's own `.name: _Z...` sits in the middle of its block, behind the `.name` entries of its arguments)
+        for block in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
+            mname = re.search(r"\n\s+\.name:\s+(_Z\S+)", block)
+            if not mname or flt not in mname.group(1):
                 continue
-            b = m.group(2)
-            g = lambda k: (re.search(rf"\.{k}:\s+(\d+)", b) or [None, "-"])[1]
-            dem = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-            print(f"vgpr {g('vgpr_count'):>4} agpr {g('agpr_count'):>3} sgpr {g('sgpr_count'):>4} scratch {g('private_segment_fixed_size'):>5} lds {g('group_segment_fixed_size'):>6} spill {g('vgpr_spill_count'):>3}  {dem[:150]}")
+            g = lambda k: (re.search(rf"\n\s+\.{k}:\s+(\d+)", block) or [None, "-"])[1]
+            agpr = re.match(r"\s*(\d+)", block)
+            dem = subprocess.run(["c++filt", mname.group(1)], capture_output=True, text=True).stdout.strip()
+            print(f"vgpr {g('vgpr_count'):>4} agpr {agpr.group(1) if agpr else '-':>3} sgpr {g('sgpr_count'):>4} scratch "
+                  f"{g('private_segment_fixed_size'):>5} lds {g('group_segment_fixed_size'):>6} spill {g('vgpr_spill_count'):>3}  {dem[:150]}")
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
