@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SHACIRA_ABI_VERSION 9
+#define SHACIRA_ABI_VERSION 10
 
 #if defined(__GNUC__)
 #define SHACIRA_API __attribute__((visibility("default")))
@@ -136,6 +136,39 @@ SHACIRA_API int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, in
                                      const int32_t *codebook_first_idx, int64_t table_rows, const float *coords,
                                      const void *grad_output, int dtype, void *grad_codebook, int level_begin,
                                      int level_end, int flags, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * The PLAN of a coordinate batch (round 6, ABI 10): forward and backward of one training step see the same coordinates
+ * (the reference saves `coords` for the backward, wisp/ops/grid.py:86,106) -- what the forward of a large batch computes
+ * first, the batch counting-sorted by spatial block (16-byte records {x, y, z, sample index} + block offsets), is exactly
+ * what lets the backward accumulate its coarse levels block by block on chip instead of through the item stream. The two
+ * calls below are shacira_hashgrid_forward / shacira_hashgrid_backward with one more CALLER-OWNED buffer: the forward
+ * writes the batch's plan into it, the backward of the same (dim, num_coords, coords) reads it. Results are those of the
+ * plain calls (forward: bit-identical; backward: the same products, summed in a different order).
+ *
+ *   shacira_hashgrid_plan_bytes      size of the plan buffer for this shape; 0 = the forward of this shape sorts nothing
+ *                                    (small batches, cache-resident tables): pass plan = NULL, the calls are the plain ones
+ *   plan                             device buffer of at least that size (256-byte aligned), or NULL. The forward overwrites
+ *                                    it; the backward only reads it. A plan is a function of (dim, num_coords, coords): a
+ *                                    caller that trains on a FIXED batch (the reference's image trainer revisits the same
+ *                                    pixel lattice every step, wisp/trainers/image_trainer.py:234-266) may keep it across
+ *                                    steps and pass plan_flags = SHACIRA_PLAN_READY to the forward, which then skips its sort
+ *   plan_bytes                       size of the buffer; SHACIRA_EWORKSPACE when it is non-NULL and too small
+ */
+#define SHACIRA_PLAN_READY 1
+SHACIRA_API size_t shacira_hashgrid_plan_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                               int codebook_bitwidth, const int32_t *resolutions_host, int64_t table_rows,
+                                               int dtype);
+SHACIRA_API int shacira_hashgrid_forward_planned(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                                 int codebook_bitwidth, const int32_t *resolutions_host,
+                                                 const int32_t *codebook_first_idx, int64_t table_rows, const float *coords,
+                                                 const void *codebook, int dtype, void *feats, void *plan, size_t plan_bytes,
+                                                 int plan_flags, void *workspace, size_t workspace_bytes, void *stream);
+SHACIRA_API int shacira_hashgrid_backward_planned(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                                  int codebook_bitwidth, const int32_t *resolutions_host,
+                                                  const int32_t *codebook_first_idx, int64_t table_rows, const float *coords,
+                                                  const void *grad_output, int dtype, void *grad_codebook, const void *plan,
+                                                  size_t plan_bytes, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Latent decode, deterministic (non-SGA) path of LatentDecoder.forward with num_layers_dec == 0

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("SHACIRA_HIP_LIB") or os.path.join(_HERE, "lib", "libs
 F32, F16, F64 = 0, 1, 2
 EINVAL, EDTYPE, EODD, EWORKSPACE = -1, -2, -3, -4
 BWD_STAGE_ALL_LEVELS, BWD_REUSE_STAGED = 1, 2
+PLAN_READY = 1
 
 _lock = threading.Lock()
 _lib = None
@@ -30,6 +31,9 @@ SIGNATURES = {
     "shacira_hashgrid_forward_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i, _p, _i64, _i]),
     "shacira_hashgrid_forward": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p]),
     "shacira_hashgrid_debug_corners": (_i, [_i, _i64, _i, _i, _p, _p, _p, _p, _p]),
+    "shacira_hashgrid_plan_bytes": (_sz, [_i, _i64, _i, _i, _i, _p, _i64, _i]),
+    "shacira_hashgrid_forward_planned": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _i, _p, _sz, _p]),
+    "shacira_hashgrid_backward_planned": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p, _sz, _p]),
     "shacira_hashgrid_backward_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i, _p, _i64, _i]),
     "shacira_hashgrid_backward": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p]),
     "shacira_hashgrid_backward_levels": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _i, _i, _i, _p, _sz,

@@ -31,6 +31,11 @@ static OptionSlot g_slots[] = {
     {"bin_batch_mib", &Options::bin_batch_mib, 1, 1 << 20, {1536}},
     {"tiled", &Options::tiled, -1, 1, {-1}},
     {"tiled_lc_fwd", &Options::tiled_lc_fwd, -1, SHACIRA_MAX_LODS, {-1}},
+    {"bwd_brick", &Options::bwd_brick, -1, 1, {-1}},
+    {"bwd_brick_lo", &Options::bwd_brick_lo, -1, SHACIRA_MAX_LODS, {-1}},
+    {"bwd_brick_hi", &Options::bwd_brick_hi, -1, SHACIRA_MAX_LODS, {-1}},
+    {"bwd_brick_fork", &Options::bwd_brick_fork, 0, 2, {0}},
+    {"bwd_brick_span", &Options::bwd_brick_span, 0, 64, {0}},
 };
 static thread_local Options tl_options;
 const Options &opt() { return tl_options; }
@@ -123,6 +128,25 @@ int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feat
                              const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
                              const float *coords, const void *codebook, int dtype, void *feats, void *workspace,
                              size_t workspace_bytes, void *stream) {
+    return shacira_hashgrid_forward_planned(dim, num_coords, num_lods, feature_dim, codebook_bitwidth, resolutions_host,
+                                            codebook_first_idx, table_rows, coords, codebook, dtype, feats, nullptr, 0, 0,
+                                            workspace, workspace_bytes, stream);
+}
+
+size_t shacira_hashgrid_plan_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                                   const int32_t *resolutions_host, int64_t table_rows, int dtype) {
+    options_snapshot();
+    LevelTable lt;
+    if (build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt)) return 0;
+    if (dtype == SHACIRA_F64 || table_rows == 0 || !tiled_supported(dim, dtype, lt, num_coords)) return 0;
+    return sample_plan_bytes(dim, num_coords);
+}
+
+int shacira_hashgrid_forward_planned(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                                     const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
+                                     const float *coords, const void *codebook, int dtype, void *feats, void *plan,
+                                     size_t plan_bytes, int plan_flags, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
     options_snapshot();
     LevelTable lt;
     int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
@@ -133,8 +157,13 @@ int shacira_hashgrid_forward(int dim, int64_t num_coords, int num_lods, int feat
     if (!codebook_first_idx || !coords || !codebook || !feats) return SHACIRA_EINVAL;
     const size_t need = hashgrid_forward_workspace(dim, dtype, lt, num_coords);
     if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
+    // a plan buffer is used only by the shapes that sort (shacira_hashgrid_plan_bytes > 0); others ignore it
+    const bool sorts = dtype != SHACIRA_F64 && table_rows > 0 && tiled_supported(dim, dtype, lt, num_coords);
+    if (plan != nullptr && sorts && plan_bytes < sample_plan_bytes(dim, num_coords)) return SHACIRA_EWORKSPACE;
+    if ((plan_flags & ~SHACIRA_PLAN_READY) != 0 || ((plan_flags & SHACIRA_PLAN_READY) != 0 && plan == nullptr)) return SHACIRA_EINVAL;
     return (int)hashgrid_forward_dispatch(dim, dtype, lt, codebook_first_idx, coords, codebook, feats, workspace,
-                                          num_coords, (hipStream_t)stream);
+                                          num_coords, (hipStream_t)stream, sorts ? plan : nullptr,
+                                          (plan_flags & SHACIRA_PLAN_READY) != 0);
 }
 
 int shacira_hashgrid_debug_corners(int dim, int64_t num_coords, int num_lods, int codebook_bitwidth,
@@ -166,11 +195,37 @@ int shacira_hashgrid_backward(int dim, int64_t num_coords, int num_lods, int fea
                                             0, num_lods, 0, workspace, workspace_bytes, stream);
 }
 
+static int backward_call(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                         const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
+                         const float *coords, const void *grad_output, int dtype, void *grad_codebook, int level_begin,
+                         int level_end, int flags, const void *plan, size_t plan_bytes, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
+int shacira_hashgrid_backward_planned(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                                      const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
+                                      const float *coords, const void *grad_output, int dtype, void *grad_codebook,
+                                      const void *plan, size_t plan_bytes, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
+    return backward_call(dim, num_coords, num_lods, feature_dim, codebook_bitwidth, resolutions_host, codebook_first_idx,
+                         table_rows, coords, grad_output, dtype, grad_codebook, 0, num_lods, 0, plan, plan_bytes, workspace,
+                         workspace_bytes, stream);
+}
+
 int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
                                      const int32_t *resolutions_host, const int32_t *codebook_first_idx,
                                      int64_t table_rows, const float *coords, const void *grad_output, int dtype,
                                      void *grad_codebook, int level_begin, int level_end, int flags, void *workspace,
                                      size_t workspace_bytes, void *stream) {
+    return backward_call(dim, num_coords, num_lods, feature_dim, codebook_bitwidth, resolutions_host, codebook_first_idx,
+                         table_rows, coords, grad_output, dtype, grad_codebook, level_begin, level_end, flags, nullptr, 0,
+                         workspace, workspace_bytes, stream);
+}
+
+static int backward_call(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
+                         const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
+                         const float *coords, const void *grad_output, int dtype, void *grad_codebook, int level_begin,
+                         int level_end, int flags, const void *plan, size_t plan_bytes, void *workspace,
+                         size_t workspace_bytes, void *stream) {
     options_snapshot();
     LevelTable lt;
     int rc = build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt);
@@ -189,8 +244,17 @@ int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, int num_lods, 
     if (num_coords > 0 && (!codebook_first_idx || !coords || !grad_output)) return SHACIRA_EINVAL;
     const size_t need = hashgrid_backward_workspace(dim, dtype, lt, num_coords);
     if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
+    // the plan of a shape whose forward sorts nothing does not exist: such a buffer is ignored
+    if (plan != nullptr) {
+        LevelTable full = lt;
+        full.level_begin = 0;
+        full.level_end = num_lods;
+        const bool sorts = dtype != SHACIRA_F64 && table_rows > 0 && tiled_supported(dim, dtype, full, num_coords);
+        if (!sorts) plan = nullptr;
+        else if (plan_bytes < sample_plan_bytes(dim, num_coords)) return SHACIRA_EWORKSPACE;
+    }
     return (int)hashgrid_backward_dispatch(dim, dtype, lt, codebook_first_idx, coords, grad_output, grad_codebook,
-                                           workspace, workspace_bytes, num_coords, (hipStream_t)stream);
+                                           workspace, workspace_bytes, num_coords, (hipStream_t)stream, plan);
 }
 
 int shacira_latent_decode_forward(int64_t num_rows, int latent_dim, int feature_dim, const float *latent,

@@ -83,12 +83,17 @@ __global__ __launch_bounds__(256) void transpose_grad_kernel(const T *__restrict
 // (workgroup, non-empty bucket) into totals[] -- the per-(tile, bucket) matrix and its scan are gone: the scatter pass
 // reserves its runs with returning atomics on per-bucket cursors instead.
 constexpr int kFrontThreads = 512;
-template <int DIM, typename T, int F, bool GMAX, bool COUNT>
+// SORTED (round 6): the batch's plan is at hand -- `sorted4` = its 16-byte records {x, y, z, sample index} in block order. The
+// tile's samples are then records s0 .. s0 + TS: their gradient rows are GATHERED (row = the record's index; a row is whole
+// 128-byte lines, so the gather moves the same bytes), the counting takes its coordinates from the records, and gT comes out
+// in SORTED order -- every later pass (scatter, brick, direct) walks sorted samples with coalesced gradient loads.
+template <int DIM, typename T, int F, bool GMAX, bool COUNT, bool SORTED = false>
 __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, BinPlan plan, const T *__restrict__ go,
                                                                 float *__restrict__ gT, const float *__restrict__ coords,
                                                                 uint32_t *__restrict__ totals, uint32_t *__restrict__ cnt,
                                                                 int64_t N, int64_t NP, int lb, int le, int ts_log2,
-                                                                int rounds, uint32_t *__restrict__ gmax, uint32_t cps) {
+                                                                int rounds, uint32_t *__restrict__ gmax, uint32_t cps,
+                                                                const float4 *__restrict__ sorted4 = nullptr) {
     constexpr int K = 16 / (int)(sizeof(T) * F);   // level pieces per 16-byte input vector
     constexpr int HE = SHACIRA_MAX_LODS * kMaxLevelBuckets / kFrontThreads;   // histogram words per thread (<= 8)
     constexpr int M = 16 / (4 * F);                // samples per 16-byte output vector
@@ -99,6 +104,7 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     struct alignas(sizeof(float) * F) PieceOut { float v[F]; };
     __shared__ uint32_t s_max[SHACIRA_MAX_LODS];
+    __shared__ uint32_t s_idx[SORTED ? kFrontThreads : 1];   // SORTED: row (= original sample index) of the tile's k-th record
     extern __shared__ __align__(16) unsigned char s_raw_g[];
     const int L = lt.num_lods;
     const int TS = 1 << ts_log2;                   // samples per tile: a power of two in [128, 512]
@@ -124,24 +130,26 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
     // the histogram is per ROUND: after each tile a thread moves its words (k = tid + j * 512 <-> (level k / 128, bucket
     // k % 128)) to the tile's row of cnt[tile][bucket] -- what lets the scatter pass reserve its runs before it has ranked
     // anything -- and keeps the workgroup's sums in registers for the totals
-    int hcol[HE];
     uint32_t hsum[HE];
     uint32_t hacc[HE];   // items of the current SCATTER tile (cps counting tiles) so far: its runs are reserved in multiples of plan.pad
+    // word k = tid + j * 512 <-> (level slot k / 128, bucket k % 128): the slot is uniform over a wave (128 = two waves), so
+    // it is made a scalar and the two plan words come by scalar loads. (Round 4: with a lane-dependent index into the
+    // by-value plan the compiler read the kernel arguments through VECTOR loads -- blevel[li] -> lv[..].nb -> bstart[li],
+    // 3 dependent global loads x 8 words, each behind its own s_waitcnt: 24 serialised round trips at the start of
+    // every workgroup, most of this kernel's time on the small NeRF batches.) The column is recomputed where it is used
+    // (round 6: kept in an array it cost eight registers, the sorted form's margin to two workgroups per CU).
+    static_assert(!COUNT || kFrontThreads % kMaxLevelBuckets == 0, "a wave maps to one level slot");
+    const uint32_t hli0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kMaxLevelBuckets));
+    const uint32_t hb = threadIdx.x % kMaxLevelBuckets;
+    auto hcol_of = [&](int j) -> int {
+        const uint32_t li = hli0 + (uint32_t)j * (kFrontThreads / kMaxLevelBuckets);
+        const uint32_t lc = li < (uint32_t)SHACIRA_MAX_LODS ? li : 0u;
+        const uint32_t nbq = li < plan.nbl ? plan.bnb[lc] : 0u, bsq = plan.bstart[lc];
+        return (hb < nbq) ? (int)(bsq + hb) : -1;
+    };
     if constexpr (COUNT) {
-        // word k = tid + j * 512 <-> (level slot k / 128, bucket k % 128): the slot is uniform over a wave (128 = two waves), so
-        // it is made a scalar and the two plan words come by scalar loads. (Round 4: with a lane-dependent index into the
-        // by-value plan the compiler read the kernel arguments through VECTOR loads -- blevel[li] -> lv[..].nb -> bstart[li],
-        // 3 dependent global loads x 8 words, each behind its own s_waitcnt: 24 serialised round trips at the start of
-        // every workgroup, most of this kernel's time on the small NeRF batches.)
-        static_assert(kFrontThreads % kMaxLevelBuckets == 0, "a wave maps to one level slot");
-        const uint32_t li0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kMaxLevelBuckets));
-        const uint32_t b = threadIdx.x % kMaxLevelBuckets;
 #pragma unroll
         for (int j = 0; j < HE; ++j) {
-            const uint32_t li = li0 + (uint32_t)j * (kFrontThreads / kMaxLevelBuckets);
-            const uint32_t lc = li < (uint32_t)SHACIRA_MAX_LODS ? li : 0u;
-            const uint32_t nbq = li < plan.nbl ? plan.bnb[lc] : 0u, bsq = plan.bstart[lc];
-            hcol[j] = (b < nbq) ? (int)(bsq + b) : -1;
             hsum[j] = 0;
             hacc[j] = 0;
         }
@@ -151,16 +159,25 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
     // with s_waitcnt vmcnt(0), i.e. after every row had arrived instead of while they were in flight. A value carried over
     // the back edge cannot be sunk; being older than the round's row loads it costs vmcnt(8), not vmcnt(0).)
     float cc[DIM];
+    uint32_t cidx = 0;   // SORTED: the record's sample index, loaded with the coordinates
     auto load_coords = [&](int r) {
         int64_t t = tile0 + r;
         if (t >= tiles) t = tiles - 1;
         const int64_t s0r = t << ts_log2;
         const int nsr = (int)((N - s0r < TS) ? (N - s0r) : TS);
         const int64_t ci = s0r + (csm < nsr ? csm : nsr - 1);
+        if constexpr (SORTED) {
+            const float4 rc = sorted4[ci];
+            cc[0] = rc.x;
+            cc[1] = rc.y;
+            if constexpr (DIM == 3) cc[2] = rc.z;
+            cidx = __float_as_uint(rc.w);
+        } else {
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) cc[a] = coords[ci * DIM + a];
+            for (int a = 0; a < DIM; ++a) cc[a] = coords[ci * DIM + a];
+        }
     };
-    if constexpr (COUNT) {
+    if constexpr (COUNT || SORTED) {
         if (tile0 < tiles) load_coords(0);
     }
     for (int r = 0; r < rounds && tile0 + r < tiles; ++r) {
@@ -170,19 +187,36 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
         // row vectors: all loads unconditional with clamped indices (a branch around a load makes the compiler wait with
         // vmcnt(0) in front of the counting, which would serialise it with the row loads)
         // (the sample's coordinates are already in flight or in: loaded one round ahead, see the end of the loop body)
-        const u32x4 *in = reinterpret_cast<const u32x4 *>(go) + s0 * VPR;
-        u32x4 raw[UL];
-#pragma unroll
-        for (int u = 0; u < UL; ++u) {
-            const int e = (int)threadIdx.x + u * kFrontThreads;
-            raw[u] = __builtin_nontemporal_load(in + (e < total ? e : total - 1));   // idle lanes: one merged request
+        const u32x4 *in = reinterpret_cast<const u32x4 *>(go) + (SORTED ? 0 : s0 * VPR);
+        if constexpr (SORTED) {   // the tile's row numbers (the records arrived one round ahead, with the coordinates)
+            if (cslot == 0) s_idx[csm] = cidx;
+            lds_barrier();
         }
-        if constexpr (COUNT) {
+        // element e of the tile -> (sample e / VPR, vector e % VPR): stepped like the parking loop below
+        auto src_of = [&](int e, int smq, int vq) -> const u32x4 * {
+            if constexpr (SORTED) return in + (uint32_t)(s_idx[smq] * (uint32_t)VPR + (uint32_t)vq);   // (host: N * VPR < 2^32)
+            else return in + e;
+        };
+        u32x4 raw[UL];
+        {
+            int smq = sm_first, vq = v_first;
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int e = (int)threadIdx.x + u * kFrontThreads;
+                const bool in_tile = e < total;
+                // idle lanes: one merged request (the tile's last element)
+                raw[u] = __builtin_nontemporal_load(in_tile ? src_of(e, smq, vq) : src_of(total - 1, ns - 1, VPR - 1));
+                smq += q512;
+                vq += r512;
+                if (vq >= VPR) { vq -= VPR; ++smq; }
+            }
+        }
+        if constexpr (COUNT || SORTED) {
             double t[DIM];
 #pragma unroll
             for (int a = 0; a < DIM; ++a) t[a] = axis_unit(cc[a]);
             load_coords(r + 1);   // next round's (clamped to the last tile): in flight behind this round's rows
-            if (csm < ns) {
+            if (COUNT && csm < ns) {
 #pragma unroll 2
                 for (uint32_t li = (uint32_t)cslot; li < plan.nbl; li += (uint32_t)cslots)
                     count_level<DIM>(t, plan.cl[li], lt.mask, s_hist + li * kMaxLevelBuckets);
@@ -209,7 +243,7 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
             if (v >= VPR) { v -= VPR; ++sm; }
         }
         for (int e = (int)threadIdx.x + kFrontThreads * UL; e < total; e += kFrontThreads) {   // rows wider than 8 vectors
-            park1(__builtin_nontemporal_load(in + e), sm, v);
+            park1(__builtin_nontemporal_load(src_of(e, sm, v)), sm, v);
             sm += q512;
             v += r512;
             if (v >= VPR) { v -= VPR; ++sm; }
@@ -224,10 +258,11 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
             const bool close = plan.pad > 1u && ((uint32_t)((tile0 + r + 1) % (int64_t)cps) == 0u || tile0 + r + 1 == tiles);
 #pragma unroll
             for (int j = 0; j < HE; ++j) {
-                if (hcol[j] >= 0) {
+                const int hc = hcol_of(j);
+                if (hc >= 0) {
                     const uint32_t h = s_hist[threadIdx.x + j * kFrontThreads];
                     s_hist[threadIdx.x + j * kFrontThreads] = 0;
-                    row[hcol[j]] = h;
+                    row[hc] = h;
                     hacc[j] += h;
                     hsum[j] += h;
                     if (close) {
@@ -286,8 +321,10 @@ __global__ __launch_bounds__(kFrontThreads) void front16_kernel(LevelTable lt, B
         // on 65 536 samples); the bucket scan adds the copies up
         uint32_t *mine = totals + (size_t)(blockIdx.x % kTotalShards) * kMaxBuckets;
 #pragma unroll
-        for (int j = 0; j < HE; ++j)
-            if (hcol[j] >= 0 && hsum[j]) atomicAdd(&mine[hcol[j]], hsum[j]);
+        for (int j = 0; j < HE; ++j) {
+            const int hc = hcol_of(j);
+            if (hc >= 0 && hsum[j]) atomicAdd(&mine[hc], hsum[j]);
+        }
     }
     if constexpr (GMAX) {
         if ((int)threadIdx.x >= lb && (int)threadIdx.x < le && s_max[threadIdx.x])

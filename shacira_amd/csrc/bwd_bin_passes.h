@@ -28,7 +28,8 @@ __global__ __launch_bounds__((ScatterThreads<DIM, F, FMT>::value)) SHACIRA_SCATT
                                                                   int64_t sample0, int64_t N, int64_t gpitch,
                                                                   float *__restrict__ zero_acc,
                                                                   const int32_t *__restrict__ first_idx,
-                                                                  const uint32_t *__restrict__ unit_first) {
+                                                                  const uint32_t *__restrict__ unit_first,
+                                                                  int cstride = DIM) {   // floats per coordinate record
     typedef typename ItemSel<F, FMT>::type ItemT;
     constexpr bool H = FMT == 1;      // half-precision stream (fp16 tables)
     constexpr bool P12 = FMT == 2;    // 12-byte units (fp32 tables, 3-D, F = 2, large batches)
@@ -53,7 +54,11 @@ __global__ __launch_bounds__((ScatterThreads<DIM, F, FMT>::value)) SHACIRA_SCATT
     __shared__ uint64_t s_gbase[kMaxLevelBuckets];
 
     // (tile-fastest numbering; level-fastest -- a tile's levels back to back -- measured 3 % slower, round 3)
+#ifdef SCATTER_LEVEL_FAST   // A/B builds: a tile's levels back to back (grid = (levels, tiles))
+    const uint32_t tile = blockIdx.y, bi = blockIdx.x;
+#else
     const uint32_t tile = blockIdx.x, bi = blockIdx.y;
+#endif
     const uint32_t lvl = plan.blevel[bi];
     const BinLevel bl = plan.lv[lvl];
     if (threadIdx.x < kMaxLevelBuckets) s_hist[threadIdx.x] = 0;
@@ -83,7 +88,7 @@ __global__ __launch_bounds__((ScatterThreads<DIM, F, FMT>::value)) SHACIRA_SCATT
         i = (i * 2654435761ll) & 1023;
 #endif
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) craw[u][a] = coords[i * DIM + a];
+        for (int a = 0; a < DIM; ++a) craw[u][a] = coords[i * cstride + a];
         const float *gp = gT + ((int64_t)lvl * gpitch + i) * F;
         if constexpr (F == 2) {
             const float2 v = *reinterpret_cast<const float2 *>(gp);
@@ -105,7 +110,11 @@ __global__ __launch_bounds__((ScatterThreads<DIM, F, FMT>::value)) SHACIRA_SCATT
         uint32_t c = 0;
         for (uint32_t k = 0; k < cps && tile * cps + k < cnt_rows; ++k) c += row[(size_t)k * plan.total_buckets];
         c = (c + plan.pad - 1u) & ~(plan.pad - 1u);
+#ifdef ABL_NO_CURSOR   // ablation: no reservation (runs overlap: wrong results on purpose)
+        if (c) run_base = cursor[gb] + (unsigned long long)tile * c;
+#else
         if (c) run_base = atomicAdd(&cursor[gb], (unsigned long long)c);
+#endif
     }
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
@@ -348,7 +357,7 @@ __global__ __launch_bounds__((ScatterThreads<DIM, F, FMT>::value)) SHACIRA_SCATT
     // added to atomically -- those are zeroed here, by the workgroups of the level's first tiles, behind their own item
     // stores (the consume pass runs after this kernel either way).
     if (zero_acc != nullptr && !dense) {
-        for (uint32_t b = tile; b < bl.nb; b += gridDim.x) {
+        for (uint32_t b = tile; b < bl.nb; b += plan.num_tiles) {
             const uint32_t gb = bl.bucket0 + b;
             if (unit_first[gb + 1] - unit_first[gb] == 1u) continue;
             const uint32_t row0 = b * bl.rows_pb;
@@ -971,7 +980,7 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
                                                                             float *__restrict__ grad_table,
                                                                             int64_t N, int64_t gpitch,
                                                                             const uint32_t *__restrict__ gmax,
-                                                                            int headroom) {
+                                                                            int headroom, int cstride = DIM) {
     constexpr int NC = 1 << DIM;
     extern __shared__ double s_acc[];
     __shared__ double s_scale[SHACIRA_MAX_LODS], s_inv[SHACIRA_MAX_LODS];
@@ -1073,7 +1082,7 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
     {
         const int64_t ic = i < N ? i : N - 1;
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) cn[a] = coords[ic * DIM + a];
+        for (int a = 0; a < DIM; ++a) cn[a] = coords[ic * cstride + a];
     }
     for (; i < N; i += stride) {
         double t[DIM];
@@ -1082,7 +1091,7 @@ __global__ __launch_bounds__(kConsumeThreads) void direct_accumulate_kernel(Leve
         {
             const int64_t in = (i + stride < N) ? i + stride : N - 1;
 #pragma unroll
-            for (int a = 0; a < DIM; ++a) cn[a] = coords[in * DIM + a];
+            for (int a = 0; a < DIM; ++a) cn[a] = coords[in * cstride + a];
         }
         for (int q0 = 0; q0 < nl; q0 += kLv) {
             float g[kLv][F];

@@ -269,7 +269,7 @@ size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n);
 float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace);
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                         const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table,
-                        void *half_table, bool *converted);
+                        void *half_table, bool *converted, const SortedBatch *sb);
 
 // variant 1 ("bin") whenever the shape allows it and the batch is big enough to amortise its fixed passes
 static bool use_bin(int dim, const LevelTable &lt, int64_t n) {
@@ -301,8 +301,15 @@ size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int
 
 hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                       const float *coords, const void *grad_out, void *grad_table, void *workspace,
-                                      size_t workspace_bytes, int64_t n, hipStream_t s) {
+                                      size_t workspace_bytes, int64_t n, hipStream_t s, const void *plan) {
     (void)workspace_bytes;
+    // the batch's plan (hashgrid_tiled.hip), when the caller kept the one its forward call built
+    SortedBatch sbv{};
+    const SortedBatch *sb = nullptr;
+    if (plan != nullptr && n > 0 && n < ((int64_t)1 << 31)) {
+        sample_plan_view(dim, n, plan, sbv);
+        sb = &sbv;
+    }
     const int64_t numel = lt.table_rows * lt.feature_dim;
     if (dtype == SHACIRA_F64) {   // the reference-shaped form only: zeros_like, then one atomicAdd(double) per corner and feature
         hipError_t e64 = zero_fill_async(static_cast<float *>(grad_table), 2 * numel, s);
@@ -331,7 +338,7 @@ hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, 
     bool converted = false;   // fp16 tables: the binned path may write the half table itself (single-unit buckets + a skipping conversion)
     if (bin) {
         e = bin_backward(dim, dtype, lt, first_idx, coords, grad_out, acc, workspace, n, s, full,
-                         (dtype == SHACIRA_F16 && full) ? grad_table : nullptr, &converted);
+                         (dtype == SHACIRA_F16 && full) ? grad_table : nullptr, &converted, sb);
         if (e != hipSuccess) return e;
     } else if (n > 0) {
         if (dim == 3) {

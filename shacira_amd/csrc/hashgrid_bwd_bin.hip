@@ -37,6 +37,7 @@
 #include "bwd_bin_types.h"
 #include "bwd_bin_front.h"
 #include "bwd_bin_passes.h"
+#include "bwd_brick.h"
 
 namespace shacira {
 
@@ -46,8 +47,9 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // `one_image_compact`: a dense 3-D level that fits ONE image travels as compact items too (one bucket whose units flush
 // atomically) instead of the direct pass in front of the scatter pass; decided per CALL from the total batch (below), so
 // that every plan of a call classifies the levels alike
+// `skip_mask`: levels (bit l) another pass accumulates (the brick pass): neither binned nor direct here
 static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
-                      bool one_image_compact);
+                      bool one_image_compact, uint32_t skip_mask = 0u);
 static inline bool half_items(int dtype, const LevelTable &lt);
 static inline int item_format(int dim, int dtype, const LevelTable &lt, int64_t n);
 static inline size_t item_unit_bytes(int fmt, const LevelTable &lt);
@@ -130,16 +132,17 @@ bool bin_supported(int dim, const LevelTable &lt) {
 }
 
 static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
-                               bool one_image_compact);
+                               bool one_image_compact, uint32_t skip_mask);
 
 // A backward call plans several times (workspace query, carving, image-size rule, the run itself), and a plan costs a few
 // microseconds of host time (the magic-division checks of the compact levels walk every line): small batches became
 // HOST-bound (2-D bw-19 table at 2^17 samples: 0.123 ms per call against 0.094 ms of GPU time). Plans are pure functions of
 // their arguments and two options, so each thread keeps its last few.
 static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
-                      bool one_image_compact) {
+                      bool one_image_compact, uint32_t skip_mask) {
     struct Key {
         int dim, dtype, acc_kib, oic, compact, run_pad, item12;
+        uint32_t skip_mask;
         int64_t n_batch;
         LevelTable lt;
     };
@@ -156,6 +159,7 @@ static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch,
     k.dim = dim; k.dtype = dtype; k.acc_kib = acc_kib; k.oic = one_image_compact ? 1 : 0; k.compact = opt().bwd_compact;
     k.run_pad = opt().bwd_run_pad;
     k.item12 = opt().bwd_item12;
+    k.skip_mask = skip_mask;
     k.n_batch = n_batch;
     std::memcpy(&k.lt, &lt, sizeof(LevelTable));
     for (int e = 0; e < kEntries; ++e) {
@@ -164,7 +168,7 @@ static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch,
             return;
         }
     }
-    make_plan_uncached(dim, dtype, lt, n_batch, plan, acc_kib, one_image_compact);
+    make_plan_uncached(dim, dtype, lt, n_batch, plan, acc_kib, one_image_compact, skip_mask);
     Entry &slot = cache[next];
     next = (next + 1) % kEntries;
     slot.key = k;
@@ -173,9 +177,9 @@ static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch,
 }
 
 static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
-                               bool one_image_compact) {
+                               bool one_image_compact, uint32_t skip_mask) {
     if (one_image_compact) {   // tables whose levels are ALL direct stay that way (no transposing pass at all)
-        make_plan_uncached(dim, dtype, lt, n_batch, plan, acc_kib, false);
+        make_plan_uncached(dim, dtype, lt, n_batch, plan, acc_kib, false, skip_mask);
         if (plan.nbl == 0) return;
     }
     const int F = lt.feature_dim;
@@ -194,7 +198,7 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
         bl.drow0 = 0;
         bl.compact = 0;
         bl.slab = 0;
-        if (l < lt.level_begin || l >= lt.level_end) {  // not part of this call
+        if (l < lt.level_begin || l >= lt.level_end || ((skip_mask >> l) & 1u)) {  // not part of this call / the brick pass's
             bl.nb = 0;
             bl.used = 0;
             bl.rows_pb = 0;
@@ -506,6 +510,7 @@ float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *work
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr, staged = nullptr;
+    hipEvent_t bfork = nullptr, bjoin = nullptr;   // brick pass beside the item passes
 };
 static hipError_t side_stream(SideStream **out) {
     static thread_local SideStream per_device[kMaxDevices];
@@ -515,14 +520,18 @@ static hipError_t side_stream(SideStream **out) {
     SideStream &ss = per_device[dev];
     if (!ss.stream) {
         hipStream_t st;
-        hipEvent_t a, b, c;
+        hipEvent_t a, b, c, d, e;
         SHACIRA_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         SHACIRA_CHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
         SHACIRA_CHECK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
         SHACIRA_CHECK(hipEventCreateWithFlags(&c, hipEventDisableTiming));
+        SHACIRA_CHECK(hipEventCreateWithFlags(&d, hipEventDisableTiming));
+        SHACIRA_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ss.fork = a;
         ss.join = b;
         ss.staged = c;
+        ss.bfork = d;
+        ss.bjoin = e;
         ss.stream = st;
     }
     *out = &ss;
@@ -555,17 +564,77 @@ static int front_tile(int L, int F, uint32_t nbl, int64_t n, size_t *shmem) {
 template <int DIM, int F>
 static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                           const void *grad_out, float *acc, const BinWorkspace &w, int64_t n, hipStream_t s,
-                          bool zero_table, __half *half_table, bool *converted) {
+                          bool zero_table, __half *half_table, bool *converted, const SortedBatch *sb) {
     const int L = lt.num_lods;
     const int64_t NP = level_pitch(n);
     BinPlan whole;
     const int acc_kib = choose_acc_kib(DIM, dtype, lt, n);
     const bool oic = one_image_compact_rule(n);
-    make_plan(DIM, dtype, lt, n, whole, acc_kib, oic);
     const int64_t nb = bin_batch_samples(DIM, dtype, lt, n);
     const bool multi = nb < n;
     const bool stage_all = (lt.stage_flags & SHACIRA_BWD_STAGE_ALL_LEVELS) != 0;
     const bool staged = (lt.stage_flags & SHACIRA_BWD_REUSE_STAGED) != 0;
+    // Brick pass (bwd_brick.h): with the batch's plan at hand (the cell-sorted forward's records), coarse 3-D levels are
+    // accumulated block by block in LDS and leave the item stream. Whole calls over one sub-batch that accumulate in
+    // fixed point (>= 2^17 samples: the regime the item stream binds in); never for tables whose levels are all direct.
+    BrickPlan brick;
+    brick.nlev = 0;
+    uint32_t skip_mask = 0;
+    if constexpr (DIM == 3) {
+        // (sorted mode rides on the fused 16-byte front kernel: rows of whole 16-byte vectors, 16-byte aligned input)
+        const int kvec0 = (int)(16 / ((dtype == SHACIRA_F32 ? 4 : 2) * F));
+        if (sb != nullptr && opt().bwd_brick != 0 && !multi && !stage_all && !staged && zero_table &&
+            n >= SHACIRA_FX_MIN && n * L < ((int64_t)1 << 31) && !table_all_direct(DIM, dtype, lt, n) && (L % kvec0) == 0 &&
+            (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0) {
+            if (make_brick_plan(lt, n, *sb, opt().bwd_brick_lo, opt().bwd_brick_hi, opt().bwd_brick_span, (size_t)64 * 1024, brick))
+                for (uint32_t q = 0; q < brick.nlev; ++q) skip_mask |= 1u << brick.lv[q].level;
+        }
+    }
+    make_plan(DIM, dtype, lt, n, whole, acc_kib, oic, skip_mask);
+    {
+        size_t sh0 = 0;
+        // (nothing left for the item passes, or no tile size for the fused front kernel: keep the plain pipeline)
+        if (skip_mask != 0u && (whole.nbl == 0 || front_tile(L, F, whole.nbl, n, &sh0) <= 0)) {
+            skip_mask = 0u;
+            brick.nlev = 0;
+            make_plan(DIM, dtype, lt, n, whole, acc_kib, oic, 0u);
+        }
+    }
+    // SORTED mode: the whole call walks the batch in the plan's block order -- the front kernel gathers the gradient rows in
+    // that order, so gT and every later pass's sample index mean "k-th sorted sample" and coordinates come from the records
+    const bool sorted = brick.nlev > 0;
+    const float *cptr = sorted ? reinterpret_cast<const float *>(sb->sorted4) : coords;
+    const int cstride = sorted ? 4 : DIM;
+    // Where the brick pass runs (it is bound by LDS atomics and touches HBM hardly at all; it needs the zeroed table, the
+    // sorted gT and gmax, i.e. the front pass): option bwd_brick_fork 0 = last on the caller's stream (behind the scatter pass,
+    // which wants the transposed gradients still in the Infinity Cache); 1 / 2 = on the side stream, forked behind the front pass /
+    // behind the scatter pass, joined at the end -- beside the consume pass, whose workgroups (128 KiB image, 1 024 threads) leave
+    // room for brick workgroups on every CU and wait on HBM while the LDS atomic units idle
+    int brick_mode = -1;   // -1: no brick pass
+    SideStream *bss = nullptr;
+    if (brick.nlev > 0) {
+        brick_mode = opt().bwd_brick_fork;
+        if (brick_mode > 0) SHACIRA_CHECK(side_stream(&bss));
+    }
+    auto launch_brick = [&](hipStream_t bs) -> hipError_t {
+        if constexpr (DIM == 3) {
+            const size_t img = (size_t)brick.rows_total * F * sizeof(double);
+            const int hr = fx_headroom((uint64_t)kBrickUnit * 8u);
+            const dim3 grid(brick.groups_x * (uint32_t)(brick.nb[1] * brick.nb[2]), kBrickSplit);
+            hipLaunchKernelGGL((brick_accumulate_kernel<F>), grid, dim3(kBrickThreads), img, bs, lt, brick, first_idx,
+                               sb->sorted4, sb->block_start, w.gT, NP, acc, w.gmax, hr);
+            return hipGetLastError();
+        } else {
+            (void)bs;
+            return hipSuccess;
+        }
+    };
+    auto fork_brick = [&]() -> hipError_t {
+        SHACIRA_CHECK(hipEventRecord(bss->bfork, s));
+        SHACIRA_CHECK(hipStreamWaitEvent(bss->stream, bss->bfork, 0));
+        SHACIRA_CHECK(launch_brick(bss->stream));
+        return hipEventRecord(bss->bjoin, bss->stream);
+    };
     // only binned levels consume the transposed gradients (a later call on this workspace may, too: stage_all) -- a table
     // whose levels are all direct has none in any level range, so its calls never stage (and carve() reserves no gT)
     const bool need_T = whole.nbl > 0 || ((stage_all || staged) && !table_all_direct(DIM, dtype, lt, n));
@@ -590,7 +659,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     const int64_t fork_work = n * lt.num_lods * lt.feature_dim;
     const int64_t fork_min = DIM == 3 ? ((int64_t)7 << 21) : ((int64_t)1 << 23);
     // (an event pair costs ~10-20 us of cross-stream latency here: only worth it with direct levels to hide)
-    const bool fork = whole.nbl > 0 && whole.ngroups > 0 && !multi && opt().bwd_fork != 0 && fork_work >= fork_min;
+    const bool fork = whole.nbl > 0 && whole.ngroups > 0 && !multi && opt().bwd_fork != 0 && fork_work >= fork_min &&
+                      brick_mode <= 0;   // (one side stream: the brick pass has it when it runs there)
     // selective zeroing (see zero_unowned_rows_kernel): a single sub-batch whose plan has hashed binned levels
     bool any_hashed = false;
     for (uint32_t q = 0; q < whole.nbl; ++q) any_hashed = any_hashed || lt.dense[whole.blevel[q]] == 0;
@@ -638,7 +708,14 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             hipLaunchKernelGGL((front16_kernel<DIM, TT, F, GM, CN>), dim3(blocks), dim3(kFrontThreads), front_shmem, s, lt, \
                                whole, static_cast<const TT *>(grad_out), w.gT, coords, w.totals, w.cnt, n, NP, t_lb, t_le, ts_log2, \
                                rounds, GM ? w.gmax : nullptr, (uint32_t)cps16)
-            if (dtype == SHACIRA_F32) {
+#define SHACIRA_FRONT_SORTED(TT)                                                                                          \
+            hipLaunchKernelGGL((front16_kernel<DIM, TT, F, true, true, true>), dim3(blocks), dim3(kFrontThreads), front_shmem, s, lt, \
+                               whole, static_cast<const TT *>(grad_out), w.gT, coords, w.totals, w.cnt, n, NP, t_lb, t_le, ts_log2, \
+                               rounds, w.gmax, (uint32_t)cps16, sb->sorted4)
+            if (sorted) {   // (implies use_fx and front_counts)
+                if (dtype == SHACIRA_F32) SHACIRA_FRONT_SORTED(float);
+                else SHACIRA_FRONT_SORTED(__half);
+            } else if (dtype == SHACIRA_F32) {
                 if (use_fx && front_counts) SHACIRA_FRONT(float, true, true);
                 else if (use_fx) SHACIRA_FRONT(float, true, false);
                 else if (front_counts) SHACIRA_FRONT(float, false, true);
@@ -650,6 +727,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                 else SHACIRA_FRONT(__half, false, false);
             }
 #undef SHACIRA_FRONT
+#undef SHACIRA_FRONT_SORTED
         } else {
             const uint32_t blocks = (uint32_t)((n + 255) / 256);
             const size_t shmem = (size_t)256 * (L + 1) * F * sizeof(float);
@@ -672,6 +750,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         SHACIRA_CHECK(hipEventRecord(ss->staged, s));
         SHACIRA_CHECK(hipStreamWaitEvent(ss->stream, ss->staged, 0));
     }
+    if (brick_mode == 1) SHACIRA_CHECK(fork_brick());
     // When nothing is transposed (every level is direct: the image configs) there is no gmax, and a pass of its own over
     // grad_output costs more than the faster atomics return (tried: a streaming abs-max kernel, 0.103 vs 0.082 ms on config
     // B): the direct kernel's workgroups take a pilot maximum over their own samples instead (direct_accumulate_kernel).
@@ -695,7 +774,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const uint32_t *gm = (need_T && use_fx) ? w.gmax : nullptr;
         if (need_T)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, true, true>), grid, dim3(kConsumeThreads),
-                               acc_bytes, zs, lt, plan, first_idx, coords, w.gT, acc, n, NP, gm, headroom);
+                               acc_bytes, zs, lt, plan, first_idx, cptr, w.gT, acc, n, NP, gm, headroom, cstride);
         else if (dtype == SHACIRA_F32)
             hipLaunchKernelGGL((direct_accumulate_kernel<DIM, F, float, false, true>), grid, dim3(kConsumeThreads),
                                acc_bytes, zs, lt, plan, first_idx, coords, static_cast<const float *>(grad_out), acc, n,
@@ -719,11 +798,16 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const size_t units = split == 1 ? (size_t)pl.stage_cap : (size_t)TileOf<DIM>::value * NPAIR / split;
         return units * (isz + 1);
     };
+#ifdef SCATTER_LEVEL_FAST
+#define SCATTER_GRID(pl) dim3((pl).nbl, (pl).num_tiles)
+#else
+#define SCATTER_GRID(pl) dim3((pl).num_tiles, (pl).nbl)
+#endif
     bool first_batch = true;
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
         BinPlan plan;
-        make_plan(DIM, dtype, lt, hi - s0, plan, acc_kib, oic);
+        make_plan(DIM, dtype, lt, hi - s0, plan, acc_kib, oic, skip_mask);
         if (!first_batch) {
             hipLaunchKernelGGL(zero_words_kernel, dim3(32), dim3(256), 0, s, w.totals, (uint32_t)kTotalShards * kMaxBuckets);
             SHACIRA_CHECK_LAUNCH();
@@ -744,24 +828,25 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const uint32_t cnt_rows = fused_now ? (uint32_t)((n + ts16 - 1) / ts16) : plan.num_tiles;
         if (fmt == 2) {
             if constexpr (DIM == 3 && F == 2)
-                hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, 2>), dim3(plan.num_tiles, plan.nbl), dim3(ScatterThreads<DIM, F, 2>::value),
-                                   stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
-                                   reinterpret_cast<Item12 *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
+                hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, 2>), SCATTER_GRID(plan), dim3(ScatterThreads<DIM, F, 2>::value),
+                                   stage_bytes(plan), s, lt, plan, cptr, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                                   reinterpret_cast<Item12 *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first, cstride);
         } else if (half)
-            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), dim3(plan.num_tiles, plan.nbl), dim3(ScatterThreads<DIM, F, 1>::value),
-                               stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), SCATTER_GRID(plan), dim3(ScatterThreads<DIM, F, 1>::value),
+                               stage_bytes(plan), s, lt, plan, cptr, w.gT, w.cursor, w.cnt, cps, cnt_rows,
                                reinterpret_cast<typename ItemSel<F, true>::type *>(w.items), s0, hi, NP, zacc, first_idx,
-                               w.unit_first);
+                               w.unit_first, cstride);
         else if (use_fx)
-            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), dim3(plan.num_tiles, plan.nbl), dim3(ScatterThreads<DIM, F, 0>::value),
-                               stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
-                               reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false>), SCATTER_GRID(plan), dim3(ScatterThreads<DIM, F, 0>::value),
+                               stage_bytes(plan), s, lt, plan, cptr, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                               reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first, cstride);
         else   // batches below 2^17 samples: plain item stores, the consume pass reads them back from the caches
-            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false, false>), dim3(plan.num_tiles, plan.nbl), dim3(ScatterThreads<DIM, F, 0>::value),
-                               stage_bytes(plan), s, lt, plan, coords, w.gT, w.cursor, w.cnt, cps, cnt_rows,
-                               reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first);
+            hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, false, false>), SCATTER_GRID(plan), dim3(ScatterThreads<DIM, F, 0>::value),
+                               stage_bytes(plan), s, lt, plan, cptr, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                               reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first, cstride);
         SHACIRA_CHECK_LAUNCH();
         if (fork) SHACIRA_CHECK(hipStreamWaitEvent(s, ss->join, 0));   // table zeroed, direct levels in
+        if (brick_mode == 2) SHACIRA_CHECK(fork_brick());
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NPAIR +
                                    (uint64_t)plan.num_tiles * plan.total_buckets * (plan.pad - 1u);
         uint32_t grid_units = (uint32_t)(max_items / plan.chunk_min) + plan.total_buckets + 1;
@@ -796,6 +881,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                                reinterpret_cast<const Item<F> *>(w.items), acc, fa, headroom, wc);
         SHACIRA_CHECK_LAUNCH();
     }
+    if (brick_mode == 0) SHACIRA_CHECK(launch_brick(s));   // LAST on the caller's stream
+    if (brick_mode > 0) SHACIRA_CHECK(hipStreamWaitEvent(s, bss->bjoin, 0));
     if (direct_half) {
         hipLaunchKernelGGL(f32_to_f16_skip_kernel, dim3(128, (uint32_t)L), dim3(256), 0, s, acc, half_table, first_idx, lt,
                            whole, w.unit_first, F);
@@ -816,7 +903,7 @@ template <class ItemT> static constexpr size_t stage_max(size_t tile_units) {
 
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                         const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table,
-                        void *half_table, bool *converted) {
+                        void *half_table, bool *converted, const SortedBatch *sb) {
     if (converted != nullptr) *converted = false;
     __half *ht = (dtype == SHACIRA_F16) ? static_cast<__half *>(half_table) : nullptr;
     const BinWorkspace w = carve(dim, dtype, lt, n, workspace);
@@ -839,7 +926,8 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
         set(reinterpret_cast<const void *>(&front16_kernel<3, TT, FF, true, true>), 156 * 1024);        \
         set(reinterpret_cast<const void *>(&front16_kernel<3, TT, FF, true, false>), 156 * 1024);       \
         set(reinterpret_cast<const void *>(&front16_kernel<3, TT, FF, false, true>), 156 * 1024);       \
-        set(reinterpret_cast<const void *>(&front16_kernel<3, TT, FF, false, false>), 156 * 1024);
+        set(reinterpret_cast<const void *>(&front16_kernel<3, TT, FF, false, false>), 156 * 1024);      \
+        set(reinterpret_cast<const void *>(&front16_kernel<3, TT, FF, true, true, true>), 156 * 1024);
         SHACIRA_T_ATTR(float, 2) SHACIRA_T_ATTR(float, 4) SHACIRA_T_ATTR(__half, 2) SHACIRA_T_ATTR(__half, 4)
 #undef SHACIRA_T_ATTR
 #define SHACIRA_DIRECT_ATTR(D, FF)                                                                              \
@@ -874,11 +962,11 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
     });
     if (attr_err != hipSuccess) return attr_err;
     if (dim == 3) {
-        return lt.feature_dim == 2 ? run_bin<3, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted)
-                                   : run_bin<3, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted);
+        return lt.feature_dim == 2 ? run_bin<3, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted, sb)
+                                   : run_bin<3, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted, sb);
     }
-    return lt.feature_dim == 2 ? run_bin<2, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted)
-                               : run_bin<2, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted);
+    return lt.feature_dim == 2 ? run_bin<2, 2>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted, nullptr)
+                               : run_bin<2, 4>(dtype, lt, first_idx, coords, grad_out, acc, w, n, s, zero_table, ht, converted, nullptr);
 }
 
 }  // namespace shacira

@@ -989,7 +989,7 @@ size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int6
 
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                      const float *coords, const void *table, void *feats, void *ws, int64_t n,
-                                     hipStream_t s) {
+                                     hipStream_t s, void *plan, bool plan_ready) {
     if (lt.table_rows == 0) {
         // an empty table has no corner inside it: every feature is zero (and gather_row, which reads row 0 on behalf of lanes
         // that have no row, must not run; the dense 16-byte form that reads rows 0-1 is only reached by tables >= 8 MB)
@@ -999,7 +999,7 @@ hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, c
     if (dtype == SHACIRA_F64)
         return dim == 3 ? launch_fwd_f64<3>(lt, first_idx, coords, table, feats, n, s)
                         : launch_fwd_f64<2>(lt, first_idx, coords, table, feats, n, s);
-    if (tiled_supported(dim, dtype, lt, n)) return tiled_forward(dim, dtype, lt, first_idx, coords, table, feats, ws, n, s);
+    if (tiled_supported(dim, dtype, lt, n)) return tiled_forward(dim, dtype, lt, first_idx, coords, table, feats, ws, n, s, plan, plan_ready);
     if (dim == 3) {
         return dtype == SHACIRA_F32 ? dispatch_f<3, float>(lt, first_idx, coords, table, feats, ws, n, s)
                                     : dispatch_f<3, __half>(lt, first_idx, coords, table, feats, ws, n, s);

@@ -11,7 +11,8 @@
 // block ("coarse" levels: 0-7 of S1), so walking the samples block by block turns those levels' gathers into L1 hits.
 // Levels finer than that (one sample per cell: no reuse possible in any order) keep the level-per-XCD pair kernel.
 //
-//   sort      counting sort of the samples by block id -> 16-byte records {coordinates (exact copies), sample index}
+//   sort      counting sort of the samples by block id (two partitioning passes, three launches: psort_*) -> 16-byte records
+//             {coordinates (exact copies), sample index} + block offsets = the batch's PLAN, which the backward can reuse
 //   fine      hashgrid_fwd_level_pair_kernel over the sorted coordinates, levels [lc, L) -> staging [L][N][F]
 //   rows      hashgrid_fwd_rows_kernel: coarse levels [0, lc) over the sorted coordinates (lane pairs, L1-resident
 //             lines), then whole feature rows (coarse from the wave's LDS + fine from the staging) are scattered back
@@ -32,25 +33,36 @@
 namespace shacira {
 
 constexpr int kTargetPerBlock = 352;  // mean samples per block
-constexpr int kSortTileS = 4096;      // samples per workgroup in the sort passes
+#ifndef SHACIRA_SORT_TILE
+#define SHACIRA_SORT_TILE 4096
+#endif
+constexpr int kSortTileS = SHACIRA_SORT_TILE;      // samples per workgroup in the sort passes
 constexpr int kSortThreadsS = 1024;
 constexpr int kMaxBlocksS = 4096;     // blocks (LDS histogram of the sort passes: 16 KiB)
 constexpr int kMaxAxisBlocks = 64;    // blocks per axis
 constexpr uint32_t kCtxMagic = 0x53484354u;   // "SHCT"
 
+constexpr int kMaxCoarse = 256;       // coarse bins of the partition sort (first pass)
+constexpr int kMaxSortTiles = 512;    // workgroups of its first two passes
+
 struct TilePlan {
     int32_t nb[3];          // blocks per axis (x, y, z); block id = qx + nb[0] * (qy + nb[1] * qz)
     uint32_t num_blocks;
-    uint32_t num_tiles;     // workgroups of the sort passes
     int32_t lc;             // coarse levels: [0, lc)
+    // partition sort: coarse bin = block id >> coarse_shift (a contiguous range of <= 16 blocks); tiles of whole chunks
+    uint32_t coarse_shift, num_coarse;
+    uint32_t ptiles, chunks_per_tile;
+    uint32_t slices;        // workgroups per coarse bin in the last pass
 };
 
-struct TileCtx {            // device pointers into the sort's scratch / outputs
+struct TileCtx {            // device pointers into the sort's outputs (the plan) and its scratch
     uint32_t *header;       // [0] magic, [1] num_blocks, [2] n
     float4 *sorted4;        // [n] sample records in sorted order: {x, y, z (0 in 2-D) -- exact copies --, bits of the sample index}
     uint32_t *block_start;  // [num_blocks + 1]
-    uint32_t *cnt;          // [num_blocks][num_tiles] sort scratch
-    uint32_t *totals;       // [num_blocks]
+    uint32_t *cnt;          // scratch: [ptiles][kMaxCoarse] samples per (tile, coarse bin)
+    float4 *inter4;         // scratch: [n] records grouped by coarse bin
+    uint32_t *gcursor;      // scratch: [kMaxBlocksS] per-block cursors of over-full bins
+    uint32_t *cbase;        // scratch: [kMaxCoarse + 1] first record of every coarse bin
 };
 
 static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
@@ -71,7 +83,8 @@ template <int DIM> __device__ __forceinline__ uint32_t block_key(const float (&c
     return k;
 }
 
-static void make_tile_plan(int dim, const LevelTable &lt, int64_t n, TilePlan &tp) {
+// block grid + sort geometry: a function of (dim, n) alone, so that a plan built by one call can be read by another
+static void make_sort_plan(int dim, int64_t n, TilePlan &tp) {
     // blocks: ~n / kTargetPerBlock boxes; twice as many along the slowest axis as along x and y (3-D) resp. along y as
     // along x (2-D), so that x -- the direction table lines run in -- stays long
     const double want = (double)n / kTargetPerBlock;
@@ -92,7 +105,19 @@ static void make_tile_plan(int dim, const LevelTable &lt, int64_t n, TilePlan &t
         tp.nb[1] = y;
     }
     tp.num_blocks = (uint32_t)(tp.nb[0] * tp.nb[1] * tp.nb[2]);
-    tp.num_tiles = (uint32_t)((n + kSortTileS - 1) / kSortTileS);
+    tp.lc = 0;
+    tp.coarse_shift = 0;
+    while (((tp.num_blocks + (1u << tp.coarse_shift) - 1) >> tp.coarse_shift) > (uint32_t)kMaxCoarse) ++tp.coarse_shift;
+    tp.num_coarse = (tp.num_blocks + (1u << tp.coarse_shift) - 1) >> tp.coarse_shift;
+    const int64_t chunks = (n + kSortTileS - 1) / kSortTileS;
+    tp.chunks_per_tile = (uint32_t)((chunks + kMaxSortTiles - 1) / kMaxSortTiles);
+    if (tp.chunks_per_tile < 1) tp.chunks_per_tile = 1;
+    tp.ptiles = (uint32_t)((chunks + tp.chunks_per_tile - 1) / tp.chunks_per_tile);
+    tp.slices = 4;   // last pass, grid.y: workgroups that share an OVER-FULL bin (all but the first leave at once otherwise)
+}
+
+static void make_tile_plan(int dim, const LevelTable &lt, int64_t n, TilePlan &tp) {
+    make_sort_plan(dim, n, tp);
     // coarse levels (rows kernel) vs fine levels (level-per-XCD kernel), measured (tools/tiled_sweep.py): 3-D -- the levels
     // whose cell count does not exceed ~4x the batch keep enough reuse inside a block (S1: 8 or 9 of 16 are equally good,
     // 12 costs +30 %); 2-D -- every level (lines are shared along x at any resolution: 0.140 ms against 0.157 ms with one
@@ -109,205 +134,322 @@ static void make_tile_plan(int dim, const LevelTable &lt, int64_t n, TilePlan &t
     tp.lc = lc;
 }
 
-static TileCtx carve_ctx(int dim, int64_t n, void *buf, size_t *bytes) {
-    TilePlan tp;
-    LevelTable none{};
-    none.num_lods = 0;
-    none.feature_dim = 2;
-    make_tile_plan(dim, none, n, tp);
+// The PLAN of a coordinate batch (what a later call may reuse: the sorted records and the block offsets) and the sort's
+// SCRATCH are carved separately: a caller-owned plan buffer outlives the forward call, the scratch does not.
+static size_t carve_plan(int64_t n, void *buf, TileCtx &c) {
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off = up256(off + b); return o; };
     const size_t o_hdr = take(256);
     const size_t o_sorted = take((size_t)n * sizeof(float4));
     const size_t o_bs = take((size_t)(kMaxBlocksS + 1) * 4);
-    const size_t o_cnt = take((size_t)tp.num_blocks * tp.num_tiles * 4);
-    const size_t o_tot = take((size_t)kMaxBlocksS * 4);
-    TileCtx c{};
     unsigned char *p = static_cast<unsigned char *>(buf);
     if (p) {
         c.header = reinterpret_cast<uint32_t *>(p + o_hdr);
         c.sorted4 = reinterpret_cast<float4 *>(p + o_sorted);
         c.block_start = reinterpret_cast<uint32_t *>(p + o_bs);
-        c.cnt = reinterpret_cast<uint32_t *>(p + o_cnt);
-        c.totals = reinterpret_cast<uint32_t *>(p + o_tot);
     }
-    if (bytes) *bytes = off;
-    return c;
+    return off;
+}
+static size_t carve_scratch(int dim, int64_t n, void *buf, TileCtx &c) {
+    (void)dim;
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off = up256(off + b); return o; };
+    const size_t o_cnt = take((size_t)kMaxSortTiles * kMaxCoarse * 4);
+    const size_t o_inter = take((size_t)n * sizeof(float4));
+    const size_t o_cb = take((size_t)(kMaxCoarse + 1) * 4);
+    const size_t o_gc = take((size_t)kMaxBlocksS * 4);
+    unsigned char *p = static_cast<unsigned char *>(buf);
+    if (p) {
+        c.cnt = reinterpret_cast<uint32_t *>(p + o_cnt);
+        c.inter4 = reinterpret_cast<float4 *>(p + o_inter);
+        c.cbase = reinterpret_cast<uint32_t *>(p + o_cb);
+        c.gcursor = reinterpret_cast<uint32_t *>(p + o_gc);
+    }
+    return off;
+}
+static size_t plan_bytes_of(int64_t n) {
+    TileCtx c{};
+    return carve_plan(n, nullptr, c);
+}
+static size_t scratch_bytes_of(int dim, int64_t n) {
+    TileCtx c{};
+    return carve_scratch(dim, n, nullptr, c);
 }
 
-static size_t sort_bytes(int dim, int64_t n) {
-    size_t b = 0;
-    carve_ctx(dim, n, nullptr, &b);
-    return b;
-}
-
-// ----------------------------------------------------------------------------------------------- sort
+// ----------------------------------------------------------------------------------------------- partition sort (round 6)
+// Counting sort by block id in two partitioning passes, every write stream private to one workgroup:
+//   count       per tile of whole 4 096-sample chunks: samples per COARSE bin (<= 256 contiguous ranges of <= 16 block ids)
+//   partition   the same tiles: bin bases + this tile's offsets from the count matrix (column sums, no atomics, no scan
+//               launch), then each record goes to its bin's next slot (LDS returning atomic = final position)
+//   local       one workgroup per coarse bin keeps the bin's records in registers (<= 8 192; ~5 500 on a uniform batch): the
+//               returning LDS atomic that counts a record per block is its rank; block offsets = scan of <= 16 counts; the
+//               records go out block by block (runs of a few KB written by one workgroup) and the bin's block offsets with
+//               them. Over-full bins (a batch concentrated in few blocks) are counted by `slices` workgroups and placed in
+//               rounds with ranks from global per-block cursors; waves whose lanes all name one block add once per wave
+// The four-launch sort it replaces wrote every record straight to its block's slot: 2^20 scattered 16-byte stores into lines
+// shared by 256 workgroups (25 us of its 47). Order inside a block is arbitrary in both (ranks come from atomics).
 template <int DIM>
-__global__ __launch_bounds__(kSortThreadsS) void ctx_count_kernel(TilePlan tp, const float *__restrict__ coords,
-                                                                  int64_t N, uint32_t *__restrict__ cnt) {
-    __shared__ uint32_t s_hist[kMaxBlocksS];
-    for (uint32_t k = threadIdx.x; k < tp.num_blocks; k += kSortThreadsS) s_hist[k] = 0;
-    __syncthreads();
-    const int64_t s0 = (int64_t)blockIdx.x * kSortTileS;
+__device__ __forceinline__ void load_chunk_coords(const float *__restrict__ coords, int64_t s0, int64_t N,
+                                                  float (&c)[kSortTileS / kSortThreadsS][DIM]) {
     constexpr int U = kSortTileS / kSortThreadsS;
-    // every coordinate load of the thread first, unconditional from a clamped index (round 4: under `if (i < N)` each
-    // iteration's loads were closed by their own s_waitcnt -- U serialised round trips per thread)
-    float c[U][DIM];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
-        const int64_t ic = i < N ? i : N - 1;
+        const int64_t ic = i < N ? i : N - 1;   // unconditional loads from a clamped index (see ctx_count_kernel)
 #pragma unroll
         for (int a = 0; a < DIM; ++a) c[u][a] = coords[ic * DIM + a];
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
-        if (i < N) atomicAdd(&s_hist[block_key<DIM>(c[u], tp)], 1u);
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < tp.num_blocks; k += kSortThreadsS)
-        cnt[(size_t)k * tp.num_tiles + blockIdx.x] = s_hist[k];
 }
 
-// one wave per block id: exclusive scan of cnt[key][0..num_tiles) in place, total -> totals[key]
-__global__ __launch_bounds__(256) void ctx_scan_tiles_kernel(uint32_t *__restrict__ cnt, uint32_t *__restrict__ totals,
-                                                             uint32_t num_tiles, uint32_t num_keys) {
-    const uint32_t key = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (key >= num_keys) return;
-    uint32_t *row = cnt + (size_t)key * num_tiles;
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < num_tiles; base += 256) {
-        const uint32_t idx = base + lane * 4;
-        uint32_t v[4];
+template <int DIM>
+__global__ __launch_bounds__(kSortThreadsS) void psort_count_kernel(TilePlan tp, const float *__restrict__ coords,
+                                                                    int64_t N, uint32_t *__restrict__ cnt) {
+    __shared__ uint32_t s_hist[kMaxCoarse];
+    if (threadIdx.x < kMaxCoarse) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    constexpr int U = kSortTileS / kSortThreadsS;
+    for (uint32_t ch = 0; ch < tp.chunks_per_tile; ++ch) {
+        const int64_t s0 = ((int64_t)blockIdx.x * tp.chunks_per_tile + ch) * kSortTileS;
+        if (s0 >= N) break;
+        float c[U][DIM];
+        load_chunk_coords<DIM>(coords, s0, N, c);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (idx + k < num_tiles) ? row[idx + k] : 0u;
-        const uint32_t sum = (v[0] + v[1]) + (v[2] + v[3]);
-        uint32_t incl = sum;
+        for (int u = 0; u < U; ++u)
+            if (s0 + u * kSortThreadsS + threadIdx.x < N) atomicAdd(&s_hist[block_key<DIM>(c[u], tp) >> tp.coarse_shift], 1u);
+    }
+    __syncthreads();
+    // bin-major: a bin's counts over the tiles are one contiguous row (the partition pass sums it with one load per lane)
+    if (threadIdx.x < kMaxCoarse) cnt[(size_t)threadIdx.x * kMaxSortTiles + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+template <int DIM>
+__global__ __launch_bounds__(kSortThreadsS) void psort_partition_kernel(TilePlan tp, const float *__restrict__ coords,
+                                                                        int64_t N, const uint32_t *__restrict__ cnt,
+                                                                        uint32_t *__restrict__ cbase,
+                                                                        uint32_t *__restrict__ gcursor,
+                                                                        float4 *__restrict__ inter4) {
+    __shared__ uint32_t s_cursor[kMaxCoarse], s_tot[kMaxCoarse], s_before[kMaxCoarse];
+    __shared__ uint32_t s_wave[kMaxCoarse / 64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int U = kSortTileS / kSortThreadsS;
+    // this tile's first chunk: in flight while the offsets below are computed
+    float c0[U][DIM];
+    const int64_t first_s0 = (int64_t)blockIdx.x * tp.chunks_per_tile * kSortTileS;
+    load_chunk_coords<DIM>(coords, first_s0 < N ? first_s0 : 0, N, c0);
+    // bin totals and this tile's offset inside every bin: a wave sums one bin's row of the count matrix (16-byte loads, four
+    // tiles per lane), 16 bins per wave, eight rows in flight
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int kWaves = kSortThreadsS / 64, kBinsPerWave = kMaxCoarse / kWaves;
+    const bool wide = tp.ptiles > 256u;   // a second 256-tile half
+#ifndef SHACIRA_SORT_RB
+#define SHACIRA_SORT_RB 8
+#endif
+    constexpr int RB = SHACIRA_SORT_RB;
+#pragma unroll 1
+    for (int g = 0; g < kBinsPerWave; g += RB) {
+        u32x4 v[RB], w[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const u32x4 *row = reinterpret_cast<const u32x4 *>(cnt + (size_t)(wave * kBinsPerWave + g + k) * kMaxSortTiles);
+            v[k] = row[lane];
+            w[k] = wide ? row[64 + lane] : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            uint32_t tot = 0, before = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t t0 = lane * 4u + (uint32_t)e, t1 = 256u + t0;
+                const uint32_t a = t0 < tp.ptiles ? v[k][e] : 0u, b2 = t1 < tp.ptiles ? w[k][e] : 0u;
+                tot += a + b2;
+                before += (t0 < blockIdx.x ? a : 0u) + (t1 < blockIdx.x ? b2 : 0u);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                tot += __shfl_xor(tot, off, 64);
+                before += __shfl_xor(before, off, 64);
+            }
+            if (lane == 0) {
+                s_tot[wave * kBinsPerWave + g + k] = tot;
+                s_before[wave * kBinsPerWave + g + k] = before;
+            }
+        }
+    }
+    __syncthreads();
+    const bool owner = threadIdx.x < kMaxCoarse;   // (whole waves)
+    uint32_t tot = 0;
+    if (owner) {
+        tot = s_tot[threadIdx.x];
+        uint32_t incl = tot;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t nbr = __shfl_up(incl, off, 64);
             if (lane >= (uint32_t)off) incl += nbr;
         }
-        uint32_t run = carry + incl - sum;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (idx + k < num_tiles) row[idx + k] = run;
-            run += v[k];
-        }
-        carry += __shfl(incl, 63, 64);
+        if (lane == 63) s_wave[wave] = incl;
+        s_cursor[threadIdx.x] = incl - tot;   // exclusive inside the wave; the wave bases are added behind the barrier
     }
-    if (lane == 0) totals[key] = carry;
+    __syncthreads();
+    uint32_t base = 0;
+    if (owner) {
+        for (uint32_t wv = 0; wv < wave; ++wv) base += s_wave[wv];
+        base += s_cursor[threadIdx.x];
+        if (blockIdx.x == 0) {
+            cbase[threadIdx.x] = base;
+            if (threadIdx.x == kMaxCoarse - 1) cbase[kMaxCoarse] = base + tot;
+        }
+    }
+    // (the last pass's per-block cursors, used for over-full bins only, start at zero: cleared here, one launch ahead)
+    if (blockIdx.x == 0)
+        for (uint32_t k = threadIdx.x; k < tp.num_blocks; k += kSortThreadsS) gcursor[k] = 0u;
+    __syncthreads();
+    if (owner) s_cursor[threadIdx.x] = base + s_before[threadIdx.x];
+    __syncthreads();
+    for (uint32_t ch = 0; ch < tp.chunks_per_tile; ++ch) {
+        const int64_t s0 = first_s0 + (int64_t)ch * kSortTileS;
+        if (s0 >= N) break;
+        float c[U][DIM];
+        if (ch == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) c[u][a] = c0[u][a];
+        } else {
+            load_chunk_coords<DIM>(coords, s0, N, c);
+        }
+        uint32_t pos[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
+            pos[u] = (i < N) ? atomicAdd(&s_cursor[block_key<DIM>(c[u], tp) >> tp.coarse_shift], 1u) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
+            if (pos[u] != 0xFFFFFFFFu) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 rec = {c[u][0], c[u][1], DIM == 3 ? c[u][DIM - 1] : 0.0f, __uint_as_float((uint32_t)i)};
+#ifdef SHACIRA_SORT_NT
+                __builtin_nontemporal_store(rec, reinterpret_cast<f32x4 *>(inter4 + pos[u]));
+#else
+                *reinterpret_cast<f32x4 *>(inter4 + pos[u]) = rec;
+#endif
+            }
+        }
+    }
 }
 
-// one workgroup: block offsets (exclusive scan of the totals)
-__global__ __launch_bounds__(1024) void ctx_scan_blocks_kernel(const uint32_t *__restrict__ totals,
-                                                               uint32_t *__restrict__ block_start,
-                                                               uint32_t *__restrict__ header, uint32_t num_blocks,
-                                                               uint32_t n) {
-    constexpr int PER = kMaxBlocksS / 1024;
-    __shared__ uint32_t s_wc[16];
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    uint32_t c[PER], cs = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const uint32_t b = t * PER + k;
-        c[k] = (b < num_blocks) ? totals[b] : 0u;
-        cs += c[k];
+// A wave adds `one` per lane to counters[j] and learns its lanes' ranks; when every lane names the same counter (a batch
+// concentrated in one block) lane 0 adds for all of them instead of 64 serialised same-address atomics.
+__device__ __forceinline__ uint32_t wave_rank_add(uint32_t *counters, uint32_t j, bool live, uint32_t lane) {
+    const uint64_t lm = __ballot(live);
+    if (lm == 0ull) return 0u;
+    const uint32_t leader = (uint32_t)__builtin_ctzll(lm);
+    const uint32_t j0 = (uint32_t)__shfl((int)j, (int)leader, 64);
+    const uint64_t same = __ballot(live && j == j0);
+    if (same == lm) {
+        uint32_t b = 0;
+        if (lane == leader) b = atomicAdd(&counters[j0], (uint32_t)__popcll(lm));
+        b = (uint32_t)__shfl((int)b, (int)leader, 64);
+        return b + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull));
     }
-    uint32_t ci = cs;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t nc = __shfl_up(ci, off, 64);
-        if (lane >= (uint32_t)off) ci += nc;
-    }
-    if (lane == 63) s_wc[wave] = ci;
-    __syncthreads();
-    uint32_t pc = ci - cs;
-    for (uint32_t w = 0; w < wave; ++w) pc += s_wc[w];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const uint32_t b = t * PER + k;
-        if (b < num_blocks) block_start[b] = pc;
-        pc += c[k];
-    }
-    if (t == 1023) {
-        block_start[num_blocks] = pc;
-        header[0] = kCtxMagic;
-        header[1] = num_blocks;
-        header[2] = n;
-    }
+    return live ? atomicAdd(&counters[j], 1u) : 0u;
 }
 
 template <int DIM>
-__global__ __launch_bounds__(kSortThreadsS) void ctx_scatter_kernel(TilePlan tp, const float *__restrict__ coords,
-                                                                    int64_t N, const uint32_t *__restrict__ tile_off,
-                                                                    const uint32_t *__restrict__ block_start,
-                                                                    float4 *__restrict__ sorted4) {
-    __shared__ uint32_t s_hist[kMaxBlocksS];
-    for (uint32_t k = threadIdx.x; k < tp.num_blocks; k += kSortThreadsS) s_hist[k] = 0;
+__global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp, const float4 *__restrict__ inter4,
+                                                                    const uint32_t *__restrict__ cbase,
+                                                                    uint32_t *__restrict__ gcursor,
+                                                                    float4 *__restrict__ sorted4,
+                                                                    uint32_t *__restrict__ block_start,
+                                                                    uint32_t *__restrict__ header, uint32_t n) {
+    constexpr int kBpc = kMaxBlocksS / kMaxCoarse;   // blocks per coarse bin (<= 16)
+    constexpr int R = 8;                             // records a thread keeps: a bin of <= R * 1024 records is read once
+    constexpr uint32_t kCap = R * kSortThreadsS;
+    __shared__ uint32_t s_tot[kBpc], s_next[kBpc], s_off[kBpc + 1];
+    const uint32_t bin = blockIdx.x, sl = blockIdx.y;
+    const uint32_t lo = cbase[bin], hi = cbase[bin + 1];
+    const uint32_t len = hi - lo;
+    const uint32_t rounds = (len + kCap - 1u) / kCap;
+    if (sl > 0 && rounds <= 1u) return;              // the bin fits one workgroup's registers: slice 0 does it all
+    if (threadIdx.x < kBpc) {
+        s_tot[threadIdx.x] = 0;
+        s_next[threadIdx.x] = 0;
+    }
     __syncthreads();
-    const int64_t s0 = (int64_t)blockIdx.x * kSortTileS;
-    constexpr int U = kSortTileS / kSortThreadsS;
-    // three batches of memory operations instead of U dependent chains (see ctx_count_kernel): coordinates, then the two
-    // offsets of every sample, then the records
-    float c[U][DIM];
+    const uint32_t key0 = bin << tp.coarse_shift;
+    const uint32_t bpc = 1u << tp.coarse_shift;
+    const uint32_t lane = threadIdx.x & 63;
+    auto key_of = [&](const float4 &r) {
+        float c[DIM];
+        c[0] = r.x;
+        c[1] = r.y;
+        if constexpr (DIM == 3) c[2] = r.z;
+        return block_key<DIM>(c, tp) - key0;
+    };
+    auto finish_offsets = [&]() {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (uint32_t b = 0; b < bpc; ++b) {
+                s_off[b] = run;
+                run += s_tot[b];
+            }
+            s_off[bpc] = run;
+        }
+        __syncthreads();
+        if (sl == 0) {
+            if (threadIdx.x < bpc && key0 + threadIdx.x < tp.num_blocks) block_start[key0 + threadIdx.x] = lo + s_off[threadIdx.x];
+            if (bin + 1u == tp.num_coarse && threadIdx.x == 0) block_start[tp.num_blocks] = hi;
+            if (bin == 0 && threadIdx.x == 0) {
+                header[0] = kCtxMagic;
+                header[1] = tp.num_blocks;
+                header[2] = n;
+            }
+        }
+    };
+    if (rounds <= 1u) {
+        // the usual case: every record of the bin in registers -- counted, ranked (the returning LDS atomic of the count IS the
+        // rank) and written to its block's run
+        float4 r[R];
+        uint32_t j[R], rk[R];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
-        const int64_t ic = i < N ? i : N - 1;
+        for (int u = 0; u < R; ++u) {
+            const uint32_t p = lo + (uint32_t)u * kSortThreadsS + threadIdx.x;
+            r[u] = inter4[p < hi ? p : (hi > 0u ? hi - 1u : 0u)];
+        }
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) c[u][a] = coords[ic * DIM + a];
+        for (int u = 0; u < R; ++u) {
+            const bool live = lo + (uint32_t)u * kSortThreadsS + threadIdx.x < hi;
+            j[u] = live ? key_of(r[u]) : 0u;
+            rk[u] = wave_rank_add(s_tot, j[u], live, lane);
+        }
+        finish_offsets();
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+            if (lo + (uint32_t)u * kSortThreadsS + threadIdx.x < hi) sorted4[lo + s_off[j[u]] + rk[u]] = r[u];
+        return;
     }
-    uint32_t key[U], rank[U], b0[U], t0[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
-        key[u] = block_key<DIM>(c[u], tp);
-        rank[u] = (i < N) ? atomicAdd(&s_hist[key[u]], 1u) : 0u;
+    // an over-full bin (a batch concentrated in a few blocks): every workgroup of the bin counts all of it, then places
+    // rounds sl, sl + gridDim.y, ... of its records with ranks drawn from the blocks' GLOBAL cursors (zeroed by the partition pass)
+    for (uint32_t p0 = lo; p0 < hi; p0 += kSortThreadsS) {
+        const uint32_t p = p0 + threadIdx.x;
+        const bool live = p < hi;
+        const float4 rr = inter4[live ? p : hi - 1u];
+        wave_rank_add(s_tot, live ? key_of(rr) : 0u, live, lane);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        b0[u] = block_start[key[u]];
-        t0[u] = tile_off[(size_t)key[u] * tp.num_tiles + blockIdx.x];
+    finish_offsets();
+    for (uint32_t rd = sl; rd < rounds; rd += gridDim.y) {
+        const uint32_t r_lo = lo + rd * kCap, r_hi = (r_lo + kCap < hi) ? r_lo + kCap : hi;
+        for (uint32_t p0 = r_lo; p0 < r_hi; p0 += kSortThreadsS) {
+            const uint32_t p = p0 + threadIdx.x;
+            const bool live = p < r_hi;
+            const float4 rr = inter4[live ? p : r_hi - 1u];
+            const uint32_t jj = live ? key_of(rr) : 0u;
+            const uint32_t rank = wave_rank_add(gcursor + key0, jj, live, lane);
+            if (live) sorted4[lo + s_off[jj] + rank] = rr;
+        }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
-        if (i < N)
-            sorted4[b0[u] + t0[u] + rank[u]] =
-                make_float4(c[u][0], c[u][1], DIM == 3 ? c[u][DIM - 1] : 0.0f, __uint_as_float((uint32_t)i));
-    }
-}
-
-#define SHACIRA_CHECK_LAUNCH()                 \
-    do {                                       \
-        hipError_t e_ = hipGetLastError();     \
-        if (e_ != hipSuccess) return e_;       \
-    } while (0)
-
-static hipError_t sort_samples(int dim, const TilePlan &tp, const float *coords, int64_t n, const TileCtx &c,
-                               hipStream_t s) {
-    if (dim == 3)
-        hipLaunchKernelGGL(ctx_count_kernel<3>, dim3(tp.num_tiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt);
-    else
-        hipLaunchKernelGGL(ctx_count_kernel<2>, dim3(tp.num_tiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt);
-    SHACIRA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ctx_scan_tiles_kernel, dim3((tp.num_blocks + 3) / 4), dim3(256), 0, s, c.cnt, c.totals,
-                       tp.num_tiles, tp.num_blocks);
-    SHACIRA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ctx_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, c.totals, c.block_start, c.header,
-                       tp.num_blocks, (uint32_t)n);
-    SHACIRA_CHECK_LAUNCH();
-    if (dim == 3)
-        hipLaunchKernelGGL(ctx_scatter_kernel<3>, dim3(tp.num_tiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt,
-                           c.block_start, c.sorted4);
-    else
-        hipLaunchKernelGGL(ctx_scatter_kernel<2>, dim3(tp.num_tiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt,
-                           c.block_start, c.sorted4);
-    SHACIRA_CHECK_LAUNCH();
-    return hipSuccess;
 }
 
 // ----------------------------------------------------------------------------------------------- host side
@@ -334,26 +476,86 @@ static size_t staged_bytes(int dtype, const LevelTable &lt, int64_t n) {
     return up256((size_t)n * lt.num_lods * lt.feature_dim * (dtype == SHACIRA_F32 ? 4 : 2));
 }
 
+#define SHACIRA_CHECK_LAUNCH()                 \
+    do {                                       \
+        hipError_t e_ = hipGetLastError();     \
+        if (e_ != hipSuccess) return e_;       \
+    } while (0)
+
+size_t sample_plan_bytes(int dim, int64_t n) {
+    (void)dim;
+    return n > 0 ? plan_bytes_of(n) : 0;
+}
+size_t sample_plan_scratch_bytes(int dim, int64_t n) { return n > 0 ? scratch_bytes_of(dim, n) : 0; }
+
+// the sort: coordinates -> plan (sorted records + block offsets); three launches on `s`
+hipError_t sample_plan_build(int dim, const float *coords, int64_t n, void *plan, void *scratch, hipStream_t s) {
+    TilePlan tp;
+    make_sort_plan(dim, n, tp);
+    TileCtx c{};
+    carve_plan(n, plan, c);
+    carve_scratch(dim, n, scratch, c);
+    if (dim == 3) {
+        hipLaunchKernelGGL(psort_count_kernel<3>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt);
+        SHACIRA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(psort_partition_kernel<3>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt,
+                           c.cbase, c.gcursor, c.inter4);
+        SHACIRA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(psort_local_kernel<3>, dim3(tp.num_coarse, tp.slices), dim3(kSortThreadsS), 0, s, tp, c.inter4,
+                           c.cbase, c.gcursor, c.sorted4, c.block_start, c.header, (uint32_t)n);
+    } else {
+        hipLaunchKernelGGL(psort_count_kernel<2>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt);
+        SHACIRA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(psort_partition_kernel<2>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt,
+                           c.cbase, c.gcursor, c.inter4);
+        SHACIRA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(psort_local_kernel<2>, dim3(tp.num_coarse, tp.slices), dim3(kSortThreadsS), 0, s, tp, c.inter4,
+                           c.cbase, c.gcursor, c.sorted4, c.block_start, c.header, (uint32_t)n);
+    }
+    SHACIRA_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+// host-side view of a plan buffer built for (dim, n): pointers + block grid (no device read)
+void sample_plan_view(int dim, int64_t n, const void *plan, SortedBatch &out) {
+    TilePlan tp;
+    make_sort_plan(dim, n, tp);
+    TileCtx c{};
+    carve_plan(n, const_cast<void *>(plan), c);
+    out.sorted4 = c.sorted4;
+    out.block_start = c.block_start;
+    out.num_blocks = tp.num_blocks;
+    for (int a = 0; a < 3; ++a) out.nb[a] = tp.nb[a];
+}
+
+// workspace of the cell-sorted forward: the fine levels' staging, the sort's scratch, and -- when the caller keeps no plan
+// buffer of its own -- the plan
 size_t tiled_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n) {
-    return staged_bytes(dtype, lt, n) + sort_bytes(dim, n);
+    return staged_bytes(dtype, lt, n) + scratch_bytes_of(dim, n) + plan_bytes_of(n);
 }
 
 hipError_t tiled_forward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                         const void *table, void *feats, void *workspace, int64_t n, hipStream_t s) {
+                         const void *table, void *feats, void *workspace, int64_t n, hipStream_t s, void *plan,
+                         bool plan_ready) {
     TilePlan tp;
     make_tile_plan(dim, lt, n, tp);
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     void *staged = ws;
-    const TileCtx ctx = carve_ctx(dim, n, ws + staged_bytes(dtype, lt, n), nullptr);
-    hipError_t e = sort_samples(dim, tp, coords, n, ctx, s);
-    if (e != hipSuccess) return e;
+    unsigned char *scratch = ws + staged_bytes(dtype, lt, n);
+    if (plan == nullptr) plan = scratch + scratch_bytes_of(dim, n);
+    if (!plan_ready) {
+        hipError_t e = sample_plan_build(dim, coords, n, plan, scratch, s);
+        if (e != hipSuccess) return e;
+    }
+    TileCtx ctx{};
+    carve_plan(n, plan, ctx);
     const int L = lt.num_lods;
     if (tp.lc < L) {   // fine levels: level-per-XCD pair kernel over the sorted coordinates -> staging [L][N][F]
         LevelTable fine = lt;
         fine.level_begin = tp.lc;
         fine.level_end = L;
-        e = hashgrid_forward_levels_staged(dim, dtype, fine, first_idx, reinterpret_cast<const float *>(ctx.sorted4), table,
-                                           staged, n, s);
+        hipError_t e = hashgrid_forward_levels_staged(dim, dtype, fine, first_idx, reinterpret_cast<const float *>(ctx.sorted4),
+                                                      table, staged, n, s);
         if (e != hipSuccess) return e;
     }
     return hashgrid_forward_rows(dim, dtype, lt, first_idx, reinterpret_cast<const float *>(ctx.sorted4), table, staged,

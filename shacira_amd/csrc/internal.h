@@ -29,7 +29,7 @@ struct PerDeviceOnce {
 size_t hashgrid_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
 hipError_t hashgrid_forward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                      const float *coords, const void *table, void *feats, void *workspace, int64_t n,
-                                     hipStream_t s);
+                                     hipStream_t s, void *plan = nullptr, bool plan_ready = false);
 // levels [lt.level_begin, lt.level_end) of the level-per-XCD pair kernel into a level-major staging buffer [L][N][F]
 hipError_t hashgrid_forward_levels_staged(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                           const float *coords, const void *table, void *staged, int64_t n,
@@ -40,8 +40,24 @@ hipError_t hashgrid_forward_rows(int dim, int dtype, const LevelTable &lt, const
 // hashgrid_tiled.hip: cell-sorted ("tiled") forward for large batches
 bool tiled_supported(int dim, int dtype, const LevelTable &lt, int64_t n);
 size_t tiled_forward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
+// `plan`: caller-owned plan buffer (sample_plan_bytes) the sort writes into, NULL = inside the workspace; `plan_ready`: it
+// already holds this batch's plan (the sort is skipped)
 hipError_t tiled_forward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
-                         const void *table, void *feats, void *workspace, int64_t n, hipStream_t s);
+                         const void *table, void *feats, void *workspace, int64_t n, hipStream_t s, void *plan = nullptr,
+                         bool plan_ready = false);
+// The PLAN of a coordinate batch: its samples counting-sorted by spatial block (16-byte records {x, y, z, sample index}) and
+// the blocks' offsets -- what the cell-sorted forward computes first and the backward's brick pass walks again. A function
+// of (dim, n, coords) only; (dim, n) fix its layout and block grid.
+struct SortedBatch {
+    const float4 *sorted4;        // [n]
+    const uint32_t *block_start;  // [num_blocks + 1]
+    uint32_t num_blocks;
+    int32_t nb[3];                // blocks per axis; block id = qx + nb[0] * (qy + nb[1] * qz)
+};
+size_t sample_plan_bytes(int dim, int64_t n);
+size_t sample_plan_scratch_bytes(int dim, int64_t n);
+hipError_t sample_plan_build(int dim, const float *coords, int64_t n, void *plan, void *scratch, hipStream_t s);
+void sample_plan_view(int dim, int64_t n, const void *plan, SortedBatch &out);
 hipError_t hashgrid_debug_corners(int dim, const LevelTable &lt, const float *coords, int64_t n, int32_t *idx, float *w,
                                   hipStream_t s);
 // hashgrid_bwd.hip
@@ -49,7 +65,7 @@ hipError_t zero_fill_async(float *p, int64_t n, hipStream_t s);   // zero fill a
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
 hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                       const float *coords, const void *grad_out, void *grad_table, void *workspace,
-                                      size_t workspace_bytes, int64_t n, hipStream_t s);
+                                      size_t workspace_bytes, int64_t n, hipStream_t s, const void *plan = nullptr);
 
 // latent.hip
 struct DecodeArgs {
@@ -166,6 +182,11 @@ struct Options {
     int bin_batch_mib = 1536;     // cap of the backward's item array per sub-batch
     int tiled = -1;               // cell-sorted forward: -1 by batch size, 0 never, 1 whenever the shape allows
     int tiled_lc_fwd = -1;        // its number of coarse levels (rows kernel), -1 = planner
+    int bwd_brick = -1;           // brick pass of the backward (needs the batch's plan): -1 / 1 whenever the shape allows, 0 never
+    int bwd_brick_lo = -1;        // explicit brick level range [lo, hi) instead of the planner's rule (-1 = planner)
+    int bwd_brick_hi = -1;
+    int bwd_brick_fork = 0;       // where the brick pass runs: 0 last on the caller's stream, 1 / 2 side stream from behind the front / scatter pass
+    int bwd_brick_span = 0;       // blocks per brick unit along x (0 = planner)
 };
 const Options &opt();             // the calling thread's snapshot
 void options_snapshot();          // taken at every extern "C" entry point that reads options

@@ -137,8 +137,24 @@ def retained_workspace_bytes():
 # workspace sizes are pure functions of the shape and the library's tunables: one C call per new shape, not per call
 @functools.lru_cache(maxsize=4096)   # (NeRF steps change N every step: 256 entries thrashed)
 def _ws_bytes(kind, dim, N, L, F, bw, res, T, dt, epoch):
-    fn = _lib.lib().shacira_hashgrid_forward_workspace_bytes if kind == 0 else _lib.lib().shacira_hashgrid_backward_workspace_bytes
+    fn = (_lib.lib().shacira_hashgrid_forward_workspace_bytes, _lib.lib().shacira_hashgrid_backward_workspace_bytes,
+          _lib.lib().shacira_hashgrid_plan_bytes)[kind]
     return int(fn(dim, N, L, F, bw, _res_array(res), T, dt))
+
+
+def hashgrid_plan_bytes(dim, num_coords, table_rows, table_dtype, resolution, codebook_bitwidth, feature_dim):
+    """Size of the plan buffer the forward of this shape fills (0: it sorts nothing -- pass ``plan=None``)."""
+    res = tuple(int(r) for r in resolution)
+    return _ws_bytes(2, dim, int(num_coords), len(res), int(feature_dim), int(codebook_bitwidth), res, int(table_rows),
+                     _DTYPES[table_dtype], _lib.options_epoch)
+
+
+def hashgrid_plan_buffer(dim, coords, codebook, resolution, codebook_bitwidth):
+    """A plan buffer for this batch and table (uint8 tensor), or None when the forward of this shape builds no plan. Pass it
+    to the forward (``plan=``), keep it with the coordinates, pass it to the backward of the same batch."""
+    n = hashgrid_plan_bytes(dim, coords.shape[0], codebook.shape[0], codebook.dtype, resolution, codebook_bitwidth,
+                            codebook.shape[1])
+    return torch.empty((n,), dtype=torch.uint8, device=codebook.device) if n > 0 else None
 
 
 class _on_device:
@@ -164,7 +180,7 @@ def _dtype_code(t):
         raise RuntimeError(f"shacira_amd: unsupported table dtype {t.dtype} (fp32, fp16 and fp64 are implemented)")
 
 
-def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth):
+def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth, plan=None, plan_ready=False):
     _need_gpu(coords, codebook, codebook_first_idx)
     if coords.dtype != torch.float32:
         raise RuntimeError("expected scalar type Float for coords")  # data_ptr<float>() in the reference
@@ -177,16 +193,26 @@ def _hashgrid_forward(dim, coords, codebook, codebook_first_idx, resolution, cod
     with _on_device(codebook.device):
         nbytes = _ws_bytes(0, dim, N, len(res), F, int(codebook_bitwidth), res, T, dt, _lib.options_epoch)
         ws = _workspace(codebook.device, nbytes)
-        rc = L.shacira_hashgrid_forward(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
-                                        _ptr(codebook_first_idx), T, _ptr(coords), _ptr(codebook), dt, _ptr(feats),
-                                        _ptr(ws), nbytes, _stream(codebook))
+        if plan is None:
+            rc = L.shacira_hashgrid_forward(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
+                                            _ptr(codebook_first_idx), T, _ptr(coords), _ptr(codebook), dt, _ptr(feats),
+                                            _ptr(ws), nbytes, _stream(codebook))
+        else:
+            _need_gpu(plan)
+            rc = L.shacira_hashgrid_forward_planned(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
+                                                    _ptr(codebook_first_idx), T, _ptr(coords), _ptr(codebook), dt,
+                                                    _ptr(feats), _ptr(plan), plan.numel(),
+                                                    _lib.PLAN_READY if plan_ready else 0, _ptr(ws), nbytes,
+                                                    _stream(codebook))
     _lib.check(rc, "hashgrid_interpolate")
     return feats
 
 
 def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codebook_first_idx, resolution,
-                      codebook_bitwidth, feature_dim, levels=None, out=None, workspace=None, flags=0):
+                      codebook_bitwidth, feature_dim, levels=None, out=None, workspace=None, flags=0, plan=None):
     """grad_codebook [table_rows, feature_dim] of ``table_dtype`` (the codebook's values are not needed).
+
+    ``plan``: the buffer the forward of the SAME coordinate batch filled (``hashgrid_plan_buffer``); whole calls only.
 
     ``levels=(begin, end)`` computes (and overwrites) only the rows of those levels inside ``out`` (an existing
     gradient buffer) -- used to overlap the all-reduce of finished rows with the remaining levels. A series of such
@@ -223,10 +249,17 @@ def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codeboo
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
         else:
             ws = _workspace(device, nbytes)
-        rc = L.shacira_hashgrid_backward_levels(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
-                                                _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
-                                                _ptr(grad_codebook), lb, le, int(flags), _ptr(ws), nbytes,
-                                                _stream(grad_output))
+        if plan is not None and (lb, le) == (0, len(res)) and not flags:
+            _need_gpu(plan)
+            rc = L.shacira_hashgrid_backward_planned(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
+                                                     _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
+                                                     _ptr(grad_codebook), _ptr(plan), plan.numel(), _ptr(ws), nbytes,
+                                                     _stream(grad_output))
+        else:
+            rc = L.shacira_hashgrid_backward_levels(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
+                                                    _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
+                                                    _ptr(grad_codebook), lb, le, int(flags), _ptr(ws), nbytes,
+                                                    _stream(grad_output))
     _lib.check(rc, "hashgrid_interpolate_backward")
     return grad_codebook
 
@@ -258,14 +291,16 @@ def backward_workspace(dim, num_coords, table_rows, table_dtype, resolution, cod
     return torch.empty((max(n, 1),), dtype=torch.uint8, device=device)
 
 
-def hashgrid_interpolate_cuda(coords, codebook, codebook_first_idx, resolution, codebook_bitwidth):
-    """hashgrid_interpolate.h:18-23 -> feats [N, L*F] (3-D coords)."""
-    return _hashgrid_forward(3, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth)
+def hashgrid_interpolate_cuda(coords, codebook, codebook_first_idx, resolution, codebook_bitwidth, plan=None,
+                              plan_ready=False):
+    """hashgrid_interpolate.h:18-23 -> feats [N, L*F] (3-D coords). ``plan``: see ``hashgrid_plan_buffer``."""
+    return _hashgrid_forward(3, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth, plan, plan_ready)
 
 
-def hashgrid_interpolate2d_cuda(coords, codebook, codebook_first_idx, resolution, codebook_bitwidth):
+def hashgrid_interpolate2d_cuda(coords, codebook, codebook_first_idx, resolution, codebook_bitwidth, plan=None,
+                                plan_ready=False):
     """hashgrid_interpolate.h:35-40 -> feats [N, L*F] (2-D coords)."""
-    return _hashgrid_forward(2, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth)
+    return _hashgrid_forward(2, coords, codebook, codebook_first_idx, resolution, codebook_bitwidth, plan, plan_ready)
 
 
 def hashgrid_interpolate_backward_cuda(coords, grad_output, codebook, codebook_first_idx, resolution,

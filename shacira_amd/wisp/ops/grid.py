@@ -25,9 +25,16 @@ def _check_feature_dim(codebook):
 def _forward(ctx, dim, coords, resolutions, codebook_bitwidth, codebook, codebook_first_idx):
     _check_feature_dim(codebook)
     op = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
+    # the batch's plan (its samples sorted by spatial block: what the forward of a large batch computes first) is kept with
+    # the coordinates the reference saves (grid.py:86), so that the backward does not have to rediscover the batch's layout
+    plan = None
+    if coords.is_cuda and ctx.needs_input_grad[4]:   # (codebook is forward()'s fifth argument)
+        plan = hip_ops.hashgrid_plan_buffer(dim, coords, codebook, resolutions, codebook_bitwidth)
+    extra = {} if plan is None else {"plan": plan}   # (the operator's own signature when there is none: hashgrid_interpolate.h)
     feats_out = op(coords.float().contiguous(), codebook.contiguous(), codebook_first_idx, resolutions,
-                   codebook_bitwidth).contiguous()
+                   codebook_bitwidth, **extra).contiguous()
     ctx.save_for_backward(coords, codebook_first_idx)
+    ctx.plan = plan
     ctx.resolutions = resolutions
     ctx.num_lods = len(resolutions)
     ctx.codebook_size = 2 ** codebook_bitwidth
@@ -42,7 +49,8 @@ def _backward(ctx, dim, grad_output):
     coords, codebook_first_idx = ctx.saved_tensors
     grad_codebook = hip_ops.hashgrid_backward(dim, coords.float().contiguous(), grad_output.contiguous(),
                                               ctx.table_rows, ctx.table_dtype, codebook_first_idx, ctx.resolutions,
-                                              ctx.codebook_bitwidth, ctx.feature_dim)
+                                              ctx.codebook_bitwidth, ctx.feature_dim,
+                                              **({} if ctx.plan is None else {"plan": ctx.plan}))
     return (None, None, None, None, grad_codebook, None, None)
 
 
