@@ -22,9 +22,18 @@
 namespace shacira {
 
 constexpr int kBrickMaxLevels = 6;
-constexpr int kBrickThreads = 512;
-constexpr int kBrickUnit = 1024;                   // samples per unit (one zero / accumulate / flush round of a workgroup)
-constexpr int kBrickSplit = 4;                     // workgroups that share an over-full block (grid.y)
+#ifndef SHACIRA_BRICK_THREADS
+#define SHACIRA_BRICK_THREADS 512
+#endif
+#ifndef SHACIRA_BRICK_UNIT
+#define SHACIRA_BRICK_UNIT 1024
+#endif
+#ifndef SHACIRA_BRICK_SPLIT
+#define SHACIRA_BRICK_SPLIT 4
+#endif
+constexpr int kBrickThreads = SHACIRA_BRICK_THREADS;
+constexpr int kBrickUnit = SHACIRA_BRICK_UNIT;     // samples per unit (one zero / accumulate / flush round of a workgroup)
+constexpr int kBrickSplit = SHACIRA_BRICK_SPLIT;   // workgroups that share an over-full block (grid.y)
 constexpr double kBrickSlack = 1e-3;               // cells: the block rule (fp32) and the cell rule (fp64 -> fp32) agree to ~1e-5
 
 struct BrickLevel {
@@ -281,6 +290,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(LevelTa
         }
         lds_barrier();
         // flush: lanes run along x (and over the F features of a row): adjacent rows of a dense level, rows x ^ h of a hashed one
+        // (walking a hashed level's aligned 16-row groups in ADDRESS order instead changed nothing: measured, round 6)
 #pragma unroll 1
         for (uint32_t q = 0; q < bp.nlev; ++q) {
             const BrickLevel b = bp.lv[q];

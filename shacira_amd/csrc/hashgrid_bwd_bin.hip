@@ -583,10 +583,19 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     if constexpr (DIM == 3) {
         // (sorted mode rides on the fused 16-byte front kernel: rows of whole 16-byte vectors, 16-byte aligned input)
         const int kvec0 = (int)(16 / ((dtype == SHACIRA_F32 ? 4 : 2) * F));
-        if (sb != nullptr && opt().bwd_brick != 0 && !multi && !stage_all && !staged && zero_table &&
+        // Measured rule (option bwd_brick = -1; tools/brick_cfg_ab.py, profiles/r06_experiments.md): the pass pays where the
+        // item stream is the bound it relieves -- fp32 item streams of F = 2 tables from ~3/4 M samples (S1 at 2^20: backward
+        // 0.481 -> 0.443 ms; 2^19: 0.264 -> 0.273, 2^18: equal; half-precision streams, whose items are half the bytes: S1
+        // 0.413 -> 0.445; nerf_lego.yaml's F = 4 table, 32 LDS atomics per sample and level: 0.593 -> 0.594). bwd_brick = 1
+        // takes it wherever the shape allows.
+        const int bopt = opt().bwd_brick;
+        const bool wanted = bopt == 1 || (bopt < 0 && F == 2 && dtype == SHACIRA_F32 && n >= ((int64_t)3 << 18));
+        if (sb != nullptr && wanted && !multi && !stage_all && !staged && zero_table &&
             n >= SHACIRA_FX_MIN && n * L < ((int64_t)1 << 31) && !table_all_direct(DIM, dtype, lt, n) && (L % kvec0) == 0 &&
             (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0) {
-            if (make_brick_plan(lt, n, *sb, opt().bwd_brick_lo, opt().bwd_brick_hi, opt().bwd_brick_span, (size_t)64 * 1024, brick))
+            if (make_brick_plan(lt, n, *sb, opt().bwd_brick_lo, opt().bwd_brick_hi, opt().bwd_brick_span,
+                                // beside the consume pass (mode 2) a brick workgroup must fit the LDS its 128 KiB image leaves
+                                (size_t)(opt().bwd_brick_fork == 2 ? 30 : 64) * 1024, brick))
                 for (uint32_t q = 0; q < brick.nlev; ++q) skip_mask |= 1u << brick.lv[q].level;
         }
     }

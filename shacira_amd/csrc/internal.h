@@ -185,7 +185,7 @@ struct Options {
     int bwd_brick = -1;           // brick pass of the backward (needs the batch's plan): -1 / 1 whenever the shape allows, 0 never
     int bwd_brick_lo = -1;        // explicit brick level range [lo, hi) instead of the planner's rule (-1 = planner)
     int bwd_brick_hi = -1;
-    int bwd_brick_fork = 0;       // where the brick pass runs: 0 last on the caller's stream, 1 / 2 side stream from behind the front / scatter pass
+    int bwd_brick_fork = 2;       // where the brick pass runs: 0 last on the caller's stream, 1 / 2 side stream from behind the front / scatter pass
     int bwd_brick_span = 0;       // blocks per brick unit along x (0 = planner)
 };
 const Options &opt();             // the calling thread's snapshot
