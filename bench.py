@@ -3,8 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" = one pass of the hot path over one batch: the forward operator (all 16 levels), the backward operator
-(gradient scatter-add into the 48.8 MB codebook) and, for N > 1, ONE RCCL all-reduce of that gradient over xGMI.
+A "step" = one pass of the hot path over one batch: the forward operator (all 16 levels; it builds the batch's plan -- the
+sample sort -- INSIDE the timed step, every step, into a caller-owned buffer), the backward operator (gradient scatter-add
+into the 48.8 MB codebook, reading that plan: the hand-off the autograd Function makes, shacira_amd/wisp/ops/grid.py) and,
+for N > 1, ONE RCCL all-reduce of that gradient over xGMI.
 Workload = BASELINE.json's headline point "H"/config D shape: 3-D `nerf_hash` grid (L=16, F=2, bw=19, res 17..2049,
 T = 6 098 925 rows, fp32), 2^20 uniformly random samples per GPU (weak scaling), inputs resident in HBM.
 Rank 0 prints ONE JSON line (see the driver contract); `roofline` prices the dominant operator against the
@@ -82,18 +84,22 @@ def quick_measure(name, device, iters=20):
         coords = (torch.rand(n, dim, generator=g) * 2 - 1).to(device)
     go = torch.randn(n, L * F, generator=g).to(device).to(table.dtype)
     fwd = hip_ops.hashgrid_interpolate_cuda if dim == 3 else hip_ops.hashgrid_interpolate2d_cuda
+    # the plan hand-off of the autograd Function (shacira_amd/wisp/ops/grid.py): the forward fills it every call, the backward
+    # reads it; None for the shapes whose forward sorts nothing
+    plan = hip_ops.hashgrid_plan_buffer(dim, coords, table, res, bw)
+    pkw = {} if plan is None else {"plan": plan}
     for _ in range(3):
-        fwd(coords, table, first, res, bw)
-        hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F)
+        fwd(coords, table, first, res, bw, **pkw)
+        hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F, **pkw)
     torch.cuda.synchronize()
     # the headline loop's protocol: steps issued back to back (no host synchronisation inside the region, so that small
     # batches are not charged the Python wrapper's ~20 us per call while the GPU sits idle), HIP events around each operator
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
     for ev in evs:
         ev[0].record()
-        fwd(coords, table, first, res, bw)
+        fwd(coords, table, first, res, bw, **pkw)
         ev[1].record()
-        hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F)
+        hip_ops.hashgrid_backward(dim, coords, go, T, table.dtype, first, res, bw, F, **pkw)
         ev[2].record()
     torch.cuda.synchronize()
     tf = float(np.mean([ev[0].elapsed_time(ev[1]) for ev in evs]))
@@ -295,7 +301,34 @@ def ranks_proof(rank, world, device):
     return info
 
 
-def build_step(device, rank, world, dim, res, bw, F, n_local, ar_chunks=1, collective="allreduce"):
+def roofline_record(ms_fwd, ms_bwd, b_fwd, b_bwd, n_local, traffic_fwd=None, traffic_bwd=None, traffic_source=None,
+                    kernels=None):
+    """The `roofline` object of the bench line. Top level = the BASELINE metric itself, hash-grid fwd+bwd: ALGORITHMIC bytes
+    of both operators (2328 B per sample in 3-D, L16, F2) over their summed HIP-event times, against the
+    8 TB/s HBM roof. `operators` nests the same figures per operator (what the contract calls the dominant kernel is
+    `operators[dominant]`), `hbm_utilisation` = counter-measured HBM bytes of both operators over the same time over the peak
+    (how busy the memory system is, on whatever bytes), `traffic_source` says where the counter bytes come from. Every value is
+    None in the launch self-test (no kernels run there); the keys are the same."""
+    def op(ms, b, traffic):
+        if ms is None:
+            return {"achieved": None, "frac": None, "ms_per_launch": None, "algorithmic_bytes_per_launch": None,
+                    "traffic": None}
+        ach = b * n_local / (ms * 1e-3) / 1e9
+        return {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "ms_per_launch": ms, "algorithmic_bytes_per_launch": b * n_local,
+                "traffic": traffic}
+    have = ms_fwd is not None and ms_bwd is not None
+    path = (b_fwd + b_bwd) * n_local / ((ms_fwd + ms_bwd) * 1e-3) / 1e9 if have else None
+    traffic = (traffic_fwd + traffic_bwd) if (traffic_fwd is not None and traffic_bwd is not None) else None
+    return {"bound": "hbm", "what": "hash-grid forward + backward operators (the BASELINE metric), algorithmic bytes / HIP-event time",
+            "kernel": kernels, "achieved": path, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (path / HBM_PEAK_GBS) if have else None,
+            "bytes_per_sample": b_fwd + b_bwd, "traffic": traffic, "traffic_source": traffic_source,
+            "hbm_utilisation": (traffic / ((ms_fwd + ms_bwd) * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic is not None and have) else None,
+            "dominant": (("backward" if ms_bwd >= ms_fwd else "forward") if have else None),
+            "operators": {"forward": op(ms_fwd, b_fwd, traffic_fwd), "backward": op(ms_bwd, b_bwd, traffic_bwd)}}
+
+
+def build_step(device, rank, world, dim, res, bw, F, n_local, ar_chunks=1, collective="allreduce", use_plan=True):
     """The benchmark step on this rank: synthetic inputs resident on `device` (parameters replicated: same seed; samples
     per rank), forward operator, backward operator into the communication buffer, gradient reduction. Used by main() and,
     on CPU with the oracle standing in for the operators, by tests/test_dist_cpu.py (world-size-4 gloo run of the same loop)."""
@@ -325,15 +358,20 @@ def build_step(device, rank, world, dim, res, bw, F, n_local, ar_chunks=1, colle
     grad_buf = grad_flat[:T * F].view(T, F)
     ws_shared = (hip_ops.backward_workspace(dim, n_local, T, table.dtype, res, bw, F, device)
                  if (len(groups) > 1 or world > 1) else None)
+    # the batch's plan: written by every forward call of the timed loop (never reused across steps here), read by the
+    # backward of the same step. None for shapes whose forward sorts nothing (and on CPU, where the oracle stands in).
+    plan = (hip_ops.hashgrid_plan_buffer(dim, coords, table, res, bw)
+            if device.type == "cuda" and len(groups) == 1 and use_plan else None)
+    pkw = {} if plan is None else {"plan": plan}
 
     def step(ev=None):
         if ev:
             ev[0].record()
-        feats = fwd(coords, table, first, res, bw)
+        feats = fwd(coords, table, first, res, bw, **pkw)
         if ev:
             ev[1].record()
         if len(groups) == 1 and world == 1:
-            grad = hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F)
+            grad = hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F, **pkw)
             if ev:
                 ev[2].record()
         else:
@@ -344,7 +382,7 @@ def build_step(device, rank, world, dim, res, bw, F, n_local, ar_chunks=1, colle
             def backward_levels(lb, le, first_group):
                 if len(groups) == 1:
                     hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F, out=grad,
-                                              workspace=ws_shared)
+                                              workspace=ws_shared, **pkw)
                 else:
                     hip_ops.hashgrid_backward(dim, coords, grad_out, T, table.dtype, first, res, bw, F, levels=(lb, le),
                                               out=grad, workspace=ws_shared,
@@ -357,7 +395,7 @@ def build_step(device, rank, world, dim, res, bw, F, n_local, ar_chunks=1, colle
         return feats, grad
 
     return {"step": step, "groups": groups, "first_np": first_np, "T": T, "table": table, "coords": coords,
-            "grad_out": grad_out, "first": first}
+            "grad_out": grad_out, "first": first, "plan_bytes": 0 if plan is None else plan.numel()}
 
 
 SWEEP_CASES = [
@@ -445,6 +483,8 @@ def main():
                          "with NCCL_ALGO=Ring|Tree for the comparison SURVEY.md section 5 asks for), or reduce_scatter + "
                          "all_gather on the flat buffer (every xGMI link carries 1/world of each phase)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the quick figures for the other BASELINE configs")
+    ap.add_argument("--no-plan", action="store_true",
+                    help="A/B switch: call the plain operators (no plan hand-off from the forward to the backward)")
     ap.add_argument("--psnr-steps", type=int, default=1000, help="image-fit steps for the PSNR figure (0 = skip)")
     ap.add_argument("--nerf-steps", type=int, default=500,
                     help="steps of the NeRF-style render-and-fit on the analytic scene for the second PSNR figure (0 = skip)")
@@ -514,7 +554,9 @@ def main():
                               "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
                               "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "none",
                               "config": {"workload": "launch self-test (gloo, no kernels)", "scaling": args.scaling,
-                                         "allreduce_check": float(t.item()) == world * (world + 1) / 2, **proof}}), flush=True)
+                                         "allreduce_check": float(t.item()) == world * (world + 1) / 2, **proof},
+                              "roofline": roofline_record(None, None, *algorithmic_bytes_per_sample(3, 16, 2), 0),
+                              "cpu_baseline": None}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -536,9 +578,10 @@ def main():
         lo, hi = sdist.shard_bounds(n_local, rank, world)
         n_local = hi - lo
     L = len(res)
-    st = build_step(device, rank, world, dim, res, bw, F, n_local, args.ar_chunks, args.collective)
+    st = build_step(device, rank, world, dim, res, bw, F, n_local, args.ar_chunks, args.collective, use_plan=not args.no_plan)
     step, groups, first_np, T, table, coords, grad_out = (st["step"], st["groups"], st["first_np"], st["T"], st["table"],
                                                           st["coords"], st["grad_out"])
+    st_plan_bytes = st["plan_bytes"]
 
     def fence():
         if dist.is_initialized():
@@ -667,7 +710,7 @@ def main():
         # HBM bytes per launch from the PMC counters (collected offline with rocprofv3 --pmc in separate passes on
         # the same operators and workload; see the note inside the file). Only valid for the workload it was taken on.
         # Attached ONLY when the file was measured on exactly these kernel sources (kernel_source_hash); else null.
-        traffic, traffic_note = None, None
+        traffic_fwd, traffic_bwd, traffic_source = None, None, None
         # (the newest round's file: profiles/rNN_pmc_traffic.json)
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
@@ -676,12 +719,15 @@ def main():
             with open(tpath) as fh:
                 rec = json.load(fh)
             if rec.get("kernel_source_hash") == kernel_source_hash():
-                traffic = rec["operators"].get(dom[0], {}).get("hbm_bytes_per_launch")
+                traffic_fwd = rec["operators"].get("forward", {}).get("hbm_bytes_per_launch")
+                traffic_bwd = rec["operators"].get("backward", {}).get("hbm_bytes_per_launch")
+                traffic_source = (f"profiles/{os.path.basename(tpath)}: rocprofv3 --pmc passes of the same operators and workload "
+                                  "on the builder's box (same kernel sources by hash), NOT counters of this run; the time it is "
+                                  "divided by IS this run's")
             else:
-                traffic_note = (f"profiles/{os.path.basename(tpath)} was measured on other kernel sources "
-                                f"({rec.get('kernel_source_hash')} != {kernel_source_hash()}): not attached")
-        achieved = dom[2] * n_local / (dom[1] * 1e-3) / 1e9
-        path_gbs = (b_fwd + b_bwd) * n_local / ((ms_fwd + ms_bwd) * 1e-3) / 1e9
+                traffic_source = (f"none: profiles/{os.path.basename(tpath)} was measured on other kernel sources "
+                                  f"({rec.get('kernel_source_hash')} != {kernel_source_hash()})")
+        traffic = traffic_bwd if dom[0] == "backward" else traffic_fwd
         # what this chip's memory system sustains on plain streams, measured in the same run (SURVEY 8d asks for the
         # nominal AND the measured peak): a 1 GiB device-to-device copy (read + write), a fill (write only) and a
         # reduction (read only), bytes moved / time. The nominal 8 TB/s stays the `peak` of the contract.
@@ -724,12 +770,7 @@ def main():
         lines = n_fine * n_local * (2 ** (dim - 1))
         cus, clk_ghz = 256, 2.4
         fwd_floor_ms = lines * 2.0 / (cus * clk_ghz * 1e9) * 1e3
-        bwd_traffic = None
-        if args.workload.startswith("S1_") and os.path.exists(tpath):
-            with open(tpath) as fh:
-                rec2 = json.load(fh)
-            if rec2.get("kernel_source_hash") == kernel_source_hash():
-                bwd_traffic = rec2["operators"].get("backward", {}).get("hbm_bytes_per_launch")
+        bwd_traffic = traffic_bwd
         bwd_bytes = bwd_traffic if bwd_traffic is not None else 1.93 * b_bwd * n_local
         bwd_floor_ms = bwd_bytes / (measured["copy_read+write"] * 1e9) * 1e3
         bound_model = {
@@ -750,6 +791,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "dim": dim, "levels": L, "feature_dim": F, "bitwidth": bw,
                        "table_rows": T, "samples_per_gpu": n_local, "scaling": args.scaling,
+                       "plan_hand_off": ("forward builds the batch's plan every step, backward reads it"
+                                         if st_plan_bytes else "none (plain operators)"), "plan_bytes": st_plan_bytes,
                        "collective": args.collective if world > 1 else None,
                        "nccl_algo": (os.environ.get("NCCL_ALGO") or "unset (RCCL chooses)") if world > 1 else None,
                        **proof,
@@ -758,17 +801,12 @@ def main():
                                                       if len(groups) == 1 else
                                                       f"+allreduce(grad_codebook) in {len(groups)} level groups "
                                                       f"{groups}, overlapped with the backward")},
-            "roofline": {"bound": "hbm",
-                         "kernel": (f"hashgrid_{dom[0]} operator = one C-ABI call, HIP events on its stream; kernels: "
-                                    + ("front16 (transpose + bucket counts) + bucket scan + bin_scatter + bin_consume"
-                                       if dom[0] == "backward" else
-                                       "sample sort + hashgrid_fwd_level_pair (fine levels) + hashgrid_fwd_rows")),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_note": traffic_note,
-                         "algorithmic_bytes_per_launch": dom[2] * n_local,
-                         "ms_per_launch": dom[1],
-                         "fwd_bwd_path": {"achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS,
-                                          "bytes_per_sample": b_fwd + b_bwd},
+            "roofline": {**roofline_record(
+                             ms_fwd, ms_bwd, b_fwd, b_bwd, n_local, traffic_fwd, traffic_bwd, traffic_source,
+                             kernels=("one C-ABI call per operator, HIP events on its stream. forward: psort_count + psort_partition + "
+                                      "psort_local (the batch's plan) + hashgrid_fwd_level_pair (fine levels) + hashgrid_fwd_rows; backward: "
+                                      "zero_unowned_rows + front16 (gradient rows gathered in plan order + bucket counts) + bin_scan_buckets "
+                                      "+ bin_scatter + bin_consume, brick_accumulate (coarse levels) beside the consume pass")),
                          "bound_model": bound_model,
                          "measured_stream_rates": measured},
             "ms": {"forward": ms_fwd, "backward": ms_bwd, "allreduce": ms_ar,

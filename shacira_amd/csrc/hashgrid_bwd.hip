@@ -45,25 +45,13 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(LevelTable lt,
         compute_corners<DIM>(t, s_res[lvl], s_hi[lvl], s_dense[lvl] != 0, lt.mask, c);
         const int64_t base = (int64_t)s_first[lvl];
         const T *g = grad_out + (i * L + lvl) * Fr;
-        if constexpr (F == 2) {
-            float g0 = Scalar<T>::load(g), g1 = Scalar<T>::load(g + 1);
+        for (int j = 0; j < Fr; ++j) {
+            const float gj = Scalar<T>::load(g + j);
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 const int64_t row = base + (int64_t)c.row[k];
-                if ((uint64_t)row < (uint64_t)lt.table_rows) {
-                    unsafeAtomicAdd(grad_table + row * 2, g0 * c.w[k]);
-                    unsafeAtomicAdd(grad_table + row * 2 + 1, g1 * c.w[k]);
-                }
-            }
-        } else {
-            for (int j = 0; j < Fr; ++j) {
-                const float gj = Scalar<T>::load(g + j);
-#pragma unroll
-                for (int k = 0; k < NC; ++k) {
-                    const int64_t row = base + (int64_t)c.row[k];
-                    if ((uint64_t)row < (uint64_t)lt.table_rows)
-                        unsafeAtomicAdd(grad_table + row * Fr + j, gj * c.w[k]);
-                }
+                if ((uint64_t)row < (uint64_t)lt.table_rows)
+                    unsafeAtomicAdd(grad_table + row * Fr + j, gj * c.w[k]);
             }
         }
     }
@@ -94,10 +82,12 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_pair_kernel(LevelTabl
         s_first[threadIdx.x] = first_idx[threadIdx.x];
     }
     __syncthreads();
-    const uint32_t stride = gridDim.x * blockDim.x;
     static_assert(F == 2 || F == 4, "2 F lanes per (sample, level)");
     constexpr uint32_t LOGF = (F == 2) ? 1u : 2u;
-    for (uint32_t t2 = blockIdx.x * blockDim.x + threadIdx.x; (t2 >> (LOGF + 1u)) < num_items; t2 += stride) {
+    // the grid covers every lane (launch_bwd_atomic): ONE guarded pass -- a grid-stride loop on a 32-bit index wrapped for the
+    // last threads of a full-size chunk (items * 2 F close to 2^31) and added the first items twice (round-5 advisor finding)
+    const uint32_t t2 = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((t2 >> (LOGF + 1u)) < num_items) {
         // four lanes per (sample, level): (x offset, feature). The rows x and x + 1 of a corner pair are neighbours (dense
         // levels) or differ in a few low bits (hashed levels: x ^ (x + 1)), so the four lanes' atomics of one instruction
         // mostly fall into one 64-byte piece and travel as ONE request: 8 192 ray points 67 -> ~45 us (pairs only: 121 -> 67)
@@ -105,7 +95,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_pair_kernel(LevelTabl
         const uint32_t w = t2 >> (LOGF + 1u), dx = (t2 >> LOGF) & 1u, j = t2 & (uint32_t)(F - 1);
         const uint32_t s = w / L;
         const uint32_t lvl = w - s * L;
-        if ((int32_t)lvl < lt.level_begin || (int32_t)lvl >= lt.level_end) continue;
+        if ((int32_t)lvl < lt.level_begin || (int32_t)lvl >= lt.level_end) return;
         const int64_t i = sample0 + s;
         double t[DIM];
 #pragma unroll
@@ -243,13 +233,13 @@ static hipError_t launch_bwd_atomic(const LevelTable &lt, const int32_t *first_i
                                coords, static_cast<const T *>(grad_out), acc, s0, items);
             hipError_t e2 = hipGetLastError();
             if (e2 != hipSuccess) return e2;
-            continue;
+        } else {   // any other (even) feature count: the reference's shape, one thread per (sample, level)
+            const uint32_t blocks = (items + 255u) / 256u;
+            hipLaunchKernelGGL((hashgrid_bwd_atomic_kernel<DIM, T, F>), dim3(blocks), dim3(256), 0, stream, lt, first_idx,
+                               coords, static_cast<const T *>(grad_out), acc, s0, items);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
         }
-        const uint32_t blocks = (items + 255u) / 256u;
-        hipLaunchKernelGGL((hashgrid_bwd_atomic_kernel<DIM, T, F>), dim3(blocks), dim3(256), 0, stream, lt, first_idx,
-                           coords, static_cast<const T *>(grad_out), acc, s0, items);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }

@@ -48,8 +48,10 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // atomically) instead of the direct pass in front of the scatter pass; decided per CALL from the total batch (below), so
 // that every plan of a call classifies the levels alike
 // `skip_mask`: levels (bit l) another pass accumulates (the brick pass): neither binned nor direct here
+// `n_call`: samples of the whole CALL (0 = n_batch). The item format is chosen per call (run_bin, carve), so a sub-batch's plan
+// must size its pad units and staging for THAT format, not for the one its own sample count would pick (round-5 advisor finding)
 static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
-                      bool one_image_compact, uint32_t skip_mask = 0u);
+                      bool one_image_compact, uint32_t skip_mask = 0u, int64_t n_call = 0);
 static inline bool half_items(int dtype, const LevelTable &lt);
 static inline int item_format(int dim, int dtype, const LevelTable &lt, int64_t n);
 static inline size_t item_unit_bytes(int fmt, const LevelTable &lt);
@@ -132,16 +134,17 @@ bool bin_supported(int dim, const LevelTable &lt) {
 }
 
 static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
-                               bool one_image_compact, uint32_t skip_mask);
+                               bool one_image_compact, uint32_t skip_mask, int64_t n_call);
 
 // A backward call plans several times (workspace query, carving, image-size rule, the run itself), and a plan costs a few
 // microseconds of host time (the magic-division checks of the compact levels walk every line): small batches became
 // HOST-bound (2-D bw-19 table at 2^17 samples: 0.123 ms per call against 0.094 ms of GPU time). Plans are pure functions of
 // their arguments and two options, so each thread keeps its last few.
 static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
-                      bool one_image_compact, uint32_t skip_mask) {
+                      bool one_image_compact, uint32_t skip_mask, int64_t n_call) {
+    if (n_call <= 0) n_call = n_batch;
     struct Key {
-        int dim, dtype, acc_kib, oic, compact, run_pad, item12;
+        int dim, dtype, acc_kib, oic, compact, run_pad, item12, fmt;
         uint32_t skip_mask;
         int64_t n_batch;
         LevelTable lt;
@@ -160,6 +163,7 @@ static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch,
     k.run_pad = opt().bwd_run_pad;
     k.item12 = opt().bwd_item12;
     k.skip_mask = skip_mask;
+    k.fmt = item_format(dim, dtype, lt, n_call);
     k.n_batch = n_batch;
     std::memcpy(&k.lt, &lt, sizeof(LevelTable));
     for (int e = 0; e < kEntries; ++e) {
@@ -168,7 +172,7 @@ static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch,
             return;
         }
     }
-    make_plan_uncached(dim, dtype, lt, n_batch, plan, acc_kib, one_image_compact, skip_mask);
+    make_plan_uncached(dim, dtype, lt, n_batch, plan, acc_kib, one_image_compact, skip_mask, n_call);
     Entry &slot = cache[next];
     next = (next + 1) % kEntries;
     slot.key = k;
@@ -177,9 +181,9 @@ static void make_plan(int dim, int dtype, const LevelTable &lt, int64_t n_batch,
 }
 
 static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t n_batch, BinPlan &plan, int acc_kib,
-                               bool one_image_compact, uint32_t skip_mask) {
+                               bool one_image_compact, uint32_t skip_mask, int64_t n_call) {
     if (one_image_compact) {   // tables whose levels are ALL direct stay that way (no transposing pass at all)
-        make_plan_uncached(dim, dtype, lt, n_batch, plan, acc_kib, false, skip_mask);
+        make_plan_uncached(dim, dtype, lt, n_batch, plan, acc_kib, false, skip_mask, n_call);
         if (plan.nbl == 0) return;
     }
     const int F = lt.feature_dim;
@@ -319,7 +323,8 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
     // the item array was then written in two pieces by different 16-lane groups of a store (and the lines at a run's ends by
     // different workgroups), and scattered runs written that way reach 3.2 TB/s at 1 KB per run against 5.3 TB/s for the same
     // runs on line boundaries -- where the run LENGTH stops mattering at all (tools/microbench3.hip, profiles/r05_experiments.md).
-    // So runs are reserved in multiples of 128 bytes (pad units = all-zero items, which no consumer adds): large batches only
+    // So runs are reserved in multiples of SHACIRA_RUN_ALIGN = 64 bytes (4 units of 16 bytes, or 16 units of 12 bytes = 192 bytes;
+    // pad units = all-zero items, which no consumer adds): large batches only
     // (below 2^17 samples the item array lives in the caches, which merge the pieces), 16-byte units only (a 24-byte unit would
     // need 192-byte multiples and goes through staging windows; the half-precision streams of fp16 tables -- 8-byte units, and
     // the 16-byte units of F = 4 -- are written with plain stores, which the L2 merges, and lose with pads: S1 fp16 backward
@@ -327,7 +332,7 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
     // pad slots staged.
     plan.pad = 1;
     {
-        const int fmt_p = item_format(dim, dtype, lt, n_batch);
+        const int fmt_p = item_format(dim, dtype, lt, n_call);   // the CALL's format (see the declaration)
         const size_t unit = item_unit_bytes(fmt_p, lt);
         const uint32_t tile_units = (uint32_t)tile_samples(dim) * plan.pairs;
         uint32_t maxnb = 0;
@@ -336,7 +341,7 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
 #ifdef SHACIRA_SCATTER_SPLIT
         windows = SHACIRA_SCATTER_SPLIT > 1;
 #endif
-        if (opt().bwd_run_pad != 0 && !windows && plan.nbl > 0 && n_batch >= SHACIRA_FX_MIN &&
+        if (opt().bwd_run_pad != 0 && !windows && plan.nbl > 0 && n_call >= SHACIRA_FX_MIN &&
             ((fmt_p != 1 && (unit == 16 || unit == 12)) || (SHACIRA_PAD_HALF && fmt_p == 1 && (unit == 8 || unit == 16)))) {
             const uint32_t P = unit == 12 ? (uint32_t)(SHACIRA_RUN_ALIGN / 4) : (uint32_t)(SHACIRA_RUN_ALIGN / unit);   // 12-byte units: lcm(12, 64) = 16 of them
             const size_t staged = (size_t)(tile_units + maxnb * (P - 1u)) * (unit + 1);
@@ -346,7 +351,7 @@ static void make_plan_uncached(int dim, int dtype, const LevelTable &lt, int64_t
     }
     const uint32_t cmask = plan.pad > 2u ? plan.pad - 1u : 1u;
     plan.chunk = (uint32_t)chunk & ~cmask;   // even: a compact item (two 16-byte slots) never straddles two work units; a
-                                             // multiple of the run pad: every unit starts on a 128-byte line
+                                             // multiple of the run pad: every unit starts on a 64-byte boundary
     // Unit order = bucket order (dense compact levels first, then the hashed levels, coarse to fine) is the measured best for
     // the persistent consume pass: hashed levels first or reverse order cost +45 us on S1, smaller units for the dense levels
     // or for the last hashed levels changed nothing (round 3, tools/r3_ab.py).
@@ -443,7 +448,7 @@ static uint64_t slots_per_sample(const BinPlan &plan) {
 static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, void *ws) {
     BinPlan plan;
     const int64_t nb = bin_batch_samples(dim, dtype, lt, n);
-    make_plan(dim, dtype, lt, nb, plan, choose_acc_kib(dim, dtype, lt, n), one_image_compact_rule(n));
+    make_plan(dim, dtype, lt, nb, plan, choose_acc_kib(dim, dtype, lt, n), one_image_compact_rule(n), 0u, n);
     const size_t item = item_unit_bytes(item_format(dim, dtype, lt, n), lt);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -599,14 +604,14 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                 for (uint32_t q = 0; q < brick.nlev; ++q) skip_mask |= 1u << brick.lv[q].level;
         }
     }
-    make_plan(DIM, dtype, lt, n, whole, acc_kib, oic, skip_mask);
+    make_plan(DIM, dtype, lt, n, whole, acc_kib, oic, skip_mask, n);
     {
         size_t sh0 = 0;
         // (nothing left for the item passes, or no tile size for the fused front kernel: keep the plain pipeline)
         if (skip_mask != 0u && (whole.nbl == 0 || front_tile(L, F, whole.nbl, n, &sh0) <= 0)) {
             skip_mask = 0u;
             brick.nlev = 0;
-            make_plan(DIM, dtype, lt, n, whole, acc_kib, oic, 0u);
+            make_plan(DIM, dtype, lt, n, whole, acc_kib, oic, 0u, n);
         }
     }
     // SORTED mode: the whole call walks the batch in the plan's block order -- the front kernel gathers the gradient rows in
@@ -816,7 +821,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     for (int64_t s0 = 0; s0 < n; s0 += nb) {
         const int64_t hi = (s0 + nb < n) ? (s0 + nb) : n;
         BinPlan plan;
-        make_plan(DIM, dtype, lt, hi - s0, plan, acc_kib, oic, skip_mask);
+        make_plan(DIM, dtype, lt, hi - s0, plan, acc_kib, oic, skip_mask, n);
         if (!first_batch) {
             hipLaunchKernelGGL(zero_words_kernel, dim3(32), dim3(256), 0, s, w.totals, (uint32_t)kTotalShards * kMaxBuckets);
             SHACIRA_CHECK_LAUNCH();

@@ -177,7 +177,8 @@ struct Options {
     int bwd_persistent = 1;       // consume pass: persistent workgroups fetching units from a counter
     int bwd_fork = 1;             // table zeroing + direct levels on a side stream when the batch is large
     int bwd_item12 = 0;           // 12-byte item units for fp32 tables (3-D, F = 2, batches >= 2^17): 0 keeps the 16-byte stream
-    int bwd_run_pad = 1;          // scatter pass: (tile, bucket) runs padded to whole 128-byte lines (large batches, 8- / 16-byte items)
+    int bwd_run_pad = 1;          // scatter pass: (tile, bucket) runs reserved in whole 64-byte pieces (SHACIRA_RUN_ALIGN; large batches:
+                                  // 4 units of 16 bytes, 16 units of 12 bytes = 192 bytes; the 8-byte half-precision units are not padded)
     int bin_acc_kib = 0;          // LDS accumulator image per consumer workgroup: 64, 128, 0 = by batch size
     int bin_batch_mib = 1536;     // cap of the backward's item array per sub-batch
     int tiled = -1;               // cell-sorted forward: -1 by batch size, 0 never, 1 whenever the shape allows

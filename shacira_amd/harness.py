@@ -703,18 +703,21 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
         fitter = GraphedNerfFitter(nef, tracer, groups, pool, near, far, device, latent=lat)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        eager_before = 0                     # shape warm-up steps taken BEFORE the clock below starts: not in the timed region
         for it in range(steps):
             if it == warm:
-                fitter.prepare()             # capture after the eager warm-up steps (timed from here, captures included)
+                fitter.prepare()             # capture after the eager warm-up steps (captures are timed, see capture_seconds)
                 torch.cuda.synchronize()
+                eager_before = fitter.extra_eager_steps
                 t0 = time.perf_counter()
             fitter.step()
             if prune_every and (it + 1) % prune_every == 0:
                 nef.prune()
                 fitter.after_prune()
         torch.cuda.synchronize()
-        # (the timed region holds steps - warm loop steps plus the shape warm-up steps prepare() took inside it)
-        ms = (time.perf_counter() - t0) / max(1, steps - warm + fitter.extra_eager_steps) * 1e3
+        # (the timed region holds steps - warm loop steps plus the shape warm-up steps taken AFTER the clock started -- those of
+        # re-captures behind a prune; the first prepare()'s ran before t0 was reset: round-5 advisor finding)
+        ms = (time.perf_counter() - t0) / max(1, steps - warm + fitter.extra_eager_steps - eager_before) * 1e3
         fitter.eager_mode()
         with torch.no_grad():
             o, d = camera_rays(val_rays, torch.Generator().manual_seed(4242), device)

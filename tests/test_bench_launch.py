@@ -19,6 +19,28 @@ def test_bench_self_launches_ranks():
     # the line proves by itself that the backend joined both ranks
     assert rec["config"]["ranks_seen"] == 2 and rec["config"]["backend"] == "gloo"
     assert rec["config"]["rank_devices"] == [-1, -1] and "nccl_version" in rec["config"]
+    # the line says what the metric is: top-level roofline = forward + backward (the BASELINE metric),
+    # operators nested, counter traffic with its source, HBM utilisation -- the keys exist in the self-test line too (no values)
+    roof = rec["roofline"]
+    assert {"frac", "achieved", "peak", "traffic", "traffic_source", "hbm_utilisation", "operators", "dominant",
+            "bytes_per_sample"} <= set(roof)
+    assert roof["frac"] is None and roof["bytes_per_sample"] == 2328 and set(roof["operators"]) == {"forward", "backward"}
+    assert {"achieved", "frac", "ms_per_launch", "traffic"} <= set(roof["operators"]["backward"]) and "cpu_baseline" in rec
+
+
+def test_roofline_record_prices_the_metric_itself():
+    """roofline.frac is forward + backward (algorithmic bytes of both operators over both times), the per-operator figures
+    are nested, and hbm_utilisation uses the counter bytes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = 1 << 20
+    r = bench.roofline_record(0.3, 0.5, 1164, 1164, n, traffic_fwd=1.0e9, traffic_bwd=2.0e9, traffic_source="test")
+    assert abs(r["achieved"] - 2328 * n / 0.8e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert r["dominant"] == "backward" and abs(r["operators"]["backward"]["frac"] - 1164 * n / 0.5e-3 / 1e9 / 8000.0) < 1e-12
+    assert r["traffic"] == 3.0e9 and abs(r["hbm_utilisation"] - 3.0e9 / 0.8e-3 / 1e9 / 8000.0) < 1e-12
+    assert r["traffic_source"] == "test"
 
 
 def test_bench_self_launch_eight_ranks_never_touches_the_gpu_in_the_parent():

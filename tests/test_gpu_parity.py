@@ -459,6 +459,28 @@ def test_optional_12_byte_item_stream(dev):
     assert margin <= 5e-6, margin
 
 
+def test_12_byte_item_stream_in_sub_batches(dev):
+    """bwd_item12 with the call split into sub-batches smaller than 2^17 samples (bin_batch_mib): the item format is the
+    CALL's, so every sub-batch's plan must be sized for 12-byte units (round-5 advisor finding: it took the format its own
+    sample count would pick)."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    n = 300_001
+    sizes, first, T, coords, _, go = _problem(dim, res, bw, n, seed=125)
+    tc, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(first).to(dev)
+    ref = oc.backward(coords, go, (T, 2), first, res, bw)
+    _lib.set_option("bwd_item12", 1)
+    _lib.set_option("bin_batch_mib", 64)          # ~100 K samples per sub-batch: below SHACIRA_FX_MIN
+    try:
+        grad = ops.hashgrid_backward(dim, tc, torch.from_numpy(go).to(dev), T, torch.float32, tf, res, bw, 2).cpu().numpy()
+    finally:
+        _lib.set_option("bwd_item12", 0)
+        _lib.set_option("bin_batch_mib", 1536)
+    _assert_grad_close(grad, ref, first, sizes)
+    assert _level_margin(grad, ref, first, sizes) <= 5e-6
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_an_outlier_gradient_does_not_swamp_ordinary_rows(dev, dtype):
     """Heavy-tailed gradients (a loss spike, one high-transmittance ray: NeRF gradients span 10^4 and more across a batch). The
