@@ -369,7 +369,7 @@ __global__ __launch_bounds__((ScatterThreads<DIM, F, FMT>::value)) SHACIRA_SCATT
 }
 
 #ifdef CONSUME_TRACE
-// Instrumented build only (make variant ... EXTRA=-DCONSUME_TRACE; tools/consume_trace.py): per work unit, wave 0's clock
+// Instrumented build only (make variant ... EXTRA=-DCONSUME_TRACE; tools/attic/consume_trace.py): per work unit, wave 0's clock
 // (100 MHz) at the phase boundaries of consume_unit. Never compiled into the shipped library.
 __device__ unsigned long long g_consume_trace[16384 * 8];
 __device__ unsigned int g_consume_trace_n;

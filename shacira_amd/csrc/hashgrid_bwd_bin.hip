@@ -773,7 +773,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         const BinPlan &plan = whole;
         // one level group (S1's level 0): ~512 workgroups measured best; several groups (the all-direct image tables,
         // 128 KiB images = one resident workgroup per CU): 256 in total = one wave of workgroups, no tail
-        // (config B backward 65 vs 77 us, tools/direct_blocks.py)
+        // (config B backward 65 vs 77 us, tools/attic/direct_blocks.py)
         uint32_t bpg = (plan.ngroups > 1 ? 256u : 512u) / plan.ngroups;
         const uint32_t need = (uint32_t)((n + 2047) / 2048);      // at least ~2 samples per thread each
         if (bpg > need) bpg = need;
@@ -986,7 +986,7 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
 }  // namespace shacira
 
 #ifdef CONSUME_TRACE
-// instrumented build only: copies the trace out and clears it (tools/consume_trace.py)
+// instrumented build only: copies the trace out and clears it (tools/attic/consume_trace.py)
 extern "C" __attribute__((visibility("default"))) int shacira_debug_consume_trace(unsigned long long *host, unsigned int cap,
                                                                                    unsigned int *count) {
     unsigned int n = 0;

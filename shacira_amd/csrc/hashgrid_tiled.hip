@@ -462,7 +462,7 @@ bool tiled_supported(int dim, int dtype, const LevelTable &lt, int64_t n) {
     if (lt.feature_dim != 2 && lt.feature_dim != 4) return false;
     if (n < 1 || n >= ((int64_t)1 << 31)) return false;
     if (t_opt == 1 || v == 8) return true;
-    // measured rule (tools/tiled_check.py, tools/lego_fwd_check.py): tables that do not fit an XCD's L2 (the Kodak tables of
+    // measured rule (tools/attic/tiled_check.py, tools/attic/lego_fwd_check.py): tables that do not fit an XCD's L2 (the Kodak tables of
     // configs B / C are L1 / LDS resident: sorting only costs there); 3-D F = 2 batches from 2^18 samples (equal there, -6 %
     // at 320 K, -20 % at 2^20), 3-D F = 4 (nerf_lego.yaml's 24-level table: 16-byte rows) from 80 K (-15 % at 96 K, -35 %
     // at 400 K), 2-D from 192 K (-15 % at 2^18, -40 % at 2^19)

@@ -637,7 +637,7 @@ def fit_nerf(device, steps=300, rays=4096, num_steps=128, seed=0, codebook_bitwi
     `latent=True`: the compressed variant the reference's nerf_lego.yaml trains -- a 3-D LatentGrid (latent_dim 1, SGA
     warm-up with temperature 1.0 until decay_period 0.9, entropy model with one layer, lambda = `entropy_reg`); the
     result then also carries the size estimate and the bytes of the entropy-coded model file. nerf_lego.yaml's shape is
-    feature_dim=4, num_lods=24, max_grid_res=512, hidden_dim=128 (tools/lego_fit.py).
+    feature_dim=4, num_lods=24, max_grid_res=512, hidden_dim=128 (tools/attic/lego_fit.py).
     `ray_pool=P` > 0: the P batches of rays and their target colours are rendered ONCE before the timed loop and the steps
     walk them in order -- the role of the reference's MultiviewDataset (rays + pixels of the training images); with 0 every
     step draws fresh rays and renders their targets from the closed-form scene inside the step (rounds 1-3 protocol).

@@ -59,7 +59,7 @@ def test_wide_decoders_at_nerf_batch_sizes(dims, n):
     """The NeRF decoders (width 64: nerf_hash.yaml, width 128: nerf_lego.yaml) at the batch sizes nerf_lego.yaml runs (4 096
     rays x 100 steps = 409 600 samples) and at 2^20, against the same layers in float64 with the same bad-row accounting as
     the small cases: a handful of samples per million take the other ReLU branch than the fp64 evaluation (that is what the
-    1e-2..9e-2 "max rel grad diff" of profiles/r03_mlp_mfma_util.md was: tools/mlp128_check.py compared with torch's fp32
+    1e-2..9e-2 "max rel grad diff" of profiles/r03_mlp_mfma_util.md was: tools/attic/mlp128_check.py compared with torch's fp32
     layers without dropping those rows); every other row and every weight gradient holds 1e-5."""
     _check_fused_mlp(dims, n, torch.device("cuda:0"))
 

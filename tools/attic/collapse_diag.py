@@ -3,7 +3,7 @@
 the share of hidden units of the decoder MLP that are dead on the whole batch (ReLU output 0 for every pixel), the spread of the
 prediction over the pixels and of the decoded table.   usage: collapse_diag.py <seed> [height width steps]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from shacira_amd import harness
 from shacira_amd.dist import shard_batch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Config C (24 Kodak images batched: N = 9 437 184 lattice samples, 2-D 16-level grids): timing + properties."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from shacira_amd import hip_ops
 def geo(mn, mx, L):

@@ -7,7 +7,7 @@ unit end (flush issued). Prints per-level averages and the busy fraction of the 
 import ctypes
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from shacira_amd import hip_ops, _lib

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """All-direct Kodak tables: backward time (the direct-level kernel runs 256 workgroups in total)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from shacira_amd import hip_ops, _lib
 def geo(mn, mx, L):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Quick on-GPU parity + timing check through the C-ABI (dev tool; the real tests live in tests/)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from shacira_amd import hip_ops, _lib
 from oracle import hashgrid_c as oc

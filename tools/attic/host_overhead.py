@@ -2,7 +2,7 @@
 """Host cost of one forward + backward call pair: batches so small that the GPU is idle between launches (the S1 table,
 N = 2^18 takes the forked large-batch path with all its launches and events but ~0.3 ms of GPU time)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from shacira_amd import hip_ops
 def geo(mn, mx, L):

@@ -5,7 +5,7 @@ import cProfile
 import os
 import pstats
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from shacira_amd import harness
 what = sys.argv[1] if len(sys.argv) > 1 else "image"

@@ -2,7 +2,7 @@
 """Host time inside individual C-ABI calls of an eager image-fit step (perf_counter around the ctypes call).
 usage: launch_cost.py [steps]"""
 import os, sys, time, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from shacira_amd import _lib, harness
 L = _lib.lib()

@@ -2,7 +2,7 @@
 """nerf_lego.yaml-shaped NeRF fit (LatentGrid F=4 x 24 levels, res 16..512, bw 19, decoders of width 128, SGA + entropy
 model): ms/step with the fused width-128 decoders and with the same decoders as torch Linear layers."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from shacira_amd import harness, hip_ops
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PSNR of the nerf_lego-shaped fit over seeds, fused width-128 decoders vs torch layers (is a gap systematic or run noise?)."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from shacira_amd import harness, hip_ops
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 600

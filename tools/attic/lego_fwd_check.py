@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """nerf_lego.yaml grid (3-D, 24 levels, F=4, bw 19): forward, automatic path vs cell-sorted path forced, by batch size."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from shacira_amd import hip_ops, _lib
 def geo(mn, mx, L):

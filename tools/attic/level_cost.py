@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Forward cost of a 16-level grid made of 16 copies of one resolution (dense vs hashed levels). Dev tool."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from shacira_amd import hip_ops, _lib
 def run(dim, res1, bw=19, N=1 << 20, L=16, variant=-1):

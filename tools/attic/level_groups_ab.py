@@ -2,7 +2,7 @@
 """Cost of running the S1 backward as G sequential level groups that could share one item array (workspace diet).
 usage: level_groups_ab.py [workload=S1]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from shacira_amd import hip_ops, _lib
 

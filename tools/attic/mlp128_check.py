@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Width-128 decoders (nerf_lego.yaml): fused MFMA kernels vs the same layers through torch (rocBLAS), fwd + bwd."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn as nn
 from shacira_amd import hip_ops
 from shacira_amd.wisp.models.decoders import BasicDecoder

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel-level timing target for the decoder MLPs (run under rocprofv3 --kernel-trace --stats)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from shacira_amd import hip_ops, _lib
 dev = torch.device("cuda:0")

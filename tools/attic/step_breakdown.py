@@ -2,7 +2,7 @@
 """One workload's training loop for `rocprofv3 --kernel-trace --stats`: prints wall ms/step so that the kernel-time sum of
 the trace can be set against it (host gaps). usage: step_breakdown.py nerf|nerf_pool|nerf_graphed|image|image_graphed [steps]"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from shacira_amd import harness
 what = sys.argv[1]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cell-sorted ("tiled") forward vs the other variants and the oracle: bit-exactness + timing over batch sizes."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from shacira_amd import hip_ops, _lib
 from oracle import hashgrid_c as oc

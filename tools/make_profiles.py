@@ -27,7 +27,7 @@ stats_line = json.load(open(os.path.join(src, "stats_line.json")))
 stats = max(glob.glob(os.path.join(src, "stats/*/*kernel_stats.csv")), key=os.path.getmtime)   # newest run
 shutil.copy(stats, os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
-fwd_k = ("hashgrid_fwd", "untranspose_feats", "ctx_")
+fwd_k = ("hashgrid_fwd", "untranspose_feats", "psort_")
 with open(os.path.join(out, f"{tag}_bench_rocprof_summary.md"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline "
             "--psnr-steps 0 --nerf-steps 0 --no-secondary\n\n")
@@ -47,11 +47,12 @@ with open(os.path.join(out, f"{tag}_bench_rocprof_summary.md"), "w") as f:
             tf += per_step
         elif "shacira::" in r["Name"] or "fillBuffer" in r["Name"]:
             tb += per_step
-    f.write(f"\nforward operator = sample sort (ctx_count + 2 scans + ctx_scatter) + hashgrid_fwd_level_pair (fine levels) + "
-            f"hashgrid_fwd_rows (coarse levels + row assembly) = {tf:.1f} us of kernel time; backward "
-            f"operator = zero_words + zero_unowned_rows + front16 (16-byte transpose + bucket counts) + bin_scan_buckets + "
-            f"zero_odd_buckets + bin_scatter + bin_consume = {tb:.1f} us of kernel time per step, all on the caller's stream "
-            f"(S1 has no LDS-resident level left at this batch size: level 0 travels as compact items; DESIGN.md 4.3).\n")
+    f.write(f"\nforward operator = sample sort (psort_count + psort_partition + psort_local: the batch's plan) + "
+            f"hashgrid_fwd_level_pair (fine levels) + hashgrid_fwd_rows (coarse levels + row assembly) = {tf:.1f} us of kernel "
+            f"time; backward operator (planned: sorted order) = zero_unowned_rows + front16<SORTED> (gradient rows gathered in plan "
+            f"order, 16-byte transpose + bucket counts) + bin_scan_buckets + bin_scatter + bin_consume with brick_accumulate "
+            f"(dense coarse levels) on the side stream beside it = {tb:.1f} us of kernel time per step -- a SUM of durations: the "
+            f"brick pass overlaps the consume pass, so the operator's wall time is shorter (DESIGN.md 4.3).\n")
 
 def counter(dirname):
     f = max(glob.glob(os.path.join(src, dirname, "*/*counter_collection.csv")), key=os.path.getmtime)
@@ -63,22 +64,26 @@ def counter(dirname):
     return acc, calls
 
 ops = {}
-for op, key in (("fwd", "forward"), ("bwd", "backward")):
-    fe, calls = counter(f"pmc_{op}_FETCH_SIZE")
-    wr, _ = counter(f"pmc_{op}_WRITE_SIZE")
-    iters = 3
+fe, calls = counter("pmc_pair_FETCH_SIZE")
+wr, _ = counter("pmc_pair_WRITE_SIZE")
+iters = 3
+for key in ("forward", "backward"):
     kern = {}
     rd = wt = 0.0
     for name in fe:
-        if "copyBuffer" in name or "at::native" in name or "rocprim" in name:
+        if "shacira::" not in name:
+            continue
+        is_fwd = any(k in name for k in fwd_k)
+        if is_fwd != (key == "forward"):
             continue
         kern[name] = {"FETCH_SIZE_KiB_raw": fe[name] / iters, "WRITE_SIZE_KiB_raw": wr.get(name, 0.0) / iters}
         rd += 2 * fe[name] / iters * 1024
         wt += wr.get(name, 0.0) / iters * 1024
     ops[key] = {"read_bytes_corrected": rd, "write_bytes": wt, "hbm_bytes_per_launch": rd + wt, "kernels": kern}
 json.dump({"kernel_source_hash": kernel_source_hash(),
-           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over `python3 tools/fwd_only.py "
-                   "{fwd|bwd} -1 3 3` (workload S1: 3-D L16 F2 bw19, N=2^20; 3 calls, per-call averages). Counters are in "
+           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over `python3 tools/plan_prof.py 3` "
+                   "(the PLANNED operator pair of bench.py's step on workload S1: 3-D L16 F2 bw19, N=2^20; 3 calls, per-call "
+                   "averages; kernels attributed to forward / backward by name). Counters are in "
                    "KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section), so read "
                    "bytes = 2*FETCH_SIZE*1024 (verified: the transposes read 128 MiB and report 64 MiB); WRITE_SIZE is "
                    "exact.",
@@ -137,12 +142,12 @@ print("wrote", f"{tag}_fwd_counters.md")
 # backward unit counters (round 3)
 with open(os.path.join(out, f"{tag}_bwd_counters.md"), "w") as f:
     f.write(f"# Backward kernels on S1 (N = 2^20), unit counters per launch ({tag}, source hash {kernel_source_hash()})\n\n"
-            "`rocprofv3 --pmc <group> --kernel-trace -- python3 tools/fwd_only.py bwd -1 3 3`, one pass per counter group "
+            "`rocprofv3 --pmc <group> --kernel-trace -- python3 tools/plan_prof.py 3` (the planned pair; backward kernels listed), one pass per counter group "
             "(SQ / LDS / TCC), averages over 3 calls.\n\n")
     merged = defaultdict(dict)
     for grp in ("sq", "lds", "tcc"):
         for k, d in ctr(f"ctr_bwd_{grp}").items():
-            if "shacira::" in k:
+            if "shacira::" in k and not any(fk in k for fk in fwd_k):
                 merged[k].update(d)
     for k, d in merged.items():
         f.write(f"### `{k}`\n\n| counter | per launch |\n|---|---|\n")
