@@ -210,10 +210,23 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(LevelTa
         float4 rec[SPT];
         bool live[SPT];
         uint32_t pos[SPT];
+        // Slot k of the unit takes sample (k & 7) * S + (k >> 3), S = ceil(samples / 8): the eight neighbouring lanes of an LDS
+        // atomic come from eight distant stretches of the unit (the plan orders a block's records by octant, so neighbours in
+        // memory sit in the same cells and would pile onto the same image rows); a bijection onto the unit's samples.
+#ifndef SHACIRA_BRICK_INTERLEAVE
+#define SHACIRA_BRICK_INTERLEAVE 1
+#endif
+        const uint32_t nloc = u1 - u0, S8 = (nloc + 7u) >> 3;
 #pragma unroll
         for (int u = 0; u < SPT; ++u) {
-            const uint32_t i = u0 + (uint32_t)u * kBrickThreads + threadIdx.x;
+            const uint32_t k = (uint32_t)u * kBrickThreads + threadIdx.x;
+            uint32_t i = u0 + k;
             live[u] = i < u1;
+            if (SHACIRA_BRICK_INTERLEAVE) {
+                const uint32_t kk = (k & 7u) * S8 + (k >> 3);
+                live[u] = (k >> 3) < S8 && kk < nloc;
+                i = u0 + kk;
+            }
             pos[u] = live[u] ? i : u1 - 1u;
             rec[u] = sorted4[pos[u]];
         }

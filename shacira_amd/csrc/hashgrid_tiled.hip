@@ -118,15 +118,18 @@ static void make_sort_plan(int dim, int64_t n, TilePlan &tp) {
 
 static void make_tile_plan(int dim, const LevelTable &lt, int64_t n, TilePlan &tp) {
     make_sort_plan(dim, n, tp);
-    // coarse levels (rows kernel) vs fine levels (level-per-XCD kernel), measured (tools/tiled_sweep.py): 3-D -- the levels
-    // whose cell count does not exceed ~4x the batch keep enough reuse inside a block (S1: 8 or 9 of 16 are equally good,
-    // 12 costs +30 %); 2-D -- every level (lines are shared along x at any resolution: 0.140 ms against 0.157 ms with one
-    // fine level and 0.235 ms for the unsorted kernels on 2^20 samples)
+    // coarse levels (rows kernel) vs fine levels (level-per-XCD kernel). 3-D: the levels whose cell count does not exceed ~32x
+    // the batch. Round 6 (tools/fwd_lc_ab.py, profiles/r06_experiments.md 6): with the records ordered by sub-cell inside a block
+    // the rows kernel takes a level for less than the fine kernel's staging round trip costs, until the hashed tables of too
+    // many levels compete for the XCD's L2 -- best split S1 (2^20): 10 levels (0.299 -> 0.282 ms; 12: 0.323), 2^19: 9, 2^18: 8,
+    // nerf_lego.yaml's F = 4 table at 409 600 samples: 18 of 24 (0.300 -> 0.265 ms), at 102 400: 15-16; the last level taken
+    // has 14-25x the batch's cells, the first one left 35-64x. (Rounds 2-5, block order only: 4x the batch.)
+    // 2-D: every level (lines are shared along x at any resolution).
     int lc = 0;
     while (lc < lt.num_lods) {
         double cells = 1.0;
         for (int a = 0; a < dim; ++a) cells *= (double)lt.res[lc];
-        if (dim == 3 && cells > 4.0 * (double)n) break;
+        if (dim == 3 && cells > 32.0 * (double)n) break;
         ++lc;
     }
     const int lc_opt = opt().tiled_lc_fwd;
@@ -410,7 +413,33 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp,
     };
     if (rounds <= 1u) {
         // the usual case: every record of the bin in registers -- counted, ranked (the returning LDS atomic of the count IS the
-        // rank) and written to its block's run
+        // rank) and written to its block's run. Inside a block the records are ordered by sub-cell of the block (SHACIRA_SORT_SUB
+        // bits per axis; the key is block * cells + cell, block_start still addresses whole blocks): consecutive samples then
+        // share a box of 1/2 or 1/4 of the block's side -- more lanes of one gather instruction fall into one table line on the
+        // levels around the batch's density, at no extra pass.
+#ifndef SHACIRA_SORT_SUB
+#define SHACIRA_SORT_SUB 2          // bits per axis: 0 = block order only, 1 = octants, 2 = 4 x 4 x 4 cells of a block
+#endif
+        constexpr int kSubBits = SHACIRA_SORT_SUB;
+        constexpr int kSub = 1 << (kSubBits * DIM);
+        constexpr int kKeys = kBpc * kSub;                 // <= 16 * 64
+        __shared__ uint32_t s_tot8[kKeys], s_off8[kKeys + 1], s_wtot[16];
+        for (uint32_t k = threadIdx.x; k < (uint32_t)kKeys; k += kSortThreadsS) s_tot8[k] = 0;
+        __syncthreads();
+        auto sub_of = [&](const float4 &r) -> uint32_t {
+            if constexpr (kSub == 1) return 0u;
+            uint32_t sb = 0;
+            const float cc[3] = {r.x, r.y, r.z};
+#pragma unroll
+            for (int a = 0; a < DIM; ++a) {
+                const float u = (cc[a] + 1.0f) * (0.5f * (float)tp.nb[a]);
+                const float fr = u - floorf(u);            // (NaN / out-of-range coordinates: any cell is as good)
+                uint32_t q = (uint32_t)(int)(fr * (float)(1 << kSubBits));
+                q = q < (1u << kSubBits) ? q : (1u << kSubBits) - 1u;
+                sb |= q << (a * kSubBits);
+            }
+            return sb;
+        };
         float4 r[R];
         uint32_t j[R], rk[R];
 #pragma unroll
@@ -421,13 +450,36 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp,
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             const bool live = lo + (uint32_t)u * kSortThreadsS + threadIdx.x < hi;
-            j[u] = live ? key_of(r[u]) : 0u;
-            rk[u] = wave_rank_add(s_tot, j[u], live, lane);
+            j[u] = live ? key_of(r[u]) * (uint32_t)kSub + sub_of(r[u]) : 0u;
+            rk[u] = wave_rank_add(s_tot8, j[u], live, lane);
         }
-        finish_offsets();
+        __syncthreads();
+        // exclusive scan of the counts (<= 1 024: one per thread, wave scans + wave totals)
+        {
+            const uint32_t cnt = threadIdx.x < (uint32_t)kKeys ? s_tot8[threadIdx.x] : 0u;
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t nbr = __shfl_up(incl, off, 64);
+                if (lane >= (uint32_t)off) incl += nbr;
+            }
+            if (lane == 63) s_wtot[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t wb = 0;
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wb += s_wtot[w];
+            if (threadIdx.x < (uint32_t)kKeys) s_off8[threadIdx.x] = wb + incl - cnt;
+        }
+        __syncthreads();
+        if (threadIdx.x < bpc && key0 + threadIdx.x < tp.num_blocks) block_start[key0 + threadIdx.x] = lo + s_off8[threadIdx.x * kSub];
+        if (bin + 1u == tp.num_coarse && threadIdx.x == 0) block_start[tp.num_blocks] = hi;
+        if (bin == 0 && threadIdx.x == 0) {
+            header[0] = kCtxMagic;
+            header[1] = tp.num_blocks;
+            header[2] = n;
+        }
 #pragma unroll
         for (int u = 0; u < R; ++u)
-            if (lo + (uint32_t)u * kSortThreadsS + threadIdx.x < hi) sorted4[lo + s_off[j[u]] + rk[u]] = r[u];
+            if (lo + (uint32_t)u * kSortThreadsS + threadIdx.x < hi) sorted4[lo + s_off8[j[u]] + rk[u]] = r[u];
         return;
     }
     // an over-full bin (a batch concentrated in a few blocks): every workgroup of the bin counts all of it, then places
