@@ -423,7 +423,8 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp,
         constexpr int kSubBits = SHACIRA_SORT_SUB;
         constexpr int kSub = 1 << (kSubBits * DIM);
         constexpr int kKeys = kBpc * kSub;                 // <= 16 * 64
-        __shared__ uint32_t s_tot8[kKeys], s_off8[kKeys + 1], s_wtot[16];
+        __shared__ uint32_t s_tot8[kKeys], s_wtot[16];
+        uint32_t *s_off8 = s_tot8;                         // the scan below turns the counts into offsets in place
         for (uint32_t k = threadIdx.x; k < (uint32_t)kKeys; k += kSortThreadsS) s_tot8[k] = 0;
         __syncthreads();
         auto sub_of = [&](const float4 &r) -> uint32_t {
@@ -454,10 +455,18 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp,
             rk[u] = wave_rank_add(s_tot8, j[u], live, lane);
         }
         __syncthreads();
-        // exclusive scan of the counts (<= 1 024: one per thread, wave scans + wave totals)
+        // exclusive scan of the counts, IN PLACE (a thread reads and rewrites only its own KPT consecutive keys; the ranks are
+        // in registers already): wave scans + wave totals
         {
-            const uint32_t cnt = threadIdx.x < (uint32_t)kKeys ? s_tot8[threadIdx.x] : 0u;
-            uint32_t incl = cnt;
+            constexpr int KPT = (kKeys + kSortThreadsS - 1) / kSortThreadsS;
+            uint32_t cnt[KPT], sum = 0;
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const uint32_t k = threadIdx.x * KPT + q;
+                cnt[q] = k < (uint32_t)kKeys ? s_tot8[k] : 0u;
+                sum += cnt[q];
+            }
+            uint32_t incl = sum;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t nbr = __shfl_up(incl, off, 64);
@@ -465,9 +474,14 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp,
             }
             if (lane == 63) s_wtot[threadIdx.x >> 6] = incl;
             __syncthreads();
-            uint32_t wb = 0;
-            for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wb += s_wtot[w];
-            if (threadIdx.x < (uint32_t)kKeys) s_off8[threadIdx.x] = wb + incl - cnt;
+            uint32_t run = incl - sum;
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) run += s_wtot[w];
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                const uint32_t k = threadIdx.x * KPT + q;
+                if (k < (uint32_t)kKeys) s_off8[k] = run;
+                run += cnt[q];
+            }
         }
         __syncthreads();
         if (threadIdx.x < bpc && key0 + threadIdx.x < tp.num_blocks) block_start[key0 + threadIdx.x] = lo + s_off8[threadIdx.x * kSub];
