@@ -14,7 +14,9 @@ def geo(mn, mx, L):
 
 
 W = {"S1": (3, 19, 1 << 20, 2048, 16, 2), "S1h": (3, 19, 1 << 19, 2048, 16, 2), "S1q": (3, 19, 1 << 18, 2048, 16, 2),
-     "S1x": (3, 19, 3 << 19, 2048, 16, 2), "LEGO": (3, 19, 409600, 512, 24, 4), "LEGOq": (3, 19, 102400, 512, 24, 4)}
+     "S1x": (3, 19, 3 << 19, 2048, 16, 2), "S1e": (3, 19, 1 << 17, 2048, 16, 2), "S1s": (3, 19, 1 << 16, 2048, 16, 2),
+     "S1m": (3, 19, 3 << 16, 2048, 16, 2), "LEGOs": (3, 19, 51200, 512, 24, 4), "LEGOt": (3, 19, 25600, 512, 24, 4),
+     "S2": (2, 19, 1 << 20, 2048, 16, 2), "S2q": (2, 19, 1 << 18, 2048, 16, 2), "S2e": (2, 19, 1 << 17, 2048, 16, 2), "LEGO": (3, 19, 409600, 512, 24, 4), "LEGOq": (3, 19, 102400, 512, 24, 4)}
 name = os.environ.get("WORKLOAD", "S1")
 dim, bw, N, mx, L, F = W[name]
 DT = torch.float16 if os.environ.get("R3_DTYPE") == "f16" else torch.float32

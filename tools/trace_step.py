@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Per-step kernel timeline from a rocprofv3 kernel trace: wall span of the last step's backward kernels and overlaps.
-usage: trace_step.py <kernel_trace.csv>"""
+usage: trace_step.py <kernel_trace.csv> [name of the step's first kernel]"""
 import csv
 import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last occurrence of the sort's first kernel marks the last step
-starts = [i for i, r in enumerate(rows) if 'psort_count' in r['Kernel_Name']]
+first_kernel = sys.argv[2] if len(sys.argv) > 2 else 'psort_count'
+starts = [i for i, r in enumerate(rows) if first_kernel in r['Kernel_Name']]
 last = rows[starts[-2]:starts[-1]] if len(starts) > 1 else rows[starts[-1]:]
 t0 = int(last[0]['Start_Timestamp'])
 for r in last:
