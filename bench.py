@@ -775,7 +775,9 @@ def main():
         bwd_floor_ms = bwd_bytes / (measured["copy_read+write"] * 1e9) * 1e3
         bound_model = {
             "forward": {"resource": "L2 -> L1 line path of the CUs: 64 B/clk/CU = 2 clk per 128-byte line, 256 CUs at 2.4 GHz",
-                        "what": f"{n_fine} fine levels x {n_local} samples x {2 ** (dim - 1)} lines (one per x-pair of corners)",
+                        "what": (f"{n_fine} levels with more than 4 cells per sample (no two samples share a table line in any order; "
+                                 f"the kernel split is another matter: the rows kernel takes levels up to 32 cells per sample) x "
+                                 f"{n_local} samples x {2 ** (dim - 1)} lines (one per x-pair of corners)"),
                         "ms": fwd_floor_ms, "operator_ms": ms_fwd,
                         "frac_of_floor": (fwd_floor_ms / ms_fwd) if ms_fwd > 0 else None},
             "backward": {"resource": "copy rate measured in this run (shacira_stream_probe, read + write)",
