@@ -26,7 +26,7 @@ static OptionSlot g_slots[] = {
     {"bwd_persistent", &Options::bwd_persistent, 0, 1, {1}},
     {"bwd_fork", &Options::bwd_fork, 0, 1, {1}},
     {"bwd_run_pad", &Options::bwd_run_pad, 0, 1, {1}},
-    {"bwd_item12", &Options::bwd_item12, 0, 1, {0}},
+    {"bwd_item12", &Options::bwd_item12, -1, 1, {-1}},
     {"bin_acc_kib", &Options::bin_acc_kib, 0, 128, {0}},
     {"bin_batch_mib", &Options::bin_batch_mib, 1, 1 << 20, {1536}},
     {"tiled", &Options::tiled, -1, 1, {-1}},
@@ -42,6 +42,7 @@ const Options &opt() { return tl_options; }
 void options_snapshot() {
     for (OptionSlot &sl : g_slots) tl_options.*(sl.field) = sl.value.load(std::memory_order_relaxed);
 }
+void options_resolve_item12(int value) { tl_options.bwd_item12 = value; }
 static bool option_value_ok(const OptionSlot &sl, int v) {
     if (v < sl.lo || v > sl.hi) return false;
     if (!std::strcmp(sl.name, "fwd_variant")) return v == -1 || v == 0 || v == 3 || v == 6 || v == 8 || v == 9;

@@ -386,7 +386,9 @@ static inline bool half_items(int dtype, const LevelTable &lt) {
 // units (fp32 tables, 3-D, F = 2, batches that accumulate in fixed-point images; option "bwd_item12")
 static inline int item_format(int dim, int dtype, const LevelTable &lt, int64_t n) {
     if (half_items(dtype, lt)) return 1;
-    if (dim == 3 && lt.feature_dim == 2 && dtype == SHACIRA_F32 && n >= SHACIRA_FX_MIN && opt().bwd_item12 != 0) return 2;
+    // (bwd_item12 = -1, the automatic setting, is resolved per call by bin_backward before anything is sized; a workspace query
+    // sees -1 and sizes for the 16-byte stream, the larger of the two)
+    if (dim == 3 && lt.feature_dim == 2 && dtype == SHACIRA_F32 && n >= SHACIRA_FX_MIN && opt().bwd_item12 == 1) return 2;
     return 0;
 }
 static inline size_t item_unit_bytes(int fmt, const LevelTable &lt) {
@@ -588,13 +590,15 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     if constexpr (DIM == 3) {
         // (sorted mode rides on the fused 16-byte front kernel: rows of whole 16-byte vectors, 16-byte aligned input)
         const int kvec0 = (int)(16 / ((dtype == SHACIRA_F32 ? 4 : 2) * F));
-        // Measured rule (option bwd_brick = -1; tools/brick_cfg_ab.py, profiles/r06_experiments.md): the pass pays where the
-        // item stream is the bound it relieves -- fp32 item streams of F = 2 tables from ~3/4 M samples (S1 at 2^20: backward
-        // 0.481 -> 0.443 ms; 2^19: 0.264 -> 0.273, 2^18: equal; half-precision streams, whose items are half the bytes: S1
-        // 0.413 -> 0.445; nerf_lego.yaml's F = 4 table, 32 LDS atomics per sample and level: 0.593 -> 0.594). bwd_brick = 1
-        // takes it wherever the shape allows.
+        // Measured rule (option bwd_brick = -1; tools/brick_cfg_ab.py, profiles/r06_experiments.md 3 + 7): fp32 item streams of
+        // F = 2 tables, at every batch size that has a plan (the forward sorts from 2^18 samples) -- with the 12-byte item units
+        // the pass brings along, S1 backward at 2^20 / 2^19 / 2^18 samples: 0.468 -> 0.417 / 0.270 -> 0.252 / 0.166 -> 0.161 ms.
+        // Not taken: half-precision item streams (items are half the bytes already: S1 fp16 0.420 -> 0.438) and F = 4
+        // (nerf_lego.yaml's table: 32 LDS atomics per sample and level, six of its eleven dense levels do not fit the images
+        // and would stay compact items in sorted order: 0.600 -> 0.607, fp16 0.517 -> 0.556). bwd_brick = 1 takes it wherever
+        // the shape allows.
         const int bopt = opt().bwd_brick;
-        const bool wanted = bopt == 1 || (bopt < 0 && F == 2 && dtype == SHACIRA_F32 && n >= ((int64_t)3 << 18));
+        const bool wanted = bopt == 1 || (bopt < 0 && F == 2 && dtype == SHACIRA_F32);
         if (sb != nullptr && wanted && !multi && !stage_all && !staged && zero_table &&
             n >= SHACIRA_FX_MIN && n * L < ((int64_t)1 << 31) && !table_all_direct(DIM, dtype, lt, n) && (L % kvec0) == 0 &&
             (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0) {
@@ -920,6 +924,16 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
                         void *half_table, bool *converted, const SortedBatch *sb) {
     if (converted != nullptr) *converted = false;
     __half *ht = (dtype == SHACIRA_F16) ? static_cast<__half *>(half_table) : nullptr;
+    // 12-byte item units, automatic setting: with the brick pass, i.e. on planned calls of the shapes its rule takes (run_bin). In
+    // sorted order with the dense levels out of the item stream the consume pass has the instruction slots the unpacking costs
+    // (S1 backward 0.440 -> 0.417 ms; on the plain path the format returns 1-3 %; profiles/r06_experiments.md 7). Decided here,
+    // before the workspace is carved: every plan and pass of the call then sees one format.
+    if (opt().bwd_item12 < 0) {
+        const bool brick_shape = sb != nullptr && dim == 3 && lt.feature_dim == 2 && dtype == SHACIRA_F32 &&
+                                 lt.level_begin == 0 && lt.level_end == lt.num_lods && lt.stage_flags == 0 && zero_table &&
+                                 opt().bwd_brick != 0;
+        options_resolve_item12(brick_shape ? 1 : 0);
+    }
     const BinWorkspace w = carve(dim, dtype, lt, n, workspace);
     static PerDeviceOnce once;  // kernels that use more than 64 KiB of dynamic LDS must opt in once per device
     const hipError_t attr_err = once.run([]() -> hipError_t {

@@ -176,7 +176,8 @@ struct Options {
     int bwd_selective_zero = 1;   // zero only the rows the consume pass does not overwrite (0: the whole table)
     int bwd_persistent = 1;       // consume pass: persistent workgroups fetching units from a counter
     int bwd_fork = 1;             // table zeroing + direct levels on a side stream when the batch is large
-    int bwd_item12 = 0;           // 12-byte item units for fp32 tables (3-D, F = 2, batches >= 2^17): 0 keeps the 16-byte stream
+    int bwd_item12 = -1;          // 12-byte item units for fp32 tables (3-D, F = 2, batches >= 2^17): 1 always, 0 never (the 16-byte
+                                  // stream), -1 = with the brick pass (planned calls in sorted order: the one place they pay)
     int bwd_run_pad = 1;          // scatter pass: (tile, bucket) runs reserved in whole 64-byte pieces (SHACIRA_RUN_ALIGN; large batches:
                                   // 4 units of 16 bytes, 16 units of 12 bytes = 192 bytes; the 8-byte half-precision units are not padded)
     int bin_acc_kib = 0;          // LDS accumulator image per consumer workgroup: 64, 128, 0 = by batch size
@@ -191,5 +192,6 @@ struct Options {
 };
 const Options &opt();             // the calling thread's snapshot
 void options_snapshot();          // taken at every extern "C" entry point that reads options
+void options_resolve_item12(int value);   // a call's decision for the automatic setting (-1), into the calling thread's snapshot
 
 }  // namespace shacira

@@ -118,6 +118,6 @@ def test_backward_workspace_is_sized_by_the_selected_path():
     try:
         s1 = query(dim, res, bw, n)
     finally:
-        _lib.set_option("bwd_item12", 0)
+        _lib.set_option("bwd_item12", -1)
     slots, pads = n * (5 * 2 + 11 * 4) * 12, 1024 * 733 * 15 * 12
     assert staged + slots <= s1 <= staged + slots + pads + (48 << 20), s1  # 0.98 GB

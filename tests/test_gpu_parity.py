@@ -452,7 +452,7 @@ def test_optional_12_byte_item_stream(dev):
     try:
         grad = ops.hashgrid_backward(dim, tc, torch.from_numpy(go).to(dev), T, torch.float32, tf, res, bw, 2).cpu().numpy()
     finally:
-        _lib.set_option("bwd_item12", 0)
+        _lib.set_option("bwd_item12", -1)
     _assert_grad_close(grad, ref, first, sizes)
     margin = _level_margin(grad, ref, first, sizes)
     print(f"gradient margin, 12-byte items: {margin:.2e} of the level maximum (bar 1e-5)")
@@ -475,7 +475,7 @@ def test_12_byte_item_stream_in_sub_batches(dev):
     try:
         grad = ops.hashgrid_backward(dim, tc, torch.from_numpy(go).to(dev), T, torch.float32, tf, res, bw, 2).cpu().numpy()
     finally:
-        _lib.set_option("bwd_item12", 0)
+        _lib.set_option("bwd_item12", -1)
         _lib.set_option("bin_batch_mib", 1536)
     _assert_grad_close(grad, ref, first, sizes)
     assert _level_margin(grad, ref, first, sizes) <= 5e-6

@@ -81,10 +81,12 @@ def test_planned_forward_and_backward_against_the_oracle(dev, n):
 
 @pytest.mark.parametrize("opts", [{"bwd_brick_fork": 0}, {"bwd_brick_fork": 1}, {"bwd_brick_fork": 2, "bwd_brick_span": 1},
                                   {"bwd_brick_span": 3}, {"bwd_brick_lo": 2, "bwd_brick_hi": 7, "bwd_brick_fork": 0},
-                                  {"bwd_brick_lo": 5, "bwd_brick_hi": 6}, {"bwd_brick": 0}])
+                                  {"bwd_brick_lo": 5, "bwd_brick_hi": 6}, {"bwd_brick": 0}, {"bwd_item12": 0},
+                                  {"bwd_item12": 1, "bwd_brick_fork": 0}])
 def test_brick_pass_placements_and_level_ranges(dev, opts):
     """Every placement of the brick pass (last on the stream, beside the scatter / consume pass), unit widths, explicit level
-    ranges incl. hashed levels, and the plan given but the brick pass switched off: same gradient, within the bar."""
+    ranges incl. hashed levels, the plan given but the brick pass switched off, and the item stream in 16-byte units (the
+    planned path's default is the 12-byte stream): same gradient, within the bar."""
     from shacira_amd import _lib
     ops = _ops()
     dim, res, bw = CONFIGS["D"]

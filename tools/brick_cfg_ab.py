@@ -30,16 +30,18 @@ go = torch.randn(N, L * F, generator=g).cuda().to(DT)
 table = (torch.randn(T, F, generator=g) * 0.01).cuda().to(DT)
 plan = hip_ops.hashgrid_plan_buffer(dim, coords, table, res, bw)
 hip_ops.hashgrid_interpolate_cuda(coords, table, first, res, bw, plan=plan)
-DEFAULTS = {"bwd_brick": -1, "bwd_brick_lo": -1, "bwd_brick_hi": -1, "bwd_brick_fork": 0, "bwd_brick_span": 0}
+DEFAULTS = {"bwd_brick": -1, "bwd_brick_lo": -1, "bwd_brick_hi": -1, "bwd_brick_fork": 2, "bwd_brick_span": 0, "bwd_item12": -1}
 
 
 def run(optset, it=40):
     for k, v in DEFAULTS.items():
         _lib.set_option(k, v)
     use_plan = optset != "plain"
+    saved = []
     if use_plan and optset != "-":
         for kv in optset.split(","):
             k, v = kv.split("=")
+            saved.append((k, _lib.get_option(k)))
             _lib.set_option(k, int(v))
     fn = lambda: hip_ops.hashgrid_backward(dim, coords, go, T, DT, first, res, bw, F, plan=plan if use_plan else None)
     for _ in range(3):
@@ -51,6 +53,8 @@ def run(optset, it=40):
         fn()
     b.record()
     torch.cuda.synchronize()
+    for k, v in saved:
+        _lib.set_option(k, v)
     return a.elapsed_time(b) / it
 
 
