@@ -33,7 +33,7 @@ constexpr int kBrickMaxLevels = 6;
 #endif
 constexpr int kBrickThreads = SHACIRA_BRICK_THREADS;
 constexpr int kBrickUnit = SHACIRA_BRICK_UNIT;     // samples per unit (one zero / accumulate / flush round of a workgroup)
-constexpr int kBrickSplit = SHACIRA_BRICK_SPLIT;   // workgroups that share an over-full block (grid.y)
+constexpr int kBrickSplit = SHACIRA_BRICK_SPLIT;   // (unused since the unit list; kept for the A/B builds' command lines)
 constexpr double kBrickSlack = 1e-3;               // cells: the block rule (fp32) and the cell rule (fp64 -> fp32) agree to ~1e-5
 
 struct BrickLevel {
@@ -182,30 +182,81 @@ __device__ __forceinline__ void brick_direct_add(const BrickLevel &b, uint32_t m
     }
 }
 
+// The pass's work list: one unit = up to kBrickUnit consecutive records of one GROUP (`span` x-adjacent blocks). One small
+// workgroup writes it from the plan's block offsets, so that a batch concentrated in few blocks becomes many units on many
+// workgroups instead of a loop inside a few (round 6: with grid.y = 4 workgroups per group a 2^20-sample batch inside one block
+// took 4.4 ms, tools/skew_check.py). units[u] = {first record, last record + 1, group, 0}; units_count[0] = their number.
+constexpr int kBrickUnitThreads = 1024;
+__global__ __launch_bounds__(kBrickUnitThreads) void brick_units_kernel(BrickPlan bp, const uint32_t *__restrict__ block_start,
+                                                                        uint4 *__restrict__ units,
+                                                                        uint32_t *__restrict__ units_count) {
+    constexpr int GPT = 4;                                     // groups per thread (<= 4 096 groups)
+    __shared__ uint32_t s_wave[kBrickUnitThreads / 64];
+    const uint32_t nbx = (uint32_t)bp.nb[0];
+    const uint32_t groups = bp.groups_x * (uint32_t)(bp.nb[1] * bp.nb[2]);
+    uint32_t lo[GPT], hi[GPT], nu[GPT], sum = 0;
+#pragma unroll
+    for (int q = 0; q < GPT; ++q) {
+        const uint32_t g = threadIdx.x * GPT + q;
+        lo[q] = hi[q] = nu[q] = 0;
+        if (g < groups) {
+            const uint32_t gx = g % bp.groups_x, gyz = g / bp.groups_x;
+            const uint32_t qx = gx * bp.span;
+            const uint32_t blk0 = qx + nbx * gyz;
+            const uint32_t blk1 = (qx + bp.span < nbx) ? blk0 + bp.span : nbx * (gyz + 1u);
+            lo[q] = block_start[blk0];
+            hi[q] = block_start[blk1];
+            nu[q] = (hi[q] - lo[q] + (uint32_t)kBrickUnit - 1u) / (uint32_t)kBrickUnit;
+        }
+        sum += nu[q];
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t nbr = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += nbr;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t w = 0; w < wave; ++w) run += s_wave[w];
+#pragma unroll
+    for (int q = 0; q < GPT; ++q) {
+        const uint32_t g = threadIdx.x * GPT + q;
+        for (uint32_t k = 0; k < nu[q]; ++k) {
+            const uint32_t u0 = lo[q] + k * (uint32_t)kBrickUnit;
+            const uint32_t u1 = (u0 + (uint32_t)kBrickUnit < hi[q]) ? u0 + (uint32_t)kBrickUnit : hi[q];
+            units[run + k] = make_uint4(u0, u1, g, 0u);
+        }
+        run += nu[q];
+    }
+    if (threadIdx.x == kBrickUnitThreads - 1) units_count[0] = run;
+}
+
 // gT: the transposed gradients [L][gpitch][F] fp32 in SORTED order (front16_kernel<.., SORTED>): sample i of the sorted batch
 template <int F>
 __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(LevelTable lt, BrickPlan bp,
                                                                          const int32_t *__restrict__ first_idx,
                                                                          const float4 *__restrict__ sorted4,
-                                                                         const uint32_t *__restrict__ block_start,
+                                                                         const uint4 *__restrict__ units,
+                                                                         const uint32_t *__restrict__ units_count,
                                                                          const float *__restrict__ gT, int64_t gpitch,
                                                                          float *__restrict__ acc,
                                                                          const uint32_t *__restrict__ gmax, int headroom) {
     extern __shared__ double s_img[];                 // [rows_total][F]: 64-bit fixed point (or fp64)
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_img);
-    // the unit's box: `span` consecutive blocks along x at (qy, qz); block ids are x-fastest, so its records are contiguous
-    const uint32_t nbx = (uint32_t)bp.nb[0], nby = (uint32_t)bp.nb[1];
-    const uint32_t gx = blockIdx.x % bp.groups_x, gyz = blockIdx.x / bp.groups_x;
+    // the unit (brick_units_kernel): up to kBrickUnit records of one group = `span` consecutive blocks along x at (qy, qz)
+    if (blockIdx.x >= units_count[0]) return;
+    const uint4 unit = units[blockIdx.x];
+    const uint32_t nby = (uint32_t)bp.nb[1];
+    const uint32_t gx = unit.z % bp.groups_x, gyz = unit.z / bp.groups_x;
     const int32_t qx = (int32_t)(gx * bp.span), qy = (int32_t)(gyz % nby), qz = (int32_t)(gyz / nby);
-    const uint32_t blk0 = (uint32_t)qx + nbx * gyz;
-    const uint32_t blk1 = (qx + (int32_t)bp.span < (int32_t)nbx) ? blk0 + bp.span : nbx * (gyz + 1u);
-    const uint32_t b_lo = block_start[blk0], b_hi = block_start[blk1];
-    if (b_lo + blockIdx.y * (uint32_t)kBrickUnit >= b_hi) return;
     const int rot = (int)(threadIdx.x & (F - 1));
     const int rotc = (int)((threadIdx.x >> 1) & 7u);
     constexpr int SPT = kBrickUnit / kBrickThreads;   // records a thread keeps per unit
-    for (uint32_t u0 = b_lo + blockIdx.y * (uint32_t)kBrickUnit; u0 < b_hi; u0 += (uint32_t)(kBrickUnit * kBrickSplit)) {
-        const uint32_t u1 = (u0 + (uint32_t)kBrickUnit < b_hi) ? u0 + (uint32_t)kBrickUnit : b_hi;
+    {
+        const uint32_t u0 = unit.x, u1 = unit.y;
         // the thread's records: unconditional loads from clamped positions, in flight while the image is zeroed
         float4 rec[SPT];
         bool live[SPT];
@@ -332,7 +383,6 @@ __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(LevelTa
                 if ((uint64_t)grow < (uint64_t)lt.table_rows) unsafeAtomicAdd(acc + grow * F + j, v);
             }
         }
-        lds_barrier();   // the next unit zeroes the image
     }
 }
 

@@ -11,7 +11,7 @@
 // block ("coarse" levels: 0-7 of S1), so walking the samples block by block turns those levels' gathers into L1 hits.
 // Levels finer than that (one sample per cell: no reuse possible in any order) keep the level-per-XCD pair kernel.
 //
-//   sort      counting sort of the samples by block id (two partitioning passes, three launches: psort_*) -> 16-byte records
+//   sort      counting sort of the samples by block id (two partitioning passes, four launches: psort_*) -> 16-byte records
 //             {coordinates (exact copies), sample index} + block offsets = the batch's PLAN, which the backward can reuse
 //   fine      hashgrid_fwd_level_pair_kernel over the sorted coordinates, levels [lc, L) -> staging [L][N][F]
 //   rows      hashgrid_fwd_rows_kernel: coarse levels [0, lc) over the sorted coordinates (lane pairs, L1-resident
@@ -52,7 +52,6 @@ struct TilePlan {
     // partition sort: coarse bin = block id >> coarse_shift (a contiguous range of <= 16 blocks); tiles of whole chunks
     uint32_t coarse_shift, num_coarse;
     uint32_t ptiles, chunks_per_tile;
-    uint32_t slices;        // workgroups per coarse bin in the last pass
 };
 
 struct TileCtx {            // device pointers into the sort's outputs (the plan) and its scratch
@@ -113,7 +112,6 @@ static void make_sort_plan(int dim, int64_t n, TilePlan &tp) {
     tp.chunks_per_tile = (uint32_t)((chunks + kMaxSortTiles - 1) / kMaxSortTiles);
     if (tp.chunks_per_tile < 1) tp.chunks_per_tile = 1;
     tp.ptiles = (uint32_t)((chunks + tp.chunks_per_tile - 1) / tp.chunks_per_tile);
-    tp.slices = 4;   // last pass, grid.y: workgroups that share an OVER-FULL bin (all but the first leave at once otherwise)
 }
 
 static void make_tile_plan(int dim, const LevelTable &lt, int64_t n, TilePlan &tp) {
@@ -160,7 +158,7 @@ static size_t carve_scratch(int dim, int64_t n, void *buf, TileCtx &c) {
     const size_t o_cnt = take((size_t)kMaxSortTiles * kMaxCoarse * 4);
     const size_t o_inter = take((size_t)n * sizeof(float4));
     const size_t o_cb = take((size_t)(kMaxCoarse + 1) * 4);
-    const size_t o_gc = take((size_t)kMaxBlocksS * 4);
+    const size_t o_gc = take((size_t)2 * kMaxBlocksS * 4);   // per-block cursors | per-block counts of over-full bins
     unsigned char *p = static_cast<unsigned char *>(buf);
     if (p) {
         c.cnt = reinterpret_cast<uint32_t *>(p + o_cnt);
@@ -185,10 +183,14 @@ static size_t scratch_bytes_of(int dim, int64_t n) {
 //   partition   the same tiles: bin bases + this tile's offsets from the count matrix (column sums, no atomics, no scan
 //               launch), then each record goes to its bin's next slot (LDS returning atomic = final position)
 //   local       one workgroup per coarse bin keeps the bin's records in registers (<= 8 192; ~5 500 on a uniform batch): the
-//               returning LDS atomic that counts a record per block is its rank; block offsets = scan of <= 16 counts; the
-//               records go out block by block (runs of a few KB written by one workgroup) and the bin's block offsets with
-//               them. Over-full bins (a batch concentrated in few blocks) are counted by `slices` workgroups and placed in
-//               rounds with ranks from global per-block cursors; waves whose lanes all name one block add once per wave
+//               returning LDS atomic that counts a record per (block, sub-cell of the block) is its rank; offsets = scan of
+//               <= 1 024 counts; the records go out run by run (a few KB each, written by one workgroup) and the bin's
+//               block offsets with them
+//   place       over-full bins only (a batch concentrated in few blocks; on a uniform batch every workgroup leaves at once): such
+//               a bin is cut into chunks of 8 192 records, one workgroup each in BOTH passes -- `local` counts its chunk per
+//               block into global counters, `place` ranks the chunk in LDS and reserves one range per block from global
+//               cursors. A Gaussian blob / a thin slab / one block of 2^20 samples sort as fast as a uniform batch
+//               (tools/skew_check.py: forward 0.30 / 0.27 / 0.23 ms against 0.30)
 // The four-launch sort it replaces wrote every record straight to its block's slot: 2^20 scattered 16-byte stores into lines
 // shared by 256 workgroups (25 us of its 47). Order inside a block is arbitrary in both (ranks come from atomics).
 template <int DIM>
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_partition_kernel(TilePlan
     }
     // (the last pass's per-block cursors, used for over-full bins only, start at zero: cleared here, one launch ahead)
     if (blockIdx.x == 0)
-        for (uint32_t k = threadIdx.x; k < tp.num_blocks; k += kSortThreadsS) gcursor[k] = 0u;
+        for (uint32_t k = threadIdx.x; k < 2u * kMaxBlocksS; k += kSortThreadsS) gcursor[k] = 0u;   // cursors + counts
     __syncthreads();
     if (owner) s_cursor[threadIdx.x] = base + s_before[threadIdx.x];
     __syncthreads();
@@ -359,59 +361,87 @@ __device__ __forceinline__ uint32_t wave_rank_add(uint32_t *counters, uint32_t j
     return live ? atomicAdd(&counters[j], 1u) : 0u;
 }
 
+constexpr int kLocalR = 8;                                   // records a thread of the local pass keeps
+constexpr uint32_t kLocalCap = kLocalR * kSortThreadsS;      // a bin of <= 8 192 records is one chunk: read once, ranked in LDS
+
+// Workgroup w of the last two passes -> (coarse bin, chunk of the bin): a bin of `len` records has max(1, ceil(len / 8 192))
+// chunks, so a uniform batch is one workgroup per bin and a batch concentrated in few blocks gets as many workgroups as it has
+// 8 192-record chunks, whatever bin they fall into (round 6: the first form gave an over-full bin four workgroups that each
+// counted ALL of it -- 0.8 ms for a Gaussian blob of 2^20 samples, tools/skew_check.py). Returns false for surplus workgroups.
+struct ChunkOf {
+    uint32_t bin, chunk, nchunks, lo, hi;    // [lo, hi): the BIN's records
+};
+__device__ __forceinline__ bool chunk_of_workgroup(const TilePlan &tp, const uint32_t *__restrict__ cbase, uint32_t *s_pre,
+                                                   uint32_t *s_wave, ChunkOf &c) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t nch = 0;
+    if (threadIdx.x < kMaxCoarse) {
+        if (threadIdx.x < tp.num_coarse) {
+            const uint32_t len = cbase[threadIdx.x + 1] - cbase[threadIdx.x];
+            nch = len > kLocalCap ? (len + kLocalCap - 1u) / kLocalCap : 1u;
+        }
+        uint32_t incl = nch;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t nbr = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += nbr;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        s_pre[threadIdx.x] = incl - nch;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMaxCoarse) {
+        uint32_t wb = 0;
+        for (uint32_t w = 0; w < wave; ++w) wb += s_wave[w];
+        s_pre[threadIdx.x] += wb;
+        if (threadIdx.x == kMaxCoarse - 1) s_pre[kMaxCoarse] = s_pre[threadIdx.x] + nch;
+    }
+    __syncthreads();
+    const uint32_t w = blockIdx.x;
+    if (w >= s_pre[kMaxCoarse]) return false;
+    uint32_t lo_b = 0, hi_b = tp.num_coarse;     // last bin whose first chunk is <= w (bins beyond num_coarse have no chunk)
+    while (hi_b - lo_b > 1u) {
+        const uint32_t mid = (lo_b + hi_b) >> 1;
+        if (s_pre[mid] <= w) lo_b = mid;
+        else hi_b = mid;
+    }
+    c.bin = lo_b;
+    c.chunk = w - s_pre[lo_b];
+    c.nchunks = s_pre[lo_b + 1] - s_pre[lo_b];
+    c.lo = cbase[lo_b];
+    c.hi = cbase[lo_b + 1];
+    return true;
+}
+
 template <int DIM>
 __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp, const float4 *__restrict__ inter4,
                                                                     const uint32_t *__restrict__ cbase,
-                                                                    uint32_t *__restrict__ gcursor,
+                                                                    uint32_t *__restrict__ gcount,
                                                                     float4 *__restrict__ sorted4,
                                                                     uint32_t *__restrict__ block_start,
                                                                     uint32_t *__restrict__ header, uint32_t n) {
     constexpr int kBpc = kMaxBlocksS / kMaxCoarse;   // blocks per coarse bin (<= 16)
-    constexpr int R = 8;                             // records a thread keeps: a bin of <= R * 1024 records is read once
-    constexpr uint32_t kCap = R * kSortThreadsS;
-    __shared__ uint32_t s_tot[kBpc], s_next[kBpc], s_off[kBpc + 1];
-    const uint32_t bin = blockIdx.x, sl = blockIdx.y;
-    const uint32_t lo = cbase[bin], hi = cbase[bin + 1];
-    const uint32_t len = hi - lo;
-    const uint32_t rounds = (len + kCap - 1u) / kCap;
-    if (sl > 0 && rounds <= 1u) return;              // the bin fits one workgroup's registers: slice 0 does it all
-    if (threadIdx.x < kBpc) {
-        s_tot[threadIdx.x] = 0;
-        s_next[threadIdx.x] = 0;
-    }
-    __syncthreads();
+    constexpr int R = kLocalR;
+    __shared__ uint32_t s_pre[kMaxCoarse + 1], s_wave[kMaxCoarse / 64];
+    ChunkOf c;
+    if (!chunk_of_workgroup(tp, cbase, s_pre, s_wave, c)) return;
+    const uint32_t bin = c.bin, lo = c.lo, hi = c.hi;
     const uint32_t key0 = bin << tp.coarse_shift;
     const uint32_t bpc = 1u << tp.coarse_shift;
     const uint32_t lane = threadIdx.x & 63;
     auto key_of = [&](const float4 &r) {
-        float c[DIM];
-        c[0] = r.x;
-        c[1] = r.y;
-        if constexpr (DIM == 3) c[2] = r.z;
-        return block_key<DIM>(c, tp) - key0;
+        float cc[DIM];
+        cc[0] = r.x;
+        cc[1] = r.y;
+        if constexpr (DIM == 3) cc[2] = r.z;
+        return block_key<DIM>(cc, tp) - key0;
     };
-    auto finish_offsets = [&]() {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (uint32_t b = 0; b < bpc; ++b) {
-                s_off[b] = run;
-                run += s_tot[b];
-            }
-            s_off[bpc] = run;
-        }
-        __syncthreads();
-        if (sl == 0) {
-            if (threadIdx.x < bpc && key0 + threadIdx.x < tp.num_blocks) block_start[key0 + threadIdx.x] = lo + s_off[threadIdx.x];
-            if (bin + 1u == tp.num_coarse && threadIdx.x == 0) block_start[tp.num_blocks] = hi;
-            if (bin == 0 && threadIdx.x == 0) {
-                header[0] = kCtxMagic;
-                header[1] = tp.num_blocks;
-                header[2] = n;
-            }
-        }
-    };
-    if (rounds <= 1u) {
+    if (bin == 0 && c.chunk == 0 && threadIdx.x == 0) {
+        header[0] = kCtxMagic;
+        header[1] = tp.num_blocks;
+        header[2] = n;
+    }
+    if (c.nchunks == 1u) {
         // the usual case: every record of the bin in registers -- counted, ranked (the returning LDS atomic of the count IS the
         // rank) and written to its block's run. Inside a block the records are ordered by sub-cell of the block (SHACIRA_SORT_SUB
         // bits per axis; the key is block * cells + cell, block_start still addresses whole blocks): consecutive samples then
@@ -486,36 +516,88 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp,
         __syncthreads();
         if (threadIdx.x < bpc && key0 + threadIdx.x < tp.num_blocks) block_start[key0 + threadIdx.x] = lo + s_off8[threadIdx.x * kSub];
         if (bin + 1u == tp.num_coarse && threadIdx.x == 0) block_start[tp.num_blocks] = hi;
-        if (bin == 0 && threadIdx.x == 0) {
-            header[0] = kCtxMagic;
-            header[1] = tp.num_blocks;
-            header[2] = n;
-        }
 #pragma unroll
         for (int u = 0; u < R; ++u)
             if (lo + (uint32_t)u * kSortThreadsS + threadIdx.x < hi) sorted4[lo + s_off8[j[u]] + rk[u]] = r[u];
         return;
     }
-    // an over-full bin (a batch concentrated in a few blocks): every workgroup of the bin counts all of it, then places
-    // rounds sl, sl + gridDim.y, ... of its records with ranks drawn from the blocks' GLOBAL cursors (zeroed by the partition pass)
-    for (uint32_t p0 = lo; p0 < hi; p0 += kSortThreadsS) {
+    // a chunk of an over-full bin (a batch concentrated in few blocks): count its records per block and add the counts to the
+    // blocks' global counters (zeroed by the partition pass); psort_place_kernel places the records once every chunk has counted
+    __shared__ uint32_t s_cnt[kBpc];
+    if (threadIdx.x < kBpc) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t c_lo = lo + c.chunk * kLocalCap, c_hi = (c_lo + kLocalCap < hi) ? c_lo + kLocalCap : hi;
+    for (uint32_t p0 = c_lo; p0 < c_hi; p0 += kSortThreadsS) {
         const uint32_t p = p0 + threadIdx.x;
-        const bool live = p < hi;
-        const float4 rr = inter4[live ? p : hi - 1u];
-        wave_rank_add(s_tot, live ? key_of(rr) : 0u, live, lane);
+        const bool live = p < c_hi;
+        const float4 rr = inter4[live ? p : c_hi - 1u];
+        wave_rank_add(s_cnt, live ? key_of(rr) : 0u, live, lane);
     }
-    finish_offsets();
-    for (uint32_t rd = sl; rd < rounds; rd += gridDim.y) {
-        const uint32_t r_lo = lo + rd * kCap, r_hi = (r_lo + kCap < hi) ? r_lo + kCap : hi;
-        for (uint32_t p0 = r_lo; p0 < r_hi; p0 += kSortThreadsS) {
-            const uint32_t p = p0 + threadIdx.x;
-            const bool live = p < r_hi;
-            const float4 rr = inter4[live ? p : r_hi - 1u];
-            const uint32_t jj = live ? key_of(rr) : 0u;
-            const uint32_t rank = wave_rank_add(gcursor + key0, jj, live, lane);
-            if (live) sorted4[lo + s_off[jj] + rank] = rr;
+    __syncthreads();
+    if (threadIdx.x < bpc && s_cnt[threadIdx.x]) atomicAdd(&gcount[key0 + threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+// Over-full bins only (every workgroup of a one-chunk bin leaves at once): block offsets of the bin from the global counts,
+// then the chunk's records to their blocks' runs, ranks drawn from the blocks' global cursors (a wave whose lanes all name one
+// block draws once). Order inside a block is arrival order: these bins keep block order only (no sub-cell order).
+template <int DIM>
+__global__ __launch_bounds__(kSortThreadsS) void psort_place_kernel(TilePlan tp, const float4 *__restrict__ inter4,
+                                                                    const uint32_t *__restrict__ cbase,
+                                                                    const uint32_t *__restrict__ gcount,
+                                                                    uint32_t *__restrict__ gcursor,
+                                                                    float4 *__restrict__ sorted4,
+                                                                    uint32_t *__restrict__ block_start) {
+    constexpr int kBpc = kMaxBlocksS / kMaxCoarse;
+    __shared__ uint32_t s_pre[kMaxCoarse + 1], s_wave[kMaxCoarse / 64], s_off[kBpc + 1];
+    ChunkOf c;
+    if (!chunk_of_workgroup(tp, cbase, s_pre, s_wave, c)) return;
+    if (c.nchunks == 1u) return;
+    const uint32_t key0 = c.bin << tp.coarse_shift;
+    const uint32_t bpc = 1u << tp.coarse_shift;
+    const uint32_t lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < bpc; ++b) {
+            s_off[b] = run;
+            run += (key0 + b < tp.num_blocks) ? gcount[key0 + b] : 0u;
         }
+        s_off[bpc] = run;
     }
+    __syncthreads();
+    if (c.chunk == 0) {
+        if (threadIdx.x < bpc && key0 + threadIdx.x < tp.num_blocks) block_start[key0 + threadIdx.x] = c.lo + s_off[threadIdx.x];
+        if (c.bin + 1u == tp.num_coarse && threadIdx.x == 0) block_start[tp.num_blocks] = c.hi;
+    }
+    // the chunk's <= 8 192 records in registers: ranked inside the workgroup with LDS atomics, then ONE global reservation per
+    // block of the bin (per-lane returning atomics on <= 16 global words serialised: 0.7 ms for a Gaussian blob of 2^20 samples)
+    constexpr int R = kLocalR;
+    __shared__ uint32_t s_cnt[kBpc], s_base[kBpc];
+    if (threadIdx.x < kBpc) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t c_lo = c.lo + c.chunk * kLocalCap, c_hi = (c_lo + kLocalCap < c.hi) ? c_lo + kLocalCap : c.hi;
+    float4 r[R];
+    uint32_t j[R], rk[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const uint32_t p = c_lo + (uint32_t)u * kSortThreadsS + threadIdx.x;
+        r[u] = inter4[p < c_hi ? p : c_hi - 1u];
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const bool live = c_lo + (uint32_t)u * kSortThreadsS + threadIdx.x < c_hi;
+        float cc[DIM];
+        cc[0] = r[u].x;
+        cc[1] = r[u].y;
+        if constexpr (DIM == 3) cc[2] = r[u].z;
+        j[u] = live ? block_key<DIM>(cc, tp) - key0 : 0u;
+        rk[u] = wave_rank_add(s_cnt, j[u], live, lane);
+    }
+    __syncthreads();
+    if (threadIdx.x < bpc) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&gcursor[key0 + threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+        if (c_lo + (uint32_t)u * kSortThreadsS + threadIdx.x < c_hi) sorted4[c.lo + s_off[j[u]] + s_base[j[u]] + rk[u]] = r[u];
 }
 
 // ----------------------------------------------------------------------------------------------- host side
@@ -561,23 +643,26 @@ hipError_t sample_plan_build(int dim, const float *coords, int64_t n, void *plan
     TileCtx c{};
     carve_plan(n, plan, c);
     carve_scratch(dim, n, scratch, c);
+    // chunks of the last two passes: one per coarse bin + one per 8 192 records beyond (upper bound; surplus workgroups leave)
+    const uint32_t chunks = tp.num_coarse + (uint32_t)(n / kLocalCap) + 1u;
+    uint32_t *gcount = c.gcursor + kMaxBlocksS;
+#define SHACIRA_SORT_LAUNCHES(D)                                                                                          \
+    hipLaunchKernelGGL(psort_count_kernel<D>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt);            \
+    SHACIRA_CHECK_LAUNCH();                                                                                                  \
+    hipLaunchKernelGGL(psort_partition_kernel<D>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt, c.cbase, \
+                       c.gcursor, c.inter4);                                                                                 \
+    SHACIRA_CHECK_LAUNCH();                                                                                                  \
+    hipLaunchKernelGGL(psort_local_kernel<D>, dim3(chunks), dim3(kSortThreadsS), 0, s, tp, c.inter4, c.cbase, gcount,        \
+                       c.sorted4, c.block_start, c.header, (uint32_t)n);                                                     \
+    SHACIRA_CHECK_LAUNCH();                                                                                                  \
+    hipLaunchKernelGGL(psort_place_kernel<D>, dim3(chunks), dim3(kSortThreadsS), 0, s, tp, c.inter4, c.cbase, gcount,        \
+                       c.gcursor, c.sorted4, c.block_start);
     if (dim == 3) {
-        hipLaunchKernelGGL(psort_count_kernel<3>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt);
-        SHACIRA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(psort_partition_kernel<3>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt,
-                           c.cbase, c.gcursor, c.inter4);
-        SHACIRA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(psort_local_kernel<3>, dim3(tp.num_coarse, tp.slices), dim3(kSortThreadsS), 0, s, tp, c.inter4,
-                           c.cbase, c.gcursor, c.sorted4, c.block_start, c.header, (uint32_t)n);
+        SHACIRA_SORT_LAUNCHES(3)
     } else {
-        hipLaunchKernelGGL(psort_count_kernel<2>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt);
-        SHACIRA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(psort_partition_kernel<2>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt,
-                           c.cbase, c.gcursor, c.inter4);
-        SHACIRA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(psort_local_kernel<2>, dim3(tp.num_coarse, tp.slices), dim3(kSortThreadsS), 0, s, tp, c.inter4,
-                           c.cbase, c.gcursor, c.sorted4, c.block_start, c.header, (uint32_t)n);
+        SHACIRA_SORT_LAUNCHES(2)
     }
+#undef SHACIRA_SORT_LAUNCHES
     SHACIRA_CHECK_LAUNCH();
     return hipSuccess;
 }
