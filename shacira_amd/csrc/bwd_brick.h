@@ -182,56 +182,21 @@ __device__ __forceinline__ void brick_direct_add(const BrickLevel &b, uint32_t m
     }
 }
 
-// The pass's work list: one unit = up to kBrickUnit consecutive records of one GROUP (`span` x-adjacent blocks). One small
-// workgroup writes it from the plan's block offsets, so that a batch concentrated in few blocks becomes many units on many
-// workgroups instead of a loop inside a few (round 6: with grid.y = 4 workgroups per group a 2^20-sample batch inside one block
-// took 4.4 ms, tools/skew_check.py). units[u] = {first record, last record + 1, group, 0}; units_count[0] = their number.
-constexpr int kBrickUnitThreads = 1024;
-__global__ __launch_bounds__(kBrickUnitThreads) void brick_units_kernel(BrickPlan bp, const uint32_t *__restrict__ block_start,
-                                                                        uint4 *__restrict__ units,
-                                                                        uint32_t *__restrict__ units_count) {
-    constexpr int GPT = 4;                                     // groups per thread (<= 4 096 groups)
-    __shared__ uint32_t s_wave[kBrickUnitThreads / 64];
+// The pass's work: one unit = up to kBrickUnit consecutive records of one GROUP (`span` x-adjacent blocks). Workgroup g < groups
+// takes group g's FIRST unit straight from the plan's block offsets (all of a uniform batch). What an over-full group holds
+// beyond its first unit is cut at the kBrickUnit-aligned windows of the sorted batch, and workgroup groups + v takes window v:
+// the group holding the window's first record is the only one whose remainder can reach into that window (the next group's
+// remainder starts >= kBrickUnit records behind its own start), so the workgroup finds its unit with one pass over the block
+// offsets and no list. A batch concentrated in few blocks thereby becomes many units on many workgroups instead of a loop inside
+// a few (round 6: with grid.y = 4 workgroups per group a 2^20-sample batch inside one block took 4.4 ms, tools/skew_check.py).
+__device__ __forceinline__ void brick_group_range(const BrickPlan &bp, const uint32_t *__restrict__ block_start, uint32_t g,
+                                                  uint32_t &lo, uint32_t &hi) {
     const uint32_t nbx = (uint32_t)bp.nb[0];
-    const uint32_t groups = bp.groups_x * (uint32_t)(bp.nb[1] * bp.nb[2]);
-    uint32_t lo[GPT], hi[GPT], nu[GPT], sum = 0;
-#pragma unroll
-    for (int q = 0; q < GPT; ++q) {
-        const uint32_t g = threadIdx.x * GPT + q;
-        lo[q] = hi[q] = nu[q] = 0;
-        if (g < groups) {
-            const uint32_t gx = g % bp.groups_x, gyz = g / bp.groups_x;
-            const uint32_t qx = gx * bp.span;
-            const uint32_t blk0 = qx + nbx * gyz;
-            const uint32_t blk1 = (qx + bp.span < nbx) ? blk0 + bp.span : nbx * (gyz + 1u);
-            lo[q] = block_start[blk0];
-            hi[q] = block_start[blk1];
-            nu[q] = (hi[q] - lo[q] + (uint32_t)kBrickUnit - 1u) / (uint32_t)kBrickUnit;
-        }
-        sum += nu[q];
-    }
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t nbr = __shfl_up(incl, off, 64);
-        if (lane >= (uint32_t)off) incl += nbr;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-    for (uint32_t w = 0; w < wave; ++w) run += s_wave[w];
-#pragma unroll
-    for (int q = 0; q < GPT; ++q) {
-        const uint32_t g = threadIdx.x * GPT + q;
-        for (uint32_t k = 0; k < nu[q]; ++k) {
-            const uint32_t u0 = lo[q] + k * (uint32_t)kBrickUnit;
-            const uint32_t u1 = (u0 + (uint32_t)kBrickUnit < hi[q]) ? u0 + (uint32_t)kBrickUnit : hi[q];
-            units[run + k] = make_uint4(u0, u1, g, 0u);
-        }
-        run += nu[q];
-    }
-    if (threadIdx.x == kBrickUnitThreads - 1) units_count[0] = run;
+    const uint32_t gx = g % bp.groups_x, gyz = g / bp.groups_x;
+    const uint32_t blk0 = gx * bp.span + nbx * gyz;
+    const uint32_t blk1 = (gx * bp.span + bp.span < nbx) ? blk0 + bp.span : nbx * (gyz + 1u);
+    lo = block_start[blk0];
+    hi = block_start[blk1];
 }
 
 // gT: the transposed gradients [L][gpitch][F] fp32 in SORTED order (front16_kernel<.., SORTED>): sample i of the sorted batch
@@ -239,16 +204,42 @@ template <int F>
 __global__ __launch_bounds__(kBrickThreads) void brick_accumulate_kernel(LevelTable lt, BrickPlan bp,
                                                                          const int32_t *__restrict__ first_idx,
                                                                          const float4 *__restrict__ sorted4,
-                                                                         const uint4 *__restrict__ units,
-                                                                         const uint32_t *__restrict__ units_count,
+                                                                         const uint32_t *__restrict__ block_start,
                                                                          const float *__restrict__ gT, int64_t gpitch,
                                                                          float *__restrict__ acc,
                                                                          const uint32_t *__restrict__ gmax, int headroom) {
     extern __shared__ double s_img[];                 // [rows_total][F]: 64-bit fixed point (or fp64)
     unsigned long long *s_fix = reinterpret_cast<unsigned long long *>(s_img);
-    // the unit (brick_units_kernel): up to kBrickUnit records of one group = `span` consecutive blocks along x at (qy, qz)
-    if (blockIdx.x >= units_count[0]) return;
-    const uint4 unit = units[blockIdx.x];
+    // the unit: up to kBrickUnit records of one group = `span` consecutive blocks along x at (qy, qz)
+    const uint32_t groups = bp.groups_x * (uint32_t)(bp.nb[1] * bp.nb[2]);
+    uint4 unit;
+    if (blockIdx.x < groups) {
+        uint32_t lo, hi;
+        brick_group_range(bp, block_start, blockIdx.x, lo, hi);
+        if (lo >= hi) return;
+        unit = make_uint4(lo, (lo + (uint32_t)kBrickUnit < hi) ? lo + (uint32_t)kBrickUnit : hi, blockIdx.x, 0u);
+    } else {
+        // window v of the sorted batch: the block holding its first record = (offsets <= that record) - 1
+        __shared__ uint32_t s_le;
+        const uint32_t p0 = (blockIdx.x - groups) * (uint32_t)kBrickUnit;
+        if (threadIdx.x == 0) s_le = 0u;
+        __syncthreads();
+        uint32_t c = 0;
+        for (uint32_t k = threadIdx.x; k < bp.num_blocks; k += kBrickThreads) c += block_start[k] <= p0 ? 1u : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        if ((threadIdx.x & 63u) == 0u && c) atomicAdd(&s_le, c);
+        __syncthreads();
+        const uint32_t blk = s_le - 1u;                      // (block_start[0] = 0 <= p0)
+        const uint32_t nbx = (uint32_t)bp.nb[0];
+        const uint32_t g = (blk % nbx) / bp.span + bp.groups_x * (blk / nbx);
+        uint32_t lo, hi;
+        brick_group_range(bp, block_start, g, lo, hi);
+        const uint32_t u0 = (lo + (uint32_t)kBrickUnit > p0) ? lo + (uint32_t)kBrickUnit : p0;
+        const uint32_t u1 = (p0 + (uint32_t)kBrickUnit < hi) ? p0 + (uint32_t)kBrickUnit : hi;
+        if (u0 >= u1) return;
+        unit = make_uint4(u0, u1, g, 0u);
+    }
     const uint32_t nby = (uint32_t)bp.nb[1];
     const uint32_t gx = unit.z % bp.groups_x, gyz = unit.z / bp.groups_x;
     const int32_t qx = (int32_t)(gx * bp.span), qy = (int32_t)(gyz % nby), qz = (int32_t)(gyz / nby);

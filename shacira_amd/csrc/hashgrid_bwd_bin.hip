@@ -420,7 +420,6 @@ struct BinWorkspace {
     UnitDesc *unit_desc;
     uint32_t *work_counter;       // next unit of the persistent consume pass (zeroed by the bucket scan)
     float *acc32;                 // fp32 accumulation image for fp16 tables
-    uint4 *brick_units;           // 3-D: work list of the brick pass (n / kBrickUnit + 4 096 units) and, behind it, its count
     size_t bytes;
 };
 
@@ -473,8 +472,6 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     const size_t o_ub = take((size_t)(max_items_ws / plan.chunk_min + plan.total_buckets + 2) * sizeof(UnitDesc));
     const size_t o_wc = take(256);
     const size_t o_acc = take(dtype == SHACIRA_F16 ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0);
-    const size_t brick_units_max = dim == 3 ? (size_t)(n / kBrickUnit) + 4096 + 1 : 0;
-    const size_t o_bu = take(brick_units_max ? (brick_units_max + 1) * sizeof(uint4) : 0);
     BinWorkspace w{};
     unsigned char *p = static_cast<unsigned char *>(ws);
     if (p) {
@@ -489,7 +486,6 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
         w.unit_desc = reinterpret_cast<UnitDesc *>(p + o_ub);
         w.work_counter = reinterpret_cast<uint32_t *>(p + o_wc);
         w.acc32 = reinterpret_cast<float *>(p + o_acc);
-        w.brick_units = reinterpret_cast<uint4 *>(p + o_bu);
     }
     w.bytes = off;
     return w;
@@ -642,15 +638,12 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         if constexpr (DIM == 3) {
             const size_t img = (size_t)brick.rows_total * F * sizeof(double);
             const int hr = fx_headroom((uint64_t)kBrickUnit * 8u);
-            // work list first (one small workgroup, same stream), then one workgroup per unit (upper bound; surplus ones leave)
+            // one workgroup per group (its first unit) + one per kBrickUnit-record window of the batch (what over-full groups
+            // hold beyond; all of them leave at once on a uniform batch)
             const uint32_t groups = brick.groups_x * (uint32_t)(brick.nb[1] * brick.nb[2]);
-            const uint32_t max_units = (uint32_t)(n / kBrickUnit) + groups + 1u;
-            uint32_t *ucount = reinterpret_cast<uint32_t *>(w.brick_units + ((size_t)(n / kBrickUnit) + 4096 + 1));
-            hipLaunchKernelGGL(brick_units_kernel, dim3(1), dim3(kBrickUnitThreads), 0, bs, brick, sb->block_start, w.brick_units,
-                               ucount);
-            SHACIRA_CHECK_LAUNCH();
-            hipLaunchKernelGGL((brick_accumulate_kernel<F>), dim3(max_units), dim3(kBrickThreads), img, bs, lt, brick, first_idx,
-                               sb->sorted4, w.brick_units, ucount, w.gT, NP, acc, w.gmax, hr);
+            const uint32_t windows = (uint32_t)((n + kBrickUnit - 1) / kBrickUnit);
+            hipLaunchKernelGGL((brick_accumulate_kernel<F>), dim3(groups + windows), dim3(kBrickThreads), img, bs, lt, brick,
+                               first_idx, sb->sorted4, sb->block_start, w.gT, NP, acc, w.gmax, hr);
             return hipGetLastError();
         } else {
             (void)bs;

@@ -206,11 +206,18 @@ __device__ __forceinline__ void load_chunk_coords(const float *__restrict__ coor
     }
 }
 
+constexpr int kLocalR = 8;                                   // records a thread of the local pass keeps
+constexpr uint32_t kLocalCap = kLocalR * kSortThreadsS;      // a bin of <= 8 192 records is one chunk: read once, ranked in LDS
+
 template <int DIM>
 __global__ __launch_bounds__(kSortThreadsS) void psort_count_kernel(TilePlan tp, const float *__restrict__ coords,
-                                                                    int64_t N, uint32_t *__restrict__ cnt) {
+                                                                    int64_t N, uint32_t *__restrict__ cnt,
+                                                                    uint32_t *__restrict__ gcursor) {
     __shared__ uint32_t s_hist[kMaxCoarse];
     if (threadIdx.x < kMaxCoarse) s_hist[threadIdx.x] = 0;
+    // (the per-block cursors | counts of over-full bins start at zero: cleared here, one launch ahead of their first use)
+    if (blockIdx.x == 0)
+        for (uint32_t k = threadIdx.x; k < 2u * kMaxBlocksS; k += kSortThreadsS) gcursor[k] = 0u;
     __syncthreads();
     constexpr int U = kSortTileS / kSortThreadsS;
     for (uint32_t ch = 0; ch < tp.chunks_per_tile; ++ch) {
@@ -304,12 +311,24 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_partition_kernel(TilePlan
             if (threadIdx.x == kMaxCoarse - 1) cbase[kMaxCoarse] = base + tot;
         }
     }
-    // (the last pass's per-block cursors, used for over-full bins only, start at zero: cleared here, one launch ahead)
-    if (blockIdx.x == 0)
-        for (uint32_t k = threadIdx.x; k < 2u * kMaxBlocksS; k += kSortThreadsS) gcursor[k] = 0u;   // cursors + counts
+    // Over-full bins (more records than the last pass keeps in one workgroup's registers: a batch concentrated in few blocks):
+    // their records are also counted per BLOCK here, so that the last pass can place every 8 192-record chunk of such a bin with
+    // its own workgroup straight away. A uniform batch has none and skips all of it (one LDS flag).
+    __shared__ uint32_t s_over_any;
+    __shared__ uint32_t s_blk[kMaxBlocksS];
+    if (threadIdx.x == 0) s_over_any = 0u;
     __syncthreads();
-    if (owner) s_cursor[threadIdx.x] = base + s_before[threadIdx.x];
+    if (owner) {
+        s_cursor[threadIdx.x] = base + s_before[threadIdx.x];
+        if (tot > kLocalCap) s_over_any = 1u;
+        s_tot[threadIdx.x] = tot > kLocalCap ? 1u : 0u;       // (from here on: the bin is over-full)
+    }
     __syncthreads();
+    const bool over_any = s_over_any != 0u;
+    if (over_any) {
+        for (uint32_t k = threadIdx.x; k < tp.num_blocks; k += kSortThreadsS) s_blk[k] = 0u;
+        __syncthreads();
+    }
     for (uint32_t ch = 0; ch < tp.chunks_per_tile; ++ch) {
         const int64_t s0 = first_s0 + (int64_t)ch * kSortTileS;
         if (s0 >= N) break;
@@ -326,7 +345,9 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_partition_kernel(TilePlan
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = s0 + u * kSortThreadsS + threadIdx.x;
-            pos[u] = (i < N) ? atomicAdd(&s_cursor[block_key<DIM>(c[u], tp) >> tp.coarse_shift], 1u) : 0xFFFFFFFFu;
+            const uint32_t key = block_key<DIM>(c[u], tp);
+            pos[u] = (i < N) ? atomicAdd(&s_cursor[key >> tp.coarse_shift], 1u) : 0xFFFFFFFFu;
+            if (over_any && i < N && s_tot[key >> tp.coarse_shift]) atomicAdd(&s_blk[key], 1u);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -341,6 +362,12 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_partition_kernel(TilePlan
 #endif
             }
         }
+    }
+    if (over_any) {
+        __syncthreads();
+        uint32_t *gcount = gcursor + kMaxBlocksS;
+        for (uint32_t k = threadIdx.x; k < tp.num_blocks; k += kSortThreadsS)
+            if (s_blk[k]) atomicAdd(&gcount[k], s_blk[k]);
     }
 }
 
@@ -361,10 +388,7 @@ __device__ __forceinline__ uint32_t wave_rank_add(uint32_t *counters, uint32_t j
     return live ? atomicAdd(&counters[j], 1u) : 0u;
 }
 
-constexpr int kLocalR = 8;                                   // records a thread of the local pass keeps
-constexpr uint32_t kLocalCap = kLocalR * kSortThreadsS;      // a bin of <= 8 192 records is one chunk: read once, ranked in LDS
-
-// Workgroup w of the last two passes -> (coarse bin, chunk of the bin): a bin of `len` records has max(1, ceil(len / 8 192))
+// Workgroup w of the last pass -> (coarse bin, chunk of the bin): a bin of `len` records has max(1, ceil(len / 8 192))
 // chunks, so a uniform batch is one workgroup per bin and a batch concentrated in few blocks gets as many workgroups as it has
 // 8 192-record chunks, whatever bin they fall into (round 6: the first form gave an over-full bin four workgroups that each
 // counted ALL of it -- 0.8 ms for a Gaussian blob of 2^20 samples, tools/skew_check.py). Returns false for surplus workgroups.
@@ -416,7 +440,8 @@ __device__ __forceinline__ bool chunk_of_workgroup(const TilePlan &tp, const uin
 template <int DIM>
 __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp, const float4 *__restrict__ inter4,
                                                                     const uint32_t *__restrict__ cbase,
-                                                                    uint32_t *__restrict__ gcount,
+                                                                    const uint32_t *__restrict__ gcount,
+                                                                    uint32_t *__restrict__ gcursor,
                                                                     float4 *__restrict__ sorted4,
                                                                     uint32_t *__restrict__ block_start,
                                                                     uint32_t *__restrict__ header, uint32_t n) {
@@ -521,40 +546,12 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp,
             if (lo + (uint32_t)u * kSortThreadsS + threadIdx.x < hi) sorted4[lo + s_off8[j[u]] + rk[u]] = r[u];
         return;
     }
-    // a chunk of an over-full bin (a batch concentrated in few blocks): count its records per block and add the counts to the
-    // blocks' global counters (zeroed by the partition pass); psort_place_kernel places the records once every chunk has counted
-    __shared__ uint32_t s_cnt[kBpc];
-    if (threadIdx.x < kBpc) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t c_lo = lo + c.chunk * kLocalCap, c_hi = (c_lo + kLocalCap < hi) ? c_lo + kLocalCap : hi;
-    for (uint32_t p0 = c_lo; p0 < c_hi; p0 += kSortThreadsS) {
-        const uint32_t p = p0 + threadIdx.x;
-        const bool live = p < c_hi;
-        const float4 rr = inter4[live ? p : c_hi - 1u];
-        wave_rank_add(s_cnt, live ? key_of(rr) : 0u, live, lane);
-    }
-    __syncthreads();
-    if (threadIdx.x < bpc && s_cnt[threadIdx.x]) atomicAdd(&gcount[key0 + threadIdx.x], s_cnt[threadIdx.x]);
-}
-
-// Over-full bins only (every workgroup of a one-chunk bin leaves at once): block offsets of the bin from the global counts,
-// then the chunk's records to their blocks' runs, ranks drawn from the blocks' global cursors (a wave whose lanes all name one
-// block draws once). Order inside a block is arrival order: these bins keep block order only (no sub-cell order).
-template <int DIM>
-__global__ __launch_bounds__(kSortThreadsS) void psort_place_kernel(TilePlan tp, const float4 *__restrict__ inter4,
-                                                                    const uint32_t *__restrict__ cbase,
-                                                                    const uint32_t *__restrict__ gcount,
-                                                                    uint32_t *__restrict__ gcursor,
-                                                                    float4 *__restrict__ sorted4,
-                                                                    uint32_t *__restrict__ block_start) {
-    constexpr int kBpc = kMaxBlocksS / kMaxCoarse;
-    __shared__ uint32_t s_pre[kMaxCoarse + 1], s_wave[kMaxCoarse / 64], s_off[kBpc + 1];
-    ChunkOf c;
-    if (!chunk_of_workgroup(tp, cbase, s_pre, s_wave, c)) return;
-    if (c.nchunks == 1u) return;
-    const uint32_t key0 = c.bin << tp.coarse_shift;
-    const uint32_t bpc = 1u << tp.coarse_shift;
-    const uint32_t lane = threadIdx.x & 63;
+    // a chunk of an over-full bin (a batch concentrated in few blocks; the partition pass counted such bins' records per block):
+    // block offsets of the bin from the global counts, then the chunk's <= 8 192 records, held in registers, ranked inside the
+    // workgroup with LDS atomics (a wave whose lanes all name one block draws once) and ONE global reservation per block of the
+    // bin (per-lane returning atomics on <= 16 global words serialised: 0.7 ms for a Gaussian blob of 2^20 samples). Order inside
+    // a block is arrival order: these bins keep block order only (no sub-cell order).
+    __shared__ uint32_t s_off[kBpc + 1], s_cnt[kBpc], s_base[kBpc];
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (uint32_t b = 0; b < bpc; ++b) {
@@ -563,18 +560,13 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_place_kernel(TilePlan tp,
         }
         s_off[bpc] = run;
     }
-    __syncthreads();
-    if (c.chunk == 0) {
-        if (threadIdx.x < bpc && key0 + threadIdx.x < tp.num_blocks) block_start[key0 + threadIdx.x] = c.lo + s_off[threadIdx.x];
-        if (c.bin + 1u == tp.num_coarse && threadIdx.x == 0) block_start[tp.num_blocks] = c.hi;
-    }
-    // the chunk's <= 8 192 records in registers: ranked inside the workgroup with LDS atomics, then ONE global reservation per
-    // block of the bin (per-lane returning atomics on <= 16 global words serialised: 0.7 ms for a Gaussian blob of 2^20 samples)
-    constexpr int R = kLocalR;
-    __shared__ uint32_t s_cnt[kBpc], s_base[kBpc];
     if (threadIdx.x < kBpc) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t c_lo = c.lo + c.chunk * kLocalCap, c_hi = (c_lo + kLocalCap < c.hi) ? c_lo + kLocalCap : c.hi;
+    if (c.chunk == 0) {
+        if (threadIdx.x < bpc && key0 + threadIdx.x < tp.num_blocks) block_start[key0 + threadIdx.x] = lo + s_off[threadIdx.x];
+        if (bin + 1u == tp.num_coarse && threadIdx.x == 0) block_start[tp.num_blocks] = hi;
+    }
+    const uint32_t c_lo = lo + c.chunk * kLocalCap, c_hi = (c_lo + kLocalCap < hi) ? c_lo + kLocalCap : hi;
     float4 r[R];
     uint32_t j[R], rk[R];
 #pragma unroll
@@ -585,11 +577,7 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_place_kernel(TilePlan tp,
 #pragma unroll
     for (int u = 0; u < R; ++u) {
         const bool live = c_lo + (uint32_t)u * kSortThreadsS + threadIdx.x < c_hi;
-        float cc[DIM];
-        cc[0] = r[u].x;
-        cc[1] = r[u].y;
-        if constexpr (DIM == 3) cc[2] = r[u].z;
-        j[u] = live ? block_key<DIM>(cc, tp) - key0 : 0u;
+        j[u] = live ? key_of(r[u]) : 0u;
         rk[u] = wave_rank_add(s_cnt, j[u], live, lane);
     }
     __syncthreads();
@@ -597,7 +585,7 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_place_kernel(TilePlan tp,
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < R; ++u)
-        if (c_lo + (uint32_t)u * kSortThreadsS + threadIdx.x < c_hi) sorted4[c.lo + s_off[j[u]] + s_base[j[u]] + rk[u]] = r[u];
+        if (c_lo + (uint32_t)u * kSortThreadsS + threadIdx.x < c_hi) sorted4[lo + s_off[j[u]] + s_base[j[u]] + rk[u]] = r[u];
 }
 
 // ----------------------------------------------------------------------------------------------- host side
@@ -643,20 +631,17 @@ hipError_t sample_plan_build(int dim, const float *coords, int64_t n, void *plan
     TileCtx c{};
     carve_plan(n, plan, c);
     carve_scratch(dim, n, scratch, c);
-    // chunks of the last two passes: one per coarse bin + one per 8 192 records beyond (upper bound; surplus workgroups leave)
+    // chunks of the last pass: one per coarse bin + one per 8 192 records beyond (upper bound; surplus workgroups leave)
     const uint32_t chunks = tp.num_coarse + (uint32_t)(n / kLocalCap) + 1u;
     uint32_t *gcount = c.gcursor + kMaxBlocksS;
 #define SHACIRA_SORT_LAUNCHES(D)                                                                                          \
-    hipLaunchKernelGGL(psort_count_kernel<D>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt);            \
+    hipLaunchKernelGGL(psort_count_kernel<D>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt, c.gcursor);  \
     SHACIRA_CHECK_LAUNCH();                                                                                                  \
     hipLaunchKernelGGL(psort_partition_kernel<D>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt, c.cbase, \
                        c.gcursor, c.inter4);                                                                                 \
     SHACIRA_CHECK_LAUNCH();                                                                                                  \
     hipLaunchKernelGGL(psort_local_kernel<D>, dim3(chunks), dim3(kSortThreadsS), 0, s, tp, c.inter4, c.cbase, gcount,        \
-                       c.sorted4, c.block_start, c.header, (uint32_t)n);                                                     \
-    SHACIRA_CHECK_LAUNCH();                                                                                                  \
-    hipLaunchKernelGGL(psort_place_kernel<D>, dim3(chunks), dim3(kSortThreadsS), 0, s, tp, c.inter4, c.cbase, gcount,        \
-                       c.gcursor, c.sorted4, c.block_start);
+                       c.gcursor, c.sorted4, c.block_start, c.header, (uint32_t)n);
     if (dim == 3) {
         SHACIRA_SORT_LAUNCHES(3)
     } else {

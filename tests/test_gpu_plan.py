@@ -129,16 +129,20 @@ def test_plan_reuse_across_steps(dev):
     assert torch.equal(f0, ops.hashgrid_interpolate_cuda(tc, tt, tf, res, bw))
 
 
-@pytest.mark.parametrize("kind", ["one_block", "one_plane", "two_points"])
+@pytest.mark.parametrize("kind", ["one_block", "blob", "one_plane", "two_points"])
 def test_degenerate_batches_through_the_plan(dev, kind):
     """Batches the sort's coarse bins and the brick units are not sized for: everything in ONE block (one over-full bin,
-    every round through the global cursors; one brick unit walked in rounds), everything on one z-plane, two points."""
+    its 8 192-record chunks on a workgroup each; the brick pass's windows beyond a group's first unit), a Gaussian blob over a
+    uniform background, everything on one z-plane, two points."""
     dim, res, bw = CONFIGS["D"]
     n = (1 << 18) + 5
     sizes, first, T, coords, table, go = _problem(dim, res, bw, n, seed=31, edge=False)
     rng = np.random.default_rng(32)
     if kind == "one_block":
         coords[:] = (0.123 + rng.uniform(-0.01, 0.01, coords.shape)).astype(np.float32)
+    elif kind == "blob":   # several over-full bins and groups of different sizes beside ordinary ones
+        coords[:] = np.clip(rng.normal(0.2, 0.07, coords.shape), -1.0, 1.0).astype(np.float32)
+        coords[::7] = rng.uniform(-1.0, 1.0, coords[::7].shape).astype(np.float32)
     elif kind == "one_plane":
         coords[:, 2] = np.float32(0.5)
     else:
