@@ -395,7 +395,10 @@ def build_step(device, rank, world, dim, res, bw, F, n_local, ar_chunks=1, colle
         return feats, grad
 
     return {"step": step, "groups": groups, "first_np": first_np, "T": T, "table": table, "coords": coords,
-            "grad_out": grad_out, "first": first, "plan_bytes": 0 if plan is None else plan.numel()}
+            "grad_out": grad_out, "first": first, "plan_bytes": 0 if plan is None else plan.numel(),
+            "backward_workspace_bytes": (hip_ops.hashgrid_backward_workspace_bytes(dim, n_local, T, table.dtype, res, bw, F,
+                                                                                   planned=plan is not None)
+                                         if device.type == "cuda" else None)}
 
 
 SWEEP_CASES = [
@@ -795,6 +798,7 @@ def main():
                        "table_rows": T, "samples_per_gpu": n_local, "scaling": args.scaling,
                        "plan_hand_off": ("forward builds the batch's plan every step, backward reads it"
                                          if st_plan_bytes else "none (plain operators)"), "plan_bytes": st_plan_bytes,
+                       "backward_workspace_bytes": st["backward_workspace_bytes"],
                        "collective": args.collective if world > 1 else None,
                        "nccl_algo": (os.environ.get("NCCL_ALGO") or "unset (RCCL chooses)") if world > 1 else None,
                        **proof,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SHACIRA_ABI_VERSION 10
+#define SHACIRA_ABI_VERSION 11
 
 #if defined(__GNUC__)
 #define SHACIRA_API __attribute__((visibility("default")))
@@ -154,11 +154,22 @@ SHACIRA_API int shacira_hashgrid_backward_levels(int dim, int64_t num_coords, in
  *                                    pixel lattice every step, wisp/trainers/image_trainer.py:234-266) may keep it across
  *                                    steps and pass plan_flags = SHACIRA_PLAN_READY to the forward, which then skips its sort
  *   plan_bytes                       size of the buffer; SHACIRA_EWORKSPACE when it is non-NULL and too small
+ *   shacira_hashgrid_backward_planned_workspace_bytes (ABI 11)
+ *                                    scratch the planned backward of this shape needs: the levels its brick pass takes write no
+ *                                    items and the others 12-byte units, S1 at 2^20 samples: 0.70 GB against the 1.10 GB of
+ *                                    shacira_hashgrid_backward_workspace_bytes (which such a call accepts, too). Holds for a
+ *                                    16-byte aligned grad_output; a planned call on an unaligned one runs the plain passes
+ *                                    and asks for the plain size (SHACIRA_EWORKSPACE below it). Equal to the plain size for
+ *                                    shapes without a plan or outside the brick pass's rule.
  */
 #define SHACIRA_PLAN_READY 1
 SHACIRA_API size_t shacira_hashgrid_plan_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
                                                int codebook_bitwidth, const int32_t *resolutions_host, int64_t table_rows,
                                                int dtype);
+SHACIRA_API size_t shacira_hashgrid_backward_planned_workspace_bytes(int dim, int64_t num_coords, int num_lods,
+                                                                     int feature_dim, int codebook_bitwidth,
+                                                                     const int32_t *resolutions_host, int64_t table_rows,
+                                                                     int dtype);
 SHACIRA_API int shacira_hashgrid_forward_planned(int dim, int64_t num_coords, int num_lods, int feature_dim,
                                                  int codebook_bitwidth, const int32_t *resolutions_host,
                                                  const int32_t *codebook_first_idx, int64_t table_rows, const float *coords,

@@ -35,6 +35,7 @@ SIGNATURES = {
     "shacira_hashgrid_forward_planned": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _i, _p, _sz, _p]),
     "shacira_hashgrid_backward_planned": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p, _sz, _p]),
     "shacira_hashgrid_backward_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i, _p, _i64, _i]),
+    "shacira_hashgrid_backward_planned_workspace_bytes": (_sz, [_i, _i64, _i, _i, _i, _p, _i64, _i]),
     "shacira_hashgrid_backward": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _sz, _p]),
     "shacira_hashgrid_backward_levels": (_i, [_i, _i64, _i, _i, _i, _p, _p, _i64, _p, _p, _i, _p, _i, _i, _i, _p, _sz,
                                               _p]),

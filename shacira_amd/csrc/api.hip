@@ -202,6 +202,18 @@ static int backward_call(int dim, int64_t num_coords, int num_lods, int feature_
                          int level_end, int flags, const void *plan, size_t plan_bytes, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+size_t shacira_hashgrid_backward_planned_workspace_bytes(int dim, int64_t num_coords, int num_lods, int feature_dim,
+                                                         int codebook_bitwidth, const int32_t *resolutions_host,
+                                                         int64_t table_rows, int dtype) {
+    options_snapshot();
+    LevelTable lt;
+    if (build_level_table(dim, num_lods, feature_dim, codebook_bitwidth, resolutions_host, table_rows, lt)) return 0;
+    LevelTable full = lt;
+    const bool sorts = dtype != SHACIRA_F64 && table_rows > 0 && tiled_supported(dim, dtype, full, num_coords);
+    if (!sorts) return hashgrid_backward_workspace(dim, dtype, lt, num_coords);   // no plan for this shape: the plain call
+    return hashgrid_backward_workspace_planned(dim, dtype, lt, num_coords, true);
+}
+
 int shacira_hashgrid_backward_planned(int dim, int64_t num_coords, int num_lods, int feature_dim, int codebook_bitwidth,
                                       const int32_t *resolutions_host, const int32_t *codebook_first_idx, int64_t table_rows,
                                       const float *coords, const void *grad_output, int dtype, void *grad_codebook,
@@ -243,8 +255,6 @@ static int backward_call(int dim, int64_t num_coords, int num_lods, int feature_
     if (dtype != SHACIRA_F32 && dtype != SHACIRA_F16 && dtype != SHACIRA_F64) return SHACIRA_EDTYPE;
     if (num_coords < 0 || !grad_codebook) return SHACIRA_EINVAL;
     if (num_coords > 0 && (!codebook_first_idx || !coords || !grad_output)) return SHACIRA_EINVAL;
-    const size_t need = hashgrid_backward_workspace(dim, dtype, lt, num_coords);
-    if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
     // the plan of a shape whose forward sorts nothing does not exist: such a buffer is ignored
     if (plan != nullptr) {
         LevelTable full = lt;
@@ -254,6 +264,13 @@ static int backward_call(int dim, int64_t num_coords, int num_lods, int feature_
         if (!sorts) plan = nullptr;
         else if (plan_bytes < sample_plan_bytes(dim, num_coords)) return SHACIRA_EWORKSPACE;
     }
+    // a planned call is sized by what it runs: shacira_hashgrid_backward_planned_workspace_bytes when its brick pass takes the
+    // coarse levels (16-byte aligned grad_output), the plain size otherwise
+    const size_t need = plan != nullptr
+                            ? hashgrid_backward_workspace_planned(dim, dtype, lt, num_coords,
+                                                                  (reinterpret_cast<uintptr_t>(grad_output) & 15u) == 0)
+                            : hashgrid_backward_workspace(dim, dtype, lt, num_coords);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return SHACIRA_EWORKSPACE;
     return (int)hashgrid_backward_dispatch(dim, dtype, lt, codebook_first_idx, coords, grad_output, grad_codebook,
                                            workspace, workspace_bytes, num_coords, (hipStream_t)stream, plan);
 }

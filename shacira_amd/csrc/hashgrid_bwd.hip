@@ -256,6 +256,7 @@ static hipError_t bwd_atomic_f(const LevelTable &lt, const int32_t *first_idx, c
 bool bin_supported(int dim, const LevelTable &lt);
 bool bin_all_direct(int dim, const LevelTable &lt);
 size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n);
+size_t bin_workspace_bytes_planned(int dim, int dtype, const LevelTable &lt, int64_t n, bool whole, bool grad_aligned);
 float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace);
 hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx, const float *coords,
                         const void *grad_out, float *acc, void *workspace, int64_t n, hipStream_t s, bool zero_table,
@@ -284,6 +285,20 @@ size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int
     size_t need = (dtype == SHACIRA_F16) ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0;
     if (bin_supported(dim, lt) && n > 0) {
         const size_t b = bin_workspace_bytes(dim, dtype, lt, n);
+        if (b > need) need = b;
+    }
+    return need;
+}
+
+size_t hashgrid_backward_workspace_planned(int dim, int dtype, const LevelTable &lt, int64_t n, bool grad_aligned) {
+    if (dtype == SHACIRA_F64) return 0;
+    size_t need = (dtype == SHACIRA_F16) ? (size_t)lt.table_rows * lt.feature_dim * sizeof(float) : 0;
+    if (bin_supported(dim, lt) && n > 0) {
+        const bool whole = lt.level_begin == 0 && lt.level_end == lt.num_lods;
+        // (a batch below the binned form's threshold runs the atomic form: no items at all; sized like the plain query, which
+        // does not look at the threshold either)
+        const size_t b = (n < ((int64_t)1 << 31)) ? bin_workspace_bytes_planned(dim, dtype, lt, n, whole, grad_aligned)
+                                                  : bin_workspace_bytes(dim, dtype, lt, n);
         if (b > need) need = b;
     }
     return need;

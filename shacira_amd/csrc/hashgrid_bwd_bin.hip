@@ -447,10 +447,55 @@ static uint64_t slots_per_sample(const BinPlan &plan) {
     return slots;
 }
 
-static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, void *ws) {
+static int front_tile(int L, int F, uint32_t nbl, int64_t n, size_t *shmem);
+
+// The brick pass's levels for a call (bwd_brick.h), or none: with the batch's plan at hand (the cell-sorted forward's records;
+// only its block grid `sb->nb` is read here), coarse 3-D levels are accumulated block by block in LDS and leave the item stream.
+// Whole calls over one sub-batch that accumulate in fixed point (>= 2^17 samples: the regime the item stream binds in); never for
+// tables whose levels are all direct. One function for the workspace query, the carving and the launch sequence.
+// Measured rule (option bwd_brick = -1; tools/brick_cfg_ab.py, profiles/r06_experiments.md 3 + 7): fp32 item streams of
+// F = 2 tables, at every batch size that has a plan (the forward sorts from 2^18 samples) -- with the 12-byte item units
+// the pass brings along, S1 backward at 2^20 / 2^19 / 2^18 samples: 0.468 -> 0.417 / 0.270 -> 0.252 / 0.166 -> 0.161 ms.
+// Not taken: half-precision item streams (items are half the bytes already: S1 fp16 0.415 -> 0.435) and F = 4
+// (nerf_lego.yaml's table: 32 LDS atomics per sample and level, six of its eleven dense levels do not fit the images
+// and would stay compact items in sorted order: 0.612 -> 0.617, fp16 0.504 -> 0.508). bwd_brick = 1 takes it wherever
+// the shape allows.
+static void brick_levels_of_call(int dim, int dtype, const LevelTable &lt, int64_t n, const SortedBatch *sb, bool zero_table,
+                                 bool grad_aligned, BrickPlan &brick, uint32_t &skip_mask) {
+    brick.nlev = 0;
+    skip_mask = 0u;
+    if (dim != 3 || sb == nullptr) return;
+    const int L = lt.num_lods, F = lt.feature_dim;
+    const bool multi = bin_batch_samples(dim, dtype, lt, n) < n;
+    // (sorted mode rides on the fused 16-byte front kernel: rows of whole 16-byte vectors, 16-byte aligned input)
+    const int kvec0 = (int)(16 / ((dtype == SHACIRA_F32 ? 4 : 2) * F));
+    const int bopt = opt().bwd_brick;
+    const bool wanted = bopt == 1 || (bopt < 0 && F == 2 && dtype == SHACIRA_F32);
+    if (!wanted || multi || lt.stage_flags != 0 || !zero_table || n < SHACIRA_FX_MIN || n * L >= ((int64_t)1 << 31) ||
+        table_all_direct(dim, dtype, lt, n) || (L % kvec0) != 0 || !grad_aligned)
+        return;
+    // beside the consume pass (mode 2) a brick workgroup must fit the LDS its 128 KiB image leaves
+    if (!make_brick_plan(lt, n, *sb, opt().bwd_brick_lo, opt().bwd_brick_hi, opt().bwd_brick_span,
+                         (size_t)(opt().bwd_brick_fork == 2 ? 30 : 64) * 1024, brick)) {
+        brick.nlev = 0;
+        return;
+    }
+    for (uint32_t q = 0; q < brick.nlev; ++q) skip_mask |= 1u << brick.lv[q].level;
+    // (nothing left for the item passes, or no tile size for the fused front kernel: keep the plain pipeline)
+    BinPlan rest;
+    make_plan(dim, dtype, lt, n, rest, choose_acc_kib(dim, dtype, lt, n), one_image_compact_rule(n), skip_mask, n);
+    size_t sh0 = 0;
+    if (rest.nbl == 0 || front_tile(L, F, rest.nbl, n, &sh0) <= 0) {
+        skip_mask = 0u;
+        brick.nlev = 0;
+    }
+}
+
+// skip_mask: the levels the call's brick pass takes (brick_levels_of_call): they emit no items
+static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, void *ws, uint32_t skip_mask = 0u) {
     BinPlan plan;
     const int64_t nb = bin_batch_samples(dim, dtype, lt, n);
-    make_plan(dim, dtype, lt, nb, plan, choose_acc_kib(dim, dtype, lt, n), one_image_compact_rule(n), 0u, n);
+    make_plan(dim, dtype, lt, nb, plan, choose_acc_kib(dim, dtype, lt, n), one_image_compact_rule(n), skip_mask, n);
     const size_t item = item_unit_bytes(item_format(dim, dtype, lt, n), lt);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -491,8 +536,40 @@ static BinWorkspace carve(int dim, int dtype, const LevelTable &lt, int64_t n, v
     return w;
 }
 
+// Item format and brick levels of one call (the thread's option snapshot of this C-ABI call is updated in place).
+// 12-byte item units, automatic setting: with the brick pass, i.e. on planned calls of the shapes its rule takes. In sorted order
+// with the dense levels out of the item stream the consume pass has the instruction slots the unpacking costs (S1 backward
+// 0.440 -> 0.417 ms; on the plain path the format returns 1-3 %; profiles/r06_experiments.md 7). Decided before the workspace is
+// sized or carved: every plan and pass of the call then sees one format.
+static void resolve_call(int dim, int dtype, const LevelTable &lt, int64_t n, const SortedBatch *sb, bool zero_table,
+                         bool grad_aligned, BrickPlan &brick, uint32_t &skip_mask) {
+    const bool auto12 = opt().bwd_item12 < 0;
+    if (auto12) {
+        const bool brick_shape = sb != nullptr && dim == 3 && lt.feature_dim == 2 && dtype == SHACIRA_F32 &&
+                                 lt.level_begin == 0 && lt.level_end == lt.num_lods && lt.stage_flags == 0 && zero_table &&
+                                 opt().bwd_brick != 0;
+        options_resolve_item12(brick_shape ? 1 : 0);
+    }
+    brick_levels_of_call(dim, dtype, lt, n, sb, zero_table, grad_aligned, brick, skip_mask);
+    if (auto12 && brick.nlev == 0) options_resolve_item12(0);
+}
+// (fp16 tables keep the full layout: the offset of their fp32 accumulation image is asked for before the call is resolved)
+static inline uint32_t carve_skip(int dtype, uint32_t skip_mask) { return dtype == SHACIRA_F32 ? skip_mask : 0u; }
+
 size_t bin_workspace_bytes(int dim, int dtype, const LevelTable &lt, int64_t n) {
     return carve(dim, dtype, lt, n, nullptr).bytes;
+}
+
+// workspace of a PLANNED call (a plan of the batch exists; `whole`: level range = all levels, table zeroed by the call;
+// `grad_aligned`: 16-byte aligned grad_output): the levels its brick pass takes emit no items, the rest 12-byte units. A call
+// the brick rule does not take is sized like the plain one.
+size_t bin_workspace_bytes_planned(int dim, int dtype, const LevelTable &lt, int64_t n, bool whole, bool grad_aligned) {
+    SortedBatch sb{};
+    sample_plan_grid(dim, n, sb);
+    BrickPlan brick;
+    uint32_t skip_mask = 0;
+    resolve_call(dim, dtype, lt, n, &sb, whole, grad_aligned, brick, skip_mask);
+    return carve(dim, dtype, lt, n, nullptr, carve_skip(dtype, skip_mask)).bytes;
 }
 
 float *bin_acc32(int dim, int dtype, const LevelTable &lt, int64_t n, void *workspace) {
@@ -585,39 +662,9 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
     // accumulated block by block in LDS and leave the item stream. Whole calls over one sub-batch that accumulate in
     // fixed point (>= 2^17 samples: the regime the item stream binds in); never for tables whose levels are all direct.
     BrickPlan brick;
-    brick.nlev = 0;
     uint32_t skip_mask = 0;
-    if constexpr (DIM == 3) {
-        // (sorted mode rides on the fused 16-byte front kernel: rows of whole 16-byte vectors, 16-byte aligned input)
-        const int kvec0 = (int)(16 / ((dtype == SHACIRA_F32 ? 4 : 2) * F));
-        // Measured rule (option bwd_brick = -1; tools/brick_cfg_ab.py, profiles/r06_experiments.md 3 + 7): fp32 item streams of
-        // F = 2 tables, at every batch size that has a plan (the forward sorts from 2^18 samples) -- with the 12-byte item units
-        // the pass brings along, S1 backward at 2^20 / 2^19 / 2^18 samples: 0.468 -> 0.417 / 0.270 -> 0.252 / 0.166 -> 0.161 ms.
-        // Not taken: half-precision item streams (items are half the bytes already: S1 fp16 0.420 -> 0.438) and F = 4
-        // (nerf_lego.yaml's table: 32 LDS atomics per sample and level, six of its eleven dense levels do not fit the images
-        // and would stay compact items in sorted order: 0.600 -> 0.607, fp16 0.517 -> 0.556). bwd_brick = 1 takes it wherever
-        // the shape allows.
-        const int bopt = opt().bwd_brick;
-        const bool wanted = bopt == 1 || (bopt < 0 && F == 2 && dtype == SHACIRA_F32);
-        if (sb != nullptr && wanted && !multi && !stage_all && !staged && zero_table &&
-            n >= SHACIRA_FX_MIN && n * L < ((int64_t)1 << 31) && !table_all_direct(DIM, dtype, lt, n) && (L % kvec0) == 0 &&
-            (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0) {
-            if (make_brick_plan(lt, n, *sb, opt().bwd_brick_lo, opt().bwd_brick_hi, opt().bwd_brick_span,
-                                // beside the consume pass (mode 2) a brick workgroup must fit the LDS its 128 KiB image leaves
-                                (size_t)(opt().bwd_brick_fork == 2 ? 30 : 64) * 1024, brick))
-                for (uint32_t q = 0; q < brick.nlev; ++q) skip_mask |= 1u << brick.lv[q].level;
-        }
-    }
+    brick_levels_of_call(DIM, dtype, lt, n, sb, zero_table, (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0, brick, skip_mask);
     make_plan(DIM, dtype, lt, n, whole, acc_kib, oic, skip_mask, n);
-    {
-        size_t sh0 = 0;
-        // (nothing left for the item passes, or no tile size for the fused front kernel: keep the plain pipeline)
-        if (skip_mask != 0u && (whole.nbl == 0 || front_tile(L, F, whole.nbl, n, &sh0) <= 0)) {
-            skip_mask = 0u;
-            brick.nlev = 0;
-            make_plan(DIM, dtype, lt, n, whole, acc_kib, oic, 0u, n);
-        }
-    }
     // SORTED mode: the whole call walks the batch in the plan's block order -- the front kernel gathers the gradient rows in
     // that order, so gT and every later pass's sample index mean "k-th sorted sample" and coordinates come from the records
     const bool sorted = brick.nlev > 0;
@@ -927,17 +974,10 @@ hipError_t bin_backward(int dim, int dtype, const LevelTable &lt, const int32_t 
                         void *half_table, bool *converted, const SortedBatch *sb) {
     if (converted != nullptr) *converted = false;
     __half *ht = (dtype == SHACIRA_F16) ? static_cast<__half *>(half_table) : nullptr;
-    // 12-byte item units, automatic setting: with the brick pass, i.e. on planned calls of the shapes its rule takes (run_bin). In
-    // sorted order with the dense levels out of the item stream the consume pass has the instruction slots the unpacking costs
-    // (S1 backward 0.440 -> 0.417 ms; on the plain path the format returns 1-3 %; profiles/r06_experiments.md 7). Decided here,
-    // before the workspace is carved: every plan and pass of the call then sees one format.
-    if (opt().bwd_item12 < 0) {
-        const bool brick_shape = sb != nullptr && dim == 3 && lt.feature_dim == 2 && dtype == SHACIRA_F32 &&
-                                 lt.level_begin == 0 && lt.level_end == lt.num_lods && lt.stage_flags == 0 && zero_table &&
-                                 opt().bwd_brick != 0;
-        options_resolve_item12(brick_shape ? 1 : 0);
-    }
-    const BinWorkspace w = carve(dim, dtype, lt, n, workspace);
+    BrickPlan brick;
+    uint32_t skip_mask = 0;
+    resolve_call(dim, dtype, lt, n, sb, zero_table, (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0, brick, skip_mask);
+    const BinWorkspace w = carve(dim, dtype, lt, n, workspace, carve_skip(dtype, skip_mask));
     static PerDeviceOnce once;  // kernels that use more than 64 KiB of dynamic LDS must opt in once per device
     const hipError_t attr_err = once.run([]() -> hipError_t {
         hipError_t attr_err = hipSuccess;

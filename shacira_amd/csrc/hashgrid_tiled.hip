@@ -652,6 +652,16 @@ hipError_t sample_plan_build(int dim, const float *coords, int64_t n, void *plan
     return hipSuccess;
 }
 
+// block grid of the plan of (dim, n), no buffer at hand (workspace queries)
+void sample_plan_grid(int dim, int64_t n, SortedBatch &out) {
+    TilePlan tp;
+    make_sort_plan(dim, n, tp);
+    out.sorted4 = nullptr;
+    out.block_start = nullptr;
+    out.num_blocks = tp.num_blocks;
+    for (int a = 0; a < 3; ++a) out.nb[a] = tp.nb[a];
+}
+
 // host-side view of a plan buffer built for (dim, n): pointers + block grid (no device read)
 void sample_plan_view(int dim, int64_t n, const void *plan, SortedBatch &out) {
     TilePlan tp;

@@ -58,11 +58,14 @@ size_t sample_plan_bytes(int dim, int64_t n);
 size_t sample_plan_scratch_bytes(int dim, int64_t n);
 hipError_t sample_plan_build(int dim, const float *coords, int64_t n, void *plan, void *scratch, hipStream_t s);
 void sample_plan_view(int dim, int64_t n, const void *plan, SortedBatch &out);
+void sample_plan_grid(int dim, int64_t n, SortedBatch &out);   // block grid only (no buffer)
 hipError_t hashgrid_debug_corners(int dim, const LevelTable &lt, const float *coords, int64_t n, int32_t *idx, float *w,
                                   hipStream_t s);
 // hashgrid_bwd.hip
 hipError_t zero_fill_async(float *p, int64_t n, hipStream_t s);   // zero fill as a kernel (graph-capture safe)
 size_t hashgrid_backward_workspace(int dim, int dtype, const LevelTable &lt, int64_t n);
+// ... of a call that brings the batch's plan (whole level range; 16-byte aligned grad_output or not)
+size_t hashgrid_backward_workspace_planned(int dim, int dtype, const LevelTable &lt, int64_t n, bool grad_aligned);
 hipError_t hashgrid_backward_dispatch(int dim, int dtype, const LevelTable &lt, const int32_t *first_idx,
                                       const float *coords, const void *grad_out, void *grad_table, void *workspace,
                                       size_t workspace_bytes, int64_t n, hipStream_t s, const void *plan = nullptr);

@@ -138,7 +138,7 @@ def retained_workspace_bytes():
 @functools.lru_cache(maxsize=4096)   # (NeRF steps change N every step: 256 entries thrashed)
 def _ws_bytes(kind, dim, N, L, F, bw, res, T, dt, epoch):
     fn = (_lib.lib().shacira_hashgrid_forward_workspace_bytes, _lib.lib().shacira_hashgrid_backward_workspace_bytes,
-          _lib.lib().shacira_hashgrid_plan_bytes)[kind]
+          _lib.lib().shacira_hashgrid_plan_bytes, _lib.lib().shacira_hashgrid_backward_planned_workspace_bytes)[kind]
     return int(fn(dim, N, L, F, bw, _res_array(res), T, dt))
 
 
@@ -147,6 +147,14 @@ def hashgrid_plan_bytes(dim, num_coords, table_rows, table_dtype, resolution, co
     res = tuple(int(r) for r in resolution)
     return _ws_bytes(2, dim, int(num_coords), len(res), int(feature_dim), int(codebook_bitwidth), res, int(table_rows),
                      _DTYPES[table_dtype], _lib.options_epoch)
+
+
+def hashgrid_backward_workspace_bytes(dim, num_coords, table_rows, table_dtype, resolution, codebook_bitwidth, feature_dim,
+                                      planned=False):
+    """Scratch bytes of the backward of this shape; ``planned=True``: of a whole call that brings the batch's plan."""
+    res = tuple(int(r) for r in resolution)
+    return _ws_bytes(3 if planned else 1, dim, int(num_coords), len(res), int(feature_dim), int(codebook_bitwidth), res,
+                     int(table_rows), _DTYPES[table_dtype], _lib.options_epoch)
 
 
 def hashgrid_plan_buffer(dim, coords, codebook, resolution, codebook_bitwidth):
@@ -239,7 +247,11 @@ def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codeboo
     lb, le = (0, len(res)) if levels is None else (int(levels[0]), int(levels[1]))
     L = _lib.lib()
     with _on_device(device):
-        nbytes = _ws_bytes(1, dim, N, len(res), F, int(codebook_bitwidth), res, T, dt, _lib.options_epoch)
+        planned = plan is not None and (lb, le) == (0, len(res)) and not flags
+        # (a planned call whose coarse levels go through the brick pass writes fewer, smaller items: its own query -- valid for
+        # 16-byte aligned gradients, which every freshly allocated tensor is)
+        kind = 3 if planned and grad_output.data_ptr() % 16 == 0 else 1
+        nbytes = _ws_bytes(kind, dim, N, len(res), F, int(codebook_bitwidth), res, T, dt, _lib.options_epoch)
         if workspace is not None:
             if workspace.numel() * workspace.element_size() < nbytes:
                 raise RuntimeError("workspace too small")
@@ -249,7 +261,7 @@ def hashgrid_backward(dim, coords, grad_output, table_rows, table_dtype, codeboo
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
         else:
             ws = _workspace(device, nbytes)
-        if plan is not None and (lb, le) == (0, len(res)) and not flags:
+        if planned:
             _need_gpu(plan)
             rc = L.shacira_hashgrid_backward_planned(dim, N, len(res), F, int(codebook_bitwidth), _res_array(res),
                                                      _ptr(codebook_first_idx), T, _ptr(coords), _ptr(grad_output), dt,
@@ -281,13 +293,16 @@ def hashgrid_debug_corners(dim, coords, resolution, codebook_bitwidth):
     return rows, w
 
 
-def backward_workspace(dim, num_coords, table_rows, table_dtype, resolution, codebook_bitwidth, feature_dim, device):
-    """Scratch buffer a caller can share between several ``hashgrid_backward(..., levels=...)`` calls."""
+def backward_workspace(dim, num_coords, table_rows, table_dtype, resolution, codebook_bitwidth, feature_dim, device,
+                       planned=False):
+    """Scratch buffer a caller can share between several ``hashgrid_backward(..., levels=...)`` calls; ``planned=True``: the
+    (smaller) buffer of whole calls that bring the batch's plan."""
     res = tuple(int(r) for r in resolution)
     with _on_device(device):
-        n = _lib.lib().shacira_hashgrid_backward_workspace_bytes(dim, int(num_coords), len(res), int(feature_dim),
-                                                                 int(codebook_bitwidth), _res_array(res),
-                                                                 int(table_rows), _DTYPES[table_dtype])
+        query = (_lib.lib().shacira_hashgrid_backward_planned_workspace_bytes if planned
+                 else _lib.lib().shacira_hashgrid_backward_workspace_bytes)
+        n = query(dim, int(num_coords), len(res), int(feature_dim), int(codebook_bitwidth), _res_array(res),
+                  int(table_rows), _DTYPES[table_dtype])
     return torch.empty((max(n, 1),), dtype=torch.uint8, device=device)
 
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(handle, name), name
-    assert _lib.lib().shacira_abi_version() == 10
+    assert _lib.lib().shacira_abi_version() == 11
 
 
 def test_argument_validation_codes():
@@ -121,3 +121,14 @@ def test_backward_workspace_is_sized_by_the_selected_path():
         _lib.set_option("bwd_item12", -1)
     slots, pads = n * (5 * 2 + 11 * 4) * 12, 1024 * 733 * 15 * 12
     assert staged + slots <= s1 <= staged + slots + pads + (48 << 20), s1  # 0.98 GB
+    # round 6: a PLANNED call (the batch's plan at hand) accumulates the five dense levels block by block on chip: they write no
+    # items, the eleven hashed levels 12-byte units. 0.84 GB (plain: 1.10)
+    arr = (ctypes.c_int32 * len(res))(*res)
+    _, _, T = table_layout(res, bw, dim)
+    planned = L.shacira_hashgrid_backward_planned_workspace_bytes(dim, n, len(res), 2, bw, arr, T, _lib.F32)
+    slots, pads = n * 11 * 4 * 12, 1024 * 704 * 15 * 12
+    assert staged + slots <= planned <= staged + slots + pads + (32 << 20), planned
+    assert planned <= 0.85e9 and planned < 0.77 * query(dim, res, bw, n)
+    # shapes without a plan / outside the brick pass's rule: the plain size
+    assert L.shacira_hashgrid_backward_planned_workspace_bytes(dim, 65536, len(res), 2, bw, arr, T, _lib.F32) == query(dim, res, bw, 65536)
+    assert L.shacira_hashgrid_backward_planned_workspace_bytes(dim, n, len(res), 2, bw, arr, T, _lib.F16) == query(dim, res, bw, n, dtype=_lib.F16)

@@ -254,6 +254,38 @@ def test_planned_pair_replays_from_one_graph(dev):
     _assert_grad_close(out.cpu().numpy(), oc.backward(coords2, go2, (T, 2), first, res, bw), first, sizes)
 
 
+def test_planned_call_in_its_own_smaller_workspace(dev):
+    """shacira_hashgrid_backward_planned_workspace_bytes: the planned call runs in exactly that many bytes (a guard pattern
+    behind them stays untouched); a planned call on a gradient that is not 16-byte aligned runs the plain passes and refuses
+    the smaller buffer loudly."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    n = (1 << 18) + 36
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, seed=91)
+    tc, tt, tg, tf = _to(dev, coords, table, go, first)
+    plan = ops.hashgrid_plan_buffer(dim, tc, tt, res, bw)
+    ops.hashgrid_interpolate_cuda(tc, tt, tf, res, bw, plan=plan)
+    small = ops.backward_workspace(dim, n, T, torch.float32, res, bw, 2, dev, planned=True).numel()
+    plain = ops.backward_workspace(dim, n, T, torch.float32, res, bw, 2, dev).numel()
+    assert small < 0.85 * plain
+    buf = torch.full((small + 4096,), 0x5A, dtype=torch.uint8, device=dev)
+    grad = ops.hashgrid_backward(dim, tc, tg, T, torch.float32, tf, res, bw, 2, workspace=buf[:small], plan=plan)
+    torch.cuda.synchronize()
+    assert bool((buf[small:] == 0x5A).all())
+    _assert_grad_close(grad.cpu().numpy(), oc.backward(coords, go, (T, 2), first, res, bw), first, sizes)
+    # unaligned gradient rows: the same values at an odd 4-byte offset
+    flat = torch.empty((tg.numel() + 1,), device=dev)
+    flat[1:].copy_(tg.reshape(-1))
+    tg_odd = flat[1:].view(tg.shape)
+    assert tg_odd.data_ptr() % 16 != 0
+    with pytest.raises(RuntimeError, match="workspace"):
+        ops.hashgrid_backward(dim, tc, tg_odd, T, torch.float32, tf, res, bw, 2, workspace=buf[:small], plan=plan)
+    grad2 = ops.hashgrid_backward(dim, tc, tg_odd, T, torch.float32, tf, res, bw, 2, plan=plan)
+    torch.cuda.synchronize()
+    _assert_grad_close(grad2.cpu().numpy(), oc.backward(coords, go, (T, 2), first, res, bw), first, sizes)
+
+
 def test_full_size_planned_step_with_the_automatic_rule(dev):
     """BASELINE's headline batch (2^20 samples, config D's table) with every option at its default: the planned pair takes
     the sorted path with the brick pass by itself; forward slices bit-identical, gradient within the bar of the oracle."""
