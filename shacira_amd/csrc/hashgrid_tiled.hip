@@ -388,55 +388,13 @@ __device__ __forceinline__ uint32_t wave_rank_add(uint32_t *counters, uint32_t j
     return live ? atomicAdd(&counters[j], 1u) : 0u;
 }
 
-// Workgroup w of the last pass -> (coarse bin, chunk of the bin): a bin of `len` records has max(1, ceil(len / 8 192))
-// chunks, so a uniform batch is one workgroup per bin and a batch concentrated in few blocks gets as many workgroups as it has
-// 8 192-record chunks, whatever bin they fall into (round 6: the first form gave an over-full bin four workgroups that each
-// counted ALL of it -- 0.8 ms for a Gaussian blob of 2^20 samples, tools/skew_check.py). Returns false for surplus workgroups.
-struct ChunkOf {
-    uint32_t bin, chunk, nchunks, lo, hi;    // [lo, hi): the BIN's records
-};
-__device__ __forceinline__ bool chunk_of_workgroup(const TilePlan &tp, const uint32_t *__restrict__ cbase, uint32_t *s_pre,
-                                                   uint32_t *s_wave, ChunkOf &c) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t nch = 0;
-    if (threadIdx.x < kMaxCoarse) {
-        if (threadIdx.x < tp.num_coarse) {
-            const uint32_t len = cbase[threadIdx.x + 1] - cbase[threadIdx.x];
-            nch = len > kLocalCap ? (len + kLocalCap - 1u) / kLocalCap : 1u;
-        }
-        uint32_t incl = nch;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t nbr = __shfl_up(incl, off, 64);
-            if (lane >= (uint32_t)off) incl += nbr;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        s_pre[threadIdx.x] = incl - nch;
-    }
-    __syncthreads();
-    if (threadIdx.x < kMaxCoarse) {
-        uint32_t wb = 0;
-        for (uint32_t w = 0; w < wave; ++w) wb += s_wave[w];
-        s_pre[threadIdx.x] += wb;
-        if (threadIdx.x == kMaxCoarse - 1) s_pre[kMaxCoarse] = s_pre[threadIdx.x] + nch;
-    }
-    __syncthreads();
-    const uint32_t w = blockIdx.x;
-    if (w >= s_pre[kMaxCoarse]) return false;
-    uint32_t lo_b = 0, hi_b = tp.num_coarse;     // last bin whose first chunk is <= w (bins beyond num_coarse have no chunk)
-    while (hi_b - lo_b > 1u) {
-        const uint32_t mid = (lo_b + hi_b) >> 1;
-        if (s_pre[mid] <= w) lo_b = mid;
-        else hi_b = mid;
-    }
-    c.bin = lo_b;
-    c.chunk = w - s_pre[lo_b];
-    c.nchunks = s_pre[lo_b + 1] - s_pre[lo_b];
-    c.lo = cbase[lo_b];
-    c.hi = cbase[lo_b + 1];
-    return true;
-}
-
+// Workgroups of the last pass. w < num_coarse: bin w -- all of it when it holds <= 8 192 records (every bin of a uniform batch:
+// nothing but the bin's two offsets is read before its records), its first 8 192 records otherwise. What an over-full bin (a
+// batch concentrated in few blocks) holds beyond is cut at the 8 192-aligned windows of the partitioned batch, and workgroup
+// num_coarse + v takes window v: the bin holding the window's first record is the only one whose remainder can reach into that
+// window (the next bin's remainder starts >= 8 192 records behind its own start). So such a batch gets as many workgroups as it
+// has 8 192-record pieces, whatever bin they fall into (round 6: the first form gave an over-full bin four workgroups that each
+// counted ALL of it -- 0.8 ms for a Gaussian blob of 2^20 samples, tools/skew_check.py), and no workgroup searches a list.
 template <int DIM>
 __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp, const float4 *__restrict__ inter4,
                                                                     const uint32_t *__restrict__ cbase,
@@ -447,10 +405,34 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp,
                                                                     uint32_t *__restrict__ header, uint32_t n) {
     constexpr int kBpc = kMaxBlocksS / kMaxCoarse;   // blocks per coarse bin (<= 16)
     constexpr int R = kLocalR;
-    __shared__ uint32_t s_pre[kMaxCoarse + 1], s_wave[kMaxCoarse / 64];
-    ChunkOf c;
-    if (!chunk_of_workgroup(tp, cbase, s_pre, s_wave, c)) return;
-    const uint32_t bin = c.bin, lo = c.lo, hi = c.hi;
+    uint32_t bin, lo, hi, c_lo, c_hi;
+    const bool first = blockIdx.x < tp.num_coarse;
+    if (first) {
+        bin = blockIdx.x;
+        lo = cbase[bin];
+        hi = cbase[bin + 1];
+        c_lo = lo;
+        c_hi = (lo + kLocalCap < hi) ? lo + kLocalCap : hi;
+    } else {
+        const uint32_t p0 = (blockIdx.x - tp.num_coarse) * kLocalCap;      // window's first record
+        if (p0 >= n) return;
+        __shared__ uint32_t s_le;
+        if (threadIdx.x == 0) s_le = 0u;
+        __syncthreads();
+        uint32_t c = (threadIdx.x < tp.num_coarse && cbase[threadIdx.x] <= p0) ? 1u : 0u;   // (whole waves: kMaxCoarse = 256)
+        if (threadIdx.x < kMaxCoarse) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+            if ((threadIdx.x & 63u) == 0u && c) atomicAdd(&s_le, c);
+        }
+        __syncthreads();
+        bin = s_le - 1u;                                                    // (cbase[0] = 0 <= p0)
+        lo = cbase[bin];
+        hi = cbase[bin + 1];
+        c_lo = (lo + kLocalCap > p0) ? lo + kLocalCap : p0;
+        c_hi = (p0 + kLocalCap < hi) ? p0 + kLocalCap : hi;
+        if (c_lo >= c_hi) return;
+    }
     const uint32_t key0 = bin << tp.coarse_shift;
     const uint32_t bpc = 1u << tp.coarse_shift;
     const uint32_t lane = threadIdx.x & 63;
@@ -461,12 +443,12 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp,
         if constexpr (DIM == 3) cc[2] = r.z;
         return block_key<DIM>(cc, tp) - key0;
     };
-    if (bin == 0 && c.chunk == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         header[0] = kCtxMagic;
         header[1] = tp.num_blocks;
         header[2] = n;
     }
-    if (c.nchunks == 1u) {
+    if (first && hi - lo <= kLocalCap) {
         // the usual case: every record of the bin in registers -- counted, ranked (the returning LDS atomic of the count IS the
         // rank) and written to its block's run. Inside a block the records are ordered by sub-cell of the block (SHACIRA_SORT_SUB
         // bits per axis; the key is block * cells + cell, block_start still addresses whole blocks): consecutive samples then
@@ -562,11 +544,10 @@ __global__ __launch_bounds__(kSortThreadsS) void psort_local_kernel(TilePlan tp,
     }
     if (threadIdx.x < kBpc) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    if (c.chunk == 0) {
+    if (first) {
         if (threadIdx.x < bpc && key0 + threadIdx.x < tp.num_blocks) block_start[key0 + threadIdx.x] = lo + s_off[threadIdx.x];
         if (bin + 1u == tp.num_coarse && threadIdx.x == 0) block_start[tp.num_blocks] = hi;
     }
-    const uint32_t c_lo = lo + c.chunk * kLocalCap, c_hi = (c_lo + kLocalCap < hi) ? c_lo + kLocalCap : hi;
     float4 r[R];
     uint32_t j[R], rk[R];
 #pragma unroll
@@ -631,8 +612,8 @@ hipError_t sample_plan_build(int dim, const float *coords, int64_t n, void *plan
     TileCtx c{};
     carve_plan(n, plan, c);
     carve_scratch(dim, n, scratch, c);
-    // chunks of the last pass: one per coarse bin + one per 8 192 records beyond (upper bound; surplus workgroups leave)
-    const uint32_t chunks = tp.num_coarse + (uint32_t)(n / kLocalCap) + 1u;
+    // workgroups of the last pass: one per coarse bin + one per 8 192-record window (the remainders of over-full bins)
+    const uint32_t chunks = tp.num_coarse + (uint32_t)((n + kLocalCap - 1) / kLocalCap);
     uint32_t *gcount = c.gcursor + kMaxBlocksS;
 #define SHACIRA_SORT_LAUNCHES(D)                                                                                          \
     hipLaunchKernelGGL(psort_count_kernel<D>, dim3(tp.ptiles), dim3(kSortThreadsS), 0, s, tp, coords, n, c.cnt, c.gcursor);  \
