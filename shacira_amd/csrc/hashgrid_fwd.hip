@@ -619,13 +619,19 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_rows_kernel(LevelTable lt, c
 #define SHACIRA_LEVEL_PAIR_U 1
 #endif
 constexpr int kLevelPairU = SHACIRA_LEVEL_PAIR_U;
+#ifndef SHACIRA_FWD_DIRECT_MAX
+#define SHACIRA_FWD_DIRECT_MAX 16384          // batches up to this many samples write the output rows straight from the level kernel
+#endif
 template <int DIM, typename T, int F, bool PACKED = false>
 __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable lt,
                                                                       const int32_t *__restrict__ first_idx,
                                                                       const float *__restrict__ coords,
                                                                       const T *__restrict__ table,
                                                                       T *__restrict__ feats, int64_t N,
-                                                                      uint32_t tiles) {
+                                                                      uint32_t tiles, int64_t level_stride,
+                                                                      int64_t sample_stride) {
+    // destination of (level, sample): feats + level * level_stride + sample * sample_stride (elements). Staging [L][N][F]:
+    // (N F, F); the caller's [N][L F] rows directly: (F, L F) -- small batches, see launch_fwd
     constexpr int NH = 1 << (DIM - 1);
     constexpr int U = kLevelPairU;   // samples per lane pair
     // work list = (level, tile) pairs, level-major, of levels [level_begin, level_end); XCD k (round-robin dispatch,
@@ -710,7 +716,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_level_pair_kernel(LevelTable
                     acc[j] = (k == 0) ? tv * w : fmaf(tv, w, acc[j]);
                 }
             }
-            T *dstT = feats + ((int64_t)lvl * N + idx[u]) * F;
+            T *dstT = feats + (int64_t)lvl * level_stride + idx[u] * sample_stride;
             if constexpr (sizeof(T) == 4 && F == 2) {   // staging stream: written once, read once (soon)
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
                 f32x2 o = {acc[0], acc[1]};
@@ -784,9 +790,21 @@ static hipError_t launch_fwd(const LevelTable &lt, const int32_t *first_idx, con
             const uint32_t tiles = (uint32_t)((num_coords + 128 * kLevelPairU - 1) / (128 * kLevelPairU));
             const uint32_t grid_v6 = 8u * (uint32_t)(((uint64_t)lt.num_lods * tiles + 7) / 8);
             hipError_t e;
+            // The smallest batches write the caller's rows themselves: F-element pieces, 8 XCDs x 2 levels into each 128-byte row of
+            // S1's shape -- partial-line stores that the memory side merges -- and the staging round trip with its second launch
+            // goes away. Measured (tools/small_ab.py, option fwd_direct, config D's table, ray points): 8 192 samples (the E
+            // shard) 17.3 -> 14.0 us, 16 384: 17.9 -> 16.2; beyond that the partial lines cost more than the launch saves
+            // (32 768: 23.3 -> 25.3, 65 536: 36.2 -> 44.4, 2^17: 61 -> 82)
+            const int d_opt = opt().fwd_direct;
+            if (d_opt == 1 || (d_opt < 0 && num_coords <= SHACIRA_FWD_DIRECT_MAX)) {
+                hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F>), dim3(grid_v6), dim3(256), 0, stream, lt,
+                                   first_idx, coords, static_cast<const T *>(table), static_cast<T *>(feats), num_coords, tiles,
+                                   (int64_t)F, (int64_t)lt.num_lods * F);
+                return hipGetLastError();
+            }
             hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F>), dim3(grid_v6),
                                dim3(256), 0, stream, lt, first_idx, coords, static_cast<const T *>(table),
-                               static_cast<T *>(workspace), num_coords, tiles);
+                               static_cast<T *>(workspace), num_coords, tiles, num_coords * F, (int64_t)F);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             const size_t shmem = (size_t)256 * (lt.num_lods + 1) * F * sizeof(T);
@@ -867,7 +885,8 @@ static hipError_t launch_levels_staged(const LevelTable &lt, const int32_t *firs
     const uint32_t tiles = (uint32_t)((n + 128 * kLevelPairU - 1) / (128 * kLevelPairU));
     hipLaunchKernelGGL((hashgrid_fwd_level_pair_kernel<DIM, T, F, true>),
                        dim3(8u * (uint32_t)(((uint64_t)nl * tiles + 7) / 8)), dim3(256), 0, s,
-                       lt, first_idx, coords, static_cast<const T *>(table), static_cast<T *>(staged), n, tiles);
+                       lt, first_idx, coords, static_cast<const T *>(table), static_cast<T *>(staged), n, tiles, n * F,
+                       (int64_t)F);
     return hipGetLastError();
 }
 

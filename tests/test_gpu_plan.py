@@ -304,3 +304,38 @@ def test_full_size_planned_step_with_the_automatic_rule(dev):
     lhs = float((feats.double() * torch.from_numpy(go).to(dev).double()).sum())
     rhs = float((torch.from_numpy(table).to(dev).double() * grad.double()).sum())
     assert lhs == pytest.approx(rhs, rel=1e-6)                      # adjointness <F t, go> == <t, F^T go>
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_through_the_plan(dev, seed):
+    """Randomised 3-D shapes and sample distributions through the planned pair with the brick pass wherever the shape allows it
+    (tools/fuzz_shapes.py runs many more seeds): level counts, resolutions, table sizes, F = 2 / 4, fp32 / fp16, batches from
+    2^18; uniform, cubed (dense centre), a blob over a background, ray points."""
+    from shacira_amd import harness
+    rng = np.random.default_rng(9000 + seed)
+    dim = 3
+    L = int(rng.choice([4, 8, 12, 16, 20]))
+    res = geo(int(rng.integers(4, 20)), int(rng.integers(256, 2049)), L)
+    bw = int(rng.integers(15, 20))
+    F = int(rng.choice([2, 4]))
+    N = int(rng.choice([(1 << 18) + 5, 300_001, 400_003]))
+    dtype = torch.float16 if seed % 3 == 2 else torch.float32
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, N, F=F, seed=seed, edge=bool(seed & 1))
+    kind = int(rng.integers(0, 4))
+    if kind == 1:
+        coords[:] = (rng.uniform(-1, 1, coords.shape) ** 3).astype(np.float32)
+    elif kind == 2:
+        coords[:] = np.clip(rng.normal(rng.uniform(-0.5, 0.5), 0.05, coords.shape), -1, 1).astype(np.float32)
+        coords[::5] = rng.uniform(-1, 1, coords[::5].shape).astype(np.float32)
+    elif kind == 3:
+        rays = harness.ray_points((N + 15) // 16, 16, torch.Generator().manual_seed(seed)).numpy()
+        coords[:] = rays[:N]
+    stored = table.astype(np.float16).astype(np.float32) if dtype == torch.float16 else table
+    go_s = go.astype(np.float16).astype(np.float32) if dtype == torch.float16 else go
+    plan, feats, grad = _planned_pair(dev, dim, res, bw, coords, table, go, first, dtype=dtype, F=F)
+    sl = np.r_[0:2048, N - 2048:N]
+    ref = oc.forward(coords[sl], stored, first, res, bw)
+    want = ref.astype(np.float16) if dtype == torch.float16 else ref
+    assert np.array_equal(feats.cpu().numpy()[sl], want), (res, bw, F, N, dtype, kind)
+    ref_g = oc.backward(coords, go_s, (T, F), first, res, bw)
+    _assert_grad_close(grad.float().cpu().numpy(), ref_g, first, sizes, rtol=RTOL if dtype == torch.float32 else 2e-3)

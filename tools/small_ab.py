@@ -16,7 +16,7 @@ def geo(mn, mx, L):
 
 which = sys.argv[1]
 optsets = sys.argv[2:] or ["-"]
-n = {"D": 65536, "E": 8192, "Q": 262144 - 4096}[which]
+n = {"D": 65536, "E": 8192, "H": 131072, "Q": 262144 - 4096, "X": 16384, "Y": 32768}[which]
 dim, bw, L, F = 3, 19, 16, 2
 res = geo(16, 2048, L)
 sizes = [min(2 ** bw, r ** dim) for r in res]
@@ -48,6 +48,9 @@ def run(optset):
             k, v = kv.split("=")
             saved.append((k, _lib.get_option(k)))
             _lib.set_option(k, int(v))
+    same = torch.equal(hip_ops.hashgrid_interpolate_cuda(coords, table, first, res, bw), ref_f)
+    if not same:
+        print("!! forward differs under", optset)
     f = timed(lambda: hip_ops.hashgrid_interpolate_cuda(coords, table, first, res, bw))
     b = timed(lambda: hip_ops.hashgrid_backward(dim, coords, go, T, torch.float32, first, res, bw, F))
     for k, v in saved:
@@ -55,6 +58,7 @@ def run(optset):
     return f, b
 
 
+ref_f = hip_ops.hashgrid_interpolate_cuda(coords, table, first, res, bw).clone()
 ref = hip_ops.hashgrid_backward(dim, coords, go, T, torch.float32, first, res, bw, F).clone()
 times = {c: [] for c in optsets}
 for rep in range(5):
