@@ -111,6 +111,30 @@ def test_forward_bit_exact_backward_within_tolerance(dev, name, variant):
                                    rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("F", [2, 4])
+@pytest.mark.parametrize("n,direct", [(8192, 0), (8192 + 37, -1), (16384, 1), (16385, -1), (40_001, 1)])
+def test_level_kernel_writes_output_rows_directly_on_small_batches(dev, n, direct, F):
+    """Round 6: batches up to 16 384 samples skip the level-major staging -- the level-per-XCD kernel stores every (sample,
+    level) piece into the caller's row itself (option fwd_direct: -1 rule, 0 never, 1 always). Same bits either way, fp32 and
+    fp16 tables, ragged sizes on both sides of the threshold."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, F=F, seed=n + F)
+    tc, tf = torch.from_numpy(coords).to(dev), torch.from_numpy(first).to(dev)
+    _lib.set_option("fwd_direct", direct)
+    try:
+        for dtype in (torch.float32, torch.float16):
+            stored = table.astype(np.float16).astype(np.float32) if dtype == torch.float16 else table
+            want = oc.forward(coords, stored, first, res, bw)
+            want = want.astype(np.float16) if dtype == torch.float16 else want
+            tt = torch.from_numpy(table).to(dev).to(dtype)
+            out = ops.hashgrid_interpolate_cuda(tc, tt, tf, res, bw)
+            assert np.array_equal(out.cpu().numpy(), want), (n, direct, F, dtype)
+    finally:
+        _lib.set_option("fwd_direct", -1)
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 257, 1000])
 def test_empty_single_and_ragged_sizes(dev, n):
     dim, res, bw = CONFIGS["D"]
