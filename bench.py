@@ -584,7 +584,7 @@ def main():
     st = build_step(device, rank, world, dim, res, bw, F, n_local, args.ar_chunks, args.collective, use_plan=not args.no_plan)
     step, groups, first_np, T, table, coords, grad_out = (st["step"], st["groups"], st["first_np"], st["T"], st["table"],
                                                           st["coords"], st["grad_out"])
-    st_plan_bytes = st["plan_bytes"]
+    st_plan_bytes, st_ws_bytes = st["plan_bytes"], st["backward_workspace_bytes"]
 
     def fence():
         if dist.is_initialized():
@@ -801,7 +801,7 @@ def main():
                        "table_rows": T, "samples_per_gpu": n_local, "scaling": args.scaling,
                        "plan_hand_off": ("forward builds the batch's plan every step, backward reads it"
                                          if st_plan_bytes else "none (plain operators)"), "plan_bytes": st_plan_bytes,
-                       "backward_workspace_bytes": st["backward_workspace_bytes"],
+                       "backward_workspace_bytes": st_ws_bytes,
                        "collective": args.collective if world > 1 else None,
                        "nccl_algo": (os.environ.get("NCCL_ALGO") or "unset (RCCL chooses)") if world > 1 else None,
                        **proof,
