@@ -339,3 +339,21 @@ def test_random_shapes_through_the_plan(dev, seed):
     assert np.array_equal(feats.cpu().numpy()[sl], want), (res, bw, F, N, dtype, kind)
     ref_g = oc.backward(coords, go_s, (T, F), first, res, bw)
     _assert_grad_close(grad.float().cpu().numpy(), ref_g, first, sizes, rtol=RTOL if dtype == torch.float32 else 2e-3)
+
+
+def test_planned_call_split_into_sub_batches_falls_back_to_the_plain_passes(dev):
+    """A call whose item array exceeds the cap (option bin_batch_mib) runs in sub-batches; the brick pass takes whole calls
+    only, so such a planned call ignores its plan in the backward -- same results, and the workspace query says the plain size."""
+    from shacira_amd import _lib
+    ops = _ops()
+    dim, res, bw = CONFIGS["D"]
+    n = 300_001
+    sizes, first, T, coords, table, go = _problem(dim, res, bw, n, seed=97)
+    _lib.set_option("bin_batch_mib", 64)
+    try:
+        assert (ops.hashgrid_backward_workspace_bytes(dim, n, T, torch.float32, res, bw, 2, planned=True)
+                == ops.hashgrid_backward_workspace_bytes(dim, n, T, torch.float32, res, bw, 2))
+        plan, feats, grad = _planned_pair(dev, dim, res, bw, coords, table, go, first)
+    finally:
+        _lib.set_option("bin_batch_mib", 1536)
+    _assert_grad_close(grad.cpu().numpy(), oc.backward(coords, go, (T, 2), first, res, bw), first, sizes)
