@@ -71,7 +71,7 @@ struct BinPlan {
     uint32_t num_tiles;
     uint32_t pairs;     // items per (sample, level) = 2^(dim-1)
     uint32_t chunk;     // items per consumer work unit
-    uint32_t chunk_min; // smallest unit size of the plan (sizes the unit list)
+    uint32_t chunk_min; // smallest unit size of the plan (sizes the consume pass's unit descriptors)
     uint32_t nbl;       // number of binned levels
     uint32_t pad;       // a (tile, bucket) run is reserved in multiples of this many item units (power of two; 1 = exact): with
                         // SHACIRA_RUN_ALIGN / unit bytes every run starts and ends on a 64-byte boundary, see make_plan

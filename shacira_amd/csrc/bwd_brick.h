@@ -7,10 +7,11 @@
 // The cell-sorted forward leaves the batch counting-sorted by spatial block (hashgrid_tiled.hip: 16-byte records {x, y, z,
 // sample index} + block offsets -- the batch's plan). On a level whose cells are not much smaller than a block, the samples of
 // one block touch only the vertices of a small box of that level (the block's BRICK: at most a few hundred to a thousand rows),
-// many times each. A workgroup therefore walks one block of the sorted records, adds every corner contribution into a
-// brick-local 64-bit fixed-point LDS image per level, and flushes the image with coalesced float atomics: x-runs of adjacent
-// rows on dense levels, rows x ^ h inside one or two 128-byte lines on hashed ones. Those levels leave the item stream
-// altogether (S1: levels 3-6 = 192 of the 864 item bytes per sample, written once and read once before).
+// many times each. A workgroup therefore walks a GROUP of x-adjacent blocks of the sorted records (up to 1 024 records at a time),
+// adds every corner contribution into a brick-local 64-bit fixed-point LDS image per level, and flushes the image with coalesced
+// float atomics: x-runs of adjacent rows on dense levels, rows x ^ h inside one or two 128-byte lines on hashed ones. Those
+// levels leave the item stream altogether (S1: the dense levels 0-4 = 5 x 32 of the 864 item bytes per sample, written once and
+// read once before; the hashed levels 5 and 6 fit, too, but cost more here than as items: profiles/r06_experiments.md 3).
 //   * scale: the level's max |grad_output| from the transposing pass (front16_kernel), as in the consume pass; a level whose
 //     maximum is not finite accumulates in fp64
 //   * a sample whose cell falls outside its block's brick (cannot happen for coordinates the block rule and the clamp agree
@@ -28,12 +29,8 @@ constexpr int kBrickMaxLevels = 6;
 #ifndef SHACIRA_BRICK_UNIT
 #define SHACIRA_BRICK_UNIT 1024
 #endif
-#ifndef SHACIRA_BRICK_SPLIT
-#define SHACIRA_BRICK_SPLIT 4
-#endif
 constexpr int kBrickThreads = SHACIRA_BRICK_THREADS;
 constexpr int kBrickUnit = SHACIRA_BRICK_UNIT;     // samples per unit (one zero / accumulate / flush round of a workgroup)
-constexpr int kBrickSplit = SHACIRA_BRICK_SPLIT;   // (unused since the unit list; kept for the A/B builds' command lines)
 constexpr double kBrickSlack = 1e-3;               // cells: the block rule (fp32) and the cell rule (fp64 -> fp32) agree to ~1e-5
 
 struct BrickLevel {

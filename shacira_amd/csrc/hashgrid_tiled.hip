@@ -11,7 +11,7 @@
 // block ("coarse" levels: 0-7 of S1), so walking the samples block by block turns those levels' gathers into L1 hits.
 // Levels finer than that (one sample per cell: no reuse possible in any order) keep the level-per-XCD pair kernel.
 //
-//   sort      counting sort of the samples by block id (two partitioning passes, four launches: psort_*) -> 16-byte records
+//   sort      counting sort of the samples by block id (two partitioning passes, three launches: psort_*) -> 16-byte records
 //             {coordinates (exact copies), sample index} + block offsets = the batch's PLAN, which the backward can reuse
 //   fine      hashgrid_fwd_level_pair_kernel over the sorted coordinates, levels [lc, L) -> staging [L][N][F]
 //   rows      hashgrid_fwd_rows_kernel: coarse levels [0, lc) over the sorted coordinates (lane pairs, L1-resident
@@ -60,7 +60,7 @@ struct TileCtx {            // device pointers into the sort's outputs (the plan
     uint32_t *block_start;  // [num_blocks + 1]
     uint32_t *cnt;          // scratch: [ptiles][kMaxCoarse] samples per (tile, coarse bin)
     float4 *inter4;         // scratch: [n] records grouped by coarse bin
-    uint32_t *gcursor;      // scratch: [kMaxBlocksS] per-block cursors of over-full bins
+    uint32_t *gcursor;      // scratch: [2][kMaxBlocksS] per-block cursors | per-block counts of over-full bins
     uint32_t *cbase;        // scratch: [kMaxCoarse + 1] first record of every coarse bin
 };
 
@@ -186,12 +186,13 @@ static size_t scratch_bytes_of(int dim, int64_t n) {
 //               returning LDS atomic that counts a record per (block, sub-cell of the block) is its rank; offsets = scan of
 //               <= 1 024 counts; the records go out run by run (a few KB each, written by one workgroup) and the bin's
 //               block offsets with them
-//   place       over-full bins only (a batch concentrated in few blocks; on a uniform batch every workgroup leaves at once): such
-//               a bin is cut into chunks of 8 192 records, one workgroup each in BOTH passes -- `local` counts its chunk per
-//               block into global counters, `place` ranks the chunk in LDS and reserves one range per block from global
-//               cursors. A Gaussian blob / a thin slab / one block of 2^20 samples sort as fast as a uniform batch
-//               (tools/skew_check.py: forward 0.30 / 0.27 / 0.23 ms against 0.30)
-// The four-launch sort it replaces wrote every record straight to its block's slot: 2^20 scattered 16-byte stores into lines
+//   over-full bins (a batch concentrated in few blocks): `partition` also counts such a bin's records per block (global
+//               counters; one LDS flag decides, a uniform batch skips it); in `local` workgroup `bin` takes the bin's first
+//               8 192 records and one more workgroup per 8 192-aligned window of the partitioned batch takes what the bin holds
+//               beyond (surplus ones leave at once); each ranks its records in LDS and reserves one range per block from
+//               global cursors. Block order only in such bins. A Gaussian blob / a thin slab / one block of 2^20 samples
+//               sort as fast as a uniform batch (tools/skew_check.py: forward 0.29 / 0.26 / 0.22 ms against 0.29)
+// The round-5 sort it replaces (four launches) wrote every record straight to its block's slot: 2^20 scattered 16-byte stores into lines
 // shared by 256 workgroups (25 us of its 47). Order inside a block is arbitrary in both (ranks come from atomics).
 template <int DIM>
 __device__ __forceinline__ void load_chunk_coords(const float *__restrict__ coords, int64_t s0, int64_t N,

@@ -1,4 +1,4 @@
-"""The batch PLAN (ABI 10): the forward's sample sort handed to the backward of the same coordinates
+"""The batch PLAN (ABI 10 / 11): the forward's sample sort handed to the backward of the same coordinates
 (shacira_hashgrid_plan_bytes / _forward_planned / _backward_planned). The planned calls must give what the plain calls give --
 forward bit-identical to the oracle, gradients within the 1e-5 bar of the fp64-accumulating oracle -- for every placement of
 the brick pass, on clustered / degenerate batches, on half tables and F = 4, and through the autograd Functions.
@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def brick_wherever_the_shape_allows():
-    """The automatic rule takes the brick pass only where it was measured to win (fp32, F = 2, >= 3/4 M samples); these
+    """The automatic rule takes the brick pass only where it was measured to win (fp32, F = 2); these
     tests run it on every shape that allows it (option bwd_brick = 1) at sizes the oracle finishes in seconds."""
     from shacira_amd import _lib
     _lib.set_option("bwd_brick", 1)
