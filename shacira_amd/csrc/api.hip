@@ -37,6 +37,7 @@ static OptionSlot g_slots[] = {
     {"bwd_brick_fork", &Options::bwd_brick_fork, 0, 2, {2}},
     {"bwd_brick_span", &Options::bwd_brick_span, 0, 64, {0}},
     {"fwd_direct", &Options::fwd_direct, -1, 1, {-1}},
+    {"bwd_ext_fork", &Options::bwd_ext_fork, 0, 1, {1}},
 };
 static thread_local Options tl_options;
 const Options &opt() { return tl_options; }

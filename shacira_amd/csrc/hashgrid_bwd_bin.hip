@@ -38,6 +38,7 @@
 #include "bwd_bin_front.h"
 #include "bwd_bin_passes.h"
 #include "bwd_brick.h"
+#include <hip/hip_ext.h>
 
 namespace shacira {
 
@@ -894,11 +895,28 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         float *zacc = selective ? acc : nullptr;
         const uint32_t cps = fused_now ? (uint32_t)(TileOf<DIM>::value / ts16) : 1u;
         const uint32_t cnt_rows = fused_now ? (uint32_t)((n + ts16 - 1) / ts16) : plan.num_tiles;
+        bool fork_signalled = false;   // the scatter launch itself signals the brick pass's fork event (below)
         if (fmt == 2) {
-            if constexpr (DIM == 3 && F == 2)
-                hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, 2>), SCATTER_GRID(plan), dim3(ScatterThreads<DIM, F, 2>::value),
-                                   stage_bytes(plan), s, lt, plan, cptr, w.gT, w.cursor, w.cnt, cps, cnt_rows,
-                                   reinterpret_cast<Item12 *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first, cstride);
+            if constexpr (DIM == 3 && F == 2) {
+                // Brick pass beside the consume pass: the event the side stream waits for rides on the scatter kernel's own
+                // completion signal (hipExtLaunchKernelGGL's stop event) instead of a marker of its own behind it -- that marker
+                // kept the consume pass from being staged behind the scatter pass (7.6 us between the two under the profiler).
+                // Not while the stream is being captured into a graph (plain launch + event record there).
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                if (brick_mode == 2 && opt().bwd_ext_fork != 0 && hipStreamIsCapturing(s, &cap) == hipSuccess &&
+                    cap == hipStreamCaptureStatusNone) {
+                    hipExtLaunchKernelGGL((bin_scatter_kernel<DIM, F, 2>), SCATTER_GRID(plan),
+                                          dim3(ScatterThreads<DIM, F, 2>::value), (uint32_t)stage_bytes(plan), s, nullptr,
+                                          bss->bfork, 0u, lt, plan, cptr, (const float *)w.gT, w.cursor, (const uint32_t *)w.cnt, cps, cnt_rows,
+                                          reinterpret_cast<Item12 *>(w.items), s0, hi, NP, zacc, first_idx,
+                                          (const uint32_t *)w.unit_first, cstride);
+                    fork_signalled = true;
+                } else {
+                    hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, 2>), SCATTER_GRID(plan), dim3(ScatterThreads<DIM, F, 2>::value),
+                                       stage_bytes(plan), s, lt, plan, cptr, w.gT, w.cursor, w.cnt, cps, cnt_rows,
+                                       reinterpret_cast<Item12 *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first, cstride);
+                }
+            }
         } else if (half)
             hipLaunchKernelGGL((bin_scatter_kernel<DIM, F, true>), SCATTER_GRID(plan), dim3(ScatterThreads<DIM, F, 1>::value),
                                stage_bytes(plan), s, lt, plan, cptr, w.gT, w.cursor, w.cnt, cps, cnt_rows,
@@ -914,7 +932,15 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
                                reinterpret_cast<Item<F> *>(w.items), s0, hi, NP, zacc, first_idx, w.unit_first, cstride);
         SHACIRA_CHECK_LAUNCH();
         if (fork) SHACIRA_CHECK(hipStreamWaitEvent(s, ss->join, 0));   // table zeroed, direct levels in
-        if (brick_mode == 2) SHACIRA_CHECK(fork_brick());
+        if (brick_mode == 2) {
+            if (fork_signalled) {
+                SHACIRA_CHECK(hipStreamWaitEvent(bss->stream, bss->bfork, 0));
+                SHACIRA_CHECK(launch_brick(bss->stream));
+                SHACIRA_CHECK(hipEventRecord(bss->bjoin, bss->stream));
+            } else {
+                SHACIRA_CHECK(fork_brick());
+            }
+        }
         const uint64_t max_items = (uint64_t)(hi - s0) * plan.nbl * NPAIR +
                                    (uint64_t)plan.num_tiles * plan.total_buckets * (plan.pad - 1u);
         uint32_t grid_units = (uint32_t)(max_items / plan.chunk_min) + plan.total_buckets + 1;

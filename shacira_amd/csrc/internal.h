@@ -192,6 +192,7 @@ struct Options {
     int bwd_brick_hi = -1;
     int bwd_brick_fork = 2;       // where the brick pass runs: 0 last on the caller's stream, 1 / 2 side stream from behind the front / scatter pass
     int bwd_brick_span = 0;       // blocks per brick unit along x (0 = planner)
+    int bwd_ext_fork = 1;         // planned calls: the brick pass's fork event rides on the scatter launch (hipExtLaunchKernelGGL)
     int fwd_direct = -1;          // level-per-XCD forward writes the output rows itself (no staging): -1 = small batches, 0 / 1
 };
 const Options &opt();             // the calling thread's snapshot
