@@ -682,7 +682,8 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         brick_mode = opt().bwd_brick_fork;
         if (brick_mode > 0) SHACIRA_CHECK(side_stream(&bss));
     }
-    auto launch_brick = [&](hipStream_t bs) -> hipError_t {
+    // `done`: an event the launch signals on completion (hipExtLaunchKernelGGL's stop event), or nullptr
+    auto launch_brick = [&](hipStream_t bs, hipEvent_t done = nullptr) -> hipError_t {
         if constexpr (DIM == 3) {
             const size_t img = (size_t)brick.rows_total * F * sizeof(double);
             const int hr = fx_headroom((uint64_t)kBrickUnit * 8u);
@@ -690,8 +691,13 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
             // hold beyond; all of them leave at once on a uniform batch)
             const uint32_t groups = brick.groups_x * (uint32_t)(brick.nb[1] * brick.nb[2]);
             const uint32_t windows = (uint32_t)((n + kBrickUnit - 1) / kBrickUnit);
-            hipLaunchKernelGGL((brick_accumulate_kernel<F>), dim3(groups + windows), dim3(kBrickThreads), img, bs, lt, brick,
-                               first_idx, sb->sorted4, sb->block_start, w.gT, NP, acc, w.gmax, hr);
+            if (done != nullptr)
+                hipExtLaunchKernelGGL((brick_accumulate_kernel<F>), dim3(groups + windows), dim3(kBrickThreads), (uint32_t)img, bs,
+                                      nullptr, done, 0u, lt, brick, first_idx, sb->sorted4, sb->block_start, (const float *)w.gT,
+                                      NP, acc, (const uint32_t *)w.gmax, hr);
+            else
+                hipLaunchKernelGGL((brick_accumulate_kernel<F>), dim3(groups + windows), dim3(kBrickThreads), img, bs, lt, brick,
+                                   first_idx, sb->sorted4, sb->block_start, w.gT, NP, acc, w.gmax, hr);
             return hipGetLastError();
         } else {
             (void)bs;
@@ -935,8 +941,7 @@ static hipError_t run_bin(int dtype, const LevelTable &lt, const int32_t *first_
         if (brick_mode == 2) {
             if (fork_signalled) {
                 SHACIRA_CHECK(hipStreamWaitEvent(bss->stream, bss->bfork, 0));
-                SHACIRA_CHECK(launch_brick(bss->stream));
-                SHACIRA_CHECK(hipEventRecord(bss->bjoin, bss->stream));
+                SHACIRA_CHECK(launch_brick(bss->stream, bss->bjoin));   // (and the join event on the brick launch)
             } else {
                 SHACIRA_CHECK(fork_brick());
             }
